@@ -1,0 +1,85 @@
+"""ctypes loader for libgslnls_hip.so (the C ABI of include/gslnls_core.h).
+
+There is no CPU fallback: if the HIP library is missing this module raises, and if no
+GPU is present the entry points return GSLNLS_E_NODEVICE which the Python layer turns
+into an exception.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgslnls_hip.so")
+
+DP = C.POINTER(C.c_double)
+IP = C.POINTER(C.c_int)
+
+E_NODEVICE = -100
+E_UNSUPPORTED = -101
+
+
+class Model(C.Structure):
+    _fields_ = [("id", C.c_int), ("p", C.c_int), ("nx", C.c_int), ("x", C.c_void_p), ("x_on_device", C.c_int)]
+
+
+class Result(C.Structure):
+    _fields_ = [("par", DP), ("covar", DP), ("resid", DP), ("grad", DP), ("niter", C.c_int), ("conv", C.c_int),
+                ("ssr", C.c_double), ("ssrtol", C.c_double), ("neval", C.c_int * 3), ("info", C.c_int),
+                ("chisq_init", C.c_double), ("irls_weights", DP), ("irls_psi", DP), ("irls_dpsi", DP),
+                ("irls_sigma", C.c_double), ("irls_tol", C.c_double), ("irls_status", C.c_int),
+                ("irls_niter", C.c_int), ("partrace", DP), ("ssrtrace", DP), ("mstart_nsp", C.c_int),
+                ("mstart_nwsp", C.c_int), ("mstart_iters", C.c_int), ("mstart_stop", C.c_int),
+                ("mstart_ssropt", C.c_double), ("loop_ms", C.c_float), ("n_launches", C.c_int)]
+
+
+# every symbol include/gslnls_core.h declares (tests/test_abi.py checks the list against the header)
+_SIGNATURES = {
+    "gslnls_nls": (C.c_int, [C.POINTER(Model), C.c_void_p, C.c_int, C.c_int, C.c_int, DP, C.c_int, C.c_void_p,
+                             C.c_int, DP, IP, DP, IP, C.c_int, DP, C.POINTER(Result)]),
+    "gslnls_dense_create": (C.c_void_p, [C.POINTER(Model), C.c_void_p, C.c_int, C.c_void_p, IP]),
+    "gslnls_dense_destroy": (None, [C.c_void_p]),
+    "gslnls_dense_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, DP, DP, IP, DP, C.c_int, C.POINTER(Result)]),
+    "gslnls_dense_time_pass": (C.c_float, [C.c_void_p, C.c_int, DP, C.c_int]),
+    "gslnls_dense_set_swts": (C.c_int, [C.c_void_p, DP]),
+    "gslnls_strerror": (C.c_char_p, [C.c_int]),
+    "gslnls_algorithm_name": (C.c_char_p, [C.c_int]),
+    "gslnls_device_count": (C.c_int, []),
+    "gslnls_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "gslnls_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C gslnls_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def symbols():
+    return sorted(_SIGNATURES)
+
+
+def strerror(code):
+    return lib().gslnls_strerror(int(code)).decode()
+
+
+class GslnlsDeviceError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc == E_NODEVICE:
+        raise GslnlsDeviceError("gslnls_amd: no usable HIP device (MI355X path has no CPU fallback)")
+    if rc == E_UNSUPPORTED:
+        raise NotImplementedError("gslnls_amd: configuration not lowered to the device")
+    return rc

@@ -1,0 +1,187 @@
+// capi.hip -- the C ABI of libgslnls_hip.so (declarations: include/gslnls_core.h).
+//
+// gslnls_nls() is the numeric body behind .Call(C_nls) (src/nls.c:54-813); the R shim in
+// integration/r_shim/ only unpacks SEXPs and packs the returned list.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/gslnls_core.h"
+#include "dense_host.hpp"
+
+using namespace gslnls;
+
+struct gslnls_dense
+{
+    DenseBase *impl;
+};
+
+static DenseBase *make_dense(const gslnls_model *fn, const double *y, int n, const double *swts, int *err)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    {
+        fprintf(stderr, "gslnls: no HIP device available -- the MI355X path cannot run (no CPU fallback exists)\n");
+        *err = GSLNLS_E_NODEVICE;
+        return nullptr;
+    }
+    DenseBase *b = nullptr;
+    int rc = GSLNLS_E_UNSUPPORTED;
+#define GSLNLS_MAKE(MODEL)                                          \
+    {                                                               \
+        if (fn->p != MODEL::P || fn->nx != MODEL::NX)               \
+        {                                                           \
+            *err = GSLNLS_EINVAL;                                   \
+            return nullptr;                                         \
+        }                                                           \
+        auto *d = new DenseFit<MODEL>();                            \
+        rc = d->init(fn, y, n, swts);                               \
+        b = d;                                                      \
+    }
+    switch (fn->id)
+    {
+    case GSLNLS_MODEL_EXPDECAY:
+        GSLNLS_MAKE(ModelExpDecay);
+        break;
+    case GSLNLS_MODEL_MISRA1A:
+        GSLNLS_MAKE(ModelMisra1a);
+        break;
+    case GSLNLS_MODEL_GAUSSPK:
+        GSLNLS_MAKE(ModelGaussPeak);
+        break;
+    case GSLNLS_MODEL_GAUSS1:
+        GSLNLS_MAKE(ModelGauss1);
+        break;
+    default:
+        *err = GSLNLS_E_UNSUPPORTED;
+        return nullptr;
+    }
+#undef GSLNLS_MAKE
+    if (rc != GSLNLS_SUCCESS)
+    {
+        delete b;
+        *err = rc;
+        return nullptr;
+    }
+    *err = GSLNLS_SUCCESS;
+    return b;
+}
+
+extern "C" {
+
+gslnls_dense *gslnls_dense_create(const gslnls_model *fn, const double *y, int n, const double *swts, int *err)
+{
+    int e = 0;
+    DenseBase *b = make_dense(fn, y, n, swts, &e);
+    if (err)
+        *err = e;
+    if (!b)
+        return nullptr;
+    gslnls_dense *h = new gslnls_dense;
+    h->impl = b;
+    return h;
+}
+
+void gslnls_dense_destroy(gslnls_dense *h)
+{
+    if (h)
+    {
+        delete h->impl;
+        delete h;
+    }
+}
+
+int gslnls_dense_solve(gslnls_dense *h, int jac, int fvv, const double *start, const double *lupars,
+                       const int *control_int, const double *control_dbl, int chunk, gslnls_result *out)
+{
+    if (!h || !h->impl)
+        return GSLNLS_EINVAL;
+    return h->impl->solve(jac, fvv, start, lupars, control_int, control_dbl, chunk, out);
+}
+
+float gslnls_dense_time_pass(gslnls_dense *h, int jac, const double *theta, int reps)
+{
+    if (!h || !h->impl)
+        return -1.f;
+    return h->impl->time_pass(jac, theta, reps);
+}
+
+int gslnls_dense_set_swts(gslnls_dense *h, const double *swts)
+{
+    if (!h || !h->impl)
+        return GSLNLS_EINVAL;
+    return h->impl->set_swts(swts);
+}
+
+int gslnls_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv, const double *start,
+               int start_is_matrix, const double *swts, int swts_is_matrix, const double *lupars,
+               const int *control_int, const double *control_dbl, const int *has_start, int loss_rho,
+               const double *loss_cc, gslnls_result *out)
+{
+    (void)has_start;
+    (void)loss_cc;
+    if (swts && swts_is_matrix)
+        return GSLNLS_E_UNSUPPORTED; // GLS: n x n factor, not lowered
+    if (start_is_matrix || loss_rho != 0)
+        return GSLNLS_E_UNSUPPORTED; // multi-start / IRLS: see mstart.hip / irls.hip
+    int err = 0;
+    DenseBase *b = make_dense(fn, y, n, swts, &err);
+    if (!b)
+        return err;
+    const int rc = b->solve(jac, fvv, start, lupars, control_int, control_dbl, 0, out);
+    delete b;
+    return rc;
+}
+
+const char *gslnls_strerror(int code)
+{
+    switch (code)
+    {
+    case GSLNLS_SUCCESS:
+        return "success";
+    case GSLNLS_FAILURE:
+        return "failure";
+    case GSLNLS_CONTINUE:
+        return "the iteration has not converged yet";
+    case GSLNLS_EINVAL:
+        return "invalid argument supplied by user";
+    case GSLNLS_EBADFUNC:
+        return "problem with user-supplied function";
+    case GSLNLS_EMAXITER:
+        return "exceeded max number of iterations";
+    case GSLNLS_ENOPROG:
+        return "iteration is not making progress towards solution";
+    case GSLNLS_E_NODEVICE:
+        return "no HIP device / HIP runtime failure";
+    case GSLNLS_E_UNSUPPORTED:
+        return "configuration not lowered to the device";
+    default:
+        return "unknown error code";
+    }
+}
+
+const char *gslnls_algorithm_name(int trs)
+{
+    switch (trs)
+    {
+    case 1:
+        return "levenberg-marquardt+accel";
+    case 5:
+        return "steihaug-toint";
+    default:
+        return "levenberg-marquardt";
+    }
+}
+
+int gslnls_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+const char *gslnls_version(void) { return "gslnls-mi355x 0.1 (gfx950)"; }
+
+} // extern "C"

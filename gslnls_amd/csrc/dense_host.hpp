@@ -1,0 +1,381 @@
+// dense_host.hpp -- host orchestration of one grid-per-fit problem resident in HBM.
+//
+// Replaces the numeric part of C_nls_internal for a single start (src/nls.c:533-576,
+// :598-608, :632-753): upload once, run the device-resident LM loop as a chain of
+// lm_step_kernel launches, read back the p-sized state, then (optionally) materialise
+// resid / grad / covar with one more kernel.  The host never computes any part of the
+// algorithm; it only enqueues launches and polls the device's own status word.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "../../include/gslnls_core.h"
+#include "dense_kernels.hpp"
+
+namespace gslnls
+{
+
+#define GSLNLS_HIP_OK(expr)                                                                           \
+    do                                                                                                \
+    {                                                                                                 \
+        hipError_t e__ = (expr);                                                                      \
+        if (e__ != hipSuccess)                                                                        \
+        {                                                                                             \
+            fprintf(stderr, "gslnls: HIP error %s at %s:%d\n", hipGetErrorString(e__), __FILE__, __LINE__); \
+            return GSLNLS_E_NODEVICE;                                                                 \
+        }                                                                                             \
+    } while (0)
+
+inline LmParams make_params(const int *ci, const double *cd, int jac, int fvv, bool has_bounds, bool has_w)
+{
+    // decode exactly as src/nls.c:94-152 does
+    LmParams prm;
+    prm.maxiter = ci[0];
+    prm.trs = (ci[2] == 1) ? 1 : 0;
+    prm.scale = ci[3];
+    prm.fdtype = ci[5] ? 1 : 0;
+    prm.jac_analytic = jac ? 1 : 0;
+    prm.fvv_analytic = fvv ? 1 : 0;
+    prm.has_bounds = has_bounds ? 1 : 0;
+    prm.has_weights = has_w ? 1 : 0;
+    prm.factor_up = cd[0];
+    prm.factor_down = cd[1];
+    prm.avmax = cd[2];
+    prm.h_df = cd[3];
+    prm.h_fvv = cd[4];
+    prm.xtol = cd[5];
+    prm.ftol = cd[6];
+    prm.gtol = cd[7];
+    return prm;
+}
+
+struct DenseBase
+{
+    virtual ~DenseBase() {}
+    virtual int solve(int jac, int fvv, const double *start, const double *lupars, const int *ci, const double *cd,
+                      int chunk, gslnls_result *out) = 0;
+    virtual float time_pass(int jac, const double *theta, int reps) = 0;
+    virtual int set_swts(const double *swts) = 0;
+    int n = 0, p = 0;
+};
+
+template <class M>
+struct DenseFit : DenseBase
+{
+    static constexpr int P = M::P;
+    static constexpr int NV = PassSums<P>::NV;
+    // wide workgroups while the accumulators fit in 128 VGPRs, narrow ones beyond that
+    static constexpr int T = (NV <= 24) ? 1024 : 256;
+
+    DenseCtx<P> ctx;
+    bool owns_data = false;
+    double *d_x = nullptr, *d_y = nullptr, *d_sw = nullptr;
+    double *d_partials = nullptr;
+    LmState<P> *d_state = nullptr;
+    LmState<P> *h_state = nullptr; // pinned
+    double *d_ssrtrace = nullptr, *d_partrace = nullptr;
+    int trace_cap = 0;
+    double *d_resid = nullptr, *d_grad = nullptr, *d_covar = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    int init(const gslnls_model *fn, const double *y, int n_, const double *swts)
+    {
+        n = n_;
+        p = P;
+        memset(&ctx, 0, sizeof(ctx));
+        GSLNLS_HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        GSLNLS_HIP_OK(hipEventCreate(&ev0));
+        GSLNLS_HIP_OK(hipEventCreate(&ev1));
+        const size_t nb = sizeof(double) * (size_t)n;
+        if (fn->x_on_device)
+        {
+            d_x = const_cast<double *>(fn->x);
+            d_y = const_cast<double *>(y);
+            d_sw = const_cast<double *>(swts);
+        }
+        else
+        {
+            owns_data = true;
+            GSLNLS_HIP_OK(hipMalloc(&d_x, nb * M::NX));
+            GSLNLS_HIP_OK(hipMalloc(&d_y, nb));
+            GSLNLS_HIP_OK(hipMemcpy(d_x, fn->x, nb * M::NX, hipMemcpyHostToDevice));
+            GSLNLS_HIP_OK(hipMemcpy(d_y, y, nb, hipMemcpyHostToDevice));
+            if (swts)
+            {
+                GSLNLS_HIP_OK(hipMalloc(&d_sw, nb));
+                GSLNLS_HIP_OK(hipMemcpy(d_sw, swts, nb, hipMemcpyHostToDevice));
+            }
+        }
+        for (int c = 0; c < M::NX; ++c)
+            ctx.x[c] = d_x + (size_t)c * n;
+        ctx.y = d_y;
+        ctx.sw = d_sw;
+        ctx.n = n;
+        // one workgroup per CU at most; fewer when the problem is small (>= 2 rows per thread)
+        int G = (int)(((long long)n + 2LL * T - 1) / (2LL * T));
+        if (G < 1)
+            G = 1;
+        if (G > 256)
+            G = 256;
+        ctx.G = G;
+        GSLNLS_HIP_OK(hipMalloc(&d_partials, sizeof(double) * 2 * NV * G));
+        GSLNLS_HIP_OK(hipMemset(d_partials, 0, sizeof(double) * 2 * NV * G));
+        ctx.partials[0] = d_partials;
+        ctx.partials[1] = d_partials + (size_t)NV * G;
+        GSLNLS_HIP_OK(hipMalloc(&d_state, sizeof(LmState<P>) * 2));
+        ctx.state[0] = d_state;
+        ctx.state[1] = d_state + 1;
+        GSLNLS_HIP_OK(hipHostMalloc(&h_state, sizeof(LmState<P>) * 2));
+        GSLNLS_HIP_OK(hipMalloc(&d_covar, sizeof(double) * P * P));
+        return GSLNLS_SUCCESS;
+    }
+
+    ~DenseFit() override
+    {
+        if (owns_data)
+        {
+            hipFree(d_x);
+            hipFree(d_y);
+            hipFree(d_sw);
+        }
+        hipFree(d_partials);
+        hipFree(d_state);
+        if (h_state)
+            hipHostFree(h_state);
+        hipFree(d_ssrtrace);
+        hipFree(d_partrace);
+        hipFree(d_resid);
+        hipFree(d_grad);
+        hipFree(d_covar);
+        if (ev0)
+            hipEventDestroy(ev0);
+        if (ev1)
+            hipEventDestroy(ev1);
+        if (stream)
+            hipStreamDestroy(stream);
+    }
+
+    int set_swts(const double *swts) override
+    {
+        if (!owns_data)
+            return GSLNLS_E_UNSUPPORTED;
+        const size_t nb = sizeof(double) * (size_t)n;
+        if (!swts)
+        {
+            ctx.sw = nullptr;
+            return GSLNLS_SUCCESS;
+        }
+        if (!d_sw)
+            GSLNLS_HIP_OK(hipMalloc(&d_sw, nb));
+        GSLNLS_HIP_OK(hipMemcpy(d_sw, swts, nb, hipMemcpyHostToDevice));
+        ctx.sw = d_sw;
+        return GSLNLS_SUCCESS;
+    }
+
+    void launch_step(int jacmode, int parity)
+    {
+        const dim3 grid(ctx.G), block(T);
+        switch (jacmode)
+        {
+        case JAC_ANALYTIC:
+            hipLaunchKernelGGL((lm_step_kernel<M, JAC_ANALYTIC, T>), grid, block, 0, stream, ctx, parity);
+            break;
+        case JAC_FORWARD:
+            hipLaunchKernelGGL((lm_step_kernel<M, JAC_FORWARD, T>), grid, block, 0, stream, ctx, parity);
+            break;
+        default:
+            hipLaunchKernelGGL((lm_step_kernel<M, JAC_CENTER, T>), grid, block, 0, stream, ctx, parity);
+            break;
+        }
+    }
+
+    void launch_finalize(int jacmode, int parity, double *resid, double *grad, double *covar)
+    {
+        int Gf = (int)(((long long)n + T - 1) / T);
+        if (Gf > 2048)
+            Gf = 2048;
+        if (Gf < 1)
+            Gf = 1;
+        const dim3 grid(Gf), block(T);
+        switch (jacmode)
+        {
+        case JAC_ANALYTIC:
+            hipLaunchKernelGGL((lm_finalize_kernel<M, JAC_ANALYTIC, T>), grid, block, 0, stream, ctx, parity, resid,
+                               grad, covar);
+            break;
+        case JAC_FORWARD:
+            hipLaunchKernelGGL((lm_finalize_kernel<M, JAC_FORWARD, T>), grid, block, 0, stream, ctx, parity, resid,
+                               grad, covar);
+            break;
+        default:
+            hipLaunchKernelGGL((lm_finalize_kernel<M, JAC_CENTER, T>), grid, block, 0, stream, ctx, parity, resid,
+                               grad, covar);
+            break;
+        }
+    }
+
+    int solve(int jac, int fvv, const double *start, const double *lupars, const int *ci, const double *cd, int chunk,
+              gslnls_result *out) override
+    {
+        if (ci[2] > 1)
+            return GSLNLS_E_UNSUPPORTED; // dogleg / ddogleg / subspace2D are not lowered
+        if (fvv && !M::HAS_FVV)
+            return GSLNLS_E_UNSUPPORTED;
+        const int jacmode = jac ? JAC_ANALYTIC : (ci[5] ? JAC_CENTER : JAC_FORWARD);
+        ctx.prm = make_params(ci, cd, jac, fvv, lupars != nullptr, ctx.sw != nullptr);
+        const int maxiter = ctx.prm.maxiter;
+        const bool trace = ci[1] != 0 && out->ssrtrace && out->partrace;
+        if (trace)
+        {
+            if (trace_cap < maxiter + 1)
+            {
+                hipFree(d_ssrtrace);
+                hipFree(d_partrace);
+                GSLNLS_HIP_OK(hipMalloc(&d_ssrtrace, sizeof(double) * (maxiter + 1)));
+                GSLNLS_HIP_OK(hipMalloc(&d_partrace, sizeof(double) * (size_t)(maxiter + 1) * P));
+                trace_cap = maxiter + 1;
+            }
+            // NaN-fill so rows of iterations that never ran stay NA like the reference's allocMatrix
+            GSLNLS_HIP_OK(hipMemsetAsync(d_ssrtrace, 0xFF, sizeof(double) * (maxiter + 1), stream));
+            GSLNLS_HIP_OK(hipMemsetAsync(d_partrace, 0xFF, sizeof(double) * (size_t)(maxiter + 1) * P, stream));
+            ctx.ssrtrace = d_ssrtrace;
+            ctx.partrace = d_partrace;
+        }
+        else
+        {
+            ctx.ssrtrace = nullptr;
+            ctx.partrace = nullptr;
+        }
+
+        // brand-new state goes to slot 1; the first launch has parity 0 and reads slot 1
+        lm_state_reset<P>(h_state[0], start, lupars);
+        h_state[0].bad_steps = -1;
+        GSLNLS_HIP_OK(hipMemcpyAsync(ctx.state[1], &h_state[0], sizeof(LmState<P>), hipMemcpyHostToDevice, stream));
+
+        if (chunk <= 0)
+            chunk = 8;
+        // upper bound on launches: every iteration may take 16 trials (x2 passes with acceleration) + init
+        const long long max_launches = ((long long)maxiter * 17 + 2) * (ctx.prm.trs ? 2 : 1) + chunk;
+        long long launches = 0;
+        int parity = 0;
+        GSLNLS_HIP_OK(hipEventRecord(ev0, stream));
+        for (;;)
+        {
+            for (int k = 0; k < chunk; ++k)
+            {
+                launch_step(jacmode, parity);
+                parity ^= 1;
+            }
+            launches += chunk;
+            const int last = parity ^ 1;
+            GSLNLS_HIP_OK(hipMemcpyAsync(&h_state[1], ctx.state[last], sizeof(LmState<P>), hipMemcpyDeviceToHost,
+                                         stream));
+            GSLNLS_HIP_OK(hipStreamSynchronize(stream));
+            if (h_state[1].phase == PH_DONE)
+                break;
+            if (launches > max_launches)
+                return GSLNLS_FAILURE;
+        }
+        GSLNLS_HIP_OK(hipEventRecord(ev1, stream));
+        const int last = parity ^ 1;
+        const LmState<P> &s = h_state[1];
+        const bool ok = (s.status == ST_SUCCESS || s.status == ST_EMAXITER);
+
+        const bool want_vecs = ok && (out->resid || out->grad);
+        if (want_vecs || (ok && out->covar))
+        {
+            if (out->resid && !d_resid)
+                GSLNLS_HIP_OK(hipMalloc(&d_resid, sizeof(double) * (size_t)n));
+            if (out->grad && !d_grad)
+                GSLNLS_HIP_OK(hipMalloc(&d_grad, sizeof(double) * (size_t)n * P));
+            launch_finalize(jacmode, last, out->resid ? d_resid : nullptr, out->grad ? d_grad : nullptr, d_covar);
+            if (out->resid)
+                GSLNLS_HIP_OK(hipMemcpyAsync(out->resid, d_resid, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost,
+                                             stream));
+            if (out->grad)
+                GSLNLS_HIP_OK(hipMemcpyAsync(out->grad, d_grad, sizeof(double) * (size_t)n * P,
+                                             hipMemcpyDeviceToHost, stream));
+            if (out->covar)
+                GSLNLS_HIP_OK(hipMemcpyAsync(out->covar, d_covar, sizeof(double) * P * P, hipMemcpyDeviceToHost,
+                                             stream));
+        }
+        if (trace)
+        {
+            GSLNLS_HIP_OK(hipMemcpyAsync(out->ssrtrace, d_ssrtrace, sizeof(double) * (maxiter + 1),
+                                         hipMemcpyDeviceToHost, stream));
+            GSLNLS_HIP_OK(hipMemcpyAsync(out->partrace, d_partrace, sizeof(double) * (size_t)(maxiter + 1) * P,
+                                         hipMemcpyDeviceToHost, stream));
+        }
+        GSLNLS_HIP_OK(hipStreamSynchronize(stream));
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, ev0, ev1);
+
+        // pack like src/nls.c:648-753
+        for (int k = 0; k < P; ++k)
+            if (out->par)
+                out->par[k] = ok ? s.x[k] : start[k];
+        if (!ok)
+        {
+            if (out->covar)
+                for (int k = 0; k < P * P; ++k)
+                    out->covar[k] = NAN;
+            if (out->resid)
+                for (int i = 0; i < n; ++i)
+                    out->resid[i] = NAN;
+            if (out->grad)
+                for (size_t i = 0; i < (size_t)n * P; ++i)
+                    out->grad[i] = NAN;
+        }
+        out->niter = s.niter;
+        out->conv = s.status;
+        out->info = s.info;
+        out->ssr = s.chisq1;
+        out->ssrtol = s.chisq0 - s.chisq1;
+        out->neval[0] = s.nevalf;
+        out->neval[1] = s.nevaldf;
+        out->neval[2] = s.nevalfvv;
+        out->chisq_init = s.chisq_init;
+        out->loop_ms = ms;
+        out->n_launches = (int)launches;
+        return s.status;
+    }
+
+    float time_pass(int jac, const double *theta, int reps) override
+    {
+        // a state parked in PH_TRIAL at theta with huge mu: every launch performs the full
+        // prologue + pass (the trial is rejected or accepted on device like any other)
+        const int jacmode = jac ? JAC_ANALYTIC : JAC_FORWARD;
+        int ci[15] = {1 << 30, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0};
+        double cd[11] = {2, 3, 0.75, 1.4901161193847656e-08, 0.02, 1e-300, 1e-300, 0.0, 0, 0, 0};
+        ctx.prm = make_params(ci, cd, jac, 0, false, ctx.sw != nullptr);
+        ctx.ssrtrace = nullptr;
+        ctx.partrace = nullptr;
+        lm_state_reset<P>(h_state[0], theta, nullptr);
+        h_state[0].bad_steps = -1;
+        if (hipMemcpyAsync(ctx.state[1], &h_state[0], sizeof(LmState<P>), hipMemcpyHostToDevice, stream) != hipSuccess)
+            return -1.f;
+        int parity = 0;
+        for (int k = 0; k < 4; ++k)
+        {
+            launch_step(jacmode, parity);
+            parity ^= 1;
+        }
+        hipEventRecord(ev0, stream);
+        for (int k = 0; k < reps; ++k)
+        {
+            launch_step(jacmode, parity);
+            parity ^= 1;
+        }
+        hipEventRecord(ev1, stream);
+        if (hipStreamSynchronize(stream) != hipSuccess)
+            return -1.f;
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, ev0, ev1);
+        return ms / (float)reps;
+    }
+};
+
+} // namespace gslnls

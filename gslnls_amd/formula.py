@@ -1,0 +1,240 @@
+"""R model-formula front end: parse `y ~ expr`, recognise registered device models.
+
+The reference builds the model closure from the formula's right-hand side,
+`.fn <- function(par, .data) eval(formula[[3]], c(as.list(par), .data))`
+(R/nls.R:565), and a Jacobian closure with stats::deriv (R/nls.R:588-599).  A GPU
+cannot evaluate R closures, so this module is the "model lowering" step of the
+drop-in boundary: the RHS is parsed into a small AST and matched
+structurally (up to renaming of parameters / data columns) against the formulas of the
+device row-model registry (gslnls_amd/csrc/models.hpp).
+
+The AST also evaluates with numpy, which the tests use to hand the *oracle* the very
+same model as Python callbacks.
+"""
+import math
+import re
+
+import numpy as np
+
+_TOKEN = re.compile(r"\s*(?:(\d+\.?\d*(?:[eE][-+]?\d+)?|\.\d+(?:[eE][-+]?\d+)?)|([A-Za-z_.][A-Za-z_.0-9]*)|(\*\*|[-+*/^()~,]))")
+
+FUNCS = {"exp": np.exp, "log": np.log, "sin": np.sin, "cos": np.cos, "tan": np.tan, "atan": np.arctan,
+         "sqrt": np.sqrt, "abs": np.abs, "tanh": np.tanh}
+CONSTS = {"pi": math.pi}
+
+
+class Node:
+    __slots__ = ("op", "args", "val")
+
+    def __init__(self, op, args=(), val=None):
+        self.op, self.args, self.val = op, tuple(args), val
+
+    def __repr__(self):
+        if self.op == "num":
+            return repr(self.val)
+        if self.op == "sym":
+            return self.val
+        if self.op == "call":
+            return "%s(%s)" % (self.val, ", ".join(map(repr, self.args)))
+        if self.op == "neg":
+            return "(-%r)" % (self.args[0],)
+        return "(%r %s %r)" % (self.args[0], self.op, self.args[1])
+
+
+def _tokenize(s):
+    pos, out = 0, []
+    s = s.strip()
+    while pos < len(s):
+        m = _TOKEN.match(s, pos)
+        if not m:
+            raise ValueError("cannot tokenize formula at %r" % s[pos:pos + 10])
+        num, sym, op = m.groups()
+        if num is not None:
+            out.append(("num", float(num)))
+        elif sym is not None:
+            out.append(("sym", sym))
+        else:
+            out.append(("op", "^" if op == "**" else op))
+        pos = m.end()
+    return out
+
+
+class _Parser:
+    # R precedence: ^ (right assoc) > unary minus > * / > + -
+    def __init__(self, toks):
+        self.t, self.i = toks, 0
+
+    def peek(self):
+        return self.t[self.i] if self.i < len(self.t) else (None, None)
+
+    def take(self):
+        tok = self.peek()
+        self.i += 1
+        return tok
+
+    def expr(self):
+        node = self.term()
+        while self.peek() in (("op", "+"), ("op", "-")):
+            op = self.take()[1]
+            node = Node(op, (node, self.term()))
+        return node
+
+    def term(self):
+        node = self.unary()
+        while self.peek() in (("op", "*"), ("op", "/")):
+            op = self.take()[1]
+            node = Node(op, (node, self.unary()))
+        return node
+
+    def unary(self):
+        if self.peek() == ("op", "-"):
+            self.take()
+            return Node("neg", (self.unary(),))
+        if self.peek() == ("op", "+"):
+            self.take()
+            return self.unary()
+        return self.power()
+
+    def power(self):
+        base = self.atom()
+        if self.peek() == ("op", "^"):
+            self.take()
+            # exponent binds a following unary minus: x^-2
+            return Node("^", (base, self.unary_pow()))
+        return base
+
+    def unary_pow(self):
+        if self.peek() == ("op", "-"):
+            self.take()
+            return Node("neg", (self.unary_pow(),))
+        return self.power()
+
+    def atom(self):
+        kind, v = self.take()
+        if kind == "num":
+            return Node("num", val=v)
+        if kind == "sym":
+            if self.peek() == ("op", "("):
+                self.take()
+                args = []
+                if self.peek() != ("op", ")"):
+                    args.append(self.expr())
+                    while self.peek() == ("op", ","):
+                        self.take()
+                        args.append(self.expr())
+                if self.take() != ("op", ")"):
+                    raise ValueError("expected )")
+                return Node("call", args, v)
+            return Node("sym", val=v)
+        if (kind, v) == ("op", "("):
+            node = self.expr()
+            if self.take() != ("op", ")"):
+                raise ValueError("expected )")
+            return node
+        raise ValueError("unexpected token %r" % (v,))
+
+
+def parse_expr(s):
+    p = _Parser(_tokenize(s))
+    node = p.expr()
+    if p.i != len(p.t):
+        raise ValueError("trailing tokens in %r" % s)
+    return node
+
+
+def parse_formula(s):
+    """'lhs ~ rhs' -> (lhs_node or None, rhs_node)"""
+    if "~" not in s:
+        raise ValueError("formula needs '~'")
+    lhs, rhs = s.split("~", 1)
+    lhs = lhs.strip()
+    return (parse_expr(lhs) if lhs else None), parse_expr(rhs)
+
+
+def symbols(node, acc=None):
+    acc = [] if acc is None else acc
+    if node.op == "sym":
+        if node.val not in acc and node.val not in CONSTS:
+            acc.append(node.val)
+    for a in node.args:
+        symbols(a, acc)
+    return acc
+
+
+def evaluate(node, env):
+    op = node.op
+    if op == "num":
+        return node.val
+    if op == "sym":
+        if node.val in env:
+            return env[node.val]
+        if node.val in CONSTS:
+            return CONSTS[node.val]
+        raise KeyError(node.val)
+    if op == "neg":
+        return -evaluate(node.args[0], env)
+    if op == "call":
+        return FUNCS[node.val](*[evaluate(a, env) for a in node.args])
+    a, b = evaluate(node.args[0], env), evaluate(node.args[1], env)
+    if op == "+":
+        return a + b
+    if op == "-":
+        return a - b
+    if op == "*":
+        return a * b
+    if op == "/":
+        return a / b
+    if op == "^":
+        return np.power(a, b)
+    raise ValueError(op)
+
+
+def _match(t, u, pmap, dmap, tparams, uparams):
+    """structural match of template t against user AST u with consistent symbol renaming"""
+    if t.op != u.op or len(t.args) != len(u.args):
+        return False
+    if t.op == "num":
+        return t.val == u.val
+    if t.op == "sym":
+        t_is_par, u_is_par = t.val in tparams, u.val in uparams
+        if t_is_par != u_is_par:
+            return False
+        m = pmap if t_is_par else dmap
+        if t.val in m:
+            return m[t.val] == u.val
+        if u.val in m.values():
+            return False
+        m[t.val] = u.val
+        return True
+    if t.op == "call" and t.val != u.val:
+        return False
+    return all(_match(a, b, pmap, dmap, tparams, uparams) for a, b in zip(t.args, u.args))
+
+
+# registry: id -> (template formula RHS, parameter names in device order, regressor names)
+REGISTRY = {
+    1: ("A*exp(-lam*x)+b", ("A", "lam", "b"), ("x",)),
+    2: ("b1*(1-exp(-b2*x))", ("b1", "b2"), ("x",)),
+    3: ("a*exp(-(x-b)^2/(2*c^2))", ("a", "b", "c"), ("x",)),
+    4: ("b1*exp(-b2*x) + b3*exp(-(x-b4)^2/b5^2) + b6*exp(-(x-b7)^2/b8^2)",
+        ("b1", "b2", "b3", "b4", "b5", "b6", "b7", "b8"), ("x",)),
+}
+
+
+def lower(rhs, param_names):
+    """Find the registered device model for AST `rhs`.
+
+    Returns (model_id, order, xnames): order[k] = index into param_names of the k-th device
+    parameter, xnames = data column names in device order.  None when nothing matches.
+    """
+    uparams = set(param_names)
+    for mid, (tmpl, tpar, tx) in REGISTRY.items():
+        if len(tpar) != len(param_names):
+            continue
+        pmap, dmap = {}, {}
+        if _match(parse_expr(tmpl), rhs, pmap, dmap, set(tpar), uparams):
+            if len(pmap) != len(tpar):
+                continue
+            order = [list(param_names).index(pmap[t]) for t in tpar]
+            return mid, order, [dmap[t] for t in tx]
+    return None

@@ -1,0 +1,278 @@
+"""gsl_nls(): host-side mirror of the reference's R entry point (R/nls.R:306-1083).
+
+It does what gsl_nls.formula does before and after `.Call(C_nls, ...)`:
+normalise start values / ranges (R/nls.R:399-437), bounds (:539-559) and weights
+(:489-495), pack the control vectors (:693-713), call the C ABI, and wrap the returned
+list (:723-762).  The call itself goes to libgslnls_hip.so -- the numeric work runs on
+the MI355X; nothing here computes any part of the fit.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from . import formula as F
+from .control import ALGORITHMS, LOSSES, gsl_nls_control, gsl_nls_loss, pack_control
+
+DP = _lib.DP
+IP = _lib.IP
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(DP)
+
+
+class GslNlsFit(dict):
+    """The list C_nls returns (src/nls.c:636-645) plus the few accessors the reference's
+    tests use (coef, deviance, sigma, df.residual; R/nls_methods.R)."""
+
+    def coef(self):
+        return dict(zip(self["parnames"], self["par"]))
+
+    def deviance(self):
+        return float(self["ssr"])
+
+    def df_residual(self):
+        return int(self["n"] - len(self["par"]))
+
+    def sigma(self):
+        return math.sqrt(self.deviance() / self.df_residual())
+
+    def vcov(self):
+        return self.sigma() ** 2 * np.asarray(self["covar"])
+
+    @property
+    def isConv(self):
+        return self["conv"] == 0
+
+
+def _normalise_start(start, parnames_hint=None):
+    """R/nls.R:399-437: vector / list of scalars -> single start; list with length-2 entries or
+    2 x p matrix -> multi-start ranges with has_start; NA/inf -> (-0.1, 0.75)."""
+    if isinstance(start, dict):
+        names = list(start.keys())
+        vals = [np.atleast_1d(np.asarray(v, dtype=np.float64)) for v in start.values()]
+        if any(len(v) > 1 for v in vals):
+            if not all(len(v) in (1, 2) for v in vals):
+                raise ValueError("List elements of 'start' must be of length 1 or 2 to specify (multi-start) "
+                                 "parameter values or ranges")
+            mat = np.stack([np.repeat(v, 2) if len(v) == 1 else v for v in vals], axis=1)  # 2 x p
+        else:
+            vec = np.array([v[0] for v in vals])
+            mat = None
+    else:
+        arr = np.asarray(start, dtype=np.float64)
+        names = list(parnames_hint) if parnames_hint is not None else ["par%d" % (i + 1) for i in range(arr.shape[-1])]
+        if arr.ndim == 2:
+            if arr.shape[0] != 2:
+                raise ValueError("Matrix 'start' must have exactly 2 rows to specify (multi-start) parameter ranges")
+            mat, vec = arr.copy(), None
+        else:
+            mat, vec = None, arr.copy()
+    has_start = None
+    if mat is None:
+        na = ~np.isfinite(vec)
+        if na.any():
+            mat = np.stack([np.where(na, -0.1, vec), np.where(na, 0.75, vec)], axis=0)
+            has_start = np.stack([~na, ~na], axis=0)
+    else:
+        na = ~np.isfinite(mat)
+        mat[0, na[0]] = -0.1
+        mat[1, na[1]] = 0.75
+        has_start = ~na
+    if mat is not None:
+        if np.any(mat[0] > mat[1]):
+            raise ValueError("Multi-start parameter lower bounds cannot be larger than upper bounds")
+        if not np.any(mat[0] < mat[1]):
+            vec, mat = mat[0].copy(), None  # degenerate ranges: single start
+    return names, vec, mat, has_start
+
+
+def _bounds(lower, upper, names):
+    """R/nls.R:539-559 -> 2 x p column-major [lower, upper] pairs, or None"""
+    if lower is None and upper is None:
+        return None
+    p = len(names)
+
+    def expand(b, fill):
+        if b is None:
+            return np.full(p, fill)
+        if isinstance(b, dict):
+            out = np.full(p, fill)
+            for k, v in b.items():
+                out[names.index(k)] = v
+            return out
+        b = np.atleast_1d(np.asarray(b, dtype=np.float64))
+        return np.full(p, b[0]) if b.size == 1 else b
+    lo, up = expand(lower, -np.inf), expand(upper, np.inf)
+    return np.ascontiguousarray(np.stack([lo, up], axis=1).reshape(-1))
+
+
+class DenseProblem:
+    """A model + data resident in HBM (gslnls_dense_create): upload once, solve many times."""
+
+    def __init__(self, model_id, p, x, y, weights=None):
+        L = _lib.lib()
+        x = np.asarray(x, dtype=np.float64)
+        self.n = int(np.asarray(y).shape[0])
+        self._x = np.asfortranarray(x.reshape(self.n, -1))
+        self._y = np.ascontiguousarray(y, dtype=np.float64)
+        self._sw = None if weights is None else np.ascontiguousarray(np.sqrt(np.asarray(weights, dtype=np.float64)))
+        self.p, self.model_id = int(p), int(model_id)
+        m = _lib.Model(self.model_id, self.p, self._x.shape[1], self._x.ctypes.data_as(C.c_void_p), 0)
+        err = C.c_int(0)
+        self._h = L.gslnls_dense_create(C.byref(m), self._y.ctypes.data_as(C.c_void_p), self.n,
+                                        None if self._sw is None else self._sw.ctypes.data_as(C.c_void_p),
+                                        C.byref(err))
+        if not self._h:
+            _lib.check(err.value)
+            raise RuntimeError("gslnls_dense_create failed: %s" % _lib.strerror(err.value))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().gslnls_dense_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa
+            pass
+
+    def solve(self, start, jac=False, fvv=False, algorithm="lm", control=None, trace=False, lupars=None,
+              want_vectors=True, chunk=0):
+        L = _lib.lib()
+        ctrl = control or gsl_nls_control()
+        ci, cd = pack_control(ctrl, algorithm, trace)
+        p, n = self.p, self.n
+        st = np.ascontiguousarray(start, dtype=np.float64)
+        out = dict(par=np.zeros(p), covar=np.zeros((p, p), order="F"))
+        res = _lib.Result()
+        res.par, res.covar = _dp(out["par"]), _dp(out["covar"])
+        if want_vectors:
+            out["resid"] = np.zeros(n)
+            out["grad"] = np.zeros((n, p), order="F")
+            res.resid, res.grad = _dp(out["resid"]), _dp(out["grad"])
+        if trace:
+            out["partrace"] = np.full((ctrl["maxiter"] + 1, p), np.nan, order="F")
+            out["ssrtrace"] = np.full(ctrl["maxiter"] + 1, np.nan)
+            res.partrace, res.ssrtrace = _dp(out["partrace"]), _dp(out["ssrtrace"])
+        rc = L.gslnls_dense_solve(self._h, int(bool(jac)), int(bool(fvv)), _dp(st), _dp(lupars),
+                                  ci.ctypes.data_as(IP), _dp(cd), int(chunk), C.byref(res))
+        _lib.check(rc)
+        return _finish(out, res, trace, algorithm, n)
+
+    def time_pass(self, theta, jac=True, reps=200):
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        return float(_lib.lib().gslnls_dense_time_pass(self._h, int(bool(jac)), _dp(th), int(reps)))
+
+
+def _finish(out, res, trace, algorithm, n):
+    out.update(niter=res.niter, conv=res.conv, status=_lib.strerror(res.conv), ssr=res.ssr, ssrtol=res.ssrtol,
+               algorithm=_lib.lib().gslnls_algorithm_name(ALGORITHMS.index(algorithm)).decode(),
+               neval=dict(f=res.neval[0], J=res.neval[1], fvv=res.neval[2]), info=res.info,
+               chisq_init=res.chisq_init, loop_ms=res.loop_ms, n_launches=res.n_launches, n=n,
+               irls=dict(irls_sigma=res.irls_sigma, irls_tol=res.irls_tol, irls_status=res.irls_status,
+                         irls_niter=res.irls_niter, irls_conv=res.irls_status),
+               mstart=dict(nsp=res.mstart_nsp, nwsp=res.mstart_nwsp, iters=res.mstart_iters,
+                           stop=res.mstart_stop, ssropt=res.mstart_ssropt))
+    if trace:
+        out["partrace"] = out["partrace"][:res.niter + 1]
+        out["ssrtrace"] = out["ssrtrace"][:res.niter + 1]
+    return GslNlsFit(out)
+
+
+def gsl_nls(fn, data=None, start=None, algorithm="lm", control=None, jac=None, fvv=None, trace=False,
+            weights=None, lower=None, upper=None, loss="default", y=None):
+    """gsl_nls(fn = y ~ f(x, theta), data, start, ...) -- same arguments as R/nls.R:306-316.
+
+    fn      : model formula string 'y ~ rhs' whose RHS must lower to a registered device model
+              (gslnls_amd/formula.py), or an int registry id together with data = {'x': ..., 'y': ...}
+    jac/fvv : True -> analytic derivatives on device (R: symbolic stats::deriv), None/False -> FD
+    """
+    if start is None:
+        raise ValueError("starting values 'start' are required")
+    _ = ALGORITHMS.index(algorithm) if algorithm in ALGORITHMS else (_ for _ in ()).throw(
+        ValueError("'algorithm' should be one of %s" % ", ".join(ALGORITHMS)))
+    ctrl = control if (control is not None and "irls_xtol" in control) else gsl_nls_control(**(control or {}))
+    loss_cfg = gsl_nls_loss(loss) if isinstance(loss, str) else gsl_nls_loss(**loss)
+    names, vec, mat, has_start = _normalise_start(start)
+    p = len(names)
+
+    if isinstance(fn, str):
+        lhs, rhs = F.parse_formula(fn)
+        if lhs is None:
+            raise ValueError("formula needs a left-hand side")
+        low = F.lower(rhs, names)
+        if low is None:
+            raise NotImplementedError("formula RHS does not match a registered device model: %s" % fn)
+        mid, order, xnames = low
+        yv = np.asarray(F.evaluate(lhs, {k: np.asarray(v, dtype=np.float64) for k, v in data.items()}),
+                        dtype=np.float64)
+        X = np.stack([np.asarray(data[c], dtype=np.float64) for c in xnames], axis=1)
+    else:
+        mid, order = int(fn), list(range(p))
+        yv = np.asarray(data["y"] if y is None else y, dtype=np.float64)
+        X = np.asarray(data["x"], dtype=np.float64).reshape(len(yv), -1)
+    n = len(yv)
+    if X.shape[0] != n:
+        raise ValueError("data columns differ in length")
+    order = np.asarray(order)
+    inv = np.argsort(order)
+
+    sw = None
+    sw_is_matrix = 0
+    if weights is not None:
+        w = np.asarray(weights, dtype=np.float64)
+        if w.ndim == 2:
+            sw = np.asfortranarray(np.linalg.cholesky(w))  # t(chol(W)), R/nls.R:489-495
+            sw_is_matrix = 1
+        else:
+            if len(w) != n or np.any(~(w > 0)):
+                raise ValueError("missing or non-positive weights not allowed")
+            sw = np.ascontiguousarray(np.sqrt(w))
+    lu = _bounds(lower, upper, names)
+    if lu is not None:
+        lu = np.ascontiguousarray(lu.reshape(p, 2)[order].reshape(-1))
+
+    any_missing = bool(has_start is not None and not np.all(has_start))
+    ci, cd = pack_control(ctrl, algorithm, trace, True, any_missing)
+    if mat is not None:
+        st = np.ascontiguousarray(mat[:, order].T.reshape(-1))
+        hs = np.ascontiguousarray(has_start[:, order].T.reshape(-1).astype(np.int32))
+    else:
+        st = np.ascontiguousarray(vec[order])
+        hs = np.ones(2 * p, dtype=np.int32)
+    cc = np.asarray(list(loss_cfg["cc"].values()) or [0.0], dtype=np.float64)
+
+    Xf = np.asfortranarray(X)
+    yc = np.ascontiguousarray(yv)
+    m = _lib.Model(mid, p, Xf.shape[1], Xf.ctypes.data_as(C.c_void_p), 0)
+    out = dict(par=np.zeros(p), covar=np.zeros((p, p), order="F"), resid=np.zeros(n),
+               grad=np.zeros((n, p), order="F"))
+    res = _lib.Result()
+    res.par, res.covar, res.resid, res.grad = _dp(out["par"]), _dp(out["covar"]), _dp(out["resid"]), _dp(out["grad"])
+    if loss_cfg["rho"] != "default":
+        for k in ("irls_weights", "irls_psi", "irls_dpsi"):
+            out[k] = np.zeros(n)
+            setattr(res, k, _dp(out[k]))
+    if trace:
+        out["partrace"] = np.full((ctrl["maxiter"] + 1, p), np.nan, order="F")
+        out["ssrtrace"] = np.full(ctrl["maxiter"] + 1, np.nan)
+        res.partrace, res.ssrtrace = _dp(out["partrace"]), _dp(out["ssrtrace"])
+    rc = _lib.lib().gslnls_nls(C.byref(m), yc.ctypes.data_as(C.c_void_p), n, int(bool(jac)), int(bool(fvv)),
+                               _dp(st), int(mat is not None), None if sw is None else sw.ctypes.data_as(C.c_void_p),
+                               sw_is_matrix, _dp(lu), ci.ctypes.data_as(IP), _dp(cd), hs.ctypes.data_as(IP),
+                               LOSSES.index(loss_cfg["rho"]), _dp(cc), C.byref(res))
+    _lib.check(rc)
+    fit = _finish(out, res, trace, algorithm, n)
+    # back to the caller's parameter order
+    fit["par"] = fit["par"][inv]
+    fit["covar"] = np.asarray(fit["covar"])[np.ix_(inv, inv)]
+    fit["grad"] = np.asarray(fit["grad"])[:, inv]
+    if trace:
+        fit["partrace"] = fit["partrace"][:, inv]
+    fit["parnames"] = names
+    fit["weights"] = weights
+    return fit

@@ -1,0 +1,131 @@
+/*
+ * gslnls_core.h -- C ABI of the MI355X-native nonlinear least-squares core
+ * (libgslnls_hip.so).  Plain pointers and sizes only; no R, GSL or torch types.
+ *
+ * This is the drop-in boundary for the reference's .Call entries
+ *     C_nls        src/init.c:15, src/nls.c:54   (12 SEXP arguments)
+ *     C_nls_large  src/init.c:16, src/nls_large.c:66
+ * An R-side shim (integration/r_shim/) unpacks the SEXPs exactly
+ * as src/nls.c:76-263 does and calls gslnls_nls(); the list it returns is filled
+ * from gslnls_result in the order of src/nls.c:636-645.
+ *
+ * The one thing that cannot cross unchanged is the model: the reference evaluates
+ * R closures fn/jac/fvv with Rf_eval (src/nls.c:836-837,:885-886,:946-948).  Here
+ * `fn` becomes a gslnls_model: a registry id of a device row model plus the data
+ * columns the closure's environment held (R/nls.R:565).  jac / fvv become flags
+ * ("analytic available and requested" vs "finite differences").
+ *
+ * All numerics are IEEE fp64.  Matrices follow R's layout (column-major) wherever
+ * the reference hands R matrices across the boundary.
+ */
+#ifndef GSLNLS_CORE_H
+#define GSLNLS_CORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* device row models (gslnls_amd/csrc/models.hpp) */
+#define GSLNLS_MODEL_EXPDECAY 1 /* A*exp(-lam*x)+b           p=3  R/nls.R:143-151 */
+#define GSLNLS_MODEL_MISRA1A 2  /* b1*(1-exp(-b2*x))         p=2  R/nls_test.R:174,:793 */
+#define GSLNLS_MODEL_GAUSSPK 3  /* a*exp(-(x-b)^2/(2c^2))    p=3  README.md:545 */
+#define GSLNLS_MODEL_GAUSS1 4   /* NIST Gauss1 family        p=8  R/nls_test.R:301 */
+
+/* status codes placed in `conv` (GSL errno values) */
+#define GSLNLS_SUCCESS 0
+#define GSLNLS_FAILURE (-1)
+#define GSLNLS_CONTINUE (-2)
+#define GSLNLS_EINVAL 4
+#define GSLNLS_EBADFUNC 9
+#define GSLNLS_EMAXITER 11
+#define GSLNLS_ENOPROG 27
+/* library-level errors (never produced by the reference): returned by the entry
+ * points themselves, never stored in `conv` */
+#define GSLNLS_E_NODEVICE (-100)   /* no HIP device / HIP runtime failure: the path fails loudly */
+#define GSLNLS_E_UNSUPPORTED (-101) /* combination not lowered to the device (e.g. GLS weight matrix) */
+
+typedef struct gslnls_model
+{
+    int id;           /* GSLNLS_MODEL_* */
+    int p;            /* number of parameters (must match the model) */
+    int nx;           /* number of regressor columns */
+    const double *x;  /* n x nx, column-major; host memory unless x_on_device */
+    int x_on_device;  /* x, y and swts are device pointers already resident in HBM */
+} gslnls_model;
+
+/* mirrors the VECSXP C_nls returns (src/nls.c:632-812).  Pointers may be NULL to skip. */
+typedef struct gslnls_result
+{
+    double *par;      /* [p]   estimated parameters (start values on failure) */
+    double *covar;    /* [p*p] column-major (J^T J)^-1 ; NaN on failure */
+    double *resid;    /* [n]   weighted residuals sqrt(w)(f - y) */
+    double *grad;     /* [n*p] column-major weighted Jacobian (src/nls.c:718) */
+    int niter;
+    int conv;         /* status code */
+    double ssr;       /* chisq1 */
+    double ssrtol;    /* chisq0 - chisq1 */
+    int neval[3];     /* f, J, fvv with the reference's accounting (App. A.8) */
+    int info;
+    double chisq_init;
+    /* irls slot (src/nls.c:756-791); arrays [n] or NULL */
+    double *irls_weights, *irls_psi, *irls_dpsi;
+    double irls_sigma, irls_tol;
+    int irls_status, irls_niter;
+    /* traces when control_int[1] != 0: (maxiter+1) x p column-major, and maxiter+1 */
+    double *partrace, *ssrtrace;
+    /* multi-start bookkeeping (not part of the R list; exposed for tests) */
+    int mstart_nsp, mstart_nwsp, mstart_iters, mstart_stop;
+    double mstart_ssropt;
+    /* device-side timing of the solve loop, milliseconds (HIP events on the library's stream) */
+    float loop_ms;
+    int n_launches;   /* step-kernel launches issued for this call */
+} gslnls_result;
+
+/*
+ * gslnls_nls -- replaces C_nls (src/nls.c:54-813).
+ *   fn, y, n       : model + response (R: fn, y, env)
+ *   jac, fvv       : 1 = analytic derivative requested (R: !is.null(jac) / !is.null(fvv))
+ *   start          : p values, or 2 x p column-major [lower, upper] ranges when start_is_matrix
+ *   swts           : sqrt(weights) [n] or NULL;  swts_is_matrix = 1 (n x n t(chol(W))) is refused
+ *                    with GSLNLS_E_UNSUPPORTED (GLS needs an n x n matrix)
+ *   lupars         : 2 x p column-major [lower, upper] with +-Inf, or NULL (src/nls.c:248-263)
+ *   control_int    : 15 ints  (R/nls.R:693-709)
+ *   control_dbl    : 11 doubles (R/nls.R:710-713, App. C.2)
+ *   has_start      : 2 x p logical, multi-start only (src/nls.c:307)
+ *   loss_rho, loss_cc : loss_config (R/nls.R:663)
+ * Returns the solver status (== out->conv) or a GSLNLS_E_* library error.
+ */
+int gslnls_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv, const double *start,
+               int start_is_matrix, const double *swts, int swts_is_matrix, const double *lupars,
+               const int *control_int, const double *control_dbl, const int *has_start, int loss_rho,
+               const double *loss_cc, gslnls_result *out);
+
+/* ---- resident-data API: the same solve with the data already in HBM -------------------
+ * (what bench.py times: H2D once at create, then repeated solves) */
+typedef struct gslnls_dense gslnls_dense;
+
+gslnls_dense *gslnls_dense_create(const gslnls_model *fn, const double *y, int n, const double *swts,
+                                  int *err);
+void gslnls_dense_destroy(gslnls_dense *h);
+/* single-start solve (default loss) on resident data; chunk = step launches per host check (0 = default) */
+int gslnls_dense_solve(gslnls_dense *h, int jac, int fvv, const double *start, const double *lupars,
+                       const int *control_int, const double *control_dbl, int chunk, gslnls_result *out);
+/* time `reps` back-to-back launches of the pass kernel at `theta` with HIP events on the
+ * library's stream; returns average milliseconds per launch (negative on error) */
+float gslnls_dense_time_pass(gslnls_dense *h, int jac, const double *theta, int reps);
+/* swap the weights of a resident problem (IRLS) */
+int gslnls_dense_set_swts(gslnls_dense *h, const double *swts);
+
+/* ---- introspection ---------------------------------------------------------------------- */
+const char *gslnls_strerror(int code);     /* gsl_strerror strings, App. C.4 */
+const char *gslnls_algorithm_name(int trs); /* gsl_multifit_nlinear_trs_name */
+int gslnls_device_count(void);
+const char *gslnls_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,55 @@
+"""ctypes wrapper of tests/hostsim/_hostsim.so: the device headers compiled for the host (test-only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+DP = C.POINTER(C.c_double)
+IP = C.POINTER(C.c_int)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "hostsim")])
+        _LIB = C.CDLL(os.path.join(_HERE, "hostsim", "_hostsim.so"))
+    return _LIB
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(DP)
+
+
+def fit(model, p, x, y, start, ci, cd, jac=1, fvv=0, sw=None, lupars=None):
+    n = len(y)
+    x = np.asfortranarray(np.asarray(x, dtype=np.float64).reshape(n, -1))
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    st = np.ascontiguousarray(start, dtype=np.float64)
+    par = np.zeros(p)
+    ints = np.zeros(8, dtype=np.int32)
+    dbls = np.zeros(8)
+    cov = np.zeros((p, p), order="F")
+    mi = int(ci[0])
+    sst = np.full(mi + 1, np.nan)
+    pt = np.full((mi + 1, p), np.nan, order="F")
+    ci = np.ascontiguousarray(ci, dtype=np.int32)
+    cd = np.ascontiguousarray(cd, dtype=np.float64)
+    lib().hostsim_fit(int(model), n, _dp(x), _dp(y), _dp(sw), _dp(st), _dp(lupars), ci.ctypes.data_as(IP), _dp(cd),
+                      int(jac), int(fvv), _dp(par), ints.ctypes.data_as(IP), _dp(dbls), _dp(cov), _dp(sst), _dp(pt))
+    k = int(ints[0])
+    return dict(par=par, niter=k, conv=int(ints[1]), info=int(ints[2]),
+                neval=dict(f=int(ints[3]), J=int(ints[4]), fvv=int(ints[5])), launches=int(ints[6]), ssr=dbls[0],
+                ssrtol=dbls[1], chisq_init=dbls[2], mu=dbls[3], delta=dbls[4], det=dbls[5], covar=cov,
+                ssrtrace=sst[:k + 1], partrace=pt[:k + 1])
+
+
+def lm_solve(p, A_packed, diag, mu, rhs):
+    sol = np.zeros(p)
+    f = {3: lib().hostsim_lm_solve3, 8: lib().hostsim_lm_solve8}[p]
+    f.argtypes = [DP, DP, C.c_double, DP, DP]
+    f(_dp(np.ascontiguousarray(A_packed, dtype=np.float64)), _dp(np.ascontiguousarray(diag, dtype=np.float64)),
+      float(mu), _dp(np.ascontiguousarray(rhs, dtype=np.float64)), _dp(sol))
+    return sol

@@ -1,0 +1,160 @@
+"""GPU parity tests of the grid-per-fit LM path, through the C ABI (libgslnls_hip.so).
+
+Bar: converged coefficients within 1e-8 relative of the oracle with the same
+solver; identical iteration counts on regular starts; README / NIST golden values at the
+reference's own tolerance eps^0.25 (unit_tests_gslnls.R:10).  At BASELINE's full size
+(n = 1e6) the checks are size-independent properties: stationarity J^T r ~ 0, run-to-run
+bit-identical results, agreement between analytic and FD Jacobians.
+"""
+import numpy as np
+import pytest
+
+from conftest import c2_data
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-8
+TOL = float(np.finfo(float).eps ** 0.25)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import gslnls_amd
+    from gslnls_amd import _lib
+    assert _lib.lib().gslnls_device_count() >= 1, "no MI355X visible: the HIP path cannot be tested"
+    return gslnls_amd
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b)) / np.maximum(np.abs(np.asarray(b)), 1e-300)))
+
+
+@pytest.mark.parametrize("n", [1000, 65537, 300000])
+@pytest.mark.parametrize("jac", [True, False])
+def test_c2_matches_oracle(amd, gslref, n, jac):
+    """C2 model and generator at sizes the oracle finishes in seconds (ragged n included)"""
+    x, y = c2_data(n)
+    ctrl = amd.gsl_nls_control(solver="cholesky")
+    prob = amd.DenseProblem(1, 3, x, y)
+    fit = prob.solve([1.0, 1.0, 0.0], jac=jac, control=ctrl, trace=True)
+    prob.close()
+    ref = gslref.nls(n, 3, [1.0, 1.0, 0.0], rowdata=dict(model=gslref.MODEL_EXPDECAY, x=x, y=y), use_jac=jac,
+                     ctrl=gslref.control(solver="cholesky"), trace=True)
+    assert fit["conv"] == 0 and ref["conv"] == 0
+    assert fit["niter"] == ref["niter"]
+    assert _rel(fit["par"], ref["par"]) < REL
+    assert abs(fit["ssr"] - ref["ssr"]) <= 1e-10 * ref["ssr"]
+    assert fit["neval"]["J"] == ref["neval"]["J"]
+    assert abs(fit["neval"]["f"] - ref["neval"]["f"]) <= 4
+    assert np.allclose(fit["partrace"], ref["partrace"], rtol=1e-6 if not jac else 1e-9)
+    assert np.allclose(fit["covar"], ref["covar"], rtol=1e-7)
+    assert np.allclose(fit["resid"], ref["resid"], rtol=0, atol=1e-9)
+    assert np.allclose(fit["grad"], ref["grad"], rtol=1e-6 if not jac else 1e-9, atol=1e-9)
+
+
+def test_c2_full_size_properties(amd):
+    """n = 1e6, p = 3 (BASELINE configs[1]): properties that need no CPU reference"""
+    n = 1_000_000
+    x, y = c2_data(n)
+    ctrl = amd.gsl_nls_control(solver="cholesky", xtol=1.49e-8, gtol=1.49e-8)
+    prob = amd.DenseProblem(1, 3, x, y)
+    a = prob.solve([1.0, 1.0, 0.0], jac=True, control=ctrl)
+    b = prob.solve([1.0, 1.0, 0.0], jac=True, control=ctrl)
+    c = prob.solve([1.0, 1.0, 0.0], jac=False, control=ctrl)
+    prob.close()
+    assert a["conv"] == 0 and c["conv"] == 0
+    # deterministic reductions: bitwise identical from run to run
+    assert np.array_equal(a["par"], b["par"]) and a["ssr"] == b["ssr"] and a["niter"] == b["niter"]
+    # truth is (5, 1.5, 1) with sd 0.25 noise on 1e6 points
+    assert np.allclose(a["par"], [5.0, 1.5, 1.0], atol=5e-3)
+    assert abs(a["ssr"] / (n - 3) - 0.0625) < 5e-4
+    # stationarity of the returned point: J^T r = 0 up to the gtol test
+    g = a["grad"].T @ a["resid"]
+    assert np.max(np.abs(g * np.maximum(a["par"], 1.0))) <= 1.49e-8 * max(0.5 * a["ssr"], 1.0) * 1.01 or a["info"] == 1
+    # ssr equals the recomputed residual sum of squares
+    assert abs(np.dot(a["resid"], a["resid"]) - a["ssr"]) <= 1e-9 * a["ssr"]
+    # FD and analytic Jacobians land on the same optimum
+    assert _rel(c["par"], a["par"]) < 1e-7
+
+
+def test_readme_golden_on_gpu(amd, readme):
+    """README.md traces through the device path (cholesky normal equations instead of the R default QR):
+    example 2: 26 LM iterations / 12 with acceleration; example 1: 9 iterations."""
+    ex = readme["ex2"]
+    ctrl = amd.gsl_nls_control()
+    fit = amd.gsl_nls("y ~ a * exp(-(x - b)^2 / (2 * c^2))", data=dict(x=ex["x"], y=ex["y"]),
+                      start=dict(a=1, b=0, c=1), control=ctrl, trace=True)
+    assert fit["conv"] == 0 and fit["niter"] == 26 and fit["algorithm"] == "levenberg-marquardt"
+    assert abs(fit["chisq_init"] - 210.146) < 5e-4
+    last = ex["lm"]["trace"][-1]
+    assert np.allclose(fit["par"], last["par"], rtol=1.2e-5) and abs(fit["ssr"] - 2.7583) < 5e-5
+    for row in ex["lm"]["trace"][:6]:
+        assert np.allclose(fit["partrace"][row["iter"]], row["par"], rtol=1.2e-5)
+        assert abs(fit["ssrtrace"][row["iter"]] - row["ssr"]) <= 1.2e-5 * row["ssr"]
+    assert fit["neval"]["J"] == 0 and 120 <= fit["neval"]["f"] <= 130
+    acc = amd.gsl_nls("y ~ a * exp(-(x - b)^2 / (2 * c^2))", data=dict(x=ex["x"], y=ex["y"]),
+                      start=dict(a=1, b=0, c=1), algorithm="lmaccel", trace=True)
+    assert acc["conv"] == 0 and acc["niter"] == 12 and acc["neval"] == dict(f=76, J=0, fvv=0)
+    assert acc["algorithm"] == "levenberg-marquardt+accel"
+    for row in ex["lmaccel"]["trace"]:
+        assert np.allclose(acc["partrace"][row["iter"]], row["par"], rtol=1.2e-5)
+    accf = amd.gsl_nls("y ~ a * exp(-(x - b)^2 / (2 * c^2))", data=dict(x=ex["x"], y=ex["y"]),
+                       start=dict(a=1, b=0, c=1), algorithm="lmaccel", fvv=True)
+    assert accf["niter"] == 12 and accf["neval"] == dict(f=58, J=0, fvv=18)
+    e1 = readme["ex1"]
+    f1 = amd.gsl_nls("y ~ A * exp(-lam * x) + b", data=dict(x=e1["x"], y=e1["y"]), start=dict(A=0, lam=0, b=0))
+    assert f1["niter"] == 9 and np.allclose(f1["par"], e1["coef"], atol=5e-7)
+    assert abs(f1.sigma() - e1["sigma"]) < 5e-5
+    assert np.allclose(np.sqrt(np.diag(f1.vcov())), e1["se"], atol=5e-5)
+
+
+def test_misra1a_c1_and_variants(amd, gslref, nist, pins):
+    """BASELINE configs[0] (Misra1a n=14, p=2) and the unit-test variants that the device path covers:
+    2.1.1 default, 2.1.3 lmaccel + fvv + marquardt, 2.1.4 weights + cholesky, 2.1.7 bounds, center FD."""
+    q = nist["Misra1a"]
+    data = q["data"]
+    tgt = np.array(list(q["target"].values()))
+    f = amd.gsl_nls(q["formula"], data=data, start=q["start"], trace=True)
+    assert f["conv"] == 0 and np.all(np.abs(f["par"] - tgt) <= TOL)
+    assert abs(f.deviance() - pins["misra1a"]["deviance"]) < 5e-8 and abs(f.sigma() - pins["misra1a"]["sigma"]) < 5e-8
+    f = amd.gsl_nls(q["formula"], data=data, start=q["start"], algorithm="lmaccel", fvv=True,
+                    control=dict(scale="marquardt"))
+    assert np.all(np.abs(f["par"] - tgt) <= TOL)
+    f = amd.gsl_nls(q["formula"], data=data, start=q["start"], weights=np.full(14, 100.0),
+                    control=dict(solver="cholesky"))
+    assert np.all(np.abs(f["par"] - tgt) <= TOL)
+    f = amd.gsl_nls(q["formula"], data=data, start=dict(b1=300, b2=0), jac=True, lower=dict(b1=250), upper=dict(b2=1))
+    assert abs(f["par"][0] - 250) <= TOL and abs(f["par"][1] - tgt[1]) <= TOL
+    f = amd.gsl_nls(q["formula"], data=data, start=q["start"], control=dict(fdtype="center"))
+    assert np.all(np.abs(f["par"] - tgt) <= TOL)
+    # weighted fit against the oracle
+    w = np.linspace(0.5, 2.0, 14)
+    f = amd.gsl_nls(q["formula"], data=data, start=q["start"], weights=w, jac=True, control=dict(solver="cholesky"))
+    o = gslref.nls(14, 2, [500.0, 1e-4], rowdata=dict(model=gslref.MODEL_MISRA1A, x=data["x"], y=data["y"]),
+                   ctrl=gslref.control(solver="cholesky"), weights=w)
+    assert f["niter"] == o["niter"] and _rel(f["par"], o["par"]) < REL
+    assert np.allclose(f["resid"], o["resid"], atol=1e-10) and np.allclose(f["grad"], o["grad"], rtol=1e-9)
+
+
+def test_gauss1_p8_on_gpu(amd, gslref, nist):
+    """NIST Gauss1 (p = 8: the C5 model family) against the oracle and the certified values"""
+    q = nist["Gauss1"]
+    f = amd.gsl_nls(q["formula"], data=q["data"], start=q["start"], jac=True, control=dict(solver="cholesky"))
+    o = gslref.nls(250, 8, list(q["start"].values()),
+                   rowdata=dict(model=gslref.MODEL_GAUSS1, x=q["data"]["x"], y=q["data"]["y"]),
+                   ctrl=gslref.control(solver="cholesky"))
+    assert f["conv"] == 0 and f["niter"] == o["niter"] and _rel(f["par"], o["par"]) < REL
+    assert np.all(np.abs(f["par"] - np.array(list(q["target"].values()))) <= TOL)
+
+
+def test_failure_paths(amd, nist):
+    """status codes and NA fills (src/nls.c:650-659): maxiter too small -> EMAXITER keeps estimates;
+    unsupported configurations fail loudly instead of falling back"""
+    q = nist["Misra1a"]
+    f = amd.gsl_nls(q["formula"], data=q["data"], start=q["start"], control=dict(maxiter=2))
+    assert f["conv"] == 11 and f["status"] == "exceeded max number of iterations" and f["niter"] == 2
+    assert np.all(np.isfinite(f["par"])) and np.all(np.isfinite(f["resid"]))
+    with pytest.raises(NotImplementedError):
+        amd.gsl_nls(q["formula"], data=q["data"], start=q["start"], algorithm="dogleg")
+    with pytest.raises(NotImplementedError):
+        amd.gsl_nls(q["formula"], data=q["data"], start=q["start"], weights=np.diag(np.full(14, 100.0)))
