@@ -107,6 +107,13 @@ float gslnls_dense_time_pass(gslnls_dense *h, int jac, const double *theta, int 
     return h->impl->time_pass(jac, theta, reps);
 }
 
+#ifdef GSLNLS_STAMPS
+int gslnls_debug_stamps(gslnls_dense *h, int jac, const double *theta, int warm, unsigned long long *out, int *nrows)
+{
+    return h->impl->debug_stamps(jac, theta, warm, out, nrows);
+}
+#endif
+
 int gslnls_dense_set_swts(gslnls_dense *h, const double *swts)
 {
     if (!h || !h->impl)

@@ -40,6 +40,7 @@ inline LmParams make_params(const int *ci, const double *cd, int jac, int fvv, b
     prm.fvv_analytic = fvv ? 1 : 0;
     prm.has_bounds = has_bounds ? 1 : 0;
     prm.has_weights = has_w ? 1 : 0;
+    prm.bench_hold = 0;
     prm.factor_up = cd[0];
     prm.factor_down = cd[1];
     prm.avmax = cd[2];
@@ -58,6 +59,7 @@ struct DenseBase
                       int chunk, gslnls_result *out) = 0;
     virtual float time_pass(int jac, const double *theta, int reps) = 0;
     virtual int set_swts(const double *swts) = 0;
+    virtual int debug_stamps(int jac, const double *theta, int warm, unsigned long long *out, int *nrows) = 0;
     int n = 0, p = 0;
 };
 
@@ -67,14 +69,14 @@ struct DenseFit : DenseBase
     static constexpr int P = M::P;
     static constexpr int NV = PassSums<P>::NV;
     // wide workgroups while the accumulators fit in 128 VGPRs, narrow ones beyond that
-    static constexpr int T = (NV <= 24) ? 1024 : 256;
+    static constexpr int T = (NV <= 24) ? 512 : 256;
 
     DenseCtx<P> ctx;
     bool owns_data = false;
     double *d_x = nullptr, *d_y = nullptr, *d_sw = nullptr;
     double *d_partials = nullptr;
     LmState<P> *d_state = nullptr;
-    LmState<P> *h_state = nullptr; // pinned
+    LmState<P> *h_state = nullptr; // pinned + mapped: the device writes the final state here
     double *d_ssrtrace = nullptr, *d_partrace = nullptr;
     int trace_cap = 0;
     double *d_resid = nullptr, *d_grad = nullptr, *d_covar = nullptr;
@@ -118,8 +120,8 @@ struct DenseFit : DenseBase
         int G = (int)(((long long)n + 2LL * T - 1) / (2LL * T));
         if (G < 1)
             G = 1;
-        if (G > 256)
-            G = 256;
+        if (G > MAX_G)
+            G = MAX_G;
         ctx.G = G;
         GSLNLS_HIP_OK(hipMalloc(&d_partials, sizeof(double) * 2 * NV * G));
         GSLNLS_HIP_OK(hipMemset(d_partials, 0, sizeof(double) * 2 * NV * G));
@@ -128,7 +130,12 @@ struct DenseFit : DenseBase
         GSLNLS_HIP_OK(hipMalloc(&d_state, sizeof(LmState<P>) * 2));
         ctx.state[0] = d_state;
         ctx.state[1] = d_state + 1;
-        GSLNLS_HIP_OK(hipHostMalloc(&h_state, sizeof(LmState<P>) * 2));
+        GSLNLS_HIP_OK(hipHostMalloc(&h_state, sizeof(LmState<P>) * 2, hipHostMallocMapped));
+        {
+            void *dptr = nullptr;
+            GSLNLS_HIP_OK(hipHostGetDevicePointer(&dptr, h_state, 0));
+            ctx.host_mirror = reinterpret_cast<LmState<P> *>(dptr);
+        }
         GSLNLS_HIP_OK(hipMalloc(&d_covar, sizeof(double) * P * P));
         return GSLNLS_SUCCESS;
     }
@@ -250,10 +257,19 @@ struct DenseFit : DenseBase
             ctx.partrace = nullptr;
         }
 
-        // brand-new state goes to slot 1; the first launch has parity 0 and reads slot 1
-        lm_state_reset<P>(h_state[0], start, lupars);
-        h_state[0].bad_steps = -1;
-        GSLNLS_HIP_OK(hipMemcpyAsync(ctx.state[1], &h_state[0], sizeof(LmState<P>), hipMemcpyHostToDevice, stream));
+        GSLNLS_HIP_OK(hipEventRecord(ev0, stream));
+        // brand-new state is built on device in slot 1; the first step launch has parity 0 and reads slot 1
+        {
+            StartArgs<P> sa;
+            for (int k = 0; k < P; ++k)
+            {
+                sa.start[k] = start[k];
+                sa.lo[k] = lupars ? lupars[2 * k] : -INFINITY;
+                sa.up[k] = lupars ? lupars[2 * k + 1] : INFINITY;
+            }
+            h_state[0].phase = PH_INIT;
+            hipLaunchKernelGGL((lm_reset_kernel<P>), dim3(1), dim3(64), 0, stream, ctx, sa);
+        }
 
         if (chunk <= 0)
             chunk = 8;
@@ -261,7 +277,6 @@ struct DenseFit : DenseBase
         const long long max_launches = ((long long)maxiter * 17 + 2) * (ctx.prm.trs ? 2 : 1) + chunk;
         long long launches = 0;
         int parity = 0;
-        GSLNLS_HIP_OK(hipEventRecord(ev0, stream));
         for (;;)
         {
             for (int k = 0; k < chunk; ++k)
@@ -270,18 +285,15 @@ struct DenseFit : DenseBase
                 parity ^= 1;
             }
             launches += chunk;
-            const int last = parity ^ 1;
-            GSLNLS_HIP_OK(hipMemcpyAsync(&h_state[1], ctx.state[last], sizeof(LmState<P>), hipMemcpyDeviceToHost,
-                                         stream));
             GSLNLS_HIP_OK(hipStreamSynchronize(stream));
-            if (h_state[1].phase == PH_DONE)
+            if (h_state[0].phase == PH_DONE)
                 break;
             if (launches > max_launches)
                 return GSLNLS_FAILURE;
         }
         GSLNLS_HIP_OK(hipEventRecord(ev1, stream));
         const int last = parity ^ 1;
-        const LmState<P> &s = h_state[1];
+        const LmState<P> &s = h_state[0];
         const bool ok = (s.status == ST_SUCCESS || s.status == ST_EMAXITER);
 
         const bool want_vecs = ok && (out->resid || out->grad);
@@ -343,6 +355,22 @@ struct DenseFit : DenseBase
         return s.status;
     }
 
+    // diagnostic: per-wave s_memtime stamps of one steady-state launch (needs a -DGSLNLS_STAMPS build)
+    int debug_stamps(int jac, const double *theta, int warm, unsigned long long *out, int *nrows) override
+    {
+        const int rows = ctx.G * (T / 64);
+        unsigned long long *d = nullptr;
+        GSLNLS_HIP_OK(hipMalloc(&d, sizeof(unsigned long long) * 8 * rows));
+        GSLNLS_HIP_OK(hipMemset(d, 0, sizeof(unsigned long long) * 8 * rows));
+        ctx.stamps = d;
+        const float t = time_pass(jac, theta, warm);
+        ctx.stamps = nullptr;
+        GSLNLS_HIP_OK(hipMemcpy(out, d, sizeof(unsigned long long) * 8 * rows, hipMemcpyDeviceToHost));
+        hipFree(d);
+        *nrows = rows;
+        return t < 0 ? GSLNLS_FAILURE : GSLNLS_SUCCESS;
+    }
+
     float time_pass(int jac, const double *theta, int reps) override
     {
         // a state parked in PH_TRIAL at theta with huge mu: every launch performs the full
@@ -351,12 +379,19 @@ struct DenseFit : DenseBase
         int ci[15] = {1 << 30, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0};
         double cd[11] = {2, 3, 0.75, 1.4901161193847656e-08, 0.02, 1e-300, 1e-300, 0.0, 0, 0, 0};
         ctx.prm = make_params(ci, cd, jac, 0, false, ctx.sw != nullptr);
+        ctx.prm.bench_hold = 1;
         ctx.ssrtrace = nullptr;
         ctx.partrace = nullptr;
-        lm_state_reset<P>(h_state[0], theta, nullptr);
-        h_state[0].bad_steps = -1;
-        if (hipMemcpyAsync(ctx.state[1], &h_state[0], sizeof(LmState<P>), hipMemcpyHostToDevice, stream) != hipSuccess)
-            return -1.f;
+        {
+            StartArgs<P> sa;
+            for (int k = 0; k < P; ++k)
+            {
+                sa.start[k] = theta[k];
+                sa.lo[k] = -INFINITY;
+                sa.up[k] = INFINITY;
+            }
+            hipLaunchKernelGGL((lm_reset_kernel<P>), dim3(1), dim3(64), 0, stream, ctx, sa);
+        }
         int parity = 0;
         for (int k = 0; k < 4; ++k)
         {

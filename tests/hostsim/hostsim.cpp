@@ -59,6 +59,7 @@ static int fit(int n, const double *x, const double *y, const double *sw, const 
     prm.fvv_analytic = fvv;
     prm.has_bounds = lupars != nullptr;
     prm.has_weights = sw != nullptr;
+    prm.bench_hold = 0;
     prm.factor_up = cd[0];
     prm.factor_down = cd[1];
     prm.avmax = cd[2];
