@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native NLS trust-region path.
+
+Workload (BASELINE.json configs[1], "C2"): exponential model y = A exp(-lam x) + b,
+n = 1e6 observations, p = 3, fp64 Levenberg-Marquardt on the normal equations
+(solver = cholesky, More' scaling, analytic Jacobian), x_i = 3(i-1)/(n-1), truth (5, 1.5, 1),
+noise 0.25 N(0,1) from numpy PCG64(20250927 + rank), start (1, 1, 0), xtol = gtol = 1.49e-8
+(SURVEY.md 8(d)).  A "step" is ONE complete fit: device-built start state -> init pass ->
+trial steps until the device's own convergence test ends the fit.  Data are resident in HBM
+before the timed region; nothing n-sized crosses PCIe inside it.
+
+    value = LM iterations (niter summed over all steps and ranks) / wall seconds
+
+N > 1: one process per GPU (torch.distributed, backend nccl == RCCL); a single large fit does
+not shard at BASELINE sizes, so the ranks run independent replicas ("weak"),
+bracketed by barriers, time = max over ranks.  The sharded multi-start path (C4) is reported in
+the extra "multistart" object of the same JSON line.
+
+Extra objects: "roofline" (dominant kernel lm_step_kernel: algorithmic bytes 16 n per launch,
+duration from HIP events on the library's stream), "cpu_baseline" (the oracle, single core).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_OBS = 1_000_000
+START = np.array([1.0, 1.0, 0.0])
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def c2_data(n, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x = 3.0 * np.arange(n, dtype=np.float64) / (n - 1)
+    y = 5.0 * np.exp(-1.5 * x) + 1.0 + 0.25 * rng.standard_normal(n)
+    return x, y
+
+
+def cpu_baseline(x, y, budget_s=20.0):
+    """The oracle (oracle/, plain C, J materialised row-major like GSL, solver=cholesky) on the same
+    workload, one host core.  Test infrastructure used here only as the reported baseline."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gslref
+    ctrl = gslref.control(solver="cholesky", xtol=1.49e-8, gtol=1.49e-8)
+    rd = dict(model=gslref.MODEL_EXPDECAY, x=x, y=y)
+    fits, iters, t0 = 0, 0, time.perf_counter()
+    while True:
+        out = gslref.nls(len(y), 3, START, rowdata=rd, use_jac=True, ctrl=ctrl)
+        fits += 1
+        iters += out["niter"]
+        el = time.perf_counter() - t0
+        if el > budget_s or fits >= 64:
+            break
+    return dict(value=iters / el, unit="LM iterations/s", cores=1, kind="port",
+                sample="%d complete fits of the same n=1e6,p=3 problem (%d iterations) in %.1f s, "
+                       "oracle/libgslref.so single thread" % (fits, iters, el),
+                niter_per_fit=out["niter"], par=[float(v) for v in out["par"]])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=N_OBS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fd", action="store_true", help="forward finite-difference Jacobian instead of analytic")
+    ap.add_argument("--chunk", type=int, default=16)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from gslnls_amd import _lib
+    from gslnls_amd.control import gsl_nls_control, pack_control
+    L = _lib.lib()
+    if L.gslnls_device_count() < 1:
+        raise SystemExit("bench.py: no MI355X visible; the HIP path has no CPU fallback")
+    _lib.check(L.gslnls_set_device(local_rank))
+
+    n = args.n
+    x, y = c2_data(n, 20250927 + rank)
+    X = np.asfortranarray(x.reshape(n, 1))
+    model = _lib.Model(1, 3, 1, X.ctypes.data_as(C.c_void_p), 0)
+    err = C.c_int(0)
+    h = L.gslnls_dense_create(C.byref(model), y.ctypes.data_as(C.c_void_p), n, None, C.byref(err))
+    if not h:
+        raise SystemExit("gslnls_dense_create failed: %s" % _lib.strerror(err.value))
+    ctrl = gsl_nls_control(solver="cholesky", xtol=1.49e-8, gtol=1.49e-8)
+    ci, cd = pack_control(ctrl, "lm")
+    par = np.zeros(3)
+    res = _lib.Result()
+    res.par = par.ctypes.data_as(_lib.DP)
+    jac = 0 if args.fd else 1
+    st = START.copy()
+
+    def one_fit():
+        rc = L.gslnls_dense_solve(h, jac, 0, st.ctypes.data_as(_lib.DP), None, ci.ctypes.data_as(_lib.IP),
+                                  cd.ctypes.data_as(_lib.DP), args.chunk, C.byref(res))
+        if rc != 0:
+            raise SystemExit("fit failed: %s" % _lib.strerror(rc))
+        return res.niter, res.n_launches, res.loop_ms
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_fit()
+    barrier()
+    t0 = time.perf_counter()
+    iters = launches = 0
+    loop_ms = 0.0
+    for _ in range(args.steps):
+        a, b, c = one_fit()
+        iters += a
+        launches += b
+        loop_ms += c
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    tot_iters = float(iters)
+    tmax = elapsed
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tmax = float(t.item())
+        it = torch.tensor([tot_iters], dtype=torch.float64, device="cuda")
+        dist.all_reduce(it, op=dist.ReduceOp.SUM)
+        tot_iters = float(it.item())
+
+    # dominant kernel: HIP events on the library's stream around back-to-back launches that each do the
+    # full prologue + one full pass over (x, y)
+    th = np.array([4.0, 1.2, 0.8])
+    ms_launch = float(L.gslnls_dense_time_pass(h, jac, th.ctypes.data_as(_lib.DP), 2000))
+    alg_bytes = 16.0 * n  # one pass reads x and y once (8 B each), nothing n-sized is written
+    achieved = alg_bytes / (ms_launch * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("lm_step_kernel_bytes_per_launch")
+        except Exception:  # noqa
+            traffic = None
+
+    line = {
+        "metric": "LM iterations/sec at n=1e6,p=3 single-GPU; multi-start fits/sec at 1/2/4/8 GPUs",
+        "value": tot_iters / tmax,
+        "unit": "LM iterations/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": tmax / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "C2: exponential model n=%d p=3, LM normal equations (cholesky), %s Jacobian, "
+                               "one step = one complete fit from (1,1,0)" % (n, "forward-FD" if args.fd else "analytic"),
+                   "niter_per_fit": iters / args.steps, "launches_per_fit": launches / args.steps,
+                   "device_loop_ms_per_fit": loop_ms / args.steps,
+                   "parallelism": "replicas only (x%d)" % world, "par": [float(v) for v in par]},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "lm_step_kernel<ModelExpDecay>", "bytes_per_launch": alg_bytes,
+                     "ms_per_launch": ms_launch},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(x, y)
+    elif rank == 0:
+        line["cpu_baseline"] = None
+    L.gslnls_dense_destroy(h)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

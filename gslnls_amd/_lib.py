@@ -43,6 +43,7 @@ _SIGNATURES = {
     "gslnls_strerror": (C.c_char_p, [C.c_int]),
     "gslnls_algorithm_name": (C.c_char_p, [C.c_int]),
     "gslnls_device_count": (C.c_int, []),
+    "gslnls_set_device": (C.c_int, [C.c_int]),
     "gslnls_version": (C.c_char_p, []),
 }
 

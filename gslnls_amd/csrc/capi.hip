@@ -189,6 +189,11 @@ int gslnls_device_count(void)
     return n;
 }
 
+int gslnls_set_device(int ordinal)
+{
+    return hipSetDevice(ordinal) == hipSuccess ? GSLNLS_SUCCESS : GSLNLS_E_NODEVICE;
+}
+
 const char *gslnls_version(void) { return "gslnls-mi355x 0.1 (gfx950)"; }
 
 } // extern "C"

@@ -123,6 +123,7 @@ int gslnls_dense_set_swts(gslnls_dense *h, const double *swts);
 const char *gslnls_strerror(int code);     /* gsl_strerror strings, App. C.4 */
 const char *gslnls_algorithm_name(int trs); /* gsl_multifit_nlinear_trs_name */
 int gslnls_device_count(void);
+int gslnls_set_device(int ordinal);        /* hipSetDevice for this process (one process per GPU) */
 const char *gslnls_version(void);
 
 #ifdef __cplusplus
