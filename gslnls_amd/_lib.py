@@ -40,6 +40,12 @@ _SIGNATURES = {
     "gslnls_dense_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, DP, DP, IP, DP, C.c_int, C.POINTER(Result)]),
     "gslnls_dense_time_pass": (C.c_float, [C.c_void_p, C.c_int, DP, C.c_int]),
     "gslnls_dense_set_swts": (C.c_int, [C.c_void_p, DP]),
+    "gslnls_set_comm": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
+                                  C.c_int]),
+    "gslnls_dense_mstart": (C.c_int, [C.c_void_p, C.c_int, C.c_int, DP, DP, IP, DP, IP, C.POINTER(Result)]),
+    "gslnls_mstart_batch": (C.c_int, [C.c_void_p, C.c_int, DP, DP, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_double, IP, DP, DP, C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
+    "gslnls_mstart_record_size": (C.c_int, [C.c_int]),
     "gslnls_strerror": (C.c_char_p, [C.c_int]),
     "gslnls_algorithm_name": (C.c_char_p, [C.c_int]),
     "gslnls_device_count": (C.c_int, []),

@@ -1,0 +1,136 @@
+// batch_core.hpp -- one complete small fit executed by ONE lane (multi-start) .
+//
+// Device twin of what the reference does for a single sampled point inside
+// gsl_multistart_driver (src/nls_mstart.c:72-95 and :245-255):
+//     det_eval_jtj            src/nls_utils.c:23-53   f, J at the point, det(J^T J)
+//     if det > dtol:
+//         gsl_multifit_nlinear_(w)init + gsl_multifit_nlinear_driver2(maxiter, xtol, 1e-3, ftol)
+//         det_cholesky_jtj    src/nls_utils.c:55-73   at the point the fit ended on
+// The sequential bookkeeping around it (running best with its 0.99 hysteresis, top-q
+// retention, dynamic ranges, acceptance of stationary points) stays on the host
+// (mstart_driver.hpp) and is replayed in the reference's order from these per-point
+// records, so thousands of points can be fitted at once without changing the result.
+#pragma once
+#include "lm_core.hpp"
+#include "rowops.hpp"
+#include "sobol.hpp"
+
+namespace gslnls
+{
+
+struct MsParams
+{
+    LmParams prm;   // maxiter = mstart_p (concentration) or mstart_maxiter (local search); gtol = 1e-3
+    double dtol;    // determinant tolerance of the det filter
+    int n;          // residual rows
+    int always_fit; // local search stage: no det filter in front of the fit
+};
+
+// per-point record, all doubles so one all-gather moves it: K = 3P + 8
+template <int P>
+struct MsRecord
+{
+    static constexpr int K = 3 * P + 8;
+    double x[P];     // where the fit ended (or the sampled point itself when not fitted)
+    double diag[P];  // trust_state->diag at the end (src/nls_mstart.c:324-326)
+    double x0[P];    // the point the fit started from (the freshly sampled point for new draws)
+    double chisq0;   // ssr before the last iteration
+    double chisq1;   // ssr at the end
+    double det0;     // det(J^T J) at the sampled point
+    double det1;     // det(J^T J) where the fit ended
+    double ssr_start;
+    double niter;
+    double status;   // GSL status of driver2, or -2 (CONTINUE) when the point was not fitted
+    double nevalf;
+};
+
+// RowSrc: void operator()(int i, double *xr, double &y, double &sw) const
+template <class M, int JAC, class RowSrc>
+GSLNLS_HD void ms_pass(const LmState<M::P> &s, const MsParams &mp, const RowSrc &rows, PassSums<M::P> &acc)
+{
+    constexpr int P = M::P;
+    double th[P], delta[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k)
+        th[k] = (s.phase == PH_FVV) ? s.x[k] : s.xt[k];
+    fd_deltas<P>(th, mp.prm.h_df, delta);
+    pass_zero<P>(acc);
+    for (int i = 0; i < mp.n; ++i)
+    {
+        double xr[M::NX], y, sw;
+        rows(i, xr, y, sw);
+        double Jrow[P];
+        if (s.phase == PH_FVV)
+        {
+            const double fv = row_fvv<M, JAC>(th, s.vel, delta, mp.prm.h_fvv, mp.prm.fvv_analytic != 0, xr, y, sw,
+                                              Jrow, &acc.badj);
+#pragma unroll
+            for (int k = 0; k < P; ++k)
+                acc.g[k] += Jrow[k] * fv;
+        }
+        else
+        {
+            const double f = row_fj<M, JAC>(th, delta, xr, y, sw, Jrow, &acc.badj);
+            acc_fj<P>(acc, f, Jrow);
+        }
+    }
+}
+
+template <class M, int JAC, class RowSrc>
+GSLNLS_HD void ms_fit_point(const MsParams &mp, const RowSrc &rows, const double *start, const double *lupars,
+                            MsRecord<M::P> &rec)
+{
+    constexpr int P = M::P;
+    LmState<P> s;
+    lm_state_reset<P>(s, start, lupars);
+    PassSums<P> acc;
+    ms_pass<M, JAC>(s, mp, rows, acc);
+    double det0 = det_cholesky<P>(acc.A);
+    if (mp.prm.jac_analytic && acc.badj > 0.0)
+        det0 = 0.0; // eval_df failed (src/nls_utils.c:47-48)
+    rec.det0 = det0;
+    rec.ssr_start = acc.ssr;
+#pragma unroll
+    for (int k = 0; k < P; ++k)
+        rec.x0[k] = start[k];
+    if (mp.always_fit || det0 > mp.dtol)
+    {
+        lm_advance<P>(s, acc, mp.prm);
+        int guard = 0;
+        while (s.phase != PH_DONE && guard < 100000)
+        {
+            ms_pass<M, JAC>(s, mp, rows, acc);
+            lm_advance<P>(s, acc, mp.prm);
+            ++guard;
+        }
+        rec.det1 = det_cholesky<P>(s.A);
+        rec.chisq0 = s.chisq0;
+        rec.chisq1 = s.chisq1;
+        rec.niter = (double)s.niter;
+        rec.status = (double)s.status;
+        rec.nevalf = (double)s.nevalf;
+#pragma unroll
+        for (int k = 0; k < P; ++k)
+        {
+            rec.x[k] = s.x[k];
+            rec.diag[k] = s.diag[k];
+        }
+    }
+    else
+    {
+        rec.det1 = 0.0;
+        rec.chisq0 = INFINITY;
+        rec.chisq1 = acc.ssr;
+        rec.niter = 0.0;
+        rec.status = (double)ST_CONTINUE;
+        rec.nevalf = 1.0;
+#pragma unroll
+        for (int k = 0; k < P; ++k)
+        {
+            rec.x[k] = start[k];
+            rec.diag[k] = 1.0;
+        }
+    }
+}
+
+} // namespace gslnls

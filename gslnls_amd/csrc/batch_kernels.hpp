@@ -1,0 +1,125 @@
+// batch_kernels.hpp -- lane-per-fit kernel for multi-start (BASELINE config C4: thousands of
+// independent starts on a tiny data set, e.g. BoxBOD n = 6, p = 2).
+//
+// Each lane owns one sample slot of gsl_multistart_driver's point loop
+// (src/nls_mstart.c:42-128 / :236-349): it generates its own Sobol point from the global
+// draw index (sobol.hpp), maps it to the sampling range, runs the det filter and the short
+// LM fit entirely in registers (batch_core.hpp) and writes one fixed-size record.  The data
+// set is staged once per workgroup in LDS and read as broadcasts (every lane reads the same
+// row at the same time: conflict-free), so the kernel touches HBM only for the records.
+// Bound by fp64 VALU + exp latency, not by memory.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "batch_core.hpp"
+#include "models.hpp"
+
+namespace gslnls
+{
+
+constexpr int MS_T = 64;           // one wavefront per workgroup: lanes diverge per fit anyway
+constexpr int MS_LDS_ROWS = 1536;  // rows staged in LDS (x NX + y + sw doubles each)
+
+template <int P>
+struct MsKernelArgs
+{
+    const double *x[4];
+    const double *y;
+    const double *sw;
+    const long long *draw; // per point, -1 = explicit start
+    const double *start;   // count x P
+    double *records;       // count x K
+    const SobolTable *sobol;
+    int lo, hi;
+    double l0[P], l1[P], kd[P];
+    double lu[2 * P];
+    int has_lu;
+    MsParams mp;
+};
+
+template <int NX>
+struct RowsLds
+{
+    const double *base;
+    int n;
+    __device__ void operator()(int i, double *xr, double &y, double &sw) const
+    {
+#pragma unroll
+        for (int c = 0; c < NX; ++c)
+            xr[c] = base[c * n + i];
+        y = base[NX * n + i];
+        sw = base[(NX + 1) * n + i];
+    }
+};
+
+template <int NX>
+struct RowsGlobal
+{
+    const double *x[4];
+    const double *y;
+    const double *sw;
+    __device__ void operator()(int i, double *xr, double &yy, double &w) const
+    {
+#pragma unroll
+        for (int c = 0; c < NX; ++c)
+            xr[c] = x[c][i];
+        yy = y[i];
+        w = sw ? sw[i] : 1.0;
+    }
+};
+
+template <class M, int JAC>
+__global__ __launch_bounds__(MS_T) void ms_fit_kernel(MsKernelArgs<M::P> a)
+{
+    constexpr int P = M::P, NX = M::NX;
+    extern __shared__ __attribute__((aligned(16))) double lds_rows[];
+    const int n = a.mp.n;
+    const bool staged = n <= MS_LDS_ROWS;
+    if (staged)
+    {
+        for (int i = threadIdx.x; i < n; i += MS_T)
+        {
+#pragma unroll
+            for (int c = 0; c < NX; ++c)
+                lds_rows[c * n + i] = a.x[c][i];
+            lds_rows[NX * n + i] = a.y[i];
+            lds_rows[(NX + 1) * n + i] = a.sw ? a.sw[i] : 1.0;
+        }
+        __syncthreads();
+    }
+    const int idx = a.lo + blockIdx.x * MS_T + threadIdx.x;
+    if (idx >= a.hi)
+        return;
+    double start[P];
+    const long long d = a.draw[idx];
+#pragma unroll
+    for (int k = 0; k < P; ++k)
+    {
+        if (d >= 0)
+            start[k] = sobol_to_range(sobol_coord(*a.sobol, (unsigned int)d, k), a.l0[k], a.l1[k], a.kd[k]);
+        else
+            start[k] = a.start[(size_t)idx * P + k];
+    }
+    MsRecord<P> rec;
+    if (staged)
+    {
+        RowsLds<NX> rows{lds_rows, n};
+        ms_fit_point<M, JAC>(a.mp, rows, start, a.has_lu ? a.lu : nullptr, rec);
+    }
+    else
+    {
+        RowsGlobal<NX> rows;
+#pragma unroll
+        for (int c = 0; c < NX; ++c)
+            rows.x[c] = a.x[c];
+        rows.y = a.y;
+        rows.sw = a.sw;
+        ms_fit_point<M, JAC>(a.mp, rows, start, a.has_lu ? a.lu : nullptr, rec);
+    }
+    double *out = a.records + (size_t)idx * MsRecord<P>::K;
+    const double *src = reinterpret_cast<const double *>(&rec);
+#pragma unroll
+    for (int k = 0; k < MsRecord<P>::K; ++k)
+        out[k] = src[k];
+}
+
+} // namespace gslnls

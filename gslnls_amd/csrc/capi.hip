@@ -9,6 +9,7 @@
 #include <string.h>
 #include "../../include/gslnls_core.h"
 #include "dense_host.hpp"
+#include "mstart_host.hpp"
 
 using namespace gslnls;
 
@@ -16,6 +17,9 @@ struct gslnls_dense
 {
     DenseBase *impl;
 };
+
+// process-wide communicator of the multi-start sharding (one process per GPU)
+static MsComm g_comm;
 
 static DenseBase *make_dense(const gslnls_model *fn, const double *y, int n, const double *swts, int *err)
 {
@@ -114,6 +118,43 @@ int gslnls_debug_stamps(gslnls_dense *h, int jac, const double *theta, int warm,
 }
 #endif
 
+int gslnls_set_comm(int rank, int world, gslnls_allgather_fn fn, void *ctx, double *shard_buf, double *all_buf,
+                    long long cap_points, int buffers_on_device)
+{
+    if (world < 1 || rank < 0 || rank >= world)
+        return GSLNLS_EINVAL;
+    g_comm.rank = rank;
+    g_comm.world = world;
+    g_comm.allgather = fn;
+    g_comm.ctx = ctx;
+    g_comm.shard_buf = shard_buf;
+    g_comm.all_buf = all_buf;
+    g_comm.cap_points = cap_points;
+    g_comm.buffers_on_device = buffers_on_device;
+    return GSLNLS_SUCCESS;
+}
+
+int gslnls_dense_mstart(gslnls_dense *h, int jac, int fvv, const double *start2p, const double *lupars,
+                        const int *control_int, const double *control_dbl, const int *has_start, gslnls_result *out)
+{
+    if (!h || !h->impl)
+        return GSLNLS_EINVAL;
+    return h->impl->mstart(jac, fvv, start2p, lupars, control_int, control_dbl, has_start, g_comm, out);
+}
+
+int gslnls_mstart_batch(gslnls_dense *h, int jac, const double *ranges, const double *kd, long long first_draw,
+                        int count, int lo, int hi, int maxiter, double dtol, const int *control_int,
+                        const double *control_dbl, const double *lupars, double *records, int records_on_device,
+                        float *kernel_ms)
+{
+    if (!h || !h->impl || lo < 0 || hi > count || lo > hi)
+        return GSLNLS_EINVAL;
+    return h->impl->mstart_batch(jac, ranges, kd, first_draw, count, lo, hi, maxiter, dtol, control_int, control_dbl,
+                                 lupars, records, records_on_device, kernel_ms);
+}
+
+int gslnls_mstart_record_size(int p) { return 3 * p + 8; }
+
 int gslnls_dense_set_swts(gslnls_dense *h, const double *swts)
 {
     if (!h || !h->impl)
@@ -126,17 +167,20 @@ int gslnls_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv,
                const int *control_int, const double *control_dbl, const int *has_start, int loss_rho,
                const double *loss_cc, gslnls_result *out)
 {
-    (void)has_start;
     (void)loss_cc;
     if (swts && swts_is_matrix)
         return GSLNLS_E_UNSUPPORTED; // GLS: n x n factor, not lowered
-    if (start_is_matrix || loss_rho != 0)
-        return GSLNLS_E_UNSUPPORTED; // multi-start / IRLS: see mstart.hip / irls.hip
+    if (loss_rho != 0)
+        return GSLNLS_E_UNSUPPORTED; // IRLS
     int err = 0;
     DenseBase *b = make_dense(fn, y, n, swts, &err);
     if (!b)
         return err;
-    const int rc = b->solve(jac, fvv, start, lupars, control_int, control_dbl, 0, out);
+    int rc;
+    if (start_is_matrix)
+        rc = b->mstart(jac, fvv, start, lupars, control_int, control_dbl, has_start, g_comm, out);
+    else
+        rc = b->solve(jac, fvv, start, lupars, control_int, control_dbl, 0, out);
     delete b;
     return rc;
 }

@@ -13,6 +13,7 @@
 #include <vector>
 #include "../../include/gslnls_core.h"
 #include "dense_kernels.hpp"
+#include "mstart_driver.hpp"
 
 namespace gslnls
 {
@@ -59,6 +60,13 @@ struct DenseBase
                       int chunk, gslnls_result *out) = 0;
     virtual float time_pass(int jac, const double *theta, int reps) = 0;
     virtual int set_swts(const double *swts) = 0;
+    // multi-start branch of C_nls (src/nls.c:274-532) followed by the final single-start solve
+    virtual int mstart(int jac, int fvv, const double *start2p, const double *lupars, const int *ci, const double *cd,
+                       const int *has_start, const MsComm &comm, gslnls_result *out) = 0;
+    // one concentration batch of `count` fresh Sobol points (first_draw + i), shard [lo, hi)
+    virtual int mstart_batch(int jac, const double *ranges, const double *kd, long long first_draw, int count, int lo,
+                             int hi, int maxiter, double dtol, const int *ci, const double *cd, const double *lupars,
+                             double *records, int records_on_device, float *kernel_ms) = 0;
     virtual int debug_stamps(int jac, const double *theta, int warm, unsigned long long *out, int *nrows) = 0;
     int n = 0, p = 0;
 };
@@ -354,6 +362,12 @@ struct DenseFit : DenseBase
         out->n_launches = (int)launches;
         return s.status;
     }
+
+    int mstart(int jac, int fvv, const double *start2p, const double *lupars, const int *ci, const double *cd,
+               const int *has_start, const MsComm &comm, gslnls_result *out) override;
+    int mstart_batch(int jac, const double *ranges, const double *kd, long long first_draw, int count, int lo, int hi,
+                     int maxiter, double dtol, const int *ci, const double *cd, const double *lupars, double *records,
+                     int records_on_device, float *kernel_ms) override;
 
     // diagnostic: per-wave s_memtime stamps of one steady-state launch (needs a -DGSLNLS_STAMPS build)
     int debug_stamps(int jac, const double *theta, int warm, unsigned long long *out, int *nrows) override

@@ -1,0 +1,204 @@
+// mstart_host.hpp -- the HIP BatchEvaluator behind multi-start and the numeric body of the
+// multi-start branch of C_nls_internal (src/nls.c:274-532).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "batch_kernels.hpp"
+#include "dense_host.hpp"
+#include "mstart_driver.hpp"
+
+namespace gslnls
+{
+
+template <class M>
+struct HipMsEvaluator : MsEvaluator
+{
+    static constexpr int P = M::P;
+    static constexpr int K = MsRecord<P>::K;
+    DenseFit<M> &fit;
+    LmParams prm; // tolerances / scaling / FD settings of the fit (maxiter, gtol overridden per batch)
+    int jacmode;
+    const double *lupars;
+    SobolTable *d_sobol = nullptr;
+    long long *d_draw = nullptr;
+    double *d_start = nullptr, *d_rec = nullptr;
+    int cap = 0;
+    float last_kernel_ms = 0.f;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+
+    HipMsEvaluator(DenseFit<M> &f, const int *ci, const double *cd, int jac, int fvv, const double *lu)
+        : fit(f), lupars(lu)
+    {
+        prm = make_params(ci, cd, jac, fvv, lu != nullptr, f.ctx.sw != nullptr);
+        jacmode = jac ? JAC_ANALYTIC : (ci[5] ? JAC_CENTER : JAC_FORWARD);
+        SobolTable t;
+        sobol_build(t, P);
+        hipMalloc(&d_sobol, sizeof(SobolTable));
+        hipMemcpy(d_sobol, &t, sizeof(SobolTable), hipMemcpyHostToDevice);
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+    }
+    ~HipMsEvaluator() override
+    {
+        hipFree(d_sobol);
+        hipFree(d_draw);
+        hipFree(d_start);
+        hipFree(d_rec);
+        if (e0)
+            hipEventDestroy(e0);
+        if (e1)
+            hipEventDestroy(e1);
+    }
+
+    int ensure(int count)
+    {
+        if (count <= cap)
+            return 0;
+        hipFree(d_draw);
+        hipFree(d_start);
+        hipFree(d_rec);
+        GSLNLS_HIP_OK(hipMalloc(&d_draw, sizeof(long long) * count));
+        GSLNLS_HIP_OK(hipMalloc(&d_start, sizeof(double) * (size_t)count * P));
+        GSLNLS_HIP_OK(hipMalloc(&d_rec, sizeof(double) * (size_t)count * K));
+        cap = count;
+        return 0;
+    }
+
+    int run(MsBatch &b, int lo, int hi, double *out, bool out_on_device) override
+    {
+        if (b.p != P || b.K != K)
+            return GSLNLS_EINVAL;
+        int rc = ensure(b.count);
+        if (rc)
+            return rc;
+        hipStream_t st = fit.stream;
+        GSLNLS_HIP_OK(hipMemcpyAsync(d_draw, b.draw.data(), sizeof(long long) * b.count, hipMemcpyHostToDevice, st));
+        GSLNLS_HIP_OK(hipMemcpyAsync(d_start, b.start.data(), sizeof(double) * (size_t)b.count * P,
+                                     hipMemcpyHostToDevice, st));
+        MsKernelArgs<P> a;
+        for (int c = 0; c < 4; ++c)
+            a.x[c] = c < M::NX ? fit.ctx.x[c] : nullptr;
+        a.y = fit.ctx.y;
+        a.sw = fit.ctx.sw;
+        a.draw = d_draw;
+        a.start = d_start;
+        // records of point idx land at records + idx*K: shift the base so that point `lo` lands at out[0]
+        double *dev_out = out_on_device ? out : d_rec;
+        a.records = dev_out - (size_t)lo * K;
+        a.sobol = d_sobol;
+        a.lo = lo;
+        a.hi = hi;
+        for (int k = 0; k < P; ++k)
+        {
+            a.l0[k] = b.range[2 * k];
+            a.l1[k] = b.range[2 * k + 1];
+            a.kd[k] = b.kd[k];
+            a.lu[2 * k] = lupars ? lupars[2 * k] : -INFINITY;
+            a.lu[2 * k + 1] = lupars ? lupars[2 * k + 1] : INFINITY;
+        }
+        a.has_lu = lupars != nullptr;
+        a.mp.prm = prm;
+        a.mp.prm.maxiter = b.maxiter;
+        a.mp.prm.gtol = 1e-3; // src/nls_mstart.c:91, :254
+        a.mp.dtol = b.dtol;
+        a.mp.n = fit.n;
+        a.mp.always_fit = b.always_fit;
+        const int nblk = (hi - lo + MS_T - 1) / MS_T;
+        const size_t lds = (fit.n <= MS_LDS_ROWS) ? sizeof(double) * (size_t)fit.n * (M::NX + 2) : 0;
+        hipEventRecord(e0, st);
+        switch (jacmode)
+        {
+        case JAC_ANALYTIC:
+            hipLaunchKernelGGL((ms_fit_kernel<M, JAC_ANALYTIC>), dim3(nblk), dim3(MS_T), lds, st, a);
+            break;
+        case JAC_FORWARD:
+            hipLaunchKernelGGL((ms_fit_kernel<M, JAC_FORWARD>), dim3(nblk), dim3(MS_T), lds, st, a);
+            break;
+        default:
+            hipLaunchKernelGGL((ms_fit_kernel<M, JAC_CENTER>), dim3(nblk), dim3(MS_T), lds, st, a);
+            break;
+        }
+        hipEventRecord(e1, st);
+        if (!out_on_device)
+            GSLNLS_HIP_OK(hipMemcpyAsync(out, d_rec, sizeof(double) * (size_t)(hi - lo) * K, hipMemcpyDeviceToHost, st));
+        GSLNLS_HIP_OK(hipStreamSynchronize(st));
+        hipEventElapsedTime(&last_kernel_ms, e0, e1);
+        return 0;
+    }
+
+    int fetch(const double *src, bool src_on_device, double *dst, size_t nd) override
+    {
+        if (src_on_device)
+            GSLNLS_HIP_OK(hipMemcpy(dst, src, sizeof(double) * nd, hipMemcpyDeviceToHost));
+        else
+            memcpy(dst, src, sizeof(double) * nd);
+        return 0;
+    }
+};
+
+template <class M>
+int DenseFit<M>::mstart(int jac, int fvv, const double *start2p, const double *lupars, const int *ci, const double *cd,
+                        const int *has_start, const MsComm &comm, gslnls_result *out)
+{
+    if (ci[2] > 1)
+        return GSLNLS_E_UNSUPPORTED;
+    if (fvv && !M::HAS_FVV)
+        return GSLNLS_E_UNSUPPORTED;
+    MsState m;
+    ms_init(m, P, ci, cd, start2p, has_start, lupars);
+    HipMsEvaluator<M> ev(*this, ci, cd, jac, fvv, lupars);
+    int rc = ms_major_loop(m, ev, comm, start2p);
+    if (rc)
+        return rc < 0 && rc > -100 ? GSLNLS_FAILURE : rc;
+    // src/nls.c:518-531
+    if (m.mssropt[1] < m.mssropt[0])
+    {
+        m.mssropt[0] = m.mssropt[1];
+        m.ssrconv[0] = m.ssrconv[1];
+        m.mpopt = m.mpopt1;
+    }
+    const double ftol = cd[6];
+    if (m.mssropt[0] < ftol || m.ssrconv[0] < ftol)
+    {
+        if (lupars)
+            m.mpopt[0] = fmin(m.mpopt[0] + 1.0e-4, isfinite(lupars[1]) ? lupars[1] : INFINITY);
+        else
+            m.mpopt[0] = m.mpopt[0] + 1.0e-4;
+    }
+    rc = solve(jac, fvv, m.mpopt.data(), lupars, ci, cd, 0, out);
+    out->mstart_nsp = m.nsp;
+    out->mstart_nwsp = m.nwsp;
+    out->mstart_iters = m.mstarts;
+    out->mstart_stop = m.mstop;
+    out->mstart_ssropt = m.mssropt[0];
+    return rc;
+}
+
+template <class M>
+int DenseFit<M>::mstart_batch(int jac, const double *ranges, const double *kd, long long first_draw, int count, int lo,
+                              int hi, int maxiter, double dtol, const int *ci, const double *cd, const double *lupars,
+                              double *records, int records_on_device, float *kernel_ms)
+{
+    HipMsEvaluator<M> ev(*this, ci, cd, jac, 0, lupars);
+    MsBatch b;
+    b.count = count;
+    b.p = P;
+    b.K = MsRecord<P>::K;
+    b.draw.resize(count);
+    for (int i = 0; i < count; ++i)
+        b.draw[i] = first_draw + i;
+    b.start.assign((size_t)count * P, 0.0);
+    b.range.assign(ranges, ranges + 2 * P);
+    b.kd.resize(P);
+    for (int k = 0; k < P; ++k)
+        b.kd[k] = kd ? kd[k] : 0.75;
+    b.maxiter = maxiter;
+    b.dtol = dtol;
+    b.always_fit = 0;
+    const int rc = ev.run(b, lo, hi, records, records_on_device != 0);
+    if (kernel_ms)
+        *kernel_ms = ev.last_kernel_ms;
+    return rc;
+}
+
+} // namespace gslnls

@@ -119,6 +119,32 @@ float gslnls_dense_time_pass(gslnls_dense *h, int jac, const double *theta, int 
 /* swap the weights of a resident problem (IRLS) */
 int gslnls_dense_set_swts(gslnls_dense *h, const double *swts);
 
+/* ---- multi-start (src/nls_mstart.c, src/nls.c:274-532) ----------------------------------------
+ * gslnls_nls() with start_is_matrix runs the whole procedure.  The pieces below expose the
+ * resident-data form and the sharding hooks for one-process-per-GPU jobs.
+ *
+ * Per-point record of a batch: K = 3p + 8 doubles
+ *   x[p] (where the fit ended), diag[p] (trust-region scaling at the end), x0[p] (sampled point),
+ *   chisq0, chisq1, det0, det1, ssr_start, niter, status, nevalf.                                   */
+typedef int (*gslnls_allgather_fn)(void *ctx, int per_points, int K);
+/* Communicator for sharding the N sample points over `world` ranks: each rank fits a contiguous
+ * block of ceil(N/world) points into shard_buf, fn() must gather the equal-sized shards of all
+ * ranks into all_buf on every rank (RCCL all-gather over xGMI when the buffers are device
+ * memory).  world = 1 (default) disables it. */
+int gslnls_set_comm(int rank, int world, gslnls_allgather_fn fn, void *ctx, double *shard_buf, double *all_buf,
+                    long long cap_points, int buffers_on_device);
+/* multi-start + final solve on resident data; start2p = 2 x p column-major ranges */
+int gslnls_dense_mstart(gslnls_dense *h, int jac, int fvv, const double *start2p, const double *lupars,
+                        const int *control_int, const double *control_dbl, const int *has_start, gslnls_result *out);
+/* one concentration batch (src/nls_mstart.c:42-128) of `count` fresh Sobol points with global draw
+ * indices first_draw..first_draw+count-1; computes the records of points [lo, hi) into
+ * records[0 : (hi-lo)*K) (host or device memory).  kernel_ms: HIP-event time of the batch kernel. */
+int gslnls_mstart_batch(gslnls_dense *h, int jac, const double *ranges, const double *kd, long long first_draw,
+                        int count, int lo, int hi, int maxiter, double dtol, const int *control_int,
+                        const double *control_dbl, const double *lupars, double *records, int records_on_device,
+                        float *kernel_ms);
+int gslnls_mstart_record_size(int p);
+
 /* ---- introspection ---------------------------------------------------------------------- */
 const char *gslnls_strerror(int code);     /* gsl_strerror strings, App. C.4 */
 const char *gslnls_algorithm_name(int trs); /* gsl_multifit_nlinear_trs_name */

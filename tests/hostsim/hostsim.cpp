@@ -9,6 +9,8 @@
 #include "lm_core.hpp"
 #include "models.hpp"
 #include "rowops.hpp"
+#include "batch_core.hpp"
+#include "mstart_driver.hpp"
 
 using namespace gslnls;
 
@@ -147,4 +149,200 @@ extern "C" void hostsim_lm_solve3(const double *Ap, const double *diag, double m
 extern "C" void hostsim_lm_solve8(const double *Ap, const double *diag, double mu, const double *rhs, double *sol)
 {
     lm_solve<8>(Ap, diag, mu, rhs, sol);
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-start: the product's host driver (mstart_driver.hpp) around a CPU evaluator that runs the
+// device per-point routine (batch_core.hpp) serially.  Test-only.
+template <int NX>
+struct RowsHost
+{
+    const double *x, *y, *sw;
+    int n;
+    void operator()(int i, double *xr, double &yy, double &w) const
+    {
+        for (int c = 0; c < NX; ++c)
+            xr[c] = x[i + (size_t)n * c];
+        yy = y[i];
+        w = sw ? sw[i] : 1.0;
+    }
+};
+
+template <class M>
+struct CpuEvaluator : MsEvaluator
+{
+    static constexpr int P = M::P;
+    RowsHost<M::NX> rows;
+    LmParams prm;
+    int jacmode;
+    const double *lupars;
+    SobolTable tab;
+    int run(MsBatch &b, int lo, int hi, double *out, bool) override
+    {
+        MsParams mp;
+        mp.prm = prm;
+        mp.prm.maxiter = b.maxiter;
+        mp.prm.gtol = 1e-3;
+        mp.dtol = b.dtol;
+        mp.n = rows.n;
+        mp.always_fit = b.always_fit;
+        for (int idx = lo; idx < hi; ++idx)
+        {
+            double st[P];
+            for (int k = 0; k < P; ++k)
+                st[k] = b.draw[idx] >= 0 ? sobol_to_range(sobol_coord(tab, (unsigned int)b.draw[idx], k), b.range[2 * k],
+                                                           b.range[2 * k + 1], b.kd[k])
+                                         : b.start[(size_t)idx * P + k];
+            MsRecord<P> rec;
+            if (jacmode == JAC_ANALYTIC)
+                ms_fit_point<M, JAC_ANALYTIC>(mp, rows, st, lupars, rec);
+            else if (jacmode == JAC_FORWARD)
+                ms_fit_point<M, JAC_FORWARD>(mp, rows, st, lupars, rec);
+            else
+                ms_fit_point<M, JAC_CENTER>(mp, rows, st, lupars, rec);
+            memcpy(out + (size_t)(idx - lo) * MsRecord<P>::K, &rec, sizeof(rec));
+        }
+        return 0;
+    }
+    int fetch(const double *src, bool, double *dst, size_t nd) override
+    {
+        memcpy(dst, src, sizeof(double) * nd);
+        return 0;
+    }
+};
+
+template <class M>
+static int mstart(int n, const double *x, const double *y, const double *sw, const double *start2p,
+                  const double *lupars, const int *ci, const double *cd, const int *has_start, int jac, int fvv,
+                  const MsComm &comm, double *mpopt, int *ints, double *dbls)
+{
+    constexpr int P = M::P;
+    CpuEvaluator<M> ev;
+    ev.rows = RowsHost<M::NX>{x, y, sw, n};
+    ev.prm.maxiter = ci[0];
+    ev.prm.trs = (ci[2] == 1) ? 1 : 0;
+    ev.prm.scale = ci[3];
+    ev.prm.fdtype = ci[5] ? 1 : 0;
+    ev.prm.jac_analytic = jac;
+    ev.prm.fvv_analytic = fvv;
+    ev.prm.has_bounds = lupars != nullptr;
+    ev.prm.has_weights = sw != nullptr;
+    ev.prm.bench_hold = 0;
+    ev.prm.factor_up = cd[0];
+    ev.prm.factor_down = cd[1];
+    ev.prm.avmax = cd[2];
+    ev.prm.h_df = cd[3];
+    ev.prm.h_fvv = cd[4];
+    ev.prm.xtol = cd[5];
+    ev.prm.ftol = cd[6];
+    ev.prm.gtol = cd[7];
+    ev.jacmode = jac ? JAC_ANALYTIC : (ci[5] ? JAC_CENTER : JAC_FORWARD);
+    ev.lupars = lupars;
+    sobol_build(ev.tab, P);
+    MsState m;
+    ms_init(m, P, ci, cd, start2p, has_start, lupars);
+    int rc = ms_major_loop(m, ev, comm, start2p);
+    if (rc)
+        return rc;
+    if (m.mssropt[1] < m.mssropt[0])
+    {
+        m.mssropt[0] = m.mssropt[1];
+        m.ssrconv[0] = m.ssrconv[1];
+        m.mpopt = m.mpopt1;
+    }
+    if (m.mssropt[0] < cd[6] || m.ssrconv[0] < cd[6])
+        m.mpopt[0] = lupars ? fmin(m.mpopt[0] + 1.0e-4, lupars[1]) : m.mpopt[0] + 1.0e-4;
+    for (int k = 0; k < P; ++k)
+        mpopt[k] = m.mpopt[k];
+    ints[0] = m.nsp;
+    ints[1] = m.nwsp;
+    ints[2] = m.mstarts;
+    ints[3] = m.mstop;
+    ints[4] = (int)m.total_fits;
+    ints[5] = (int)m.next_draw;
+    dbls[0] = m.mssropt[0];
+    dbls[1] = m.ssrconv[0];
+    return 0;
+}
+
+typedef int (*allgather_fn)(void *, int, int);
+
+extern "C" int hostsim_mstart(int model, int n, const double *x, const double *y, const double *sw,
+                              const double *start2p, const double *lupars, const int *ci, const double *cd,
+                              const int *has_start, int jac, int fvv, int rank, int world, allgather_fn fn,
+                              double *shard_buf, double *all_buf, long long cap_points, double *mpopt, int *ints,
+                              double *dbls)
+{
+    MsComm comm;
+    comm.rank = rank;
+    comm.world = world;
+    comm.allgather = fn;
+    comm.shard_buf = shard_buf;
+    comm.all_buf = all_buf;
+    comm.cap_points = cap_points;
+    comm.buffers_on_device = 0;
+    switch (model)
+    {
+    case 1:
+        return mstart<ModelExpDecay>(n, x, y, sw, start2p, lupars, ci, cd, has_start, jac, fvv, comm, mpopt, ints, dbls);
+    case 2:
+        return mstart<ModelMisra1a>(n, x, y, sw, start2p, lupars, ci, cd, has_start, jac, fvv, comm, mpopt, ints, dbls);
+    case 3:
+        return mstart<ModelGaussPeak>(n, x, y, sw, start2p, lupars, ci, cd, has_start, jac, fvv, comm, mpopt, ints, dbls);
+    default:
+        return -101;
+    }
+}
+
+extern "C" void hostsim_sobol(int dim, int first, int count, double *out)
+{
+    SobolTable t;
+    sobol_build(t, dim);
+    for (int i = 0; i < count; ++i)
+        for (int d = 0; d < dim; ++d)
+            out[(size_t)i * dim + d] = sobol_coord(t, (unsigned int)(first + i), d);
+}
+
+extern "C" int hostsim_mstart_batch(int n, const double *x, const double *y, const double *sw, const double *ranges,
+                                    const double *kd, long long first_draw, int count, int maxiter, double dtol,
+                                    const int *ci, const double *cd, int jac, double *records)
+{
+    using M = ModelMisra1a;
+    constexpr int P = M::P;
+    CpuEvaluator<M> ev;
+    ev.rows = RowsHost<M::NX>{x, y, sw, n};
+    ev.prm.maxiter = ci[0];
+    ev.prm.trs = 0;
+    ev.prm.scale = ci[3];
+    ev.prm.fdtype = ci[5] ? 1 : 0;
+    ev.prm.jac_analytic = jac;
+    ev.prm.fvv_analytic = 0;
+    ev.prm.has_bounds = 0;
+    ev.prm.has_weights = sw != nullptr;
+    ev.prm.bench_hold = 0;
+    ev.prm.factor_up = cd[0];
+    ev.prm.factor_down = cd[1];
+    ev.prm.avmax = cd[2];
+    ev.prm.h_df = cd[3];
+    ev.prm.h_fvv = cd[4];
+    ev.prm.xtol = cd[5];
+    ev.prm.ftol = cd[6];
+    ev.prm.gtol = cd[7];
+    ev.jacmode = jac ? JAC_ANALYTIC : (ci[5] ? JAC_CENTER : JAC_FORWARD);
+    ev.lupars = nullptr;
+    sobol_build(ev.tab, P);
+    MsBatch b;
+    b.count = count;
+    b.p = P;
+    b.K = MsRecord<P>::K;
+    b.draw.resize(count);
+    for (int i = 0; i < count; ++i)
+        b.draw[i] = first_draw + i;
+    b.start.assign((size_t)count * P, 0.0);
+    b.range.assign(ranges, ranges + 2 * P);
+    b.kd.assign(kd, kd + P);
+    b.maxiter = maxiter;
+    b.dtol = dtol;
+    b.always_fit = 0;
+    return ev.run(b, 0, count, records, false);
 }

@@ -53,3 +53,55 @@ def lm_solve(p, A_packed, diag, mu, rhs):
     f(_dp(np.ascontiguousarray(A_packed, dtype=np.float64)), _dp(np.ascontiguousarray(diag, dtype=np.float64)),
       float(mu), _dp(np.ascontiguousarray(rhs, dtype=np.float64)), _dp(sol))
     return sol
+
+
+ALLGATHER_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
+
+
+def mstart(model, p, x, y, start2p, ci, cd, has_start=None, jac=1, fvv=0, sw=None, lupars=None, rank=0, world=1,
+           allgather=None, shard_buf=None, all_buf=None, cap_points=0):
+    """product multi-start driver (mstart_driver.hpp) around the CPU evaluator; start2p is (2, p) [lower; upper]"""
+    n = len(y)
+    x = np.asfortranarray(np.asarray(x, dtype=np.float64).reshape(n, -1))
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    st = np.ascontiguousarray(np.asarray(start2p, dtype=np.float64).T.reshape(-1))
+    hs = np.ones(2 * p, dtype=np.int32) if has_start is None else np.ascontiguousarray(
+        np.asarray(has_start, dtype=np.int32).T.reshape(-1))
+    ci = np.ascontiguousarray(ci, dtype=np.int32)
+    cd = np.ascontiguousarray(cd, dtype=np.float64)
+    mpopt = np.zeros(p)
+    ints = np.zeros(8, dtype=np.int32)
+    dbls = np.zeros(4)
+    cb = ALLGATHER_T(allgather) if allgather is not None else C.cast(None, ALLGATHER_T)
+    f = lib().hostsim_mstart
+    f.argtypes = [C.c_int, C.c_int, DP, DP, DP, DP, DP, IP, DP, IP, C.c_int, C.c_int, C.c_int, C.c_int, ALLGATHER_T,
+                  DP, DP, C.c_longlong, DP, IP, DP]
+    rc = f(int(model), n, _dp(x), _dp(y), _dp(sw), _dp(st), _dp(lupars), ci.ctypes.data_as(IP), _dp(cd),
+           hs.ctypes.data_as(IP), int(jac), int(fvv), int(rank), int(world), cb, _dp(shard_buf), _dp(all_buf),
+           int(cap_points), _dp(mpopt), ints.ctypes.data_as(IP), _dp(dbls))
+    return dict(rc=rc, mpopt=mpopt, nsp=int(ints[0]), nwsp=int(ints[1]), iters=int(ints[2]), stop=int(ints[3]),
+                total_fits=int(ints[4]), draws=int(ints[5]), ssropt=dbls[0], ssrconv=dbls[1])
+
+
+def sobol(dim, count, first=0):
+    out = np.zeros((count, dim))
+    f = lib().hostsim_sobol
+    f.argtypes = [C.c_int, C.c_int, C.c_int, DP]
+    f(dim, first, count, _dp(out))
+    return out
+
+
+def mstart_batch_misra(x, y, ranges, kd, first_draw, count, maxiter, dtol, ci, cd, jac=1, sw=None):
+    """records (count x 14) of one concentration batch of the Misra1a/BoxBOD model on the CPU evaluator"""
+    n = len(y)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    rec = np.zeros((count, 14))
+    f = lib().hostsim_mstart_batch
+    f.argtypes = [C.c_int, DP, DP, DP, DP, DP, C.c_longlong, C.c_int, C.c_int, C.c_double, IP, DP, C.c_int, DP]
+    ci = np.ascontiguousarray(ci, dtype=np.int32)
+    cd = np.ascontiguousarray(cd, dtype=np.float64)
+    f(n, _dp(x), _dp(y), _dp(sw), _dp(np.ascontiguousarray(ranges, dtype=np.float64)),
+      _dp(np.ascontiguousarray(kd, dtype=np.float64)), int(first_draw), int(count), int(maxiter), float(dtol),
+      ci.ctypes.data_as(IP), _dp(cd), int(jac), _dp(rec))
+    return rec

@@ -1,0 +1,96 @@
+"""GPU parity of multi-start (BASELINE config C4: NIST BoxBOD, thousands of Sobol starts) through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = float(np.finfo(float).eps ** 0.25)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import gslnls_amd
+    from gslnls_amd import _lib
+    assert _lib.lib().gslnls_device_count() >= 1
+    return gslnls_amd
+
+
+def _boxbod(nist):
+    q = nist["BoxBOD"]
+    return q, np.array(q["data"]["x"]), np.array(q["data"]["y"]), np.array(list(q["target"].values()))
+
+
+def test_c4_concentration_batch_matches_cpu_evaluator(amd, gslref, hostsim, nist):
+    """8192 Sobol starts in b1 in [1,500], b2 in [0.01,5], mstart_p = 5 LM iterations each:
+    every per-point record from the GPU lanes equals the serial evaluation of the same routine"""
+    from gslnls_amd import _lib
+    from gslnls_amd.control import gsl_nls_control, pack_control
+    q, x, y, tgt = _boxbod(nist)
+    N = 8192
+    ctrl = gsl_nls_control(solver="cholesky")
+    ci, cd = pack_control(ctrl, "lm")
+    prob = amd.DenseProblem(2, 2, x, y)
+    ranges = np.array([1.0, 500.0, 0.01, 5.0])
+    kd = np.array([0.75, 0.75])
+    K = _lib.lib().gslnls_mstart_record_size(2)
+    rec = np.zeros((N, K))
+    ms = C.c_float(0)
+    rc = _lib.lib().gslnls_mstart_batch(prob._h, 1, ranges.ctypes.data_as(_lib.DP), kd.ctypes.data_as(_lib.DP), 0, N,
+                                        0, N, 5, 1e-6, ci.ctypes.data_as(_lib.IP), cd.ctypes.data_as(_lib.DP), None,
+                                        rec.ctypes.data_as(C.c_void_p), 0, C.byref(ms))
+    assert rc == 0
+    ref = hostsim.mstart_batch_misra(x, y, ranges, kd, 0, N, 5, 1e-6, ci, cd, jac=1)
+    # sampled points: Sobol + range transform, bit-exact integer part, pow() may differ in the last ulp
+    assert np.allclose(rec[:, 4:6], ref[:, 4:6], rtol=1e-14)
+    pts = gslref.sobol(2, N)
+    assert np.allclose(rec[:, 4], (np.power(1.0 + 499.0 * pts[:, 0] - 1.0 + 1.0, 0.75) - 1.0) / 0.75 + 1.0, rtol=1e-13)
+    fitted = ref[:, 8] > 1e-6
+    assert np.array_equal(rec[:, 8] > 1e-6, fitted)              # same det filter decisions
+    assert np.array_equal(rec[:, 11], ref[:, 11])                # same iteration counts
+    assert np.array_equal(rec[:, 12], ref[:, 12])                # same status codes
+    sel = fitted & np.isfinite(ref[:, 7])
+    assert np.allclose(rec[sel, 0:2], ref[sel, 0:2], rtol=1e-7, atol=1e-10)   # where each fit ended
+    assert np.allclose(rec[sel, 7], ref[sel, 7], rtol=1e-9)      # ssr
+    # a visible fraction of the starts lands in the wrong basin (ssr ~ 9771.5), the rest near ssr 1168.009
+    good = np.sum(np.abs(rec[sel, 7] - 1168.0088766) < 1.0)
+    assert good > 0.3 * N and np.sum(rec[sel, 7] > 5000) > 0
+    prob.close()
+
+
+CASES = [
+    dict(start=dict(b1=[200, 250], b2=[0, 1])),                                       # 4.1.1
+    dict(start=dict(b1=[200, 250], b2=1), weights=np.full(6, 10.0)),                  # 4.1.3
+    dict(start=dict(b1=200, b2=np.nan), lower=dict(b2=0)),                            # 4.1.4
+    dict(start=dict(b1=np.nan, b2=0.5), jac=True, upper=dict(b2=1)),                  # 4.1.5
+    dict(start=dict(b1=[200, 250], b2=np.nan), jac=True, lower=dict(b2=0), upper=dict(b2=1)),  # 4.1.7
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_unit_test_4_1_multistart(amd, gslref, nist, case):
+    """unit_tests_gslnls.R:137-156: gsl_nls() with start ranges / missing starts reaches the certified BoxBOD
+    optimum; the bookkeeping equals the oracle's sequential procedure"""
+    q, x, y, tgt = _boxbod(nist)
+    kw = dict(case)
+    start = kw.pop("start")
+    fit = amd.gsl_nls(q["formula"], data=q["data"], start=start,
+                      control=dict(mstart_n=5, mstart_q=1, mstart_r=1.1, solver="cholesky"), **kw)
+    assert fit["conv"] == 0
+    assert np.all(np.abs(fit["par"] - tgt) <= TOL)
+    assert fit["mstart"]["stop"] == 0 and fit["mstart"]["nsp"] >= 1
+
+
+def test_c4_full_multistart_matches_oracle(amd, gslref, nist):
+    """mstart_n = 8192 wide ranges: GPU batch + host commit vs the oracle's one-by-one loop"""
+    q, x, y, tgt = _boxbod(nist)
+    ctrlkw = dict(mstart_n=8192, mstart_q=819, solver="cholesky")
+    fit = amd.gsl_nls(q["formula"], data=q["data"], start=dict(b1=[1, 500], b2=[0.01, 5]), jac=True, control=ctrlkw)
+    o = gslref.nls(6, 2, [[1, 0.01], [500, 5]], rowdata=dict(model=gslref.MODEL_MISRA1A, x=x, y=y), use_jac=True,
+                   ctrl=gslref.control(**ctrlkw))
+    assert fit["conv"] == 0 and np.all(np.abs(fit["par"] - tgt) <= TOL)
+    m, mo = fit["mstart"], o["mstart"]
+    assert (m["nsp"], m["nwsp"], m["iters"], m["stop"]) == (mo["nsp"], mo["nwsp"], mo["iters"], mo["stop"])
+    assert abs(m["ssropt"] - mo["ssropt"]) <= 1e-7 * mo["ssropt"]
+    assert np.max(np.abs(fit["par"] - o["par"]) / np.abs(o["par"])) < 1e-6
