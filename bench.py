@@ -64,6 +64,72 @@ def cpu_baseline(x, y, budget_s=20.0):
                 niter_per_fit=out["niter"], par=[float(v) for v in out["par"]])
 
 
+BOXBOD_X = [1.0, 2.0, 3.0, 5.0, 7.0, 10.0]          # NIST BoxBOD (R/nls_test.R:790-791)
+BOXBOD_Y = [109.0, 149.0, 149.0, 191.0, 213.0, 224.0]
+
+
+def multistart_bench(L, _lib, torch, dist, rank, world, steps, warmup):
+    """C4: concentration fits/sec of multi-start (src/nls_mstart.c:42-128) on NIST BoxBOD, Sobol starts in
+    b1 in [1,500], b2 in [0.01,5], mstart_p = 5 LM iterations each, analytic Jacobian; the points of a batch are
+    sharded over the ranks in contiguous blocks and completed with ONE all-gather of the records (RCCL)."""
+    from gslnls_amd.control import gsl_nls_control, pack_control
+    x = np.asfortranarray(np.array(BOXBOD_X).reshape(6, 1))
+    y = np.array(BOXBOD_Y)
+    model = _lib.Model(2, 2, 1, x.ctypes.data_as(C.c_void_p), 0)
+    err = C.c_int(0)
+    h = L.gslnls_dense_create(C.byref(model), y.ctypes.data_as(C.c_void_p), 6, None, C.byref(err))
+    ci, cd = pack_control(gsl_nls_control(solver="cholesky"), "lm")
+    ranges = np.array([1.0, 500.0, 0.01, 5.0])
+    kd = np.array([0.75, 0.75])
+    K = L.gslnls_mstart_record_size(2)
+    out = {}
+    for label, total in (("strong_8192_total", 8192), ("weak_65536_per_gpu", 65536 * world)):
+        per = (total + world - 1) // world
+        lo, hi = min(total, rank * per), min(total, rank * per + per)
+        shard = torch.zeros(per * K, dtype=torch.float64, device="cuda")
+        allb = torch.zeros(world * per * K, dtype=torch.float64, device="cuda") if world > 1 else shard
+        ms = C.c_float(0)
+        kms = []
+
+        def step():
+            rc = L.gslnls_mstart_batch(h, 1, ranges.ctypes.data_as(_lib.DP), kd.ctypes.data_as(_lib.DP), 0, total,
+                                       lo, hi, 5, 1e-6, ci.ctypes.data_as(_lib.IP), cd.ctypes.data_as(_lib.DP), None,
+                                       C.c_void_p(shard.data_ptr()), 1, C.byref(ms))
+            if rc != 0:
+                raise SystemExit("mstart batch failed: %d" % rc)
+            kms.append(ms.value)
+            if world > 1:
+                dist.all_gather_into_tensor(allb, shard)
+        for _ in range(warmup):
+            step()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        kms.clear()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        rec = allb[:total * K].view(total, K).cpu().numpy()
+        fitted = rec[:, 3 * 2 + 2] > 1e-6
+        good = int(np.sum(np.abs(rec[fitted, 3 * 2 + 1] - 1168.0088766) < 1.0))
+        out[label] = {"fits_per_s": total * steps / el, "points_per_batch": total, "ms_per_batch": el / steps * 1e3,
+                      "kernel_ms_per_batch_rank0": float(np.mean(kms)), "points_passing_det_filter": int(fitted.sum()),
+                      "points_in_global_basin_after_5_iters": good}
+    L.gslnls_dense_destroy(h)
+    out["metric"] = "multi-start concentration fits/s (BoxBOD n=6 p=2, 5 LM iterations each, all-gather of records)"
+    out["note"] = ("working set is 96 B per fit: bound by fp64 VALU + exp latency and by launch/collective latency, "
+                   "an HBM fraction is not meaningful (SURVEY.md 8(d))")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,6 +248,7 @@ def main():
                      "kernel": "lm_step_kernel<ModelExpDecay>", "bytes_per_launch": alg_bytes,
                      "ms_per_launch": ms_launch},
     }
+    line["multistart"] = multistart_bench(L, _lib, torch, dist, rank, world, max(5, args.steps // 4), 3)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(x, y)
     elif rank == 0:

@@ -25,7 +25,8 @@ struct MsKernelArgs
     const double *x[4];
     const double *y;
     const double *sw;
-    const long long *draw; // per point, -1 = explicit start
+    const long long *draw; // per point, -1 = explicit start; nullptr = consecutive draws first_draw + idx
+    long long first_draw;
     const double *start;   // count x P
     double *records;       // count x K
     const SobolTable *sobol;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(MS_T) void ms_fit_kernel(MsKernelArgs<M::P> a)
     if (idx >= a.hi)
         return;
     double start[P];
-    const long long d = a.draw[idx];
+    const long long d = a.draw ? a.draw[idx] : a.first_draw + idx;
 #pragma unroll
     for (int k = 0; k < P; ++k)
     {

@@ -10,6 +10,7 @@
 #include "../../include/gslnls_core.h"
 #include "dense_host.hpp"
 #include "mstart_host.hpp"
+#include "formula.hpp"
 
 using namespace gslnls;
 
@@ -117,6 +118,24 @@ int gslnls_debug_stamps(gslnls_dense *h, int jac, const double *theta, int warm,
     return h->impl->debug_stamps(jac, theta, warm, out, nrows);
 }
 #endif
+
+int gslnls_lower_formula(const char *rhs, int p, const char *const *parnames, int *par_order, char *varnames_out,
+                          int varnames_cap)
+{
+    if (!rhs || p < 1 || !parnames || !par_order)
+        return 0;
+    std::vector<std::string> vars;
+    const int id = lower_formula(rhs, p, parnames, par_order, vars);
+    if (id > 0 && varnames_out && varnames_cap > 0)
+    {
+        std::string joined;
+        for (size_t i = 0; i < vars.size(); ++i)
+            joined += (i ? "," : "") + vars[i];
+        strncpy(varnames_out, joined.c_str(), (size_t)varnames_cap - 1);
+        varnames_out[varnames_cap - 1] = 0;
+    }
+    return id;
+}
 
 int gslnls_set_comm(int rank, int world, gslnls_allgather_fn fn, void *ctx, double *shard_buf, double *all_buf,
                     long long cap_points, int buffers_on_device)

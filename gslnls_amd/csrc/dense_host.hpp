@@ -90,6 +90,7 @@ struct DenseFit : DenseBase
     double *d_resid = nullptr, *d_grad = nullptr, *d_covar = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    MsEvaluator *ms_eval = nullptr; // cached batch evaluator (Sobol table, device buffers)
 
     int init(const gslnls_model *fn, const double *y, int n_, const double *swts)
     {
@@ -150,6 +151,7 @@ struct DenseFit : DenseBase
 
     ~DenseFit() override
     {
+        delete ms_eval;
         if (owns_data)
         {
             hipFree(d_x);

@@ -221,6 +221,20 @@ REGISTRY = {
 }
 
 
+def lower_c(rhs_text, param_names):
+    """The same lowering through the C ABI (gslnls_lower_formula, csrc/formula.hpp) -- what the R shim calls."""
+    import ctypes as C
+    from . import _lib
+    p = len(param_names)
+    arr = (C.c_char_p * p)(*[s.encode() for s in param_names])
+    order = (C.c_int * p)()
+    buf = C.create_string_buffer(256)
+    mid = _lib.lib().gslnls_lower_formula(rhs_text.encode(), p, arr, order, buf, 256)
+    if mid <= 0:
+        return None
+    return mid, list(order), buf.value.decode().split(",")
+
+
 def lower(rhs, param_names):
     """Find the registered device model for AST `rhs`.
 

@@ -58,6 +58,7 @@ def _normalise_start(start, parnames_hint=None):
                 raise ValueError("List elements of 'start' must be of length 1 or 2 to specify (multi-start) "
                                  "parameter values or ranges")
             mat = np.stack([np.repeat(v, 2) if len(v) == 1 else v for v in vals], axis=1)  # 2 x p
+            vec = None
         else:
             vec = np.array([v[0] for v in vals])
             mat = None

@@ -103,6 +103,16 @@ int gslnls_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv,
                const int *control_int, const double *control_dbl, const int *has_start, int loss_rho,
                const double *loss_cc, gslnls_result *out);
 
+/*
+ * Model lowering: match the deparsed right-hand side of the model formula (formula[[3]], R/nls.R:565)
+ * against the device registry, up to renaming of parameters / data columns and parameter order.
+ * Returns the GSLNLS_MODEL_* id (> 0) or 0 when the expression is not registered.
+ *   par_order[k]  = index into parnames of the k-th device parameter
+ *   varnames_out  = comma-separated data-column names in device regressor order
+ */
+int gslnls_lower_formula(const char *rhs, int p, const char *const *parnames, int *par_order, char *varnames_out,
+                         int varnames_cap);
+
 /* ---- resident-data API: the same solve with the data already in HBM -------------------
  * (what bench.py times: H2D once at create, then repeated solves) */
 typedef struct gslnls_dense gslnls_dense;

@@ -1,0 +1,182 @@
+/*
+ * gslnls_hip_shim.c -- the reference-side binding: what a gslnls maintainer adds to src/ so
+ * that .Call(C_nls, ...) runs on the MI355X core instead of GSL.
+ *
+ * NOT compiled in this repository's image (no R.h / Rinternals.h here).  It is the
+ * complete translation unit a maintainer would drop next to src/nls.c and register in src/init.c
+ * in place of C_nls:    {"C_nls", (DL_FUNC) &C_nls_hip, 12}
+ * Everything it does is SEXP <-> plain-pointer translation, in the order src/nls.c:66-263 unpacks
+ * and src/nls.c:632-812 packs; no numerics.
+ *
+ * Build (inside the R package):  PKG_LIBS += -L$(GSLNLS_HIP_LIB) -lgslnls_hip
+ */
+#define R_NO_REMAP
+#include <R.h>
+#include <Rinternals.h>
+#include <string.h>
+#include "gslnls_core.h"
+
+/* original entry, kept as the path for models that do not lower (src/nls.c:54) */
+SEXP C_nls(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP swts, SEXP lupars,
+           SEXP control_int, SEXP control_dbl, SEXP has_start, SEXP loss_config);
+
+static SEXP deparse_rhs(SEXP fn)
+{
+    /* .fn <- function(par, .data = mf) eval(formula[[3]], ...)  (R/nls.R:565): the closure's
+     * environment holds `formula` and the model frame `mf` */
+    SEXP cloenv = CLOENV(fn);
+    SEXP formula = Rf_findVar(Rf_install("formula"), cloenv);
+    if (formula == R_UnboundValue || Rf_length(formula) < 3)
+        return R_NilValue;
+    SEXP call = PROTECT(Rf_lang2(Rf_install("deparse1"), Rf_lang2(Rf_install("quote"), CADDR(formula))));
+    SEXP txt = PROTECT(Rf_eval(call, R_BaseEnv));
+    UNPROTECT(2);
+    return txt;
+}
+
+SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP swts, SEXP lupars,
+               SEXP control_int, SEXP control_dbl, SEXP has_start, SEXP loss_config)
+{
+    const int n = Rf_length(y);
+    const int mstart = Rf_isMatrix(start);                       /* src/nls.c:79 */
+    const int p = mstart ? Rf_ncols(start) : Rf_length(start);
+    SEXP parnames = mstart ? VECTOR_ELT(Rf_getAttrib(start, R_DimNamesSymbol), 1)
+                           : Rf_getAttrib(start, R_NamesSymbol); /* src/nls.c:158-161 */
+
+    /* ---- model lowering: formula RHS -> registry id, parameter order, data columns ---- */
+    SEXP rhs = deparse_rhs(fn);
+    const char *pn[64];
+    int order[64];
+    char cols[256];
+    int model_id = 0;
+    if (rhs != R_NilValue && p <= 64 && !Rf_isNull(parnames))
+    {
+        for (int k = 0; k < p; k++)
+            pn[k] = CHAR(STRING_ELT(parnames, k));
+        model_id = gslnls_lower_formula(CHAR(STRING_ELT(rhs, 0)), p, pn, order, cols, sizeof(cols));
+    }
+    if (model_id <= 0 || Rf_isMatrix(swts) ||                    /* not registered, or GLS weights */
+        INTEGER(control_int)[2] > 1)                             /* dogleg / ddogleg / subspace2D */
+        return C_nls(fn, y, jac, fvv, env, start, swts, lupars, control_int, control_dbl, has_start, loss_config);
+
+    /* data columns from the model frame, column-major n x nx in device regressor order */
+    SEXP mf = Rf_findVar(Rf_install("mf"), CLOENV(fn));
+    int nx = 1;
+    for (const char *c = cols; *c; c++)
+        nx += (*c == ',');
+    double *X = (double *)R_alloc((size_t)n * nx, sizeof(double));
+    {
+        char buf[256];
+        strncpy(buf, cols, sizeof(buf));
+        int c = 0;
+        for (char *tok = strtok(buf, ","); tok; tok = strtok(NULL, ","), c++)
+        {
+            SEXP col = PROTECT(Rf_coerceVector(Rf_eval(Rf_install(tok), mf == R_UnboundValue ? env : mf), REALSXP));
+            memcpy(X + (size_t)c * n, REAL(col), sizeof(double) * n);
+            UNPROTECT(1);
+        }
+    }
+    gslnls_model model = {model_id, p, nx, X, 0};
+
+    /* start / bounds / has_start permuted into device parameter order */
+    double *st = (double *)R_alloc(2 * p, sizeof(double)), *lu = NULL;
+    int *hs = (int *)R_alloc(2 * p, sizeof(int));
+    SEXP startvec = PROTECT(Rf_coerceVector(start, REALSXP));
+    for (int k = 0; k < p; k++)
+    {
+        if (mstart)
+        {
+            st[2 * k] = REAL(startvec)[2 * order[k]];
+            st[2 * k + 1] = REAL(startvec)[2 * order[k] + 1];
+            hs[2 * k] = LOGICAL(has_start)[2 * order[k]];
+            hs[2 * k + 1] = LOGICAL(has_start)[2 * order[k] + 1];
+        }
+        else
+            st[k] = REAL(startvec)[order[k]];
+    }
+    if (Rf_isMatrix(lupars))
+    {
+        lu = (double *)R_alloc(2 * p, sizeof(double));
+        for (int k = 0; k < p; k++)
+        {
+            lu[2 * k] = REAL(lupars)[2 * order[k]];
+            lu[2 * k + 1] = REAL(lupars)[2 * order[k] + 1];
+        }
+    }
+
+    /* outputs (src/nls.c:632-812) */
+    const int niter = INTEGER(control_int)[0], verbose = INTEGER(control_int)[1];
+    const int wgt_i = INTEGER(VECTOR_ELT(loss_config, 0))[0];
+    const char *nms14[] = {"par", "covar", "resid", "grad", "niter", "status", "conv", "ssr", "ssrtol",
+                           "algorithm", "neval", "irls", "partrace", "ssrtrace", ""};
+    const char *nms12[] = {"par", "covar", "resid", "grad", "niter", "status", "conv", "ssr", "ssrtol",
+                           "algorithm", "neval", "irls", ""};
+    SEXP ans = PROTECT(Rf_mkNamed(VECSXP, verbose ? nms14 : nms12));
+    SEXP par = PROTECT(Rf_allocVector(REALSXP, p)), cov = PROTECT(Rf_allocMatrix(REALSXP, p, p));
+    SEXP resid = PROTECT(Rf_allocVector(REALSXP, n)), grad = PROTECT(Rf_allocMatrix(REALSXP, n, p));
+    double *par_d = (double *)R_alloc(p, sizeof(double)), *cov_d = (double *)R_alloc(p * p, sizeof(double));
+    double *grad_d = (double *)R_alloc((size_t)n * p, sizeof(double));
+    gslnls_result res;
+    memset(&res, 0, sizeof(res));
+    res.par = par_d;
+    res.covar = cov_d;
+    res.resid = REAL(resid);
+    res.grad = grad_d;
+    SEXP ptrace = R_NilValue, strace = R_NilValue;
+    double *ptrace_d = NULL;
+    if (verbose)
+    {
+        ptrace = PROTECT(Rf_allocMatrix(REALSXP, niter + 1, p));
+        strace = PROTECT(Rf_allocVector(REALSXP, niter + 1));
+        ptrace_d = (double *)R_alloc((size_t)(niter + 1) * p, sizeof(double));
+        res.partrace = ptrace_d;
+        res.ssrtrace = REAL(strace);
+    }
+
+    const int rc = gslnls_nls(&model, REAL(y), n, !Rf_isNull(jac), !Rf_isNull(fvv), st, mstart,
+                              Rf_isNull(swts) ? NULL : REAL(swts), 0, lu, INTEGER(control_int), REAL(control_dbl),
+                              hs, wgt_i, REAL(VECTOR_ELT(loss_config, 1)), &res);
+    if (rc <= GSLNLS_E_NODEVICE) /* no device / not lowered after all: the GSL path still exists */
+    {
+        UNPROTECT(verbose ? 8 : 6);
+        return C_nls(fn, y, jac, fvv, env, start, swts, lupars, control_int, control_dbl, has_start, loss_config);
+    }
+
+    /* back to the caller's parameter order */
+    for (int k = 0; k < p; k++)
+    {
+        REAL(par)[order[k]] = par_d[k];
+        for (int j = 0; j < p; j++)
+            REAL(cov)[order[k] + p * order[j]] = cov_d[k + p * j];
+        memcpy(REAL(grad) + (size_t)n * order[k], grad_d + (size_t)n * k, sizeof(double) * n);
+        if (verbose)
+            memcpy(REAL(ptrace) + (size_t)(niter + 1) * order[k], ptrace_d + (size_t)(niter + 1) * k,
+                   sizeof(double) * (niter + 1));
+    }
+    Rf_setAttrib(par, R_NamesSymbol, parnames);
+    SET_VECTOR_ELT(ans, 0, par);
+    SET_VECTOR_ELT(ans, 1, cov);
+    SET_VECTOR_ELT(ans, 2, resid);
+    SET_VECTOR_ELT(ans, 3, grad);
+    SET_VECTOR_ELT(ans, 4, Rf_ScalarInteger(res.niter));
+    SET_VECTOR_ELT(ans, 5, Rf_mkString(gslnls_strerror(res.conv)));
+    SET_VECTOR_ELT(ans, 6, Rf_ScalarInteger(res.conv));
+    SET_VECTOR_ELT(ans, 7, Rf_ScalarReal(res.ssr));
+    SET_VECTOR_ELT(ans, 8, Rf_ScalarReal(res.ssrtol));
+    SET_VECTOR_ELT(ans, 9, Rf_mkString(gslnls_algorithm_name(INTEGER(control_int)[2])));
+    {
+        const char *en[] = {"f", "J", "fvv", ""};
+        SEXP ne = PROTECT(Rf_mkNamed(INTSXP, en));
+        for (int k = 0; k < 3; k++)
+            INTEGER(ne)[k] = res.neval[k];
+        SET_VECTOR_ELT(ans, 10, ne);
+        UNPROTECT(1);
+    }
+    if (verbose)
+    {
+        SET_VECTOR_ELT(ans, 12, ptrace);
+        SET_VECTOR_ELT(ans, 13, strace);
+    }
+    UNPROTECT(verbose ? 8 : 6);
+    return ans;
+}

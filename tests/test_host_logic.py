@@ -144,6 +144,13 @@ def test_formula_lowering():
     _, rhs = F.parse_formula("y ~ b1*x**b2")
     assert F.lower(rhs, ["b1", "b2"]) is None
     # R precedence: -x^2 is -(x^2); ** is ^; 2^-1
+    # the C ABI lowering (what the R shim calls) agrees with the Python one
+    for txt, names in [("A * exp(-lam * x) + b", ["A", "lam", "b"]), ("amp*exp(-rate*t)+off", ["off", "amp", "rate"]),
+                       ("b1*(1-exp(-b2*x))", ["b1", "b2"]), ("a * exp(-(x - b)^2 / (2 * c^2))", ["a", "b", "c"]),
+                       ("b1*exp( -b2*x ) + b3*exp( -(x-b4)**2 / b5**2 ) + b6*exp( -(x-b7)**2 / b8**2 )",
+                        ["b%d" % i for i in range(1, 9)]), ("b1*x**b2", ["b1", "b2"]), ("b1*(1-exp(-b2*x", ["b1", "b2"])]:
+        py = F.lower(F.parse_expr(txt), names) if txt.count("(") == txt.count(")") else None
+        assert F.lower_c(txt, names) == (None if py is None else (py[0], py[1], py[2]))
     assert F.evaluate(F.parse_expr("-x^2"), {"x": 3.0}) == -9.0
     assert F.evaluate(F.parse_expr("2**-1 + 2^3^2"), {}) == 0.5 + 512.0
     assert abs(F.evaluate(F.parse_expr("atan(1)*4/pi"), {}) - 1.0) < 1e-15
@@ -165,3 +172,24 @@ def test_control_packing_matches_appendix_c(gslref):
         assert gsl_nls_loss("barron", cc=[2.5, 1.345])["cc"]["alpha"] == 2.0
     with pytest.raises(ValueError):
         gsl_nls_control(scale="nope")
+
+
+def test_start_and_bounds_normalisation():
+    """R/nls.R:399-437 (start vector / list / ranges / NA -> (-0.1, 0.75) + has_start) and :539-559 (bounds)"""
+    from gslnls_amd.nls import _normalise_start, _bounds
+    names, vec, mat, hs = _normalise_start(dict(b1=500, b2=1e-4))
+    assert names == ["b1", "b2"] and mat is None and list(vec) == [500, 1e-4]
+    names, vec, mat, hs = _normalise_start(dict(b1=[200, 250], b2=1))
+    assert vec is None and mat.tolist() == [[200, 1], [250, 1]] and hs.all()
+    names, vec, mat, hs = _normalise_start(dict(b1=200, b2=np.nan))
+    assert mat.tolist() == [[200, -0.1], [200, 0.75]] and hs.tolist() == [[True, False], [True, False]]
+    names, vec, mat, hs = _normalise_start(dict(b1=[200, 250], b2=np.nan))
+    assert mat.tolist() == [[200, -0.1], [250, 0.75]] and hs.tolist() == [[True, False], [True, False]]
+    names, vec, mat, hs = _normalise_start(dict(b1=[-0.5, -0.5], b2=[1, 1]))   # degenerate ranges -> single start
+    assert mat is None and list(vec) == [-0.5, 1]
+    with pytest.raises(ValueError):
+        _normalise_start(dict(b1=[3, 1], b2=1))
+    lu = _bounds(dict(b1=250), dict(b2=1), ["b1", "b2"])
+    assert lu.tolist() == [250, np.inf, -np.inf, 1]
+    assert _bounds(0, 250, ["a", "b"]).tolist() == [0, 250, 0, 250]
+    assert _bounds(None, None, ["a"]) is None
