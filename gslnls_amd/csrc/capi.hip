@@ -11,6 +11,7 @@
 #include "dense_host.hpp"
 #include "mstart_host.hpp"
 #include "formula.hpp"
+#include "irls_host.hpp"
 
 using namespace gslnls;
 
@@ -186,11 +187,10 @@ int gslnls_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv,
                const int *control_int, const double *control_dbl, const int *has_start, int loss_rho,
                const double *loss_cc, gslnls_result *out)
 {
-    (void)loss_cc;
     if (swts && swts_is_matrix)
         return GSLNLS_E_UNSUPPORTED; // GLS: n x n factor, not lowered
-    if (loss_rho != 0)
-        return GSLNLS_E_UNSUPPORTED; // IRLS
+    if (loss_rho != 0 && start_is_matrix)
+        return GSLNLS_E_UNSUPPORTED; // robust multi-start second pass (src/nls.c:401-509): next round
     int err = 0;
     DenseBase *b = make_dense(fn, y, n, swts, &err);
     if (!b)
@@ -198,6 +198,8 @@ int gslnls_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv,
     int rc;
     if (start_is_matrix)
         rc = b->mstart(jac, fvv, start, lupars, control_int, control_dbl, has_start, g_comm, out);
+    else if (loss_rho != 0)
+        rc = b->irls(jac, fvv, start, lupars, control_int, control_dbl, loss_rho, loss_cc, out);
     else
         rc = b->solve(jac, fvv, start, lupars, control_int, control_dbl, 0, out);
     delete b;

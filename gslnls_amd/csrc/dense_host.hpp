@@ -42,6 +42,7 @@ inline LmParams make_params(const int *ci, const double *cd, int jac, int fvv, b
     prm.has_bounds = has_bounds ? 1 : 0;
     prm.has_weights = has_w ? 1 : 0;
     prm.bench_hold = 0;
+    prm.chisq_in = NAN;
     prm.factor_up = cd[0];
     prm.factor_down = cd[1];
     prm.avmax = cd[2];
@@ -58,6 +59,9 @@ struct DenseBase
     virtual ~DenseBase() {}
     virtual int solve(int jac, int fvv, const double *start, const double *lupars, const int *ci, const double *cd,
                       int chunk, gslnls_result *out) = 0;
+    // robust loss: IRLS around the dense solve (src/nls_irls.c:412-546, src/nls.c:577-596)
+    virtual int irls(int jac, int fvv, const double *start, const double *lupars, const int *ci, const double *cd,
+                     int loss_rho, const double *loss_cc, gslnls_result *out) = 0;
     virtual float time_pass(int jac, const double *theta, int reps) = 0;
     virtual int set_swts(const double *swts) = 0;
     // multi-start branch of C_nls (src/nls.c:274-532) followed by the final single-start solve
@@ -234,17 +238,19 @@ struct DenseFit : DenseBase
         }
     }
 
-    int solve(int jac, int fvv, const double *start, const double *lupars, const int *ci, const double *cd, int chunk,
-              gslnls_result *out) override
+    // ---- pieces of one fit -------------------------------------------------------------------
+    int last_parity = 0;
+    long long last_launches = 0;
+    float last_ms = 0.f;
+
+    int prepare(int jac, int fvv, const double *lupars, const int *ci, const double *cd, bool trace)
     {
         if (ci[2] > 1)
             return GSLNLS_E_UNSUPPORTED; // dogleg / ddogleg / subspace2D are not lowered
         if (fvv && !M::HAS_FVV)
             return GSLNLS_E_UNSUPPORTED;
-        const int jacmode = jac ? JAC_ANALYTIC : (ci[5] ? JAC_CENTER : JAC_FORWARD);
         ctx.prm = make_params(ci, cd, jac, fvv, lupars != nullptr, ctx.sw != nullptr);
         const int maxiter = ctx.prm.maxiter;
-        const bool trace = ci[1] != 0 && out->ssrtrace && out->partrace;
         if (trace)
         {
             if (trace_cap < maxiter + 1)
@@ -255,9 +261,6 @@ struct DenseFit : DenseBase
                 GSLNLS_HIP_OK(hipMalloc(&d_partrace, sizeof(double) * (size_t)(maxiter + 1) * P));
                 trace_cap = maxiter + 1;
             }
-            // NaN-fill so rows of iterations that never ran stay NA like the reference's allocMatrix
-            GSLNLS_HIP_OK(hipMemsetAsync(d_ssrtrace, 0xFF, sizeof(double) * (maxiter + 1), stream));
-            GSLNLS_HIP_OK(hipMemsetAsync(d_partrace, 0xFF, sizeof(double) * (size_t)(maxiter + 1) * P, stream));
             ctx.ssrtrace = d_ssrtrace;
             ctx.partrace = d_partrace;
         }
@@ -266,7 +269,20 @@ struct DenseFit : DenseBase
             ctx.ssrtrace = nullptr;
             ctx.partrace = nullptr;
         }
+        return GSLNLS_SUCCESS;
+    }
 
+    // device-resident LM loop from `start` with the current ctx (prm, sw, traces); on return the final
+    // state is in h_state[0] (written by the device through the mapped mirror) and in ctx.state[last_parity]
+    int run_loop(int jacmode, const double *start, const double *lupars, int chunk)
+    {
+        const int maxiter = ctx.prm.maxiter;
+        if (ctx.ssrtrace)
+        {
+            // NaN-fill so rows of iterations that never ran stay NA like the reference's allocMatrix
+            GSLNLS_HIP_OK(hipMemsetAsync(d_ssrtrace, 0xFF, sizeof(double) * (maxiter + 1), stream));
+            GSLNLS_HIP_OK(hipMemsetAsync(d_partrace, 0xFF, sizeof(double) * (size_t)(maxiter + 1) * P, stream));
+        }
         GSLNLS_HIP_OK(hipEventRecord(ev0, stream));
         // brand-new state is built on device in slot 1; the first step launch has parity 0 and reads slot 1
         {
@@ -280,9 +296,8 @@ struct DenseFit : DenseBase
             h_state[0].phase = PH_INIT;
             hipLaunchKernelGGL((lm_reset_kernel<P>), dim3(1), dim3(64), 0, stream, ctx, sa);
         }
-
         if (chunk <= 0)
-            chunk = 8;
+            chunk = 16;
         // upper bound on launches: every iteration may take 16 trials (x2 passes with acceleration) + init
         const long long max_launches = ((long long)maxiter * 17 + 2) * (ctx.prm.trs ? 2 : 1) + chunk;
         long long launches = 0;
@@ -302,10 +317,19 @@ struct DenseFit : DenseBase
                 return GSLNLS_FAILURE;
         }
         GSLNLS_HIP_OK(hipEventRecord(ev1, stream));
-        const int last = parity ^ 1;
-        const LmState<P> &s = h_state[0];
-        const bool ok = (s.status == ST_SUCCESS || s.status == ST_EMAXITER);
+        GSLNLS_HIP_OK(hipEventSynchronize(ev1));
+        hipEventElapsedTime(&last_ms, ev0, ev1);
+        last_parity = parity ^ 1;
+        last_launches = launches;
+        return GSLNLS_SUCCESS;
+    }
 
+    // resid / grad / covar / traces / scalars -> gslnls_result, like src/nls.c:648-753
+    int pack(int jacmode, const double *start, gslnls_result *out, bool trace)
+    {
+        const LmState<P> &s = h_state[0];
+        const int maxiter = ctx.prm.maxiter;
+        const bool ok = (s.status == ST_SUCCESS || s.status == ST_EMAXITER);
         const bool want_vecs = ok && (out->resid || out->grad);
         if (want_vecs || (ok && out->covar))
         {
@@ -313,7 +337,8 @@ struct DenseFit : DenseBase
                 GSLNLS_HIP_OK(hipMalloc(&d_resid, sizeof(double) * (size_t)n));
             if (out->grad && !d_grad)
                 GSLNLS_HIP_OK(hipMalloc(&d_grad, sizeof(double) * (size_t)n * P));
-            launch_finalize(jacmode, last, out->resid ? d_resid : nullptr, out->grad ? d_grad : nullptr, d_covar);
+            launch_finalize(jacmode, last_parity, out->resid ? d_resid : nullptr, out->grad ? d_grad : nullptr,
+                            d_covar);
             if (out->resid)
                 GSLNLS_HIP_OK(hipMemcpyAsync(out->resid, d_resid, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost,
                                              stream));
@@ -332,10 +357,6 @@ struct DenseFit : DenseBase
                                          hipMemcpyDeviceToHost, stream));
         }
         GSLNLS_HIP_OK(hipStreamSynchronize(stream));
-        float ms = 0.f;
-        hipEventElapsedTime(&ms, ev0, ev1);
-
-        // pack like src/nls.c:648-753
         for (int k = 0; k < P; ++k)
             if (out->par)
                 out->par[k] = ok ? s.x[k] : start[k];
@@ -360,10 +381,28 @@ struct DenseFit : DenseBase
         out->neval[1] = s.nevaldf;
         out->neval[2] = s.nevalfvv;
         out->chisq_init = s.chisq_init;
-        out->loop_ms = ms;
-        out->n_launches = (int)launches;
+        out->loop_ms = last_ms;
+        out->n_launches = (int)last_launches;
         return s.status;
     }
+
+    int solve(int jac, int fvv, const double *start, const double *lupars, const int *ci, const double *cd, int chunk,
+              gslnls_result *out) override
+    {
+        const bool trace = ci[1] != 0 && out->ssrtrace && out->partrace;
+        int rc = prepare(jac, fvv, lupars, ci, cd, trace);
+        if (rc)
+            return rc;
+        ctx.prm.chisq_in = NAN;
+        const int jacmode = jac ? JAC_ANALYTIC : (ci[5] ? JAC_CENTER : JAC_FORWARD);
+        rc = run_loop(jacmode, start, lupars, chunk);
+        if (rc)
+            return rc;
+        return pack(jacmode, start, out, trace);
+    }
+
+    int irls(int jac, int fvv, const double *start, const double *lupars, const int *ci, const double *cd, int loss_rho,
+             const double *loss_cc, gslnls_result *out) override;
 
     int mstart(int jac, int fvv, const double *start2p, const double *lupars, const int *ci, const double *cd,
                const int *has_start, const MsComm &comm, gslnls_result *out) override;

@@ -67,6 +67,9 @@ struct LmParams
     int has_weights;  // !Rf_isNull(swts)
     int bench_hold;   // timing mode of the library's own benchmark hook; 0 in every fit
     double factor_up, factor_down, avmax, h_df, h_fvv, xtol, ftol, gtol;
+    // driver2 starts every iteration with chisq0 <- chisq1; callers that re-enter it with a stale chisq1
+    // (IRLS restarts, src/nls_irls.c:447-464) pass that value here; NaN = use the ssr at the start point
+    double chisq_in;
 };
 
 template <int P>
@@ -573,7 +576,8 @@ GSLNLS_HD void lm_advance(LmState<P> &s, const PassSums<P> &r, const LmParams &p
         s.mu = 1.0e-3 * mx * mx;
         s.nu = 2.0;
         s.avratio = 0.0;
-        s.chisq_init = s.chisq0 = s.chisq1 = r.ssr;
+        s.chisq_init = r.ssr;
+        s.chisq0 = s.chisq1 = (prm.chisq_in == prm.chisq_in) ? prm.chisq_in : r.ssr;
         s.niter = 0;
         s.bad_steps = 0;
         lm_begin_step(s, prm);

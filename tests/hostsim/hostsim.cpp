@@ -11,6 +11,7 @@
 #include "rowops.hpp"
 #include "batch_core.hpp"
 #include "mstart_driver.hpp"
+#include "irls_core.hpp"
 
 using namespace gslnls;
 
@@ -62,6 +63,7 @@ static int fit(int n, const double *x, const double *y, const double *sw, const 
     prm.has_bounds = lupars != nullptr;
     prm.has_weights = sw != nullptr;
     prm.bench_hold = 0;
+    prm.chisq_in = NAN;
     prm.factor_up = cd[0];
     prm.factor_down = cd[1];
     prm.avmax = cd[2];
@@ -228,6 +230,8 @@ static int mstart(int n, const double *x, const double *y, const double *sw, con
     ev.prm.has_bounds = lupars != nullptr;
     ev.prm.has_weights = sw != nullptr;
     ev.prm.bench_hold = 0;
+    ev.prm.chisq_in = NAN;
+    ev.prm.chisq_in = NAN;
     ev.prm.factor_up = cd[0];
     ev.prm.factor_down = cd[1];
     ev.prm.avmax = cd[2];
@@ -320,6 +324,8 @@ extern "C" int hostsim_mstart_batch(int n, const double *x, const double *y, con
     ev.prm.has_bounds = 0;
     ev.prm.has_weights = sw != nullptr;
     ev.prm.bench_hold = 0;
+    ev.prm.chisq_in = NAN;
+    ev.prm.chisq_in = NAN;
     ev.prm.factor_up = cd[0];
     ev.prm.factor_down = cd[1];
     ev.prm.avmax = cd[2];
@@ -345,4 +351,17 @@ extern "C" int hostsim_mstart_batch(int n, const double *x, const double *y, con
     b.dtol = dtol;
     b.always_fit = 0;
     return ev.run(b, 0, count, records, false);
+}
+
+extern "C" void hostsim_psi(int rho, const double *cc, int n, const double *x, double *psi, double *psip)
+{
+    LossCfg L;
+    L.rho = rho;
+    for (int k = 0; k < 3; ++k)
+        L.cc[k] = cc[k];
+    for (int i = 0; i < n; ++i)
+    {
+        psi[i] = irls_psi(x[i], L);
+        psip[i] = irls_psip(x[i], L);
+    }
 }

@@ -105,3 +105,14 @@ def mstart_batch_misra(x, y, ranges, kd, first_draw, count, maxiter, dtol, ci, c
       _dp(np.ascontiguousarray(kd, dtype=np.float64)), int(first_draw), int(count), int(maxiter), float(dtol),
       ci.ctypes.data_as(IP), _dp(cd), int(jac), _dp(rec))
     return rec
+
+
+def psi(rho, cc, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    c3 = np.zeros(3)
+    c3[:len(cc)] = cc
+    a, b = np.zeros_like(x), np.zeros_like(x)
+    f = lib().hostsim_psi
+    f.argtypes = [C.c_int, DP, C.c_int, DP, DP, DP]
+    f(int(rho), _dp(c3), len(x), _dp(x), _dp(a), _dp(b))
+    return a, b

@@ -1,0 +1,92 @@
+"""GPU parity of the robust-loss IRLS path (gsl_nls(loss = ...), src/nls_irls.c) through the C ABI."""
+import numpy as np
+import pytest
+
+from conftest import c2_data
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import gslnls_amd
+    from gslnls_amd import _lib
+    assert _lib.lib().gslnls_device_count() >= 1
+    return gslnls_amd
+
+
+def test_readme_huber_on_gpu(amd, gslref, readme):
+    """README.md:493-505: Huber loss, 8 IRLS iterations, achieved tolerance 0.0001023, last NLS solve 9 iterations"""
+    e1 = readme["ex1"]
+    h = e1["huber"]
+    fit = amd.gsl_nls("y ~ A * exp(-lam * x) + b", data=dict(x=e1["x"], y=e1["y"]), start=dict(A=0, lam=0, b=0),
+                      loss="huber")
+    assert fit["conv"] == 0 and fit["irls"]["irls_status"] == 0
+    assert fit["irls"]["irls_niter"] == h["irls_niter"] and fit["niter"] == h["nls_niter"]
+    assert np.allclose(fit["par"], h["coef"], atol=5e-4)
+    assert abs(fit["ssr"] - h["wssr"]) < 5e-5 and abs(fit["irls"]["irls_tol"] - h["irls_tol"]) < 5e-8
+    # full agreement with the oracle on everything the R list carries
+    x, y = np.array(e1["x"]), np.array(e1["y"])
+    o = gslref.nls(25, 3, [0.0, 0.0, 0.0], rowdata=dict(model=gslref.MODEL_EXPDECAY, x=x, y=y), use_jac=False,
+                   ctrl=gslref.control(solver="cholesky"), loss="huber")
+    assert np.allclose(fit["par"], o["par"], rtol=1e-6)
+    assert abs(fit["irls"]["irls_sigma"] - o["irls"]["irls_sigma"]) < 1e-6 * o["irls"]["irls_sigma"]
+    assert np.allclose(fit["irls_weights"], o["irls_weights"], rtol=1e-5, atol=1e-9)
+    assert np.allclose(fit["irls_psi"], o["irls_psi"], rtol=1e-5, atol=1e-7)
+    assert np.allclose(fit["irls_dpsi"], o["irls_dpsi"], atol=1e-9)
+    assert np.allclose(fit["resid"], o["resid"], atol=1e-6)
+
+
+LOSSES = ["huber", "barron", "bisquare", "welsh", "optimal", "hampel", "ggw", "lqq"]
+
+
+@pytest.mark.parametrize("loss", LOSSES)
+@pytest.mark.parametrize("outlier", [True, False])
+def test_unit_tests_5_1_robust_losses(amd, gslref, nist, loss, outlier):
+    """unit_tests_gslnls.R:180-225: Misra1a with y[1] <- 25; pass = NLS converged, IRLS converged and
+    relative error < 1e-2; here additionally equal to the oracle run of the same loss"""
+    q = nist["Misra1a"]
+    x, y = np.array(q["data"]["x"]), np.array(q["data"]["y"])
+    if outlier:
+        y = y.copy()
+        y[0] = 25.0
+    tgt = np.array(list(q["target"].values()))
+    fit = amd.gsl_nls(q["formula"], data=dict(x=x, y=y), start=q["start"], loss=loss, control=dict(solver="cholesky"))
+    assert fit["conv"] == 0 and fit["irls"]["irls_status"] == 0
+    assert np.max(np.abs(1 - fit["par"] / tgt)) < 1e-2
+    o = gslref.nls(14, 2, [500.0, 1e-4], rowdata=dict(model=gslref.MODEL_MISRA1A, x=x, y=y), use_jac=False,
+                   ctrl=gslref.control(solver="cholesky"), loss=loss)
+    assert fit["irls"]["irls_niter"] == o["irls"]["irls_niter"]
+    assert np.allclose(fit["par"], o["par"], rtol=1e-5)
+    assert np.allclose(fit["irls_weights"], o["irls_weights"], rtol=1e-4, atol=1e-8)
+
+
+def test_irls_failure_and_weights(amd, gslref, nist):
+    """5.1.17: barron alpha = -Inf with irls_xtol = 1e-20 must report non-convergence; 5.1.8: user weights"""
+    q = nist["Misra1a"]
+    fit = amd.gsl_nls(q["formula"], data=q["data"], start=q["start"], loss=dict(rho="barron", cc=[-np.inf, 1.345]),
+                      control=dict(irls_xtol=1e-20))
+    assert fit["conv"] != 0 and fit["irls"]["irls_status"] != 0
+    tgt = np.array(list(q["target"].values()))
+    fit = amd.gsl_nls(q["formula"], data=q["data"], start=q["start"], loss="welsh", weights=np.full(14, 10.0))
+    assert fit["conv"] == 0 and fit["irls"]["irls_status"] == 0 and np.max(np.abs(1 - fit["par"] / tgt)) < 1e-2
+
+
+def test_irls_large_n_median_on_device(amd, gslref):
+    """radix-select median at a size where the reference would full-sort: n = 200001 (odd) and 200000 (even),
+    2 % gross outliers; sigma and coefficients against the oracle"""
+    for n in (200001, 200000):
+        x, y = c2_data(n, seed=11)
+        rng = np.random.default_rng(3)
+        idx = rng.choice(n, n // 50, replace=False)
+        y = y.copy()
+        y[idx] += 20.0
+        prob_fit = amd.gsl_nls("y ~ A * exp(-lam * x) + b", data=dict(x=x, y=y), start=dict(A=1, lam=1, b=0),
+                               loss="bisquare", jac=True, control=dict(solver="cholesky"))
+        o = gslref.nls(n, 3, [1.0, 1.0, 0.0], rowdata=dict(model=gslref.MODEL_EXPDECAY, x=x, y=y), use_jac=True,
+                       ctrl=gslref.control(solver="cholesky"), loss="bisquare")
+        assert prob_fit["conv"] == 0 and prob_fit["irls"]["irls_status"] == 0
+        assert prob_fit["irls"]["irls_niter"] == o["irls"]["irls_niter"]
+        assert abs(prob_fit["irls"]["irls_sigma"] - o["irls"]["irls_sigma"]) <= 1e-9 * o["irls"]["irls_sigma"]
+        assert np.allclose(prob_fit["par"], o["par"], rtol=1e-6)
+        assert np.allclose(prob_fit["par"], [5.0, 1.5, 1.0], atol=0.02)   # the outliers are rejected

@@ -193,3 +193,18 @@ def test_start_and_bounds_normalisation():
     assert lu.tolist() == [250, np.inf, -np.inf, 1]
     assert _bounds(0, 250, ["a", "b"]).tolist() == [0, 250, 0, 250]
     assert _bounds(None, None, ["a"]) is None
+
+
+@pytest.mark.parametrize("rho,cc", [(1, [1.345]), (2, [1.0, 1.345]), (2, [2.0, 1.345]), (2, [0.0, 1.345]),
+                                    (2, [-np.inf, 1.345]), (2, [-2.0, 1.0]), (3, [4.685061]), (4, [2.11]),
+                                    (5, [1.060158]), (6, [0.9016085]), (7, [1.387, 1.5, 1.063]), (8, [1.473, 0.982, 1.5])])
+def test_device_psi_functions_match_oracle(gslref, hostsim, rho, cc):
+    """irls_core.hpp (device psi / psi') == the oracle's restatement of src/nls_irls.c:10-341"""
+    x = np.concatenate([np.linspace(-12, 12, 4001), [0.0, 1e-300, -1e-300, 40.0, -40.0, 1e6]])
+    ps, pp = hostsim.psi(rho, cc, x)
+    L = gslref.lib()
+    c3 = np.zeros(3)
+    c3[:len(cc)] = cc
+    want = np.array([L.gslref_psi(v, c3.ctypes.data_as(gslref.DP), rho) for v in x])
+    wantp = np.array([L.gslref_psip(v, c3.ctypes.data_as(gslref.DP), rho) for v in x])
+    assert np.array_equal(ps, want) and np.array_equal(pp, wantp)
