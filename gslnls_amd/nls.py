@@ -196,7 +196,7 @@ def gsl_nls(fn, data=None, start=None, algorithm="lm", control=None, jac=None, f
         raise ValueError("starting values 'start' are required")
     _ = ALGORITHMS.index(algorithm) if algorithm in ALGORITHMS else (_ for _ in ()).throw(
         ValueError("'algorithm' should be one of %s" % ", ".join(ALGORITHMS)))
-    ctrl = control if (control is not None and "irls_xtol" in control) else gsl_nls_control(**(control or {}))
+    ctrl = control if (control is not None and len(control) >= 23) else gsl_nls_control(**(control or {}))
     loss_cfg = gsl_nls_loss(loss) if isinstance(loss, str) else gsl_nls_loss(**loss)
     names, vec, mat, has_start = _normalise_start(start)
     p = len(names)

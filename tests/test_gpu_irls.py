@@ -87,6 +87,11 @@ def test_irls_large_n_median_on_device(amd, gslref):
                        ctrl=gslref.control(solver="cholesky"), loss="bisquare")
         assert prob_fit["conv"] == 0 and prob_fit["irls"]["irls_status"] == 0
         assert prob_fit["irls"]["irls_niter"] == o["irls"]["irls_niter"]
-        assert abs(prob_fit["irls"]["irls_sigma"] - o["irls"]["irls_sigma"]) <= 1e-9 * o["irls"]["irls_sigma"]
+        # the fitted points of two correct implementations differ at the sqrt(eps) level, and so do their medians
+        assert abs(prob_fit["irls"]["irls_sigma"] - o["irls"]["irls_sigma"]) <= 1e-6 * o["irls"]["irls_sigma"]
+        # the device selection itself is exact: recompute the median at the device's own fitted point
+        th = prob_fit["par"]
+        r = np.abs(th[0] * np.exp(-th[1] * x) + th[2] - y)
+        assert abs(prob_fit["irls"]["irls_sigma"] - 1.482602218505602 * np.median(r)) <= 1e-12
         assert np.allclose(prob_fit["par"], o["par"], rtol=1e-6)
         assert np.allclose(prob_fit["par"], [5.0, 1.5, 1.0], atol=0.02)   # the outliers are rejected
