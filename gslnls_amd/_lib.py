@@ -31,6 +31,12 @@ class Result(C.Structure):
                 ("mstart_ssropt", C.c_double), ("loop_ms", C.c_float), ("n_launches", C.c_int)]
 
 
+class LargeResult(C.Structure):
+    _fields_ = [("par", DP), ("covar", DP), ("resid", DP), ("niter", C.c_int), ("conv", C.c_int), ("info", C.c_int),
+                ("ssr", C.c_double), ("ssrtol", C.c_double), ("chisq_init", C.c_double), ("neval", C.c_int * 4),
+                ("partrace", DP), ("ssrtrace", DP), ("n_passes", C.c_int), ("last_pass_ms", C.c_float)]
+
+
 # every symbol include/gslnls_core.h declares (tests/test_abi.py checks the list against the header)
 _SIGNATURES = {
     "gslnls_nls": (C.c_int, [C.POINTER(Model), C.c_void_p, C.c_int, C.c_int, C.c_int, DP, C.c_int, C.c_void_p,
@@ -47,6 +53,12 @@ _SIGNATURES = {
     "gslnls_mstart_batch": (C.c_int, [C.c_void_p, C.c_int, DP, DP, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_double, IP, DP, DP, C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "gslnls_mstart_record_size": (C.c_int, [C.c_int]),
+    "gslnls_nls_large": (C.c_int, [C.POINTER(Model), C.c_void_p, C.c_int, DP, C.c_void_p, IP, DP,
+                                   C.POINTER(LargeResult)]),
+    "gslnls_large_create": (C.c_void_p, [C.POINTER(Model), C.c_void_p, C.c_int, C.c_void_p, IP]),
+    "gslnls_large_destroy": (None, [C.c_void_p]),
+    "gslnls_large_solve": (C.c_int, [C.c_void_p, DP, IP, DP, C.POINTER(LargeResult)]),
+    "gslnls_large_time_pass": (C.c_float, [C.c_void_p, C.c_int, DP, DP, C.c_int]),
     "gslnls_strerror": (C.c_char_p, [C.c_int]),
     "gslnls_algorithm_name": (C.c_char_p, [C.c_int]),
     "gslnls_device_count": (C.c_int, []),

@@ -12,6 +12,7 @@
 #include "mstart_host.hpp"
 #include "formula.hpp"
 #include "irls_host.hpp"
+#include "large_host.hpp"
 
 using namespace gslnls;
 
@@ -74,6 +75,19 @@ static DenseBase *make_dense(const gslnls_model *fn, const double *y, int n, con
     return b;
 }
 
+struct gslnls_large
+{
+    DenseBase *dense = nullptr; // row models: data owner
+    LargeOps *ops = nullptr;
+    int n = 0, p = 0;
+};
+
+template <class M>
+static LargeOps *make_row_ops(DenseBase *b)
+{
+    return new RowLargeOps<M>(*static_cast<DenseFit<M> *>(b));
+}
+
 extern "C" {
 
 gslnls_dense *gslnls_dense_create(const gslnls_model *fn, const double *y, int n, const double *swts, int *err)
@@ -119,6 +133,207 @@ int gslnls_debug_stamps(gslnls_dense *h, int jac, const double *theta, int warm,
     return h->impl->debug_stamps(jac, theta, warm, out, nrows);
 }
 #endif
+
+gslnls_large *gslnls_large_create(const gslnls_model *fn, const double *y, int n, const double *weights, int *err)
+{
+    int e = GSLNLS_SUCCESS;
+    gslnls_large *h = new gslnls_large;
+    h->n = n;
+    h->p = fn->p;
+    std::vector<double> sw;
+    const double *swp = nullptr;
+    if (weights && !fn->x_on_device)
+    {
+        sw.resize(n);
+        for (int i = 0; i < n; ++i)
+            sw[i] = sqrt(weights[i]); // gsl_multilarge_nlinear_winit
+        swp = sw.data();
+    }
+    else if (weights)
+        swp = weights; // device data: caller passes sqrt(weights) already on device
+    if (fn->id == GSLNLS_MODEL_GLMEXP)
+    {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+            e = GSLNLS_E_NODEVICE;
+        else if (fn->nx != fn->p)
+            e = GSLNLS_EINVAL;
+        else
+        {
+#define GSLNLS_GLM(PP)                                                  \
+    {                                                                   \
+        auto *o = new GlmLargeOps<PP>();                                \
+        e = o->init(fn->x, y, swp, n, fn->x_on_device != 0);            \
+        h->ops = o;                                                     \
+    }
+            switch (fn->p)
+            {
+            case 16:
+                GSLNLS_GLM(16);
+                break;
+            case 32:
+                GSLNLS_GLM(32);
+                break;
+            case 64:
+                GSLNLS_GLM(64);
+                break;
+            default:
+                e = GSLNLS_E_UNSUPPORTED;
+            }
+#undef GSLNLS_GLM
+        }
+    }
+    else
+    {
+        h->dense = make_dense(fn, y, n, swp, &e);
+        if (h->dense)
+        {
+            switch (fn->id)
+            {
+            case GSLNLS_MODEL_EXPDECAY:
+                h->ops = make_row_ops<ModelExpDecay>(h->dense);
+                break;
+            case GSLNLS_MODEL_MISRA1A:
+                h->ops = make_row_ops<ModelMisra1a>(h->dense);
+                break;
+            case GSLNLS_MODEL_GAUSSPK:
+                h->ops = make_row_ops<ModelGaussPeak>(h->dense);
+                break;
+            case GSLNLS_MODEL_GAUSS1:
+                h->ops = make_row_ops<ModelGauss1>(h->dense);
+                break;
+            default:
+                e = GSLNLS_E_UNSUPPORTED;
+            }
+        }
+    }
+    if (err)
+        *err = e;
+    if (e != GSLNLS_SUCCESS || !h->ops)
+    {
+        delete h->ops;
+        delete h->dense;
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+
+void gslnls_large_destroy(gslnls_large *h)
+{
+    if (h)
+    {
+        delete h->ops;
+        delete h->dense;
+        delete h;
+    }
+}
+
+int gslnls_large_solve(gslnls_large *h, const double *start, const int *control_int, const double *control_dbl,
+                       gslnls_large_result *out)
+{
+    if (!h || !h->ops)
+        return GSLNLS_EINVAL;
+    const int p = h->p, n = h->n;
+    LargeOps &ops = *h->ops;
+    ops.nevalf = ops.nevaldfu = ops.nevaldf2 = 0;
+    ops.npass = 0;
+    LargeResult R;
+    const bool trace = control_int[1] != 0 && out->ssrtrace && out->partrace;
+    if (trace)
+    {
+        const int mi = control_int[0];
+        for (int i = 0; i <= mi; ++i)
+            out->ssrtrace[i] = NAN;
+        for (size_t i = 0; i < (size_t)(mi + 1) * p; ++i)
+            out->partrace[i] = NAN;
+    }
+    const int rc = large_solve(ops, start, control_int, control_dbl, R, trace ? out->ssrtrace : nullptr,
+                               trace ? out->partrace : nullptr);
+    if (rc)
+        return rc;
+    const bool ok = (R.status == ST_SUCCESS || R.status == ST_EMAXITER);
+    for (int k = 0; k < p; ++k)
+        if (out->par)
+            out->par[k] = ok ? R.x[k] : start[k];
+    if (out->resid)
+    {
+        if (ok)
+            ops.residual(R.x.data(), out->resid);
+        else
+            for (int i = 0; i < n; ++i)
+                out->resid[i] = NAN;
+    }
+    if (out->covar)
+    {
+        bool good = ok;
+        if (good)
+        {
+            // gsl_multilarge_nlinear_covar (src/nls_large.c:255): (J^T J)^-1 at the final point
+            std::vector<double> A((size_t)p * p);
+            good = ops.full_jtj(R.x.data(), A.data()) == 0 && lg_chol(p, A);
+            if (good)
+            {
+                lg_chol_invert(p, A);
+                for (int i = 0; i < p; ++i)
+                    for (int k = 0; k < p; ++k)
+                        out->covar[i + (size_t)p * k] = A[(size_t)i * p + k];
+            }
+        }
+        if (!good)
+            for (size_t i = 0; i < (size_t)p * p; ++i)
+                out->covar[i] = NAN;
+    }
+    out->niter = R.niter;
+    out->conv = R.status;
+    out->info = R.info;
+    out->ssr = R.chisq1;
+    out->ssrtol = R.chisq0 - R.chisq1;
+    out->chisq_init = R.chisq_init;
+    out->neval[0] = (int)ops.nevalf;
+    out->neval[1] = (int)ops.nevaldfu;
+    out->neval[2] = (int)ops.nevaldf2;
+    out->neval[3] = 0;
+    out->n_passes = (int)ops.npass;
+    out->last_pass_ms = ops.pass_ms;
+    return R.status;
+}
+
+int gslnls_nls_large(const gslnls_model *fn, const double *y, int n, const double *start, const double *weights,
+                     const int *control_int, const double *control_dbl, gslnls_large_result *out)
+{
+    int err = 0;
+    gslnls_large *h = gslnls_large_create(fn, y, n, weights, &err);
+    if (!h)
+        return err;
+    const int rc = gslnls_large_solve(h, start, control_int, control_dbl, out);
+    gslnls_large_destroy(h);
+    return rc;
+}
+
+float gslnls_large_time_pass(gslnls_large *h, int mode, const double *x, const double *u, int reps)
+{
+    if (!h || !h->ops || reps < 1)
+        return -1.f;
+    std::vector<double> g(h->p), d(h->p);
+    double ssr, bad, nw2;
+    if (h->ops->eval(x, &ssr, g.data(), d.data(), nullptr, &bad))
+        return -1.f;
+    h->ops->accept();
+    double tot = 0.0;
+    for (int r = 0; r < reps; ++r)
+    {
+        if (mode == 0)
+        {
+            if (h->ops->eval(x, &ssr, g.data(), d.data(), nullptr, &bad))
+                return -1.f;
+        }
+        else if (h->ops->jtjv(x, u, &nw2, g.data()))
+            return -1.f;
+        tot += h->ops->pass_ms;
+    }
+    return (float)(tot / reps);
+}
 
 int gslnls_lower_formula(const char *rhs, int p, const char *const *parnames, int *par_order, char *varnames_out,
                           int varnames_cap)

@@ -1,0 +1,289 @@
+// large_kernels.hpp -- matrix-free kernels behind gsl_nls_large() (gsl_multilarge_nlinear, cgst).
+//
+// In the reference every product with the Jacobian goes through gsl_df_large
+// (src/nls_large.c:474-653): it RE-EVALUATES the whole R Jacobian closure, copies it element by
+// element (:497-498, :524-526) and then calls dgemv (:629) or dsyrk (:633).  Here the Jacobian
+// is never formed; two kinds of pass over the rows produce everything the trust-region /
+// Steihaug-Toint iteration needs:
+//
+//   EVAL pass at a point x:   f = sqrt(w)(model - y),  ssr = f.f,  g = J^T f,  diag(J^T J)
+//                             (trial evaluation and, speculatively, what an accepted step needs)
+//   JTJV pass at x with u:    w = J u,  ||w||^2,  J^T w     (one CG iteration: the reference's
+//                             NoTrans + Trans pair fused, A is read once instead of twice)
+//
+// Two model classes:
+//   * registered row models (small p): thread-per-row, Jacobian row recomputed in registers;
+//   * the dense GLM family f_i = exp(a_i . theta) with A (n x p, row-major fp64) resident in HBM
+//     (BASELINE config C3: n = 1e7, p = 64, 5.12 GB): tiled kernel below, J = diag(m) A.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dense_kernels.hpp"
+
+namespace gslnls
+{
+
+enum
+{
+    LG_EVAL = 0,
+    LG_JTJV = 1
+};
+
+// ------------------------------------------------------------------------------------------------
+// row models: sums land in PassSums<P> (EVAL: ssr, J^T J, J^T f;  JTJV: ssr slot = ||J u||^2,
+// g slots = J^T J u).  Weights scale f only -- the reference's callback never weights J
+// (src/nls_large.c:629-633, quirk preserved).
+template <class M, int T>
+__global__ __launch_bounds__(T) void large_row_kernel(DenseCtx<M::P> ctx, int mode, const double *xpt,
+                                                      const double *uvec, double *partials)
+{
+    constexpr int P = M::P, NX = M::NX;
+    using Sums = PassSums<P>;
+    constexpr int NV = Sums::NV;
+    __shared__ double lds_red[(T / 64) * NV];
+    double th[P], u[P], delta[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k)
+    {
+        th[k] = xpt[k];
+        u[k] = uvec ? uvec[k] : 0.0;
+        delta[k] = 0.0;
+    }
+    Sums acc;
+    pass_zero<P>(acc);
+    const long long n = ctx.n, stride = (long long)gridDim.x * T;
+    for (long long i = (long long)blockIdx.x * T + threadIdx.x; i < n; i += stride)
+    {
+        double xr[NX];
+#pragma unroll
+        for (int c = 0; c < NX; ++c)
+            xr[c] = ctx.x[c][i];
+        double Jrow[P];
+        const double f0 = row_fj<M, JAC_ANALYTIC>(th, delta, xr, ctx.y[i], 1.0, Jrow, &acc.badj);
+        if (mode == LG_EVAL)
+        {
+            const double f = f0 * (ctx.sw ? ctx.sw[i] : 1.0);
+            acc_fj<P>(acc, f, Jrow);
+        }
+        else
+        {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < P; ++k)
+                t += Jrow[k] * u[k];
+            acc.ssr += t * t;
+#pragma unroll
+            for (int k = 0; k < P; ++k)
+                acc.g[k] += Jrow[k] * t;
+        }
+    }
+    const double tot = block_sum_slots<NV, T>(reinterpret_cast<const double *>(&acc), lds_red);
+    if (threadIdx.x < NV)
+        partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = tot;
+}
+
+// fixed-order sum of the per-workgroup partials: out[v] = sum_b partials[v][b]
+__global__ __launch_bounds__(64) void large_reduce_kernel(const double *partials, int nv, int nblk, double *out)
+{
+    const int v = blockIdx.x;
+    if (v >= nv)
+        return;
+    double a = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 64)
+        a += partials[(size_t)v * nblk + b];
+    a = wave_sum(a);
+    if (threadIdx.x == 0)
+        out[v] = a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense GLM family, P columns (compile time, even, <= 128).  One wavefront instruction loads
+// RPI = 64 / (P/2) consecutive rows, 16 B per lane (lane -> row h = lane / LPR, column pair
+// c = lane % LPR): fully coalesced 1 KiB requests.  A tile of NT instructions (NT*RPI rows) is kept
+// in registers; its per-lane partial dot products go through LDS so that lane r ends up with the
+// whole dot product of row r (one exp per row instead of one per lane), then the per-row scalars
+// come back through LDS for the transposed accumulation.  All orders are fixed.
+struct GlmArgs
+{
+    const double *A;   // n x P row-major
+    const double *y;   // n
+    const double *sw;  // n or nullptr
+    double *m;         // n: exp(a_i . x) at the point of the last EVAL pass (written by EVAL, read by JTJV)
+    double *f;         // n: weighted residual at that point (written by EVAL)
+    long long n;
+    const double *xpt; // P: evaluation point (EVAL)
+    const double *u;   // P: direction (JTJV)
+    double *partials;  // [2 + 2P][nblk]: ssr, bad, g[P], d[P]
+    int mode;
+};
+
+template <int P, int T>
+__global__ __launch_bounds__(T) void glm_pass_kernel(GlmArgs a)
+{
+    constexpr int LPR = P / 2;      // lanes per row
+    constexpr int RPI = 64 / LPR;   // rows per wave instruction
+    constexpr int NT = (64 / RPI < 16) ? 64 / RPI : 16; // instructions per tile (at most 64 rows per tile)
+    constexpr int ROWS = NT * RPI;  // rows per wave tile
+    constexpr int NW = T / 64;
+    constexpr int LD = LPR + 1;     // padded row length in LDS
+    static_assert(64 % LPR == 0 && ROWS <= 64, "tile shape");
+    __shared__ double lds_part[NW][ROWS * LD];
+    __shared__ double lds_s1[NW][ROWS], lds_s2[NW][ROWS];
+    __shared__ double lds_red[NW][2 * P + 2];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane / LPR, c = lane % LPR;
+    const double v0 = (a.mode == LG_EVAL ? a.xpt : a.u)[2 * c], v1 = (a.mode == LG_EVAL ? a.xpt : a.u)[2 * c + 1];
+    double g0 = 0.0, g1 = 0.0, d0 = 0.0, d1 = 0.0, ssr = 0.0;
+    const long long ntiles = (a.n + ROWS - 1) / ROWS;
+    const long long wstride = (long long)gridDim.x * NW;
+    // uniform trip count per workgroup (tiles past the end are all-invalid rows) so that the LDS
+    // hand-offs can use the workgroup barrier
+    for (long long base = (long long)blockIdx.x * NW; base < ntiles; base += wstride)
+    {
+        const long long row0 = (base + wave) * ROWS;
+        double2 av[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+        {
+            const long long row = row0 + k * RPI + h;
+            av[k] = (row < a.n) ? *reinterpret_cast<const double2 *>(a.A + row * P + 2 * c) : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+            lds_part[wave][(k * RPI + h) * LD + c] = av[k].x * v0 + av[k].y * v1;
+        __syncthreads();
+        double s1 = 0.0, s2 = 0.0;
+        if (lane < ROWS)
+        {
+            const long long row = row0 + lane;
+            double dot = 0.0;
+#pragma unroll
+            for (int j = 0; j < LPR; ++j)
+                dot += lds_part[wave][lane * LD + j];
+            if (row < a.n)
+            {
+                if (a.mode == LG_EVAL)
+                {
+                    const double mm = exp(dot);
+                    const double w = a.sw ? a.sw[row] : 1.0;
+                    const double ff = (isfinite(mm) ? mm - a.y[row] : INFINITY) * w;
+                    a.m[row] = mm;
+                    a.f[row] = ff;
+                    ssr += ff * ff;
+                    s1 = mm * ff;  // J^T f: row scalar m_i f_i
+                    s2 = mm * mm;  // diag(J^T J): m_i^2
+                }
+                else
+                {
+                    const double mm = a.m[row];
+                    const double t = mm * dot; // (J u)_i
+                    ssr += t * t;
+                    s1 = mm * t;
+                }
+            }
+            lds_s1[wave][lane] = s1;
+            lds_s2[wave][lane] = s2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+        {
+            const double r1 = lds_s1[wave][k * RPI + h];
+            g0 += av[k].x * r1;
+            g1 += av[k].y * r1;
+            if (a.mode == LG_EVAL)
+            {
+                const double r2 = lds_s2[wave][k * RPI + h];
+                d0 += av[k].x * av[k].x * r2;
+                d1 += av[k].y * av[k].y * r2;
+            }
+        }
+        __syncthreads();
+    }
+    // combine the RPI row groups of the wave (lanes with equal c), fixed order
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1)
+    {
+        g0 += __shfl_xor(g0, off, 64);
+        g1 += __shfl_xor(g1, off, 64);
+        d0 += __shfl_xor(d0, off, 64);
+        d1 += __shfl_xor(d1, off, 64);
+    }
+    ssr = wave_sum(ssr);
+    if (lane < LPR)
+    {
+        lds_red[wave][2 + 2 * c] = g0;
+        lds_red[wave][2 + 2 * c + 1] = g1;
+        lds_red[wave][2 + P + 2 * c] = d0;
+        lds_red[wave][2 + P + 2 * c + 1] = d1;
+    }
+    if (lane == 0)
+    {
+        lds_red[wave][0] = ssr;
+        lds_red[wave][1] = 0.0;
+    }
+    __syncthreads();
+    for (int v = threadIdx.x; v < 2 * P + 2; v += T)
+    {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+            t += lds_red[w][v];
+        a.partials[(size_t)v * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+// full J^T J = A^T diag(m^2) A for the covariance at the end (gsl_multilarge_nlinear_covar,
+// src/nls_large.c:255): one workgroup per row chunk, each thread owns a (P/16)^2 block.  Plain
+// fp64 FMA; the MFMA tall-skinny form is the next step for p = 64.
+template <int P, int T>
+__global__ __launch_bounds__(T) void glm_jtj_kernel(const double *A, const double *m, long long n, double *partials)
+{
+    constexpr int TR = 32; // rows per LDS tile
+    __shared__ double tileA[TR][P + 1];
+    constexpr int B = P / 16; // each thread: B x B outputs, 16 x 16 thread grid
+    static_assert(T == 256, "16 x 16 threads");
+    const int ti = threadIdx.x / 16, tj = threadIdx.x % 16;
+    double acc[B][B];
+#pragma unroll
+    for (int i = 0; i < B; ++i)
+#pragma unroll
+        for (int j = 0; j < B; ++j)
+            acc[i][j] = 0.0;
+    const long long ntile = (n + TR - 1) / TR;
+    for (long long t = blockIdx.x; t < ntile; t += gridDim.x)
+    {
+        const long long r0 = t * TR;
+        for (int e = threadIdx.x; e < TR * P; e += T)
+        {
+            const int r = e / P, cc = e % P;
+            const long long row = r0 + r;
+            tileA[r][cc] = (row < n) ? A[row * P + cc] * m[row] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int r = 0; r < TR; ++r)
+        {
+            double ai[B], aj[B];
+#pragma unroll
+            for (int i = 0; i < B; ++i)
+            {
+                ai[i] = tileA[r][ti * B + i];
+                aj[i] = tileA[r][tj * B + i];
+            }
+#pragma unroll
+            for (int i = 0; i < B; ++i)
+#pragma unroll
+                for (int j = 0; j < B; ++j)
+                    acc[i][j] += ai[i] * aj[j];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < B; ++i)
+#pragma unroll
+        for (int j = 0; j < B; ++j)
+            partials[((size_t)(ti * B + i) * P + (tj * B + j)) * gridDim.x + blockIdx.x] = acc[i][j];
+}
+
+} // namespace gslnls

@@ -33,6 +33,8 @@ extern "C" {
 #define GSLNLS_MODEL_MISRA1A 2  /* b1*(1-exp(-b2*x))         p=2  R/nls_test.R:174,:793 */
 #define GSLNLS_MODEL_GAUSSPK 3  /* a*exp(-(x-b)^2/(2c^2))    p=3  README.md:545 */
 #define GSLNLS_MODEL_GAUSS1 4   /* NIST Gauss1 family        p=8  R/nls_test.R:301 */
+#define GSLNLS_MODEL_GLMEXP 5   /* exp(a_i . theta), dense A n x p ROW-major in `x`, nx = p in {16,32,64};
+                                   gsl_nls_large only */
 
 /* status codes placed in `conv` (GSL errno values) */
 #define GSLNLS_SUCCESS 0
@@ -154,6 +156,34 @@ int gslnls_mstart_batch(gslnls_dense *h, int jac, const double *ranges, const do
                         const double *control_dbl, const double *lupars, double *records, int records_on_device,
                         float *kernel_ms);
 int gslnls_mstart_record_size(int p);
+
+/* ---- gsl_nls_large: replaces C_nls_large (src/init.c:16, src/nls_large.c:66-424) --------------
+ * 9 SEXP arguments there: fn, y, jac, fvv, env, start, weights, control_int[7], control_dbl[8]
+ * (SURVEY.md App. C.3).  jac is always analytic on device (the reference requires one too), fvv /
+ * lmaccel and the dogleg family are refused.  control_int[2]: 0 = lm (normal equations), 5 = cgst. */
+typedef struct gslnls_large_result
+{
+    double *par;    /* [p] */
+    double *covar;  /* [p*p] column-major (J^T J)^-1, NaN on failure */
+    double *resid;  /* [n] weighted residual */
+    int niter, conv, info;
+    double ssr, ssrtol, chisq_init;
+    int neval[4];   /* f, dfu, df2, fvv (src/nls_large.c:395-401) */
+    double *partrace, *ssrtrace;
+    int n_passes;   /* device passes over the rows issued for this call */
+    float last_pass_ms;
+} gslnls_large_result;
+
+int gslnls_nls_large(const gslnls_model *fn, const double *y, int n, const double *start, const double *weights,
+                     const int *control_int, const double *control_dbl, gslnls_large_result *out);
+
+typedef struct gslnls_large gslnls_large;
+gslnls_large *gslnls_large_create(const gslnls_model *fn, const double *y, int n, const double *weights, int *err);
+void gslnls_large_destroy(gslnls_large *h);
+int gslnls_large_solve(gslnls_large *h, const double *start, const int *control_int, const double *control_dbl,
+                       gslnls_large_result *out);
+/* average HIP-event milliseconds of `reps` passes: mode 0 = EVAL pass at x, 1 = fused J^T J u pass */
+float gslnls_large_time_pass(gslnls_large *h, int mode, const double *x, const double *u, int reps);
 
 /* ---- introspection ---------------------------------------------------------------------- */
 const char *gslnls_strerror(int code);     /* gsl_strerror strings, App. C.4 */
