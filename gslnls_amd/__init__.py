@@ -6,5 +6,6 @@ of libgslnls_hip.so.  Only what the hot path needs lives here.
 from .control import gsl_nls_control, gsl_nls_loss  # noqa: F401
 from .nls import gsl_nls, DenseProblem  # noqa: F401
 from .nls_large import gsl_nls_large, LargeProblem  # noqa: F401
+from .batch import BatchProblem  # noqa: F401
 
-__all__ = ["gsl_nls", "gsl_nls_large", "gsl_nls_control", "gsl_nls_loss", "DenseProblem", "LargeProblem"]
+__all__ = ["gsl_nls", "gsl_nls_large", "gsl_nls_control", "gsl_nls_loss", "DenseProblem", "LargeProblem", "BatchProblem"]

@@ -59,6 +59,11 @@ _SIGNATURES = {
     "gslnls_large_destroy": (None, [C.c_void_p]),
     "gslnls_large_solve": (C.c_int, [C.c_void_p, DP, IP, DP, C.POINTER(LargeResult)]),
     "gslnls_large_time_pass": (C.c_float, [C.c_void_p, C.c_int, DP, DP, C.c_int]),
+    "gslnls_batch_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_int, IP]),
+    "gslnls_batch_destroy": (None, [C.c_void_p]),
+    "gslnls_batch_irls": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, DP, DP, IP, DP, C.c_int, DP,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     "gslnls_strerror": (C.c_char_p, [C.c_int]),
     "gslnls_algorithm_name": (C.c_char_p, [C.c_int]),
     "gslnls_device_count": (C.c_int, []),

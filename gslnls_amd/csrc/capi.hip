@@ -13,6 +13,7 @@
 #include "formula.hpp"
 #include "irls_host.hpp"
 #include "large_host.hpp"
+#include "irls_batch.hpp"
 
 using namespace gslnls;
 
@@ -86,6 +87,71 @@ template <class M>
 static LargeOps *make_row_ops(DenseBase *b)
 {
     return new RowLargeOps<M>(*static_cast<DenseFit<M> *>(b));
+}
+
+struct gslnls_batch
+{
+    int model_id = 0, p = 0, nx = 0, n = 0, B = 0;
+    double *d_x = nullptr, *d_y = nullptr, *d_usw = nullptr, *d_sw = nullptr, *d_par = nullptr, *d_scal = nullptr;
+    unsigned long long *d_keys = nullptr;
+    int *d_ints = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+
+template <class M>
+static int batch_irls_run(gslnls_batch *h, int lo, int hi, int jac, int fvv, const double *start, const double *lupars,
+                          const int *ci, const double *cd, int loss_rho, const double *loss_cc, float *kernel_ms)
+{
+    constexpr int P = M::P;
+    constexpr int T = 256;
+    if (fvv && !M::HAS_FVV)
+        return GSLNLS_E_UNSUPPORTED;
+    IrlsBatchArgs<P> a;
+    a.x = h->d_x;
+    a.y = h->d_y;
+    a.usw = h->d_usw;
+    a.sw = h->d_sw;
+    a.keys = h->d_keys;
+    a.n = h->n;
+    a.lo = lo;
+    a.hi = hi;
+    for (int k = 0; k < P; ++k)
+    {
+        a.start[k] = start[k];
+        a.lu[2 * k] = lupars ? lupars[2 * k] : -INFINITY;
+        a.lu[2 * k + 1] = lupars ? lupars[2 * k + 1] : INFINITY;
+    }
+    a.has_lu = lupars != nullptr;
+    a.prm = make_params(ci, cd, jac, fvv, lupars != nullptr, true);
+    a.loss.rho = loss_rho;
+    static const int ncc[9] = {0, 1, 2, 1, 1, 1, 1, 3, 3};
+    for (int k = 0; k < 3; ++k)
+        a.loss.cc[k] = (loss_rho >= 1 && loss_rho <= 8 && k < ncc[loss_rho]) ? loss_cc[k] : 0.0;
+    a.irls_maxiter = ci[14];
+    a.irls_xtol = cd[10];
+    a.par = h->d_par;
+    a.scal = h->d_scal;
+    a.ints = h->d_ints;
+    const int jacmode = jac ? JAC_ANALYTIC : (ci[5] ? JAC_CENTER : JAC_FORWARD);
+    hipEventRecord(h->e0, h->st);
+    switch (jacmode)
+    {
+    case JAC_ANALYTIC:
+        hipLaunchKernelGGL((irls_batch_kernel<M, JAC_ANALYTIC, T>), dim3(hi - lo), dim3(T), 0, h->st, a);
+        break;
+    case JAC_FORWARD:
+        hipLaunchKernelGGL((irls_batch_kernel<M, JAC_FORWARD, T>), dim3(hi - lo), dim3(T), 0, h->st, a);
+        break;
+    default:
+        hipLaunchKernelGGL((irls_batch_kernel<M, JAC_CENTER, T>), dim3(hi - lo), dim3(T), 0, h->st, a);
+        break;
+    }
+    hipEventRecord(h->e1, h->st);
+    GSLNLS_HIP_OK(hipStreamSynchronize(h->st));
+    if (kernel_ms)
+        hipEventElapsedTime(kernel_ms, h->e0, h->e1);
+    return GSLNLS_SUCCESS;
 }
 
 extern "C" {
@@ -333,6 +399,103 @@ float gslnls_large_time_pass(gslnls_large *h, int mode, const double *x, const d
         tot += h->ops->pass_ms;
     }
     return (float)(tot / reps);
+}
+
+gslnls_batch *gslnls_batch_create(int model_id, int p, int nx, const double *x, const double *y, const double *swts,
+                                  int n, int B, int *err)
+{
+    int ndev = 0, e = GSLNLS_SUCCESS;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        e = GSLNLS_E_NODEVICE;
+    gslnls_batch *h = nullptr;
+    if (e == GSLNLS_SUCCESS)
+    {
+        h = new gslnls_batch;
+        h->model_id = model_id;
+        h->p = p;
+        h->nx = nx;
+        h->n = n;
+        h->B = B;
+        const size_t nb = sizeof(double) * (size_t)n * B;
+        bool ok = hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreate(&h->e0) == hipSuccess && hipEventCreate(&h->e1) == hipSuccess &&
+                  hipMalloc(&h->d_x, nb * nx) == hipSuccess && hipMalloc(&h->d_y, nb) == hipSuccess &&
+                  hipMalloc(&h->d_sw, nb) == hipSuccess && hipMalloc(&h->d_keys, nb) == hipSuccess &&
+                  hipMalloc(&h->d_par, sizeof(double) * (size_t)B * p) == hipSuccess &&
+                  hipMalloc(&h->d_scal, sizeof(double) * (size_t)B * 4) == hipSuccess &&
+                  hipMalloc(&h->d_ints, sizeof(int) * (size_t)B * 4) == hipSuccess &&
+                  hipMemcpy(h->d_x, x, nb * nx, hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(h->d_y, y, nb, hipMemcpyHostToDevice) == hipSuccess;
+        if (ok && swts)
+            ok = hipMalloc(&h->d_usw, nb) == hipSuccess && hipMemcpy(h->d_usw, swts, nb, hipMemcpyHostToDevice) == hipSuccess;
+        if (!ok)
+            e = GSLNLS_E_NODEVICE;
+    }
+    if (err)
+        *err = e;
+    if (e != GSLNLS_SUCCESS)
+    {
+        gslnls_batch_destroy(h);
+        return nullptr;
+    }
+    return h;
+}
+
+void gslnls_batch_destroy(gslnls_batch *h)
+{
+    if (!h)
+        return;
+    hipFree(h->d_x);
+    hipFree(h->d_y);
+    hipFree(h->d_usw);
+    hipFree(h->d_sw);
+    hipFree(h->d_keys);
+    hipFree(h->d_par);
+    hipFree(h->d_scal);
+    hipFree(h->d_ints);
+    if (h->e0)
+        hipEventDestroy(h->e0);
+    if (h->e1)
+        hipEventDestroy(h->e1);
+    if (h->st)
+        hipStreamDestroy(h->st);
+    delete h;
+}
+
+int gslnls_batch_irls(gslnls_batch *h, int lo, int hi, int jac, int fvv, const double *start, const double *lupars,
+                      const int *control_int, const double *control_dbl, int loss_rho, const double *loss_cc,
+                      double *par, double *scal, int *ints, float *kernel_ms)
+{
+    if (!h || lo < 0 || hi > h->B || lo >= hi || loss_rho < 1 || loss_rho > 8 || control_int[2] > 1)
+        return GSLNLS_EINVAL;
+    int rc;
+    switch (h->model_id)
+    {
+    case GSLNLS_MODEL_EXPDECAY:
+        rc = batch_irls_run<ModelExpDecay>(h, lo, hi, jac, fvv, start, lupars, control_int, control_dbl, loss_rho, loss_cc, kernel_ms);
+        break;
+    case GSLNLS_MODEL_MISRA1A:
+        rc = batch_irls_run<ModelMisra1a>(h, lo, hi, jac, fvv, start, lupars, control_int, control_dbl, loss_rho, loss_cc, kernel_ms);
+        break;
+    case GSLNLS_MODEL_GAUSSPK:
+        rc = batch_irls_run<ModelGaussPeak>(h, lo, hi, jac, fvv, start, lupars, control_int, control_dbl, loss_rho, loss_cc, kernel_ms);
+        break;
+    case GSLNLS_MODEL_GAUSS1:
+        rc = batch_irls_run<ModelGauss1>(h, lo, hi, jac, fvv, start, lupars, control_int, control_dbl, loss_rho, loss_cc, kernel_ms);
+        break;
+    default:
+        return GSLNLS_E_UNSUPPORTED;
+    }
+    if (rc)
+        return rc;
+    const int cnt = hi - lo, p = h->p;
+    if (par)
+        GSLNLS_HIP_OK(hipMemcpy(par, h->d_par + (size_t)lo * p, sizeof(double) * (size_t)cnt * p, hipMemcpyDeviceToHost));
+    if (scal)
+        GSLNLS_HIP_OK(hipMemcpy(scal, h->d_scal + (size_t)lo * 4, sizeof(double) * (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    if (ints)
+        GSLNLS_HIP_OK(hipMemcpy(ints, h->d_ints + (size_t)lo * 4, sizeof(int) * (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    return GSLNLS_SUCCESS;
 }
 
 int gslnls_lower_formula(const char *rhs, int p, const char *const *parnames, int *par_order, char *varnames_out,

@@ -157,6 +157,21 @@ int gslnls_mstart_batch(gslnls_dense *h, int jac, const double *ranges, const do
                         float *kernel_ms);
 int gslnls_mstart_record_size(int p);
 
+/* ---- batched robust fits (BASELINE config C5) ------------------------------------------------------
+ * B independent data sets of n rows each, one model, one start, one loss: every data set goes through
+ * exactly the procedure gsl_nls(loss = ...) runs for a single one (src/nls_irls.c:412-546), one
+ * workgroup per data set.  No batched form exists in the reference; the single-fit contract is kept per
+ * data set.  Layouts: x [B][nx][n], y [B][n], swts [B][n] (sqrt of user weights) or NULL.
+ * Outputs per data set d in [lo, hi): par[(d-lo)*p ..], scal[(d-lo)*4 ..] = sigma, weighted ssr,
+ * irls_tol, initial ssr; ints[(d-lo)*4 ..] = conv, irls_status, irls_niter, niter of the last solve. */
+typedef struct gslnls_batch gslnls_batch;
+gslnls_batch *gslnls_batch_create(int model_id, int p, int nx, const double *x, const double *y, const double *swts,
+                                  int n, int B, int *err);
+void gslnls_batch_destroy(gslnls_batch *h);
+int gslnls_batch_irls(gslnls_batch *h, int lo, int hi, int jac, int fvv, const double *start, const double *lupars,
+                      const int *control_int, const double *control_dbl, int loss_rho, const double *loss_cc,
+                      double *par, double *scal, int *ints, float *kernel_ms);
+
 /* ---- gsl_nls_large: replaces C_nls_large (src/init.c:16, src/nls_large.c:66-424) --------------
  * 9 SEXP arguments there: fn, y, jac, fvv, env, start, weights, control_int[7], control_dbl[8]
  * (SURVEY.md App. C.3).  jac is always analytic on device (the reference requires one too), fvv /

@@ -1,0 +1,68 @@
+"""GPU parity of the workgroup-per-dataset batched robust fits (BASELINE config C5) through the C ABI:
+every data set of the batch must come out exactly as the single-fit IRLS procedure of the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GAUSS1_TRUTH = np.array([98.778210871, 0.010497276517, 100.48990633, 67.481111276, 23.129773360, 71.994503004,
+                         178.99805021, 18.389389025])          # NIST Gauss1 certified values, R/nls_test.R:303-312
+GAUSS1_START = np.array([97.0, 0.009, 100.0, 65.0, 20.0, 70.0, 178.0, 16.5])  # NIST start 1, R/nls_test.R:302
+
+
+def c5_data(B, n, seed0=20250929):
+    """Gauss1-family model, x_i = 250 i/n, truth = Gauss1 target x (1 + 0.05 U(-1,1)),
+    noise N(0, 2.5^2), 2 % of the points replaced by +50 outliers; seed PCG64(seed0 + dataset)"""
+    x = 250.0 * np.arange(1, n + 1) / n
+    X = np.tile(x, (B, 1))
+    Y = np.zeros((B, n))
+    TH = np.zeros((B, 8))
+    for d in range(B):
+        rng = np.random.Generator(np.random.PCG64(seed0 + d))
+        th = GAUSS1_TRUTH * (1.0 + 0.05 * rng.uniform(-1, 1, 8))
+        y = (th[0] * np.exp(-th[1] * x) + th[2] * np.exp(-(x - th[3]) ** 2 / th[4] ** 2)
+             + th[5] * np.exp(-(x - th[6]) ** 2 / th[7] ** 2)) + 2.5 * rng.standard_normal(n)
+        idx = rng.choice(n, n // 50, replace=False)
+        y[idx] += 50.0
+        Y[d], TH[d] = y, th
+    return X, Y, TH
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import gslnls_amd
+    from gslnls_amd import _lib
+    assert _lib.lib().gslnls_device_count() >= 1
+    return gslnls_amd
+
+
+@pytest.mark.parametrize("n", [1000, 777])
+def test_batched_bisquare_matches_single_fit_oracle(amd, gslref, n):
+    B = 12
+    X, Y, TH = c5_data(B, n)
+    prob = amd.BatchProblem(4, 8, X, Y)
+    out = prob.irls(GAUSS1_START, loss="bisquare", jac=True, control=dict(solver="cholesky"))
+    prob.close()
+    for d in range(B):
+        o = gslref.nls(n, 8, GAUSS1_START, rowdata=dict(model=gslref.MODEL_GAUSS1, x=X[d], y=Y[d]), use_jac=True,
+                       ctrl=gslref.control(solver="cholesky"), loss="bisquare")
+        assert out["conv"][d] == o["conv"] == 0 and out["irls_status"][d] == o["irls"]["irls_status"] == 0
+        assert out["irls_niter"][d] == o["irls"]["irls_niter"] and out["niter"][d] == o["niter"]
+        assert np.allclose(out["par"][d], o["par"], rtol=1e-6)
+        assert abs(out["sigma"][d] - o["irls"]["irls_sigma"]) <= 1e-6 * o["irls"]["irls_sigma"]
+        assert abs(out["ssr"][d] - o["ssr"]) <= 1e-6 * o["ssr"]
+        # robust: the 2 % outliers of +50 do not pull the fit away from the generating parameters
+        assert np.max(np.abs(out["par"][d] / TH[d] - 1.0)) < 0.05
+
+
+def test_batch_shards_are_independent(amd):
+    """data sets are independent: fitting [lo, hi) shards separately == fitting the whole batch (bitwise)"""
+    B, n = 10, 600
+    X, Y, _ = c5_data(B, n)
+    prob = amd.BatchProblem(4, 8, X, Y)
+    full = prob.irls(GAUSS1_START, loss="huber", jac=True)
+    a = prob.irls(GAUSS1_START, loss="huber", jac=True, lo=0, hi=4)
+    b = prob.irls(GAUSS1_START, loss="huber", jac=True, lo=4, hi=10)
+    prob.close()
+    assert np.array_equal(np.vstack([a["par"], b["par"]]), full["par"])
+    assert np.array_equal(np.concatenate([a["irls_niter"], b["irls_niter"]]), full["irls_niter"])
