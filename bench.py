@@ -130,6 +130,66 @@ def multistart_bench(L, _lib, torch, dist, rank, world, steps, warmup):
     return out
 
 
+def large_bench(L, _lib, n=10_000_000, p=64):
+    """C3: gsl_nls_large(cgst), synthetic GLM f_i = exp(a_i . theta), A n x p row-major fp64 resident in HBM
+    (SURVEY.md 8(d)): matrix-free pass GB/s (algorithmic 8np + 16n bytes per pass) and one whole fit."""
+    from gslnls_amd.nls_large import LargeProblem
+    rng = np.random.Generator(np.random.PCG64(20250928))
+    A = rng.uniform(-1.0, 1.0, size=(n, p))
+    A /= np.sqrt(p)
+    th = 0.25 * rng.standard_normal(p)
+    y = np.exp(A @ th) * (1.0 + 0.01 * rng.standard_normal(n))
+    prob = LargeProblem(5, p, A, y)
+    del A
+    x0 = np.zeros(p)
+    u = rng.standard_normal(p)
+    byt = 8.0 * n * p + 16.0 * n
+    ms_eval = prob.time_pass(0, x0, u, reps=10)
+    ms_jtjv = prob.time_pass(1, x0, u, reps=10)
+    t0 = time.perf_counter()
+    fit = prob.solve(x0, "cgst", want_resid=False)
+    el = time.perf_counter() - t0
+    prob.close()
+    return {"workload": "C3: gsl_nls_large cgst, GLM exp(A theta), n=%d p=%d (%.2f GB)" % (n, p, 8.0 * n * p / 1e9),
+            "bytes_per_pass": byt, "eval_pass_ms": ms_eval, "eval_pass_GBs": byt / ms_eval / 1e6,
+            "jtju_pass_ms": ms_jtjv, "jtju_pass_GBs": byt / ms_jtjv / 1e6,
+            "roofline_frac_jtju": byt / ms_jtjv / 1e6 / HBM_PEAK_GBS,
+            "fit": {"niter": int(fit["niter"]), "conv": int(fit["conv"]), "passes": int(fit["n_passes"]),
+                    "wall_s": el, "outer_iterations_per_s": fit["niter"] / el, "ssr": float(fit["ssr"]),
+                    "max_abs_err_vs_truth": float(np.max(np.abs(fit["par"] - th)))}}
+
+
+def batch_irls_bench(_lib, rank, world, B=4096, n=10000):
+    """C5: B data sets x n rows, NIST Gauss1 family p = 8, 2 % outliers, loss = bisquare; data sets are
+    independent, so rank r fits the contiguous block [r B/W, (r+1) B/W) with no collective"""
+    from gslnls_amd.batch import BatchProblem
+    truth = np.array([98.778210871, 0.010497276517, 100.48990633, 67.481111276, 23.129773360, 71.994503004,
+                      178.99805021, 18.389389025])
+    start = np.array([97.0, 0.009, 100.0, 65.0, 20.0, 70.0, 178.0, 16.5])
+    per = (B + world - 1) // world
+    lo, hi = min(B, rank * per), min(B, rank * per + per)
+    x = 250.0 * np.arange(1, n + 1) / n
+    X = np.tile(x, (hi - lo, 1))
+    Y = np.zeros((hi - lo, n))
+    for d in range(lo, hi):
+        rng = np.random.Generator(np.random.PCG64(20250929 + d))
+        th = truth * (1.0 + 0.05 * rng.uniform(-1, 1, 8))
+        yy = (th[0] * np.exp(-th[1] * x) + th[2] * np.exp(-(x - th[3]) ** 2 / th[4] ** 2)
+              + th[5] * np.exp(-(x - th[6]) ** 2 / th[7] ** 2)) + 2.5 * rng.standard_normal(n)
+        yy[rng.choice(n, n // 50, replace=False)] += 50.0
+        Y[d - lo] = yy
+    prob = BatchProblem(4, 8, X, Y)
+    prob.irls(start, loss="bisquare", jac=True, control=dict(solver="cholesky"))
+    t0 = time.perf_counter()
+    out = prob.irls(start, loss="bisquare", jac=True, control=dict(solver="cholesky"))
+    el = time.perf_counter() - t0
+    prob.close()
+    return {"workload": "C5: %d data sets x n=%d, Gauss1 family p=8, bisquare IRLS (this rank: %d)" % (B, n, hi - lo),
+            "datasets_per_s_this_rank": (hi - lo) / el, "irls_iterations_per_s_this_rank": float(out["irls_niter"].sum()) / el,
+            "kernel_ms": out["kernel_ms"], "converged": int((out["conv"] == 0).sum()),
+            "irls_converged": int((out["irls_status"] == 0).sum()), "mean_irls_iterations": float(out["irls_niter"].mean())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,6 +199,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fd", action="store_true", help="forward finite-difference Jacobian instead of analytic")
     ap.add_argument("--chunk", type=int, default=16)
+    ap.add_argument("--headline-only", action="store_true", help="skip the C3 / C5 side measurements")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -249,6 +310,10 @@ def main():
                      "ms_per_launch": ms_launch},
     }
     line["multistart"] = multistart_bench(L, _lib, torch, dist, rank, world, max(5, args.steps // 4), 3)
+    if not args.headline_only:
+        line["batched_irls"] = batch_irls_bench(_lib, rank, world)
+        if world == 1:
+            line["large_cgst"] = large_bench(L, _lib)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(x, y)
     elif rank == 0:
