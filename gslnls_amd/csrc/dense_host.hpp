@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <time.h>
 #include <stdio.h>
 #include <string.h>
 #include <vector>
@@ -28,6 +29,13 @@ namespace gslnls
             return GSLNLS_E_NODEVICE;                                                                 \
         }                                                                                             \
     } while (0)
+
+inline double now_s()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 inline LmParams make_params(const int *ci, const double *cd, int jac, int fvv, bool has_bounds, bool has_w)
 {
@@ -89,11 +97,12 @@ struct DenseFit : DenseBase
     double *d_partials = nullptr;
     LmState<P> *d_state = nullptr;
     LmState<P> *h_state = nullptr; // pinned + mapped: the device writes the final state here
+    volatile unsigned int *h_done = nullptr; // pinned word the device sets to ctx.seq when a fit ends
     double *d_ssrtrace = nullptr, *d_partrace = nullptr;
     int trace_cap = 0;
     double *d_resid = nullptr, *d_grad = nullptr, *d_covar = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_chunk = nullptr;
     MsEvaluator *ms_eval = nullptr; // cached batch evaluator (Sobol table, device buffers)
 
     int init(const gslnls_model *fn, const double *y, int n_, const double *swts)
@@ -104,6 +113,7 @@ struct DenseFit : DenseBase
         GSLNLS_HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         GSLNLS_HIP_OK(hipEventCreate(&ev0));
         GSLNLS_HIP_OK(hipEventCreate(&ev1));
+        GSLNLS_HIP_OK(hipEventCreateWithFlags(&ev_chunk, hipEventDisableTiming));
         const size_t nb = sizeof(double) * (size_t)n;
         if (fn->x_on_device)
         {
@@ -143,11 +153,15 @@ struct DenseFit : DenseBase
         GSLNLS_HIP_OK(hipMalloc(&d_state, sizeof(LmState<P>) * 2));
         ctx.state[0] = d_state;
         ctx.state[1] = d_state + 1;
-        GSLNLS_HIP_OK(hipHostMalloc(&h_state, sizeof(LmState<P>) * 2, hipHostMallocMapped));
+        GSLNLS_HIP_OK(hipHostMalloc(&h_state, sizeof(LmState<P>) * 2 + 64, hipHostMallocMapped));
         {
             void *dptr = nullptr;
             GSLNLS_HIP_OK(hipHostGetDevicePointer(&dptr, h_state, 0));
             ctx.host_mirror = reinterpret_cast<LmState<P> *>(dptr);
+            h_done = reinterpret_cast<volatile unsigned int *>(reinterpret_cast<char *>(h_state) + sizeof(LmState<P>) * 2);
+            *h_done = 0;
+            ctx.done_seq = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(dptr) + sizeof(LmState<P>) * 2);
+            ctx.seq = 0;
         }
         GSLNLS_HIP_OK(hipMalloc(&d_covar, sizeof(double) * P * P));
         return GSLNLS_SUCCESS;
@@ -175,6 +189,8 @@ struct DenseFit : DenseBase
             hipEventDestroy(ev0);
         if (ev1)
             hipEventDestroy(ev1);
+        if (ev_chunk)
+            hipEventDestroy(ev_chunk);
         if (stream)
             hipStreamDestroy(stream);
     }
@@ -199,16 +215,21 @@ struct DenseFit : DenseBase
     void launch_step(int jacmode, int parity)
     {
         const dim3 grid(ctx.G), block(T);
+        const LmState<P> *prev = ctx.state[parity ^ 1];
+        const double *pp = ctx.partials[parity ^ 1];
         switch (jacmode)
         {
         case JAC_ANALYTIC:
-            hipLaunchKernelGGL((lm_step_kernel<M, JAC_ANALYTIC, T>), grid, block, 0, stream, ctx, parity);
+            hipLaunchKernelGGL((lm_step_kernel<M, JAC_ANALYTIC, T>), grid, block, 0, stream, prev, pp, ctx.x[0], ctx.y,
+                               ctx.sw, ctx.n, ctx.G, parity, ctx);
             break;
         case JAC_FORWARD:
-            hipLaunchKernelGGL((lm_step_kernel<M, JAC_FORWARD, T>), grid, block, 0, stream, ctx, parity);
+            hipLaunchKernelGGL((lm_step_kernel<M, JAC_FORWARD, T>), grid, block, 0, stream, prev, pp, ctx.x[0], ctx.y,
+                               ctx.sw, ctx.n, ctx.G, parity, ctx);
             break;
         default:
-            hipLaunchKernelGGL((lm_step_kernel<M, JAC_CENTER, T>), grid, block, 0, stream, ctx, parity);
+            hipLaunchKernelGGL((lm_step_kernel<M, JAC_CENTER, T>), grid, block, 0, stream, prev, pp, ctx.x[0], ctx.y,
+                               ctx.sw, ctx.n, ctx.G, parity, ctx);
             break;
         }
     }
@@ -283,7 +304,8 @@ struct DenseFit : DenseBase
             GSLNLS_HIP_OK(hipMemsetAsync(d_ssrtrace, 0xFF, sizeof(double) * (maxiter + 1), stream));
             GSLNLS_HIP_OK(hipMemsetAsync(d_partrace, 0xFF, sizeof(double) * (size_t)(maxiter + 1) * P, stream));
         }
-        GSLNLS_HIP_OK(hipEventRecord(ev0, stream));
+        const double t_begin = now_s();
+        ctx.seq += 1; // this fit's sequence number (0 is never used)
         // brand-new state is built on device in slot 1; the first step launch has parity 0 and reads slot 1
         {
             StartArgs<P> sa;
@@ -310,15 +332,30 @@ struct DenseFit : DenseBase
                 parity ^= 1;
             }
             launches += chunk;
-            GSLNLS_HIP_OK(hipStreamSynchronize(stream));
-            if (h_state[0].phase == PH_DONE)
+            // the device stamps the fit's sequence number into pinned host memory when it ends; poll that word
+            // (bounded) instead of draining the stream, so trailing launches overlap with the caller
+            bool done = false;
+            hipEventRecord(ev_chunk, stream);
+            for (;;)
+            {
+                if (*h_done == ctx.seq)
+                {
+                    done = true;
+                    break;
+                }
+                if (hipEventQuery(ev_chunk) == hipSuccess)
+                {
+                    done = (*h_done == ctx.seq);
+                    break;
+                }
+            }
+            if (done)
                 break;
             if (launches > max_launches)
                 return GSLNLS_FAILURE;
         }
-        GSLNLS_HIP_OK(hipEventRecord(ev1, stream));
-        GSLNLS_HIP_OK(hipEventSynchronize(ev1));
-        hipEventElapsedTime(&last_ms, ev0, ev1);
+        __sync_synchronize();
+        last_ms = (float)(1e3 * (now_s() - t_begin));
         last_parity = parity ^ 1;
         last_launches = launches;
         return GSLNLS_SUCCESS;
@@ -356,7 +393,8 @@ struct DenseFit : DenseBase
             GSLNLS_HIP_OK(hipMemcpyAsync(out->partrace, d_partrace, sizeof(double) * (size_t)(maxiter + 1) * P,
                                          hipMemcpyDeviceToHost, stream));
         }
-        GSLNLS_HIP_OK(hipStreamSynchronize(stream));
+        if (trace || want_vecs || (ok && out->covar))
+            GSLNLS_HIP_OK(hipStreamSynchronize(stream)); // only when something n- or trace-sized was requested
         for (int k = 0; k < P; ++k)
             if (out->par)
                 out->par[k] = ok ? s.x[k] : start[k];

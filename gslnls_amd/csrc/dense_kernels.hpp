@@ -66,6 +66,8 @@ struct DenseCtx
     double *partrace; // (maxiter+1) x P column-major, or nullptr
     LmState<P> *host_mirror; // pinned host memory mapped into the device: final state lands here
     unsigned long long *stamps; // diagnostic builds only
+    unsigned int *done_seq;      // pinned host word: sequence number of the last finished fit
+    unsigned int seq;            // sequence number of this fit
 };
 
 // Cross-lane move of a double through DPP (VALU, ~8 cycles) instead of ds_bpermute (LDS, ~100
@@ -102,8 +104,32 @@ __device__ __forceinline__ double wave_sum(double v)
     return (r[0] + r[1]) + (r[2] + r[3]);
 }
 
-// Block-wide sum of NV values held per thread.  lds must hold (T/64) * NV doubles.
-// After the call thread v (< NV) of wave 0 holds total v in the return value.
+// Block-wide sum of NV values held per thread, fixed order.  Every thread parks its NV values in LDS
+// ([v][thread]); wave w then owns values v = w, w + NW, ...: each lane adds the T/64 entries of its
+// column, one DPP wave_sum finishes the value.  (Doing NV wave_sums per wave instead costs ~270 cycles
+// each on the critical path of every launch.)  lds must hold NV * T doubles; out[v] receives total v.
+template <int NV, int T>
+__device__ __forceinline__ void block_sum_to(const double *vals, double *lds, double *out)
+{
+    constexpr int NW = T / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+        lds[v * T + threadIdx.x] = vals[v];
+    __syncthreads();
+    for (int v = wave; v < NV; v += NW)
+    {
+        double a = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+            a += lds[v * T + w * 64 + lane];
+        a = wave_sum(a);
+        if (lane == 0)
+            out[v] = a;
+    }
+}
+
+// legacy shape kept for the kernels that reduce a handful of values once per launch
 template <int NV, int T>
 __device__ __forceinline__ double block_sum_slots(const double *vals, double *lds)
 {
@@ -148,8 +174,14 @@ struct StepBcast
 // rows prefetched into registers before the prologue so their latency hides behind it
 constexpr int ROWS_AHEAD = 8;
 
+// The first arguments are the pointers every wave needs before it can issue a single load; they are
+// plain scalars so that the backend can preload them into SGPRs at wave launch
+// (-mllvm -amdgpu-kernarg-preload-count=16): otherwise each launch starts with a ~2000-cycle wait on
+// the kernarg segment.  The bulky rest (tolerances, trace pointers) is only needed after the loads.
 template <class M, int JAC, int T>
-__global__ __launch_bounds__(T) void lm_step_kernel(DenseCtx<M::P> ctx, int parity)
+__global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, const double *prev_partials,
+                                                    const double *x0, const double *yv_, const double *swv_,
+                                                    long long n, int G, int parity, DenseCtx<M::P> ctx)
 {
     constexpr int P = M::P;
     constexpr int NX = M::NX;
@@ -158,18 +190,16 @@ __global__ __launch_bounds__(T) void lm_step_kernel(DenseCtx<M::P> ctx, int pari
     constexpr int NW = T / 64;
     constexpr int R = ROWS_AHEAD;
 
-    __shared__ double lds_red[NW * NV];
+    __shared__ double lds_red[NV * T];
+    __shared__ double lds_tot[NV];
     __shared__ StepBcast<P> lds_bc;
 
     const int tid = threadIdx.x;
-    const int G = ctx.G;
-    const LmState<P> *prev = ctx.state[parity ^ 1];
 
     GSLNLS_STAMP(0);
     // ---------------- issue this thread's first rows now: they do not depend on the decision ----
-    const long long n = ctx.n;
-    const double *__restrict__ yv = ctx.y;
-    const double *__restrict__ swv = ctx.sw;
+    const double *__restrict__ yv = yv_;
+    const double *__restrict__ swv = swv_;
     const long long stride = (long long)G * T;
     const long long i0 = (long long)blockIdx.x * T + tid;
     double px[R][NX], py[R], pw[R];
@@ -180,26 +210,61 @@ __global__ __launch_bounds__(T) void lm_step_kernel(DenseCtx<M::P> ctx, int pari
         const long long ic = i < n ? i : (n - 1);
 #pragma unroll
         for (int c = 0; c < NX; ++c)
-            px[k][c] = ctx.x[c][ic];
+            px[k][c] = x0[(size_t)c * n + ic];
         py[k] = yv[ic];
         pw[k] = swv ? swv[ic] : 1.0;
     }
 
     GSLNLS_STAMP(1);
-    // ---------------- prologue (wavefront 0): finish the previous reduction, advance -----------
+    // ---------------- prologue: finish the previous launch's reduction (all waves), advance (wave 0) ----
+    // wave 0 issues the loads of the whole state first (same address in every lane: one request each) so
+    // that their latency overlaps with the partial sums below
+    LmState<P> s;
     if (tid < 64)
     {
         const int z = opaque_zero();
-        LmState<P> s;
-        {
-            // vector loads of the whole state (same address in every lane: one request each)
-            const double *src = reinterpret_cast<const double *>(prev) + z;
-            double *dst = reinterpret_cast<double *>(&s);
-            static_assert(sizeof(LmState<P>) % 8 == 0, "state is a whole number of doubles");
+        const double *src = reinterpret_cast<const double *>(prev) + z;
+        double *dst = reinterpret_cast<double *>(&s);
+        static_assert(sizeof(LmState<P>) % 8 == 0, "state is a whole number of doubles");
 #pragma unroll
-            for (int k = 0; k < (int)(sizeof(LmState<P>) / 8); ++k)
-                dst[k] = src[k];
+        for (int k = 0; k < (int)(sizeof(LmState<P>) / 8); ++k)
+            dst[k] = src[k];
+    }
+    // wave w sums the G partials of values v = w, w + NW, ... : lane-strided partial sums, then the butterfly
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int z0 = opaque_zero();
+        const double *pp = prev_partials + z0;
+        constexpr int PB = MAX_G / 64;
+        constexpr int VPW = (NV + NW - 1) / NW; // values per wave
+        double pv[VPW][PB];
+#pragma unroll
+        for (int q = 0; q < VPW; ++q)
+        {
+            const int v = wave + q * NW;
+#pragma unroll
+            for (int j = 0; j < PB; ++j)
+            {
+                const int b = lane + 64 * j;
+                pv[q][j] = (v < NV && b < G) ? pp[(size_t)v * G + b] : 0.0;
+            }
         }
+#pragma unroll
+        for (int q = 0; q < VPW; ++q)
+        {
+            const int v = wave + q * NW;
+            double a = pv[q][0];
+#pragma unroll
+            for (int j = 1; j < PB; ++j)
+                a += pv[q][j];
+            a = wave_sum(a);
+            if (lane == 0 && v < NV)
+                lds_tot[v] = a;
+        }
+    }
+    __syncthreads();
+    if (tid < 64)
+    {
         const bool fresh = s.bad_steps < 0; // host marks a brand-new state with bad_steps = -1
         if (s.phase == PH_DONE)
         {
@@ -211,28 +276,9 @@ __global__ __launch_bounds__(T) void lm_step_kernel(DenseCtx<M::P> ctx, int pari
         {
             Sums r;
             double *rf = reinterpret_cast<double *>(&r);
-            const double *pp = ctx.partials[parity ^ 1] + z;
-            // all loads first (static shape: G <= 64 * PB), then the sums in a fixed order:
-            // lane-strided partial sums, then the butterfly
-            constexpr int PB = MAX_G / 64;
-            double pv[NV][PB];
 #pragma unroll
             for (int v = 0; v < NV; ++v)
-#pragma unroll
-                for (int j = 0; j < PB; ++j)
-                {
-                    const int b = tid + 64 * j;
-                    pv[v][j] = (b < G) ? pp[(size_t)v * G + b] : 0.0;
-                }
-#pragma unroll
-            for (int v = 0; v < NV; ++v)
-            {
-                double a = pv[v][0];
-#pragma unroll
-                for (int j = 1; j < PB; ++j)
-                    a += pv[v][j];
-                rf[v] = wave_sum(a);
-            }
+                rf[v] = lds_tot[v];
             const int niter_before = s.niter;
             const int phase_before = s.phase;
             GSLNLS_STAMP(2);
@@ -278,7 +324,13 @@ __global__ __launch_bounds__(T) void lm_step_kernel(DenseCtx<M::P> ctx, int pari
             {
                 *ctx.state[parity] = s;
                 if (s.phase == PH_DONE)
-                    *ctx.host_mirror = s; // fire-and-forget write over PCIe; visible after stream sync
+                {
+                    // final state to pinned host memory, then the fit's sequence number with system-scope
+                    // release: the host polls the sequence word and can return without draining the stream
+                    *ctx.host_mirror = s;
+                    __threadfence_system();
+                    __hip_atomic_store(ctx.done_seq, ctx.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
         }
     }
@@ -328,15 +380,16 @@ __global__ __launch_bounds__(T) void lm_step_kernel(DenseCtx<M::P> ctx, int pari
         double xr[NX];
 #pragma unroll
         for (int c = 0; c < NX; ++c)
-            xr[c] = ctx.x[c][i];
+            xr[c] = x0[(size_t)c * n + i];
         do_row(xr, yv[i], swv ? swv[i] : 1.0);
     }
 
     GSLNLS_STAMP(5);
     // ---------------- workgroup reduction -> one partial set ---------------------------------
-    const double tot = block_sum_slots<NV, T>(reinterpret_cast<const double *>(&acc), lds_red);
+    block_sum_to<NV, T>(reinterpret_cast<const double *>(&acc), lds_red, lds_tot);
+    __syncthreads();
     if (tid < NV)
-        ctx.partials[parity][(size_t)tid * G + blockIdx.x] = tot;
+        ctx.partials[parity][(size_t)tid * G + blockIdx.x] = lds_tot[tid];
     GSLNLS_STAMP(6);
 }
 
