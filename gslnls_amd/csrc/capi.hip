@@ -14,6 +14,7 @@
 #include "irls_host.hpp"
 #include "large_host.hpp"
 #include "irls_batch.hpp"
+#include "robust_host.hpp"
 
 using namespace gslnls;
 
@@ -537,7 +538,7 @@ int gslnls_dense_mstart(gslnls_dense *h, int jac, int fvv, const double *start2p
 {
     if (!h || !h->impl)
         return GSLNLS_EINVAL;
-    return h->impl->mstart(jac, fvv, start2p, lupars, control_int, control_dbl, has_start, g_comm, out);
+    return h->impl->mstart(jac, fvv, start2p, lupars, control_int, control_dbl, has_start, g_comm, 0, nullptr, out);
 }
 
 int gslnls_mstart_batch(gslnls_dense *h, int jac, const double *ranges, const double *kd, long long first_draw,
@@ -567,15 +568,13 @@ int gslnls_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv,
 {
     if (swts && swts_is_matrix)
         return GSLNLS_E_UNSUPPORTED; // GLS: n x n factor, not lowered
-    if (loss_rho != 0 && start_is_matrix)
-        return GSLNLS_E_UNSUPPORTED; // robust multi-start second pass (src/nls.c:401-509): next round
     int err = 0;
     DenseBase *b = make_dense(fn, y, n, swts, &err);
     if (!b)
         return err;
     int rc;
     if (start_is_matrix)
-        rc = b->mstart(jac, fvv, start, lupars, control_int, control_dbl, has_start, g_comm, out);
+        rc = b->mstart(jac, fvv, start, lupars, control_int, control_dbl, has_start, g_comm, loss_rho, loss_cc, out);
     else if (loss_rho != 0)
         rc = b->irls(jac, fvv, start, lupars, control_int, control_dbl, loss_rho, loss_cc, out);
     else

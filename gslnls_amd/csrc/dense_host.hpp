@@ -74,7 +74,8 @@ struct DenseBase
     virtual int set_swts(const double *swts) = 0;
     // multi-start branch of C_nls (src/nls.c:274-532) followed by the final single-start solve
     virtual int mstart(int jac, int fvv, const double *start2p, const double *lupars, const int *ci, const double *cd,
-                       const int *has_start, const MsComm &comm, gslnls_result *out) = 0;
+                       const int *has_start, const MsComm &comm, int loss_rho, const double *loss_cc,
+                       gslnls_result *out) = 0;
     // one concentration batch of `count` fresh Sobol points (first_draw + i), shard [lo, hi)
     virtual int mstart_batch(int jac, const double *ranges, const double *kd, long long first_draw, int count, int lo,
                              int hi, int maxiter, double dtol, const int *ci, const double *cd, const double *lupars,
@@ -441,9 +442,11 @@ struct DenseFit : DenseBase
 
     int irls(int jac, int fvv, const double *start, const double *lupars, const int *ci, const double *cd, int loss_rho,
              const double *loss_cc, gslnls_result *out) override;
+    int sums_at(const double *theta, int jacmode, PassSums<P> &out);
+    int robust_weights(int jacmode, const double *mpopt, double *d_sw_robust);
 
     int mstart(int jac, int fvv, const double *start2p, const double *lupars, const int *ci, const double *cd,
-               const int *has_start, const MsComm &comm, gslnls_result *out) override;
+               const int *has_start, const MsComm &comm, int loss_rho, const double *loss_cc, gslnls_result *out) override;
     int mstart_batch(int jac, const double *ranges, const double *kd, long long first_draw, int count, int lo, int hi,
                      int maxiter, double dtol, const int *ci, const double *cd, const double *lupars, double *records,
                      int records_on_device, float *kernel_ms) override;

@@ -146,7 +146,8 @@ struct HipMsEvaluator : MsEvaluator
 
 template <class M>
 int DenseFit<M>::mstart(int jac, int fvv, const double *start2p, const double *lupars, const int *ci, const double *cd,
-                        const int *has_start, const MsComm &comm, gslnls_result *out)
+                        const int *has_start, const MsComm &comm, int loss_rho, const double *loss_cc,
+                        gslnls_result *out)
 {
     if (ci[2] > 1)
         return GSLNLS_E_UNSUPPORTED;
@@ -158,6 +159,43 @@ int DenseFit<M>::mstart(int jac, int fvv, const double *start2p, const double *l
     int rc = ms_major_loop(m, ev, comm, start2p);
     if (rc)
         return rc < 0 && rc > -100 ? GSLNLS_FAILURE : rc;
+    // robust second pass (src/nls.c:401-509): Cook's-distance outliers get zero weight, then the whole
+    // multi-start is repeated (fresh counters and quasi-random sequence, ranges and exponents carried over)
+    if (loss_rho != 0)
+    {
+        if (m.mssropt[1] < m.mssropt[0])
+            m.mpopt = m.mpopt1;
+        prepare(jac, fvv, lupars, ci, cd, false);
+        const int jacmode = jac ? JAC_ANALYTIC : (ci[5] ? JAC_CENTER : JAC_FORWARD);
+        double *d_sw_robust = nullptr;
+        GSLNLS_HIP_OK(hipMalloc(&d_sw_robust, sizeof(double) * (size_t)n));
+        const int second = robust_weights(jacmode, m.mpopt.data(), d_sw_robust);
+        if (second < 0)
+        {
+            hipFree(d_sw_robust);
+            return second;
+        }
+        if (second == 1)
+        {
+            const double *keep_sw = ctx.sw;
+            ctx.sw = d_sw_robust;
+            ev.prm.has_weights = 1;
+            m.next_draw = 0; // gsl_qrng_init
+            m.mstop = ST_CONTINUE;
+            m.mstarts = m.nsp = m.nwsp = 0;
+            m.dtol = 1.0e-6;
+            m.rejectscl = 1.25;
+            m.mssropt[0] = m.mssropt[1] = INFINITY;
+            m.ssrconv[0] = m.ssrconv[1] = 1.0;
+            std::fill(m.ntix.begin(), m.ntix.end(), 0);
+            std::fill(m.luchange.begin(), m.luchange.end(), 0);
+            rc = ms_major_loop(m, ev, comm, start2p);
+            ctx.sw = keep_sw; // "reset original weights" (src/nls.c:490-507)
+        }
+        hipFree(d_sw_robust);
+        if (rc)
+            return rc < 0 && rc > -100 ? GSLNLS_FAILURE : rc;
+    }
     // src/nls.c:518-531
     if (m.mssropt[1] < m.mssropt[0])
     {
@@ -173,7 +211,10 @@ int DenseFit<M>::mstart(int jac, int fvv, const double *start2p, const double *l
         else
             m.mpopt[0] = m.mpopt[0] + 1.0e-4;
     }
-    rc = solve(jac, fvv, m.mpopt.data(), lupars, ci, cd, 0, out);
+    if (loss_rho != 0)
+        rc = irls(jac, fvv, m.mpopt.data(), lupars, ci, cd, loss_rho, loss_cc, out);
+    else
+        rc = solve(jac, fvv, m.mpopt.data(), lupars, ci, cd, 0, out);
     out->mstart_nsp = m.nsp;
     out->mstart_nwsp = m.nwsp;
     out->mstart_iters = m.mstarts;

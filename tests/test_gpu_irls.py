@@ -95,3 +95,29 @@ def test_irls_large_n_median_on_device(amd, gslref):
         assert abs(prob_fit["irls"]["irls_sigma"] - 1.482602218505602 * np.median(r)) <= 1e-12
         assert np.allclose(prob_fit["par"], o["par"], rtol=1e-6)
         assert np.allclose(prob_fit["par"], [5.0, 1.5, 1.0], atol=0.02)   # the outliers are rejected
+
+
+@pytest.mark.parametrize("loss,start,outlier", [("hampel", dict(b1=[200, 250], b2=1e-4), False),
+                                                ("ggw", dict(b1=np.nan, b2=1e-4), False),
+                                                ("huber", dict(b1=[200, 250], b2=[1e-4, 1e-3]), True),
+                                                ("bisquare", dict(b1=[100, 400], b2=[1e-4, 1e-3]), True)])
+def test_robust_multistart_second_pass(amd, gslref, nist, loss, start, outlier):
+    """unit_tests_gslnls.R:212-216 (5.1.12, 5.1.14) + outlier variants: multi-start with a robust loss runs the
+    Cook's-distance second pass (src/nls.c:401-509) before the IRLS solve; bookkeeping and result == oracle"""
+    q = nist["Misra1a"]
+    x, y = np.array(q["data"]["x"]), np.array(q["data"]["y"])
+    if outlier:
+        y = y.copy()
+        y[0] = 25.0
+    tgt = np.array(list(q["target"].values()))
+    fit = amd.gsl_nls(q["formula"], data=dict(x=x, y=y), start=start, loss=loss, control=dict(solver="cholesky"))
+    assert fit["conv"] == 0 and fit["irls"]["irls_status"] == 0
+    assert np.max(np.abs(1 - fit["par"] / tgt)) < 1e-2
+    from gslnls_amd.nls import _normalise_start
+    names, vec, mat, hs = _normalise_start(start)
+    o = gslref.nls(14, 2, mat, rowdata=dict(model=gslref.MODEL_MISRA1A, x=x, y=y), use_jac=False,
+                   ctrl=gslref.control(solver="cholesky"), loss=loss, has_start=hs.astype(int))
+    m, mo = fit["mstart"], o["mstart"]
+    assert (m["nsp"], m["nwsp"], m["iters"], m["stop"]) == (mo["nsp"], mo["nwsp"], mo["iters"], mo["stop"])
+    assert fit["irls"]["irls_niter"] == o["irls"]["irls_niter"]
+    assert np.allclose(fit["par"], o["par"], rtol=1e-5)
