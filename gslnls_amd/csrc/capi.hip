@@ -395,6 +395,14 @@ float gslnls_large_time_pass(gslnls_large *h, int mode, const double *x, const d
             if (h->ops->eval(x, &ssr, g.data(), d.data(), nullptr, &bad))
                 return -1.f;
         }
+        else if (mode == 2)
+        {
+            std::vector<double> J((size_t)h->p * h->p);
+            const double t0 = now_s();
+            if (h->ops->full_jtj(x, J.data()))
+                return -1.f;
+            h->ops->pass_ms = (float)(1e3 * (now_s() - t0)); // kernel + reduce + 32 KB readback
+        }
         else if (h->ops->jtjv(x, u, &nw2, g.data()))
             return -1.f;
         tot += h->ops->pass_ms;

@@ -709,7 +709,12 @@ struct GlmLargeOps : LargeOps
         if (!d_jtjpart)
             GSLNLS_HIP_OK(hipMalloc(&d_jtjpart, sizeof(double) * (size_t)P * P * Gj + sizeof(double) * P * P));
         double *d_out = d_jtjpart + (size_t)P * P * Gj;
-        hipLaunchKernelGGL((glm_jtj_kernel<P, 256>), dim3(Gj), dim3(256), 0, st, d_A, d_m[cur], (long long)n, d_jtjpart);
+        if (P == 64)
+            hipLaunchKernelGGL((glm_jtj_mfma64_kernel<256>), dim3(Gj), dim3(256), 0, st, d_A, d_m[cur], (long long)n,
+                               d_jtjpart); // matrix cores
+        else
+            hipLaunchKernelGGL((glm_jtj_kernel<P, 256>), dim3(Gj), dim3(256), 0, st, d_A, d_m[cur], (long long)n,
+                               d_jtjpart);
         hipLaunchKernelGGL(large_reduce_kernel, dim3(P * P), dim3(64), 0, st, d_jtjpart, P * P, Gj, d_out);
         GSLNLS_HIP_OK(hipMemcpyAsync(jtj, d_out, sizeof(double) * P * P, hipMemcpyDeviceToHost, st));
         GSLNLS_HIP_OK(hipStreamSynchronize(st));

@@ -286,4 +286,80 @@ __global__ __launch_bounds__(T) void glm_jtj_kernel(const double *A, const doubl
             partials[((size_t)(ti * B + i) * P + (tj * B + j)) * gridDim.x + blockIdx.x] = acc[i][j];
 }
 
+// ------------------------------------------------------------------------------------------------
+// K11: J^T J = A^T diag(m^2) A for p = 64 on the matrix cores (north_star: "MFMA tall-skinny GEMM for
+// J^T J only when p fills a 16-wide tile").  v_mfma_f64_16x16x4_f64: D(16x16) += A'(16x4) B(4x16), operand
+// layout probed on gfx950 (scripts/mfma_probe): lane l supplies A'[l%16][l/16] and B[l/16][l%16] and holds
+// D[4r + l/16][l%16] in result register r.
+// One wave instruction covers 4 consecutive rows: lane l (k = l/16, i = l%16) loads the 32 contiguous
+// bytes J[row k][4i .. 4i+3] (the 16 lanes of a row read its 512 B back to back) and scales by m[row].
+// With the logical column order (b, i) -> physical column 4i + b the SAME register is the A' operand of
+// block row b and the B operand of block column b, so the 4 loaded values feed all 10 lower-triangle
+// blocks: acc[ba][bb][r] at lane l is J^T J[4(4r + l/16) + ba][4(l%16) + bb].
+typedef double v4f64_t __attribute__((ext_vector_type(4)));
+
+template <int T>
+__global__ __launch_bounds__(T) void glm_jtj_mfma64_kernel(const double *A, const double *m, long long n,
+                                                           double *partials /* [4096][gridDim.x] */)
+{
+    constexpr int P = 64, NW = T / 64;
+    __shared__ double lds_acc[NW][10 * 4 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = lane >> 4, i = lane & 15;
+    v4f64_t acc[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q)
+        acc[q] = (v4f64_t){0.0, 0.0, 0.0, 0.0};
+    const long long nchunk = (n + 3) / 4;
+    const long long wstride = (long long)gridDim.x * NW;
+    for (long long c = (long long)blockIdx.x * NW + wave; c < nchunk; c += wstride)
+    {
+        const long long row = c * 4 + k;
+        double val[4] = {0.0, 0.0, 0.0, 0.0};
+        if (row < n)
+        {
+            const double2 lo = *reinterpret_cast<const double2 *>(A + row * P + 4 * i);
+            const double2 hi = *reinterpret_cast<const double2 *>(A + row * P + 4 * i + 2);
+            const double mm = m[row];
+            val[0] = lo.x * mm;
+            val[1] = lo.y * mm;
+            val[2] = hi.x * mm;
+            val[3] = hi.y * mm;
+        }
+        int q = 0;
+#pragma unroll
+        for (int ba = 0; ba < 4; ++ba)
+#pragma unroll
+            for (int bb = 0; bb <= ba; ++bb, ++q)
+                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(val[ba], val[bb], acc[q], 0, 0, 0);
+    }
+    // waves of the workgroup -> one partial set (fixed order), scattered to J^T J element order
+#pragma unroll
+    for (int q = 0; q < 10; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            lds_acc[wave][(q * 4 + r) * 64 + lane] = acc[q][r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 10 * 4 * 64; e += T)
+    {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+            t += lds_acc[w][e];
+        const int q = e / 256, r = (e / 64) & 3, l = e & 63;
+        int ba = 0, bb = 0, cnt = 0;
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b <= a; ++b, ++cnt)
+                if (cnt == q)
+                {
+                    ba = a;
+                    bb = b;
+                }
+        const int gi = 4 * (4 * r + (l >> 4)) + ba, gj = 4 * (l & 15) + bb;
+        partials[((size_t)gi * P + gj) * gridDim.x + blockIdx.x] = t;
+        if (ba != bb)
+            partials[((size_t)gj * P + gi) * gridDim.x + blockIdx.x] = t; // mirror block
+    }
+}
+
 } // namespace gslnls

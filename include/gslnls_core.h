@@ -197,7 +197,8 @@ gslnls_large *gslnls_large_create(const gslnls_model *fn, const double *y, int n
 void gslnls_large_destroy(gslnls_large *h);
 int gslnls_large_solve(gslnls_large *h, const double *start, const int *control_int, const double *control_dbl,
                        gslnls_large_result *out);
-/* average HIP-event milliseconds of `reps` passes: mode 0 = EVAL pass at x, 1 = fused J^T J u pass */
+/* average milliseconds of `reps` passes: mode 0 = EVAL pass at x, 1 = fused J^T J u pass (HIP events),
+ * 2 = full J^T J (p = 64: MFMA kernel + reduction + readback, host clock) */
 float gslnls_large_time_pass(gslnls_large *h, int mode, const double *x, const double *u, int reps);
 
 /* ---- introspection ---------------------------------------------------------------------- */

@@ -23,6 +23,8 @@ byt = 8.0 * n * p + 16.0 * n
 for mode, nm in ((0, "EVAL (ssr, J^T f, diag J^T J; writes m, f)"), (1, "fused J^T J u")):
     ms = prob.time_pass(mode, x, u, reps=10)
     print("%-45s %.3f ms/pass -> %.0f GB/s (algorithmic %.2f GB)" % (nm, ms, byt / ms / 1e6, byt / 1e9))
+ms = prob.time_pass(2, x, u, reps=5)
+print("%-45s %.3f ms -> %.2f TFLOP/s fp64 (2 n p^2 = %.1f GFLOP), %.0f GB/s" % ("full J^T J (MFMA f64 16x16x4)", ms, 2.0 * n * p * p / ms / 1e9, 2.0 * n * p * p / 1e9, (8.0 * n * p + 8.0 * n) / ms / 1e6))
 t0 = time.time()
 fit = prob.solve(x, "cgst", want_resid=False)
 el = time.time() - t0
