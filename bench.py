@@ -207,11 +207,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    # developer dry-run of the N > 1 code path on a 1-GPU box: GSLNLS_BENCH_BACKEND=gloo GSLNLS_BENCH_ONE_DEVICE=1
+    backend = os.environ.get("GSLNLS_BENCH_BACKEND", "nccl")
+    if os.environ.get("GSLNLS_BENCH_ONE_DEVICE"):
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     from gslnls_amd import _lib
     from gslnls_amd.control import gsl_nls_control, pack_control
