@@ -17,8 +17,21 @@ E_NODEVICE = -100
 E_UNSUPPORTED = -101
 
 
+MODEL_EXPR = 100
+
+
 class Model(C.Structure):
-    _fields_ = [("id", C.c_int), ("p", C.c_int), ("nx", C.c_int), ("x", C.c_void_p), ("x_on_device", C.c_int)]
+    _fields_ = [("id", C.c_int), ("p", C.c_int), ("nx", C.c_int), ("x", C.c_void_p), ("x_on_device", C.c_int),
+                ("expr", C.c_char_p), ("parnames", C.POINTER(C.c_char_p)), ("xnames", C.POINTER(C.c_char_p))]
+
+
+def set_expr(m, expr, parnames, xnames):
+    """fill the GSLNLS_MODEL_EXPR fields of a Model; returns the objects that own the C strings"""
+    pn = (C.c_char_p * max(len(parnames), 1))(*[s.encode() for s in parnames])
+    xn = (C.c_char_p * max(len(xnames), 1))(*[s.encode() for s in xnames])
+    e = expr.encode()
+    m.expr, m.parnames, m.xnames = e, C.cast(pn, C.POINTER(C.c_char_p)), C.cast(xn, C.POINTER(C.c_char_p))
+    return e, pn, xn
 
 
 class Result(C.Structure):

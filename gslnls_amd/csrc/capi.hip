@@ -26,6 +26,11 @@ struct gslnls_dense
 // process-wide communicator of the multi-start sharding (one process per GPU)
 static MsComm g_comm;
 
+namespace gslnls
+{
+DenseBase *make_dense_expr(const gslnls_model *fn, const double *y, int n, const double *swts, int *err); // vm_models.hip
+}
+
 static DenseBase *make_dense(const gslnls_model *fn, const double *y, int n, const double *swts, int *err)
 {
     int ndev = 0;
@@ -48,6 +53,10 @@ static DenseBase *make_dense(const gslnls_model *fn, const double *y, int n, con
         rc = d->init(fn, y, n, swts);                               \
         b = d;                                                      \
     }
+#ifndef GSLNLS_NO_EXPR
+    if (fn->id == GSLNLS_MODEL_EXPR)
+        return make_dense_expr(fn, y, n, swts, err);
+#endif
     switch (fn->id)
     {
     case GSLNLS_MODEL_EXPDECAY:

@@ -1,0 +1,389 @@
+// expr_compile.hpp -- host compiler: formula right-hand side -> VmProgram (value + symbolic gradient).
+//
+// Stands in for what R does at the boundary: the model closure evaluates formula[[3]] (R/nls.R:565) and
+// jac = TRUE asks stats::deriv() for the gradient expression (R/nls.R:588-599).  The AST comes from
+// FParser (formula.hpp).  Nodes are hash-consed (structural CSE), constants are folded, and the usual
+// algebraic identities (x+0, x*1, x*0, x^1, ...) keep the derivative DAG small.
+#pragma once
+#include <math.h>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+#include "formula.hpp"
+#include "vm_program.hpp"
+
+namespace gslnls
+{
+
+struct ExprCompiler
+{
+    enum Kind
+    {
+        K_CONST,
+        K_PARAM,
+        K_VAR,
+        K_OP
+    };
+    struct Node
+    {
+        Kind kind;
+        unsigned char op;
+        int a, b;   // children (K_OP) or index (K_PARAM / K_VAR)
+        double c;   // K_CONST
+    };
+    std::vector<Node> nodes;
+    std::map<std::tuple<int, int, int, int, long long>, int> memo;
+    std::string error;
+
+    int intern(Kind k, unsigned char op, int a, int b, double c)
+    {
+        long long bits;
+        memcpy(&bits, &c, sizeof(bits));
+        auto key = std::make_tuple((int)k, (int)op, a, b, bits);
+        auto it = memo.find(key);
+        if (it != memo.end())
+            return it->second;
+        nodes.push_back({k, op, a, b, c});
+        memo[key] = (int)nodes.size() - 1;
+        return (int)nodes.size() - 1;
+    }
+    int cst(double v) { return intern(K_CONST, 0, -1, -1, v); }
+    int param(int k) { return intern(K_PARAM, 0, k, -1, 0.0); }
+    int var(int c) { return intern(K_VAR, 0, c, -1, 0.0); }
+    bool is_const(int n) const { return nodes[n].kind == K_CONST; }
+    bool is_val(int n, double v) const { return nodes[n].kind == K_CONST && nodes[n].c == v; }
+
+    int op2(unsigned char op, int a, int b)
+    {
+        if (is_const(a) && is_const(b))
+            return cst(vm_apply(op, nodes[a].c, nodes[b].c));
+        switch (op)
+        {
+        case VM_ADD:
+            if (is_val(a, 0.0))
+                return b;
+            if (is_val(b, 0.0))
+                return a;
+            break;
+        case VM_SUB:
+            if (is_val(b, 0.0))
+                return a;
+            if (is_val(a, 0.0))
+                return op1(VM_NEG, b);
+            if (a == b)
+                return cst(0.0);
+            break;
+        case VM_MUL:
+            if (is_val(a, 0.0) || is_val(b, 0.0))
+                return cst(0.0);
+            if (is_val(a, 1.0))
+                return b;
+            if (is_val(b, 1.0))
+                return a;
+            if (is_val(a, -1.0))
+                return op1(VM_NEG, b);
+            if (is_val(b, -1.0))
+                return op1(VM_NEG, a);
+            if (b < a)
+                std::swap(a, b); // commutative: canonical order helps CSE
+            break;
+        case VM_DIV:
+            if (is_val(a, 0.0))
+                return cst(0.0);
+            if (is_val(b, 1.0))
+                return a;
+            break;
+        case VM_POW:
+            if (is_val(b, 1.0))
+                return a;
+            if (is_val(b, 0.0))
+                return cst(1.0);
+            break;
+        default:
+            break;
+        }
+        if (op == VM_ADD && b < a)
+            std::swap(a, b);
+        return intern(K_OP, op, a, b, 0.0);
+    }
+    int op1(unsigned char op, int a)
+    {
+        if (is_const(a))
+            return cst(vm_apply(op, nodes[a].c, 0.0));
+        if (op == VM_NEG && nodes[a].kind == K_OP && nodes[a].op == VM_NEG)
+            return nodes[a].a;
+        return intern(K_OP, op, a, a, 0.0);
+    }
+
+    // AST -> DAG
+    int build(const FNodeP &t, const std::vector<std::string> &parnames, const std::vector<std::string> &varnames)
+    {
+        switch (t->kind)
+        {
+        case FNode::NUM:
+            return cst(t->num);
+        case FNode::SYM:
+        {
+            for (size_t k = 0; k < parnames.size(); ++k)
+                if (parnames[k] == t->name)
+                    return param((int)k);
+            for (size_t c = 0; c < varnames.size(); ++c)
+                if (varnames[c] == t->name)
+                    return var((int)c);
+            if (t->name == "pi")
+                return cst(3.14159265358979323846);
+            error = "unknown symbol '" + t->name + "'";
+            return cst(NAN);
+        }
+        case FNode::NEG:
+            return op1(VM_NEG, build(t->args[0], parnames, varnames));
+        case FNode::BIN:
+        {
+            const int a = build(t->args[0], parnames, varnames), b = build(t->args[1], parnames, varnames);
+            if (t->name == "+")
+                return op2(VM_ADD, a, b);
+            if (t->name == "-")
+                return op2(VM_SUB, a, b);
+            if (t->name == "*")
+                return op2(VM_MUL, a, b);
+            if (t->name == "/")
+                return op2(VM_DIV, a, b);
+            if (t->name == "^")
+                return op2(VM_POW, a, b);
+            error = "unknown operator " + t->name;
+            return cst(NAN);
+        }
+        case FNode::CALL:
+        {
+            static const std::map<std::string, unsigned char> f1 = {
+                {"exp", VM_EXP}, {"log", VM_LOG}, {"sin", VM_SIN}, {"cos", VM_COS}, {"tan", VM_TAN},
+                {"atan", VM_ATAN}, {"sqrt", VM_SQRT}, {"abs", VM_ABS}, {"tanh", VM_TANH}};
+            auto it = f1.find(t->name);
+            if (it == f1.end() || t->args.size() != 1)
+            {
+                error = "unsupported function " + t->name;
+                return cst(NAN);
+            }
+            return op1(it->second, build(t->args[0], parnames, varnames));
+        }
+        }
+        return cst(NAN);
+    }
+
+    bool depends(int n, int k, std::map<int, bool> &cache)
+    {
+        auto it = cache.find(n);
+        if (it != cache.end())
+            return it->second;
+        bool r = false;
+        const Node &nd = nodes[n];
+        if (nd.kind == K_PARAM)
+            r = nd.a == k;
+        else if (nd.kind == K_OP)
+            r = depends(nd.a, k, cache) || (nd.b != nd.a && depends(nd.b, k, cache));
+        cache[n] = r;
+        return r;
+    }
+
+    // d node / d theta_k
+    int diff(int n, int k, std::map<int, int> &dcache, std::map<int, bool> &dep)
+    {
+        auto it = dcache.find(n);
+        if (it != dcache.end())
+            return it->second;
+        int r;
+        const Node nd = nodes[n];
+        if (!depends(n, k, dep))
+            r = cst(0.0);
+        else if (nd.kind == K_PARAM)
+            r = cst(1.0);
+        else
+        {
+            const int a = nd.a, b = nd.b;
+            switch (nd.op)
+            {
+            case VM_ADD:
+                r = op2(VM_ADD, diff(a, k, dcache, dep), diff(b, k, dcache, dep));
+                break;
+            case VM_SUB:
+                r = op2(VM_SUB, diff(a, k, dcache, dep), diff(b, k, dcache, dep));
+                break;
+            case VM_MUL:
+                r = op2(VM_ADD, op2(VM_MUL, diff(a, k, dcache, dep), b), op2(VM_MUL, a, diff(b, k, dcache, dep)));
+                break;
+            case VM_DIV:
+            {
+                // (a/b)' = a'/b - (a/b) b'/b
+                const int da = diff(a, k, dcache, dep), db = diff(b, k, dcache, dep);
+                r = op2(VM_SUB, op2(VM_DIV, da, b), op2(VM_DIV, op2(VM_MUL, n, db), b));
+                break;
+            }
+            case VM_NEG:
+                r = op1(VM_NEG, diff(a, k, dcache, dep));
+                break;
+            case VM_POW:
+            {
+                const bool da_dep = depends(a, k, dep), db_dep = depends(b, k, dep);
+                int term = cst(0.0);
+                if (da_dep) // b a^(b-1) a'
+                    term = op2(VM_MUL, op2(VM_MUL, b, op2(VM_POW, a, op2(VM_SUB, b, cst(1.0)))), diff(a, k, dcache, dep));
+                if (db_dep) // a^b log(a) b'
+                    term = op2(VM_ADD, term, op2(VM_MUL, op2(VM_MUL, n, op1(VM_LOG, a)), diff(b, k, dcache, dep)));
+                r = term;
+                break;
+            }
+            case VM_EXP:
+                r = op2(VM_MUL, n, diff(a, k, dcache, dep));
+                break;
+            case VM_LOG:
+                r = op2(VM_DIV, diff(a, k, dcache, dep), a);
+                break;
+            case VM_SIN:
+                r = op2(VM_MUL, op1(VM_COS, a), diff(a, k, dcache, dep));
+                break;
+            case VM_COS:
+                r = op1(VM_NEG, op2(VM_MUL, op1(VM_SIN, a), diff(a, k, dcache, dep)));
+                break;
+            case VM_TAN:
+                r = op2(VM_DIV, diff(a, k, dcache, dep), op2(VM_MUL, op1(VM_COS, a), op1(VM_COS, a)));
+                break;
+            case VM_ATAN:
+                r = op2(VM_DIV, diff(a, k, dcache, dep), op2(VM_ADD, cst(1.0), op2(VM_MUL, a, a)));
+                break;
+            case VM_SQRT:
+                r = op2(VM_DIV, diff(a, k, dcache, dep), op2(VM_MUL, cst(2.0), n));
+                break;
+            case VM_ABS:
+                r = op2(VM_MUL, op1(VM_SIGN, a), diff(a, k, dcache, dep));
+                break;
+            case VM_TANH:
+                r = op2(VM_MUL, op2(VM_SUB, cst(1.0), op2(VM_MUL, n, n)), diff(a, k, dcache, dep));
+                break;
+            default:
+                r = cst(NAN);
+            }
+        }
+        dcache[n] = r;
+        return r;
+    }
+
+    // emit: topological order, the value's closure first
+    bool emit(int value, const std::vector<int> &grads, int p, int nx, VmProgram &out)
+    {
+        memset(&out, 0, sizeof(out));
+        out.p = p;
+        out.nx = nx;
+        std::map<int, int> slot_of; // node -> slot
+        std::vector<double> consts;
+        std::vector<int> order;     // op nodes in emission order
+        std::vector<char> seen(nodes.size(), 0);
+        // constants first (collect), then ops by DFS
+        std::vector<int> stack;
+        auto visit = [&](int root) {
+            stack.push_back(root);
+            std::vector<std::pair<int, int>> st; // (node, state)
+            st.push_back({root, 0});
+            while (!st.empty())
+            {
+                auto &top = st.back();
+                const int n = top.first;
+                if (seen[n])
+                {
+                    st.pop_back();
+                    continue;
+                }
+                const Node &nd = nodes[n];
+                if (nd.kind != K_OP)
+                {
+                    seen[n] = 1;
+                    if (nd.kind == K_CONST)
+                        consts.push_back(nd.c), slot_of[n] = -(int)consts.size(); // placeholder, fixed below
+                    st.pop_back();
+                    continue;
+                }
+                if (top.second == 0)
+                {
+                    top.second = 1;
+                    if (!seen[nd.a])
+                        st.push_back({nd.a, 0});
+                    if (nd.b != nd.a && !seen[nd.b])
+                        st.push_back({nd.b, 0});
+                }
+                else
+                {
+                    seen[n] = 1;
+                    order.push_back(n);
+                    st.pop_back();
+                }
+            }
+        };
+        visit(value);
+        const int nvalue = (int)order.size();
+        for (int g : grads)
+            visit(g);
+        if ((int)consts.size() > VM_MAX_CONST || (int)order.size() > VM_MAX_OPS)
+        {
+            error = "expression too large for the device program";
+            return false;
+        }
+        out.nconst = (int)consts.size();
+        for (size_t c = 0; c < consts.size(); ++c)
+            out.consts[c] = consts[c];
+        const int base = p + nx + out.nconst;
+        auto slot = [&](int n) -> int {
+            const Node &nd = nodes[n];
+            if (nd.kind == K_PARAM)
+                return nd.a;
+            if (nd.kind == K_VAR)
+                return p + nd.a;
+            if (nd.kind == K_CONST)
+                return p + nx + (-slot_of[n] - 1);
+            return slot_of[n];
+        };
+        for (size_t i = 0; i < order.size(); ++i)
+        {
+            const Node &nd = nodes[order[i]];
+            out.op[i] = nd.op;
+            out.a[i] = (unsigned short)slot(nd.a);
+            out.b[i] = (unsigned short)slot(nd.b);
+            slot_of[order[i]] = base + (int)i;
+        }
+        out.nops = (int)order.size();
+        out.nvalue = nvalue;
+        out.value_slot = slot(value);
+        for (int k = 0; k < p; ++k)
+            out.grad_slot[k] = slot(grads[k]);
+        return true;
+    }
+};
+
+// rhs text + names -> program.  Returns "" on success or an error message.
+inline std::string compile_expression(const char *rhs, const std::vector<std::string> &parnames,
+                                      const std::vector<std::string> &varnames, VmProgram &out)
+{
+    if ((int)parnames.size() > VM_MAX_P)
+        return "too many parameters for an expression model";
+    if ((int)varnames.size() > VM_NX)
+        return "too many regressors for an expression model";
+    FParser fp(rhs);
+    FNodeP ast = fp.parse();
+    if (!ast)
+        return "cannot parse expression";
+    ExprCompiler ec;
+    const int value = ec.build(ast, parnames, varnames);
+    if (!ec.error.empty())
+        return ec.error;
+    std::vector<int> grads;
+    for (size_t k = 0; k < parnames.size(); ++k)
+    {
+        std::map<int, int> dcache;
+        std::map<int, bool> dep;
+        grads.push_back(ec.diff(value, (int)k, dcache, dep));
+    }
+    if (!ec.emit(value, grads, (int)parnames.size(), VM_NX, out))
+        return ec.error;
+    return "";
+}
+
+} // namespace gslnls

@@ -47,7 +47,7 @@ struct SelectState
 };
 
 // histogram of byte `pass` over the keys whose already-fixed high bytes equal the prefix
-__global__ __launch_bounds__(256) void select_hist_kernel(const unsigned long long *keys, long long n, int pass,
+static __global__ __launch_bounds__(256) void select_hist_kernel(const unsigned long long *keys, long long n, int pass,
                                                           SelectState *st)
 {
     __shared__ unsigned int h[256];
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const unsigned long lo
 }
 
 // choose the bin that holds rank k, descend into it, clear the histogram for the next pass
-__global__ void select_pick_kernel(int pass, SelectState *st)
+static __global__ void select_pick_kernel(int pass, SelectState *st)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0)
         return;
@@ -93,7 +93,7 @@ __global__ void select_pick_kernel(int pass, SelectState *st)
         st->value = __longlong_as_double((long long)st->prefix);
 }
 
-__global__ void select_init_kernel(SelectState *st, unsigned long long k)
+static __global__ void select_init_kernel(SelectState *st, unsigned long long k)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0)
         return;
@@ -113,7 +113,7 @@ struct IrlsScalars
 };
 
 // sigma from the one or two middle order statistics (n odd / even), src/nls_utils.c:177-186
-__global__ void irls_sigma_kernel(const SelectState *lo, const SelectState *hi, IrlsScalars *sc)
+static __global__ void irls_sigma_kernel(const SelectState *lo, const SelectState *hi, IrlsScalars *sc)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0)
         sc->sigma = 1.482602218505602 * ((lo == hi) ? lo->value : (lo->value + hi->value) / 2.0);
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(T) void irls_weight_kernel(const double *r, long lo
     }
 }
 
-__global__ void irls_scale_kernel(const double *partial, int nblk, long long n, IrlsScalars *sc)
+static __global__ void irls_scale_kernel(const double *partial, int nblk, long long n, IrlsScalars *sc)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0)
         return;

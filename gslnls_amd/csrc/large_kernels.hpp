@@ -82,7 +82,7 @@ __global__ __launch_bounds__(T) void large_row_kernel(DenseCtx<M::P> ctx, int mo
 }
 
 // fixed-order sum of the per-workgroup partials: out[v] = sum_b partials[v][b]
-__global__ __launch_bounds__(64) void large_reduce_kernel(const double *partials, int nv, int nblk, double *out)
+static __global__ __launch_bounds__(64) void large_reduce_kernel(const double *partials, int nv, int nblk, double *out)
 {
     const int v = blockIdx.x;
     if (v >= nv)

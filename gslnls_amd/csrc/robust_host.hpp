@@ -57,14 +57,14 @@ __global__ __launch_bounds__(T) void cooks_kernel(DenseCtx<M::P> ctx, CooksArgs<
     }
 }
 
-__global__ void absdev_keys_kernel(const double *d, long long n, double med, unsigned long long *keys)
+static __global__ void absdev_keys_kernel(const double *d, long long n, double med, unsigned long long *keys)
 {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
         keys[i] = (unsigned long long)__double_as_longlong(fabs(d[i] - med));
 }
 
-__global__ void outlier_weights_kernel(const double *d, long long n, double thresh, const double *user_sw,
+static __global__ void outlier_weights_kernel(const double *d, long long n, double thresh, const double *user_sw,
                                        double *sw_out, int *noutlier)
 {
     const long long stride = (long long)gridDim.x * blockDim.x;

@@ -1,0 +1,143 @@
+// vm_models.hip -- the device paths instantiated for expression models ModelVM<P>.  Compiled once per
+// parameter count (-DGSLNLS_VM_P=1..9 -> _obj/vm_p<k>.o, in parallel) and once without the macro for the
+// dispatcher that compiles the expression and picks the instantiation.
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "../../include/gslnls_core.h"
+#include "dense_host.hpp"
+#include "mstart_host.hpp"
+#include "irls_host.hpp"
+#include "robust_host.hpp"
+#include "expr_compile.hpp"
+#include "vm_model.hpp"
+
+namespace gslnls
+{
+
+#ifdef GSLNLS_VM_P
+
+__constant__ VmProgram c_vm_prog; // one copy per translation unit (= per parameter count)
+
+template <int P>
+struct VmDenseFit : DenseFit<ModelVM<P>>
+{
+    using Base = DenseFit<ModelVM<P>>;
+    VmProgram prog;
+    int upload()
+    {
+        GSLNLS_HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(c_vm_prog), &prog, sizeof(VmProgram)));
+        return 0;
+    }
+    int solve(int jac, int fvv, const double *start, const double *lupars, const int *ci, const double *cd, int chunk,
+              gslnls_result *out) override
+    {
+        if (upload())
+            return GSLNLS_E_NODEVICE;
+        return Base::solve(jac, fvv, start, lupars, ci, cd, chunk, out);
+    }
+    int irls(int jac, int fvv, const double *start, const double *lupars, const int *ci, const double *cd, int loss_rho,
+             const double *loss_cc, gslnls_result *out) override
+    {
+        if (upload())
+            return GSLNLS_E_NODEVICE;
+        return Base::irls(jac, fvv, start, lupars, ci, cd, loss_rho, loss_cc, out);
+    }
+    int mstart(int jac, int fvv, const double *start2p, const double *lupars, const int *ci, const double *cd,
+               const int *has_start, const MsComm &comm, int loss_rho, const double *loss_cc, gslnls_result *out) override
+    {
+        if (upload())
+            return GSLNLS_E_NODEVICE;
+        return Base::mstart(jac, fvv, start2p, lupars, ci, cd, has_start, comm, loss_rho, loss_cc, out);
+    }
+    float time_pass(int jac, const double *theta, int reps) override
+    {
+        upload();
+        return Base::time_pass(jac, theta, reps);
+    }
+};
+
+template <int P>
+static DenseBase *make_vm_impl(const VmProgram &prog, const gslnls_model *fn, const double *y, int n, const double *swts,
+                          int *err)
+{
+    auto *d = new VmDenseFit<P>();
+    d->prog = prog;
+    // the expression always sees VM_NX regressor columns; pad the missing ones with zeros
+    gslnls_model padded = *fn;
+    std::vector<double> xpad;
+    if (!fn->x_on_device && fn->nx < VM_NX)
+    {
+        xpad.assign((size_t)n * VM_NX, 0.0);
+        for (int c = 0; c < fn->nx; ++c)
+            for (int i = 0; i < n; ++i)
+                xpad[(size_t)c * n + i] = fn->x[(size_t)c * n + i];
+        padded.x = xpad.data();
+        padded.nx = VM_NX;
+    }
+    else if (fn->nx != VM_NX)
+    {
+        *err = GSLNLS_E_UNSUPPORTED; // device-resident data must already carry VM_NX columns
+        delete d;
+        return nullptr;
+    }
+    *err = d->init(&padded, y, n, swts);
+    if (*err != GSLNLS_SUCCESS)
+    {
+        delete d;
+        return nullptr;
+    }
+    return d;
+}
+
+#define GSLNLS_CAT2(a, b) a##b
+#define GSLNLS_CAT(a, b) GSLNLS_CAT2(a, b)
+DenseBase *GSLNLS_CAT(make_vm_p, GSLNLS_VM_P)(const VmProgram &prog, const gslnls_model *fn, const double *y, int n,
+                                              const double *swts, int *err)
+{
+    return make_vm_impl<GSLNLS_VM_P>(prog, fn, y, n, swts, err);
+}
+
+#else // dispatcher
+
+#define GSLNLS_VM_DECL(k)                                                                                              \
+    DenseBase *make_vm_p##k(const VmProgram &, const gslnls_model *, const double *, int, const double *, int *);
+GSLNLS_VM_DECL(1) GSLNLS_VM_DECL(2) GSLNLS_VM_DECL(3) GSLNLS_VM_DECL(4) GSLNLS_VM_DECL(5) GSLNLS_VM_DECL(6)
+GSLNLS_VM_DECL(7) GSLNLS_VM_DECL(8) GSLNLS_VM_DECL(9)
+
+DenseBase *make_dense_expr(const gslnls_model *fn, const double *y, int n, const double *swts, int *err)
+{
+    if (!fn->expr || !fn->parnames || (fn->nx > 0 && !fn->xnames) || fn->nx > VM_NX)
+    {
+        *err = GSLNLS_EINVAL;
+        return nullptr;
+    }
+    std::vector<std::string> pn(fn->parnames, fn->parnames + fn->p), vn(fn->xnames, fn->xnames + fn->nx);
+    VmProgram prog;
+    const std::string e = compile_expression(fn->expr, pn, vn, prog);
+    if (!e.empty())
+    {
+        fprintf(stderr, "gslnls: cannot lower model expression: %s\n", e.c_str());
+        *err = GSLNLS_E_UNSUPPORTED;
+        return nullptr;
+    }
+    switch (fn->p)
+    {
+    case 1: return make_vm_p1(prog, fn, y, n, swts, err);
+    case 2: return make_vm_p2(prog, fn, y, n, swts, err);
+    case 3: return make_vm_p3(prog, fn, y, n, swts, err);
+    case 4: return make_vm_p4(prog, fn, y, n, swts, err);
+    case 5: return make_vm_p5(prog, fn, y, n, swts, err);
+    case 6: return make_vm_p6(prog, fn, y, n, swts, err);
+    case 7: return make_vm_p7(prog, fn, y, n, swts, err);
+    case 8: return make_vm_p8(prog, fn, y, n, swts, err);
+    case 9: return make_vm_p9(prog, fn, y, n, swts, err);
+    default:
+        *err = GSLNLS_E_UNSUPPORTED;
+        return nullptr;
+    }
+}
+
+#endif
+
+} // namespace gslnls

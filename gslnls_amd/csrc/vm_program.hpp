@@ -1,0 +1,95 @@
+// vm_program.hpp -- the lowered form of an arbitrary model formula: a straight-line program over
+// numbered slots, evaluated per observation by a tiny interpreter (host + device).
+//
+// This is the general answer to SURVEY.md 0.3 / 8(f).1: the reference evaluates
+//   eval(formula[[3]], c(as.list(par), .data))                       (R/nls.R:565)
+// and, for jac = TRUE, the closure stats::deriv() builds from the same expression
+// (R/nls.R:588-599).  expr_compile.hpp turns the expression into a DAG, differentiates it
+// symbolically with respect to every parameter (common subexpressions shared, constants folded)
+// and emits one program whose first `nvalue` instructions compute the model value and whose
+// remaining instructions add the P partial derivatives.
+//
+// Slot layout: [0, p) parameters | [p, p+nx) regressors of the row | [p+nx, p+nx+nconst) constants |
+// then one slot per instruction (instruction i writes slot base + i).
+#pragma once
+#include "lm_core.hpp"
+
+namespace gslnls
+{
+
+constexpr int VM_MAX_OPS = 160;
+constexpr int VM_MAX_CONST = 32;
+constexpr int VM_MAX_P = 12;
+constexpr int VM_NX = 3; // regressor columns carried per row (unused ones are zero)
+constexpr int VM_MAX_SLOTS = VM_MAX_P + VM_NX + VM_MAX_CONST + VM_MAX_OPS;
+
+enum VmOp : unsigned char
+{
+    VM_ADD = 1,
+    VM_SUB,
+    VM_MUL,
+    VM_DIV,
+    VM_NEG,
+    VM_POW,
+    VM_EXP,
+    VM_LOG,
+    VM_SIN,
+    VM_COS,
+    VM_TAN,
+    VM_ATAN,
+    VM_SQRT,
+    VM_ABS,
+    VM_TANH,
+    VM_SIGN
+};
+
+struct VmProgram
+{
+    int p, nx, nconst, nops, nvalue; // nvalue: instructions needed for the value alone
+    int value_slot;
+    int grad_slot[VM_MAX_P];
+    unsigned char op[VM_MAX_OPS];
+    unsigned short a[VM_MAX_OPS], b[VM_MAX_OPS];
+    double consts[VM_MAX_CONST];
+};
+
+GSLNLS_HD double vm_apply(unsigned char op, double x, double y)
+{
+    switch (op)
+    {
+    case VM_ADD: return x + y;
+    case VM_SUB: return x - y;
+    case VM_MUL: return x * y;
+    case VM_DIV: return x / y;
+    case VM_NEG: return -x;
+    case VM_POW: return pow(x, y);
+    case VM_EXP: return exp(x);
+    case VM_LOG: return log(x);
+    case VM_SIN: return sin(x);
+    case VM_COS: return cos(x);
+    case VM_TAN: return tan(x);
+    case VM_ATAN: return atan(x);
+    case VM_SQRT: return sqrt(x);
+    case VM_ABS: return fabs(x);
+    case VM_TANH: return tanh(x);
+    case VM_SIGN: return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : 0.0);
+    default: return NAN;
+    }
+}
+
+// run instructions [0, upto) of the program on one row
+GSLNLS_HD void vm_run(const VmProgram &prog, const double *th, const double *xr, int upto, double *slot)
+{
+    const int p = prog.p, nx = prog.nx, nc = prog.nconst;
+    for (int k = 0; k < p; ++k)
+        slot[k] = th[k];
+    for (int c = 0; c < nx; ++c)
+        slot[p + c] = xr[c];
+    for (int c = 0; c < nc; ++c)
+        slot[p + nx + c] = prog.consts[c];
+    const int base = p + nx + nc;
+    for (int i = 0; i < upto; ++i)
+        slot[base + i] = vm_apply(prog.op[i], slot[prog.a[i]], slot[prog.b[i]]);
+}
+
+} // namespace gslnls

@@ -113,7 +113,9 @@ def _bounds(lower, upper, names):
 class DenseProblem:
     """A model + data resident in HBM (gslnls_dense_create): upload once, solve many times."""
 
-    def __init__(self, model_id, p, x, y, weights=None):
+    def __init__(self, model_id, p, x, y, weights=None, expr=None, parnames=None, xnames=None):
+        """model_id: a registered device model, or _lib.MODEL_EXPR with `expr` (formula right-hand side),
+        `parnames` (order of the start vector) and `xnames` (order of the columns of x)"""
         L = _lib.lib()
         x = np.asarray(x, dtype=np.float64)
         self.n = int(np.asarray(y).shape[0])
@@ -122,6 +124,8 @@ class DenseProblem:
         self._sw = None if weights is None else np.ascontiguousarray(np.sqrt(np.asarray(weights, dtype=np.float64)))
         self.p, self.model_id = int(p), int(model_id)
         m = _lib.Model(self.model_id, self.p, self._x.shape[1], self._x.ctypes.data_as(C.c_void_p), 0)
+        if self.model_id == _lib.MODEL_EXPR:
+            keep = _lib.set_expr(m, expr, list(parnames), list(xnames))  # noqa: F841
         err = C.c_int(0)
         self._h = L.gslnls_dense_create(C.byref(m), self._y.ctypes.data_as(C.c_void_p), self.n,
                                         None if self._sw is None else self._sw.ctypes.data_as(C.c_void_p),
@@ -207,11 +211,23 @@ def gsl_nls(fn, data=None, start=None, algorithm="lm", control=None, jac=None, f
             raise ValueError("formula needs a left-hand side")
         low = F.lower(rhs, names)
         if low is None:
-            raise NotImplementedError("formula RHS does not match a registered device model: %s" % fn)
-        mid, order, xnames = low
+            # not one of the hand-written device models: compile the expression itself
+            # (GSLNLS_MODEL_EXPR, csrc/expr_compile.hpp -- the analogue of eval(formula[[3]], ...) and
+            # stats::deriv(), R/nls.R:565,588-599)
+            xnames = [v for v in F.symbols(rhs) if v not in names and v != "pi"]
+            missing = [v for v in xnames if v not in data]
+            if missing:
+                raise ValueError("formula symbols %s are neither parameters nor data columns" % missing)
+            if p > 9 or len(xnames) > 3:
+                raise NotImplementedError("expression models support p <= 9 and <= 3 data columns: %s" % fn)
+            mid, order = _lib.MODEL_EXPR, list(range(p))
+            expr_text = fn.split("~", 1)[1].strip()
+        else:
+            mid, order, xnames = low
         yv = np.asarray(F.evaluate(lhs, {k: np.asarray(v, dtype=np.float64) for k, v in data.items()}),
                         dtype=np.float64)
-        X = np.stack([np.asarray(data[c], dtype=np.float64) for c in xnames], axis=1)
+        X = (np.stack([np.asarray(data[c], dtype=np.float64) for c in xnames], axis=1) if xnames
+             else np.zeros((len(yv), 0)))
     else:
         mid, order = int(fn), list(range(p))
         yv = np.asarray(data["y"] if y is None else y, dtype=np.float64)
@@ -250,6 +266,10 @@ def gsl_nls(fn, data=None, start=None, algorithm="lm", control=None, jac=None, f
     Xf = np.asfortranarray(X)
     yc = np.ascontiguousarray(yv)
     m = _lib.Model(mid, p, Xf.shape[1], Xf.ctypes.data_as(C.c_void_p), 0)
+    if mid == _lib.MODEL_EXPR:
+        if not isinstance(fn, str):
+            raise ValueError("model id %d needs a formula" % mid)
+        keep = _lib.set_expr(m, expr_text, names, xnames)  # noqa: F841 (keeps the C strings alive)
     out = dict(par=np.zeros(p), covar=np.zeros((p, p), order="F"), resid=np.zeros(n),
                grad=np.zeros((n, p), order="F"))
     res = _lib.Result()

@@ -33,6 +33,8 @@ extern "C" {
 #define GSLNLS_MODEL_MISRA1A 2  /* b1*(1-exp(-b2*x))         p=2  R/nls_test.R:174,:793 */
 #define GSLNLS_MODEL_GAUSSPK 3  /* a*exp(-(x-b)^2/(2c^2))    p=3  README.md:545 */
 #define GSLNLS_MODEL_GAUSS1 4   /* NIST Gauss1 family        p=8  R/nls_test.R:301 */
+#define GSLNLS_MODEL_EXPR 100  /* any formula right-hand side: compiled to a device program with symbolic
+                                   gradient (csrc/expr_compile.hpp); p <= 9, at most 3 regressor columns */
 #define GSLNLS_MODEL_GLMEXP 5   /* exp(a_i . theta), dense A n x p ROW-major in `x`, nx = p in {16,32,64};
                                    gsl_nls_large only */
 
@@ -56,6 +58,10 @@ typedef struct gslnls_model
     int nx;           /* number of regressor columns */
     const double *x;  /* n x nx, column-major; host memory unless x_on_device */
     int x_on_device;  /* x, y and swts are device pointers already resident in HBM */
+    /* GSLNLS_MODEL_EXPR only: deparse(formula[[3]]) and the names its symbols resolve to */
+    const char *expr;
+    const char *const *parnames; /* [p]  parameter names, in the order of `start` */
+    const char *const *xnames;   /* [nx] data column names, in the order of the columns of x */
 } gslnls_model;
 
 /* mirrors the VECSXP C_nls returns (src/nls.c:632-812).  Pointers may be NULL to skip. */

@@ -12,6 +12,7 @@
 #include "batch_core.hpp"
 #include "mstart_driver.hpp"
 #include "irls_core.hpp"
+#include "expr_compile.hpp"
 
 using namespace gslnls;
 
@@ -364,4 +365,31 @@ extern "C" void hostsim_psi(int rho, const double *cc, int n, const double *x, d
         psi[i] = irls_psi(x[i], L);
         psip[i] = irls_psip(x[i], L);
     }
+}
+
+// expression models: compile (expr_compile.hpp) and interpret (vm_program.hpp) on the host
+extern "C" int hostsim_expr_eval(const char *rhs, int p, const char *const *parnames, int nvars,
+                                 const char *const *varnames, const double *theta, int n, const double *X,
+                                 double *value, double *grad, int *stats)
+{
+    std::vector<std::string> pn(parnames, parnames + p), vn(varnames, varnames + nvars);
+    VmProgram prog;
+    const std::string err = compile_expression(rhs, pn, vn, prog);
+    if (!err.empty())
+        return -1;
+    std::vector<double> slot(VM_MAX_SLOTS);
+    for (int i = 0; i < n; ++i)
+    {
+        double xr[VM_NX] = {0, 0, 0};
+        for (int c = 0; c < nvars; ++c)
+            xr[c] = X[i + (size_t)n * c];
+        vm_run(prog, theta, xr, prog.nops, slot.data());
+        value[i] = slot[prog.value_slot];
+        for (int k = 0; k < p; ++k)
+            grad[i + (size_t)n * k] = slot[prog.grad_slot[k]];
+    }
+    stats[0] = prog.nops;
+    stats[1] = prog.nvalue;
+    stats[2] = prog.nconst;
+    return 0;
 }

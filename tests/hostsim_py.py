@@ -116,3 +116,21 @@ def psi(rho, cc, x):
     f.argtypes = [C.c_int, DP, C.c_int, DP, DP, DP]
     f(int(rho), _dp(c3), len(x), _dp(x), _dp(a), _dp(b))
     return a, b
+
+
+def expr_eval(rhs, parnames, varnames, theta, X):
+    """compile the formula RHS to the device program and interpret it on the host: (value[n], grad[n, p], stats)"""
+    X = np.asfortranarray(np.asarray(X, dtype=np.float64).reshape(-1, max(1, len(varnames))))
+    n, p = X.shape[0], len(parnames)
+    pn = (C.c_char_p * p)(*[s.encode() for s in parnames])
+    vn = (C.c_char_p * len(varnames))(*[s.encode() for s in varnames])
+    th = np.ascontiguousarray(theta, dtype=np.float64)
+    val = np.zeros(n)
+    grad = np.zeros((n, p), order="F")
+    stats = np.zeros(4, dtype=np.int32)
+    f = lib().hostsim_expr_eval
+    f.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_char_p), DP, C.c_int, DP, DP, DP, IP]
+    rc = f(rhs.encode(), p, pn, len(varnames), vn, _dp(th), n, _dp(X), _dp(val), _dp(grad), stats.ctypes.data_as(IP))
+    if rc != 0:
+        raise ValueError("expression did not compile: %s" % rhs)
+    return val, grad, dict(nops=int(stats[0]), nvalue=int(stats[1]), nconst=int(stats[2]))

@@ -1,0 +1,69 @@
+"""Expression lowering (csrc/expr_compile.hpp + vm_program.hpp), run on the host through hostsim:
+every formula of the reference's NIST test list (inst/unit_tests/unit_tests_gslnls.R via
+tests/golden/nist_formula_problems.json) must compile, evaluate like the numpy evaluator of the same
+formula and carry a gradient that agrees with a Richardson-extrapolated numeric derivative."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from gslnls_amd import formula as F
+import hostsim_py as hs
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PROBLEMS = json.load(open(os.path.join(HERE, "golden", "nist_formula_problems.json")))
+
+
+def _split(pb):
+    lhs, rhs = F.parse_formula(pb["formula"])
+    names = list(pb["start"].keys())
+    xnames = [v for v in F.symbols(rhs) if v not in names]
+    rhs_text = pb["formula"].split("~", 1)[1].strip()
+    return rhs, rhs_text, names, xnames
+
+
+@pytest.mark.parametrize("pb", PROBLEMS, ids=[p["name"] for p in PROBLEMS])
+def test_program_value_and_gradient(pb):
+    rhs, rhs_text, names, xnames = _split(pb)
+    data = {k: np.asarray(v, dtype=np.float64) for k, v in pb["data"].items()}
+    X = np.stack([data[c] for c in xnames], axis=1)
+    th = np.array([pb["target"][k] for k in names]) * (1.0 + 0.01 * np.arange(1, len(names) + 1))
+    val, grad, st = hs.expr_eval(rhs_text, names, xnames, th, X)
+    assert 0 < st["nvalue"] <= st["nops"] <= 160
+
+    def ev(t):
+        env = dict(data)
+        env.update({k: t[i] for i, k in enumerate(names)})
+        return np.asarray(F.evaluate(rhs, env), dtype=np.float64) * np.ones(len(X))
+
+    ref = ev(th)
+    np.testing.assert_allclose(val, ref, rtol=1e-13, atol=1e-13 * np.max(np.abs(ref)))
+    # Richardson-extrapolated central differences: O(h^4) truncation, ~1e-9 relative accuracy
+    for k in range(len(names)):
+        h = 1e-4 * max(abs(th[k]), 1e-8)
+        e = np.zeros(len(names))
+        e[k] = h
+        d1 = (ev(th + e) - ev(th - e)) / (2 * h)
+        d2 = (ev(th + e / 2) - ev(th - e / 2)) / h
+        num = (4 * d2 - d1) / 3
+        scale = np.max(np.abs(num)) + 1e-300
+        # Lubricant: b8 + b9 x2^2 changes sign inside the data range, the numeric derivative is poor near the pole
+        tol = 1e-4 if pb["name"] == "Lubricant" else 1e-6
+        assert np.max(np.abs(grad[:, k] - num)) / scale < tol, (pb["name"], names[k])
+
+
+def test_constant_folding_and_sharing():
+    # exp(-b*x) appears in value and both partials: must be computed once
+    _, _, st = hs.expr_eval("a*exp(-b*x)", ["a", "b"], ["x"], [1.0, 2.0], np.linspace(0, 1, 5))
+    assert st["nops"] <= 7
+    v, g, _ = hs.expr_eval("2^3 + 0*a + x", ["a"], ["x"], [5.0], np.array([1.0, 2.0]))
+    np.testing.assert_allclose(v, [9.0, 10.0])
+    np.testing.assert_allclose(g[:, 0], 0.0)
+
+
+def test_rejects_unknown_symbols_and_functions():
+    with pytest.raises(ValueError):
+        hs.expr_eval("a*foo(x)", ["a"], ["x"], [1.0], np.array([1.0]))
+    with pytest.raises(ValueError):
+        hs.expr_eval("a*z", ["a"], ["x"], [1.0], np.array([1.0]))
