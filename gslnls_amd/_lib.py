@@ -22,11 +22,15 @@ MODEL_EXPR = 100
 
 class Model(C.Structure):
     _fields_ = [("id", C.c_int), ("p", C.c_int), ("nx", C.c_int), ("x", C.c_void_p), ("x_on_device", C.c_int),
-                ("expr", C.c_char_p), ("parnames", C.POINTER(C.c_char_p)), ("xnames", C.POINTER(C.c_char_p))]
+                ("expr", C.c_char_p), ("parnames", C.POINTER(C.c_char_p)), ("xnames", C.POINTER(C.c_char_p)), ("lowering", C.c_int)]
 
 
-def set_expr(m, expr, parnames, xnames):
+LOWERINGS = {"auto": 0, "vm": 1, "jit": 2}
+
+
+def set_expr(m, expr, parnames, xnames, lowering="auto"):
     """fill the GSLNLS_MODEL_EXPR fields of a Model; returns the objects that own the C strings"""
+    m.lowering = LOWERINGS[lowering]
     pn = (C.c_char_p * max(len(parnames), 1))(*[s.encode() for s in parnames])
     xn = (C.c_char_p * max(len(xnames), 1))(*[s.encode() for s in xnames])
     e = expr.encode()
@@ -82,6 +86,7 @@ _SIGNATURES = {
     "gslnls_device_count": (C.c_int, []),
     "gslnls_set_device": (C.c_int, [C.c_int]),
     "gslnls_version": (C.c_char_p, []),
+    "gslnls_expr_build": (C.c_int, [C.POINTER(Model), C.c_char_p, C.c_int]),
 }
 
 _lib = None

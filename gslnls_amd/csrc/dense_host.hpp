@@ -90,7 +90,7 @@ struct DenseFit : DenseBase
     static constexpr int P = M::P;
     static constexpr int NV = PassSums<P>::NV;
     // wide workgroups while the accumulators fit in 128 VGPRs, narrow ones beyond that
-    static constexpr int T = (NV <= 24) ? 512 : 256;
+    static constexpr int T = (NV <= 24) ? 512 : (NV <= 70 ? 256 : 128); // lds_red[NV * T] must fit 160 KB
 
     DenseCtx<P> ctx;
     bool owns_data = false;

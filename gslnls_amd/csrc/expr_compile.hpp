@@ -99,6 +99,22 @@ struct ExprCompiler
                 return a;
             if (is_val(b, 0.0))
                 return cst(1.0);
+            // small fixed exponents without the general pow() (R's own R_pow special-cases y == 2 the same way)
+            if (is_val(b, 2.0))
+                return op2(VM_MUL, a, a);
+            if (is_val(b, 3.0))
+                return op2(VM_MUL, op2(VM_MUL, a, a), a);
+            if (is_val(b, 4.0))
+            {
+                const int sq = op2(VM_MUL, a, a);
+                return op2(VM_MUL, sq, sq);
+            }
+            if (is_val(b, -1.0))
+                return op2(VM_DIV, cst(1.0), a);
+            if (is_val(b, -2.0))
+                return op2(VM_DIV, cst(1.0), op2(VM_MUL, a, a));
+            if (is_val(b, 0.5))
+                return op1(VM_SQRT, a);
             break;
         default:
             break;

@@ -11,6 +11,7 @@
 #include "robust_host.hpp"
 #include "expr_compile.hpp"
 #include "vm_model.hpp"
+#include "jit_host.hpp"
 
 namespace gslnls
 {
@@ -121,6 +122,36 @@ DenseBase *make_dense_expr(const gslnls_model *fn, const double *y, int n, const
         *err = GSLNLS_E_UNSUPPORTED;
         return nullptr;
     }
+    // lowering: 0 auto (native code if this expression was built before, else the interpreter), 1 interpreter,
+    // 2 build native code now (hipcc child process, cached).  GSLNLS_LOWERING=vm|jit overrides.
+    int mode = fn->lowering;
+    if (const char *e = getenv("GSLNLS_LOWERING"))
+        mode = !strcmp(e, "jit") ? GSLNLS_LOWER_JIT : (!strcmp(e, "vm") ? GSLNLS_LOWER_VM : mode);
+    if (mode != GSLNLS_LOWER_VM && !fn->x_on_device)
+    {
+        const int nxm = fn->nx > 0 ? fn->nx : 1;
+        std::string msg;
+        const std::string so = jit_artifact(prog, nxm, mode == GSLNLS_LOWER_JIT, msg);
+        jit_make_fn mk = so.empty() ? nullptr : jit_load(so, msg);
+        if (mk)
+        {
+            gslnls_model m = *fn;
+            std::vector<double> zeros;
+            if (fn->nx == 0)
+            {
+                zeros.assign((size_t)n, 0.0);
+                m.x = zeros.data();
+                m.nx = 1;
+            }
+            return mk(&m, y, n, swts, err);
+        }
+        if (mode == GSLNLS_LOWER_JIT)
+        {
+            fprintf(stderr, "gslnls: native lowering failed: %s\n", msg.c_str());
+            *err = GSLNLS_E_UNSUPPORTED;
+            return nullptr;
+        }
+    }
     switch (fn->p)
     {
     case 1: return make_vm_p1(prog, fn, y, n, swts, err);
@@ -141,3 +172,31 @@ DenseBase *make_dense_expr(const gslnls_model *fn, const double *y, int n, const
 #endif
 
 } // namespace gslnls
+
+#ifndef GSLNLS_VM_P
+// ahead-of-time build of the native code for an expression (no device needed: hipcc cross-compiles)
+extern "C" int gslnls_expr_build(const gslnls_model *fn, char *path_out, int path_cap)
+{
+    using namespace gslnls;
+    if (!fn || fn->id != GSLNLS_MODEL_EXPR || !fn->expr || !fn->parnames || (fn->nx > 0 && !fn->xnames) || fn->nx > VM_NX)
+        return GSLNLS_EINVAL;
+    std::vector<std::string> pn(fn->parnames, fn->parnames + fn->p), vn(fn->xnames, fn->xnames + fn->nx);
+    VmProgram prog;
+    const std::string e = compile_expression(fn->expr, pn, vn, prog);
+    if (!e.empty())
+    {
+        fprintf(stderr, "gslnls: cannot lower model expression: %s\n", e.c_str());
+        return GSLNLS_E_UNSUPPORTED;
+    }
+    std::string msg;
+    const std::string so = jit_artifact(prog, fn->nx > 0 ? fn->nx : 1, true, msg);
+    if (so.empty() || !jit_load(so, msg))
+    {
+        fprintf(stderr, "gslnls: native lowering failed: %s\n", msg.c_str());
+        return GSLNLS_E_UNSUPPORTED;
+    }
+    if (path_out && path_cap > 0)
+        snprintf(path_out, (size_t)path_cap, "%s", so.c_str());
+    return GSLNLS_SUCCESS;
+}
+#endif

@@ -113,7 +113,7 @@ def _bounds(lower, upper, names):
 class DenseProblem:
     """A model + data resident in HBM (gslnls_dense_create): upload once, solve many times."""
 
-    def __init__(self, model_id, p, x, y, weights=None, expr=None, parnames=None, xnames=None):
+    def __init__(self, model_id, p, x, y, weights=None, expr=None, parnames=None, xnames=None, lowering="auto"):
         """model_id: a registered device model, or _lib.MODEL_EXPR with `expr` (formula right-hand side),
         `parnames` (order of the start vector) and `xnames` (order of the columns of x)"""
         L = _lib.lib()
@@ -125,7 +125,7 @@ class DenseProblem:
         self.p, self.model_id = int(p), int(model_id)
         m = _lib.Model(self.model_id, self.p, self._x.shape[1], self._x.ctypes.data_as(C.c_void_p), 0)
         if self.model_id == _lib.MODEL_EXPR:
-            keep = _lib.set_expr(m, expr, list(parnames), list(xnames))  # noqa: F841
+            keep = _lib.set_expr(m, expr, list(parnames), list(xnames), lowering)  # noqa: F841
         err = C.c_int(0)
         self._h = L.gslnls_dense_create(C.byref(m), self._y.ctypes.data_as(C.c_void_p), self.n,
                                         None if self._sw is None else self._sw.ctypes.data_as(C.c_void_p),
@@ -189,12 +189,15 @@ def _finish(out, res, trace, algorithm, n):
 
 
 def gsl_nls(fn, data=None, start=None, algorithm="lm", control=None, jac=None, fvv=None, trace=False,
-            weights=None, lower=None, upper=None, loss="default", y=None):
+            weights=None, lower=None, upper=None, loss="default", y=None, lowering="auto"):
     """gsl_nls(fn = y ~ f(x, theta), data, start, ...) -- same arguments as R/nls.R:306-316.
 
-    fn      : model formula string 'y ~ rhs' whose RHS must lower to a registered device model
-              (gslnls_amd/formula.py), or an int registry id together with data = {'x': ..., 'y': ...}
+    fn      : model formula string 'y ~ rhs': a RHS that matches a hand-written device model
+              (gslnls_amd/formula.py) uses it, any other expression is compiled (value + symbolic gradient);
+              or an int registry id together with data = {'x': ..., 'y': ...}
     jac/fvv : True -> analytic derivatives on device (R: symbolic stats::deriv), None/False -> FD
+    lowering: compiled expressions only: "vm" interpreter, "jit" native code built by hipcc (cached),
+              "auto" = native code if already cached, else interpreter
     """
     if start is None:
         raise ValueError("starting values 'start' are required")
@@ -218,8 +221,9 @@ def gsl_nls(fn, data=None, start=None, algorithm="lm", control=None, jac=None, f
             missing = [v for v in xnames if v not in data]
             if missing:
                 raise ValueError("formula symbols %s are neither parameters nor data columns" % missing)
-            if p > 9 or len(xnames) > 3:
-                raise NotImplementedError("expression models support p <= 9 and <= 3 data columns: %s" % fn)
+            if p > 12 or len(xnames) > 3 or (p > 9 and lowering != "jit"):
+                raise NotImplementedError("expression models support p <= 9 (p <= 12 with lowering='jit') and <= 3 "
+                                          "data columns: %s" % fn)
             mid, order = _lib.MODEL_EXPR, list(range(p))
             expr_text = fn.split("~", 1)[1].strip()
         else:
@@ -269,7 +273,7 @@ def gsl_nls(fn, data=None, start=None, algorithm="lm", control=None, jac=None, f
     if mid == _lib.MODEL_EXPR:
         if not isinstance(fn, str):
             raise ValueError("model id %d needs a formula" % mid)
-        keep = _lib.set_expr(m, expr_text, names, xnames)  # noqa: F841 (keeps the C strings alive)
+        keep = _lib.set_expr(m, expr_text, names, xnames, lowering)  # noqa: F841 (keeps the C strings alive)
     out = dict(par=np.zeros(p), covar=np.zeros((p, p), order="F"), resid=np.zeros(n),
                grad=np.zeros((n, p), order="F"))
     res = _lib.Result()

@@ -62,7 +62,20 @@ typedef struct gslnls_model
     const char *expr;
     const char *const *parnames; /* [p]  parameter names, in the order of `start` */
     const char *const *xnames;   /* [nx] data column names, in the order of the columns of x */
+    int lowering;                /* GSLNLS_LOWER_AUTO / _VM / _JIT */
 } gslnls_model;
+
+/* how a GSLNLS_MODEL_EXPR reaches the device: interpreted per row (no latency), or printed as C++ and built by
+   hipcc into a cached shared object that instantiates the same kernels (runs like a hand-written model;
+   p <= 12).  AUTO uses the native build when the cache already holds it, the interpreter otherwise. */
+#define GSLNLS_LOWER_AUTO 0
+#define GSLNLS_LOWER_VM 1
+#define GSLNLS_LOWER_JIT 2
+
+/* Build (or find in the cache) the native code of an expression model ahead of time; needs hipcc but no
+   device.  The path of the shared object is copied to path_out.  Replaces nothing in the reference: the
+   analogue is the closure construction of R/nls.R:565,588-599, done once per formula. */
+int gslnls_expr_build(const gslnls_model *fn, char *path_out, int path_cap);
 
 /* mirrors the VECSXP C_nls returns (src/nls.c:632-812).  Pointers may be NULL to skip. */
 typedef struct gslnls_result

@@ -106,3 +106,35 @@ def test_expression_irls_huber(amd, gslref, nist):
     assert fit["conv"] == ref["conv"] == 0
     assert _close(fit["par"], ref["par"], rel=1e-5)
     assert fit["irls"]["irls_niter"] == ref["irls"]["irls_niter"]
+
+
+@pytest.mark.parametrize("name", ["Thurber", "ENSO", "Misra1b"])
+def test_native_lowering_matches_interpreter(amd, nist, name):
+    """lowering="jit": the same program printed as C++ and built by hipcc must give the interpreter's fit"""
+    q = nist[name]
+    data = {k: np.asarray(v, dtype=np.float64) for k, v in q["data"].items()}
+    tgt = np.array(list(q["target"].values()))
+    for jac in (True, False):
+        a = amd.gsl_nls(q["formula"], data=data, start=q["start"], jac=jac, lowering="vm")
+        b = amd.gsl_nls(q["formula"], data=data, start=q["start"], jac=jac, lowering="jit")
+        assert a["conv"] == b["conv"] == 0
+        assert _close(b["par"], tgt)
+        assert _close(a["par"], b["par"], rel=1e-6)
+        assert abs(a["ssr"] - b["ssr"]) <= 1e-9 * a["ssr"]
+
+
+def test_native_lowering_c2_full_size(amd):
+    """the headline problem (n = 1e6) written as a formula the registry does not know: native lowering must
+    reproduce the hand-written device model's fit"""
+    from conftest import c2_data
+    x, y = c2_data(1_000_000)
+    ctrl = amd.gsl_nls_control(solver="cholesky")
+    ref = amd.gsl_nls("y ~ A*exp(-lam*x) + b", data=dict(x=x, y=y), start=dict(A=1.0, lam=1.0, b=0.0), jac=True,
+                      control=ctrl)
+    formula = "y ~ b + A/exp(lam*x)"
+    assert F.lower(F.parse_formula(formula)[1], ["A", "lam", "b"]) is None
+    fit = amd.gsl_nls(formula, data=dict(x=x, y=y), start=dict(A=1.0, lam=1.0, b=0.0), jac=True, control=ctrl,
+                      lowering="jit")
+    assert fit["conv"] == 0 and fit["niter"] == ref["niter"]
+    assert np.allclose(fit["par"], ref["par"], rtol=1e-8)
+    assert abs(fit["ssr"] - ref["ssr"]) <= 1e-12 * ref["ssr"]
