@@ -286,7 +286,10 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("lm_step_kernel_bytes_per_launch")
+            # PMC passes (scripts/profile_round.sh): 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE per launch
+            pmc = json.load(open(tpath))
+            traffic = next((v.get("bytes_per_launch_corrected") for k, v in pmc.items()
+                            if k.startswith("lm_step_kernel<gslnls::ModelExpDecay")), None)
         except Exception:  # noqa
             traffic = None
 

@@ -55,7 +55,43 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
             pn[k] = CHAR(STRING_ELT(parnames, k));
         model_id = gslnls_lower_formula(CHAR(STRING_ELT(rhs, 0)), p, pn, order, cols, sizeof(cols));
     }
-    if (model_id <= 0 || Rf_isMatrix(swts) ||                    /* not registered, or GLS weights */
+    const char *xn[3] = {0, 0, 0};
+    if (model_id <= 0 && rhs != R_NilValue && p <= 9 && !Rf_isNull(parnames))
+    {
+        /* not a hand-written device model: hand the expression itself to the core (GSLNLS_MODEL_EXPR), which
+         * compiles it with its symbolic gradient -- the analogue of R/nls.R:565,588-599.  Data columns are the
+         * variables of the RHS that are not parameters: all.vars(formula[[3]]) minus names(start). */
+        SEXP vars = PROTECT(Rf_eval(Rf_lang2(Rf_install("all.vars"), Rf_lang2(Rf_install("quote"),
+                            CADDR(Rf_findVar(Rf_install("formula"), CLOENV(fn))))), R_BaseEnv));
+        int nxe = 0, ok = 1;
+        cols[0] = 0;
+        for (int v = 0; v < Rf_length(vars) && ok; v++)
+        {
+            const char *nm = CHAR(STRING_ELT(vars, v));
+            int is_par = !strcmp(nm, "pi");
+            for (int k = 0; k < p; k++)
+                is_par |= !strcmp(nm, pn[k]);
+            if (is_par)
+                continue;
+            if (nxe == 3 || strlen(cols) + strlen(nm) + 2 > sizeof(cols))
+                ok = 0;
+            else
+            {
+                if (nxe)
+                    strcat(cols, ",");
+                strcat(cols, nm);
+                xn[nxe++] = nm;
+            }
+        }
+        UNPROTECT(1);
+        if (ok)
+        {
+            model_id = GSLNLS_MODEL_EXPR;
+            for (int k = 0; k < p; k++)
+                order[k] = k;
+        }
+    }
+    if (model_id <= 0 || Rf_isMatrix(swts) ||                    /* does not lower, or GLS weights */
         INTEGER(control_int)[2] > 1)                             /* dogleg / ddogleg / subspace2D */
         return C_nls(fn, y, jac, fvv, env, start, swts, lupars, control_int, control_dbl, has_start, loss_config);
 
@@ -76,7 +112,19 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
             UNPROTECT(1);
         }
     }
-    gslnls_model model = {model_id, p, nx, X, 0};
+    gslnls_model model = {model_id, p, nx, X, 0, NULL, NULL, NULL, GSLNLS_LOWER_AUTO};
+    if (model_id == GSLNLS_MODEL_EXPR)
+    {
+        model.expr = CHAR(STRING_ELT(rhs, 0));
+        model.parnames = pn;
+        model.xnames = xn;
+        /* options(gslnls.lowering = "jit") builds native code for the formula once (hipcc, cached on disk) */
+        SEXP opt = Rf_GetOption1(Rf_install("gslnls.lowering"));
+        if (Rf_isString(opt) && !strcmp(CHAR(STRING_ELT(opt, 0)), "jit"))
+            model.lowering = GSLNLS_LOWER_JIT;
+        if (Rf_isString(opt) && !strcmp(CHAR(STRING_ELT(opt, 0)), "vm"))
+            model.lowering = GSLNLS_LOWER_VM;
+    }
 
     /* start / bounds / has_start permuted into device parameter order */
     double *st = (double *)R_alloc(2 * p, sizeof(double)), *lu = NULL;
