@@ -656,3 +656,8 @@ int gslnls_set_device(int ordinal)
 const char *gslnls_version(void) { return "gslnls-mi355x 0.1 (gfx950)"; }
 
 } // extern "C"
+
+#ifdef GSLNLS_NO_EXPR
+// diagnostic single-TU builds (make stamps) carry no expression lowering
+extern "C" int gslnls_expr_build(const gslnls_model *, char *, int) { return GSLNLS_E_UNSUPPORTED; }
+#endif

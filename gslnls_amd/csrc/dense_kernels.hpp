@@ -109,23 +109,38 @@ __device__ __forceinline__ double wave_sum(double v)
 // column, one DPP wave_sum finishes the value.  (Doing NV wave_sums per wave instead costs ~270 cycles
 // each on the critical path of every launch.)  lds must hold NV * T doubles; out[v] receives total v.
 template <int NV, int T>
-__device__ __forceinline__ void block_sum_to(const double *vals, double *lds, double *out)
+__device__ __forceinline__ void block_sum_to(const double *vals, double *lds, double *out, size_t out_stride = 1)
 {
     constexpr int NW = T / 64;
+    constexpr int VPW = (NV + NW - 1) / NW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int v = 0; v < NV; ++v)
         lds[v * T + threadIdx.x] = vals[v];
     __syncthreads();
-    for (int v = wave; v < NV; v += NW)
-    {
-        double a = 0.0;
+    // the (at most VPW) values of this wave are independent chains: unrolled so that they interleave
+    double a[VPW];
 #pragma unroll
-        for (int w = 0; w < NW; ++w)
-            a += lds[v * T + w * 64 + lane];
-        a = wave_sum(a);
-        if (lane == 0)
-            out[v] = a;
+    for (int q = 0; q < VPW; ++q)
+    {
+        const int v = wave + q * NW;
+        a[q] = 0.0;
+        if (v < NV)
+        {
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                a[q] += lds[v * T + w * 64 + lane];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < VPW; ++q)
+        a[q] = wave_sum(a[q]);
+#pragma unroll
+    for (int q = 0; q < VPW; ++q)
+    {
+        const int v = wave + q * NW;
+        if (lane == 0 && v < NV)
+            out[(size_t)v * out_stride] = a[q];
     }
 }
 
@@ -197,11 +212,79 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
     const int tid = threadIdx.x;
 
     GSLNLS_STAMP(0);
-    // ---------------- issue this thread's first rows now: they do not depend on the decision ----
+    __shared__ unsigned int lds_arrived;
+    if (tid == 0)
+        lds_arrived = 0;
+    __syncthreads(); // at entry all waves are in step: this costs a few dozen cycles under the kernarg fetch
+
+    // ---------------- loads, in the order their data is needed ---------------------------------
+    // Vector-memory results return in issue order and the L1 moves 64 B/clk, so what the critical path waits
+    // for goes first.  Wave 0 owns the state (same address in every lane: one request each) and then
+    // prefetches its rows.  Waves 1.. load the G partial sets of the previous launch, reduce them, publish the
+    // totals through LDS + an arrival counter -- and only then issue their row prefetch (64 KB per CU, 16 MB for
+    // the grid), which streams in under wave 0's lm_advance instead of ahead of the partial sums.
     const double *__restrict__ yv = yv_;
     const double *__restrict__ swv = swv_;
     const long long stride = (long long)G * T;
     const long long i0 = (long long)blockIdx.x * T + tid;
+    LmState<P> s;
+    constexpr int PB = MAX_G / 64;
+    constexpr int RW = NW - 1;                 // waves that reduce partials
+    constexpr int VPW = (NV + RW - 1) / RW;    // values per reducing wave
+    const int lane = tid & 63, wave = tid >> 6;
+    if (wave == 0)
+    {
+        const int z = opaque_zero();
+        const double *src = reinterpret_cast<const double *>(prev) + z;
+        double *dst = reinterpret_cast<double *>(&s);
+        static_assert(sizeof(LmState<P>) % 8 == 0, "state is a whole number of doubles");
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(LmState<P>) / 8); ++k)
+            dst[k] = src[k];
+    }
+    else
+    {
+        // wave w sums the G partials of values v = w-1, w-1 + RW, ...: lane-strided partial sums, DPP butterfly
+        const int z0 = opaque_zero();
+        const double *pp = prev_partials + z0;
+        double pv[VPW][PB];
+#pragma unroll
+        for (int q = 0; q < VPW; ++q)
+        {
+            const int v = (wave - 1) + q * RW;
+#pragma unroll
+            for (int j = 0; j < PB; ++j)
+            {
+                const int b = lane + 64 * j;
+                pv[q][j] = (v < NV && b < G) ? pp[(size_t)v * G + b] : 0.0;
+            }
+        }
+        double a[VPW];
+#pragma unroll
+        for (int q = 0; q < VPW; ++q)
+        {
+            a[q] = pv[q][0];
+#pragma unroll
+            for (int j = 1; j < PB; ++j)
+                a[q] += pv[q][j];
+        }
+#pragma unroll
+        for (int q = 0; q < VPW; ++q)
+            a[q] = wave_sum(a[q]);
+        if (lane == 0)
+        {
+#pragma unroll
+            for (int q = 0; q < VPW; ++q)
+            {
+                const int v = (wave - 1) + q * RW;
+                if (v < NV)
+                    lds_tot[v] = a[q];
+            }
+            // LDS operations of one wave complete in order: the totals are visible before the count
+            __hip_atomic_fetch_add(&lds_arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    GSLNLS_STAMP(7);
     double px[R][NX], py[R], pw[R];
 #pragma unroll
     for (int k = 0; k < R; ++k)
@@ -216,53 +299,12 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
     }
 
     GSLNLS_STAMP(1);
-    // ---------------- prologue: finish the previous launch's reduction (all waves), advance (wave 0) ----
-    // wave 0 issues the loads of the whole state first (same address in every lane: one request each) so
-    // that their latency overlaps with the partial sums below
-    LmState<P> s;
-    if (tid < 64)
+    // ---------------- wave 0: wait for the RW totals (every reducing wave reaches its increment) ----
+    if (wave == 0)
     {
-        const int z = opaque_zero();
-        const double *src = reinterpret_cast<const double *>(prev) + z;
-        double *dst = reinterpret_cast<double *>(&s);
-        static_assert(sizeof(LmState<P>) % 8 == 0, "state is a whole number of doubles");
-#pragma unroll
-        for (int k = 0; k < (int)(sizeof(LmState<P>) / 8); ++k)
-            dst[k] = src[k];
+        while (__hip_atomic_load(&lds_arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)RW)
+            __builtin_amdgcn_s_sleep(1);
     }
-    // wave w sums the G partials of values v = w, w + NW, ... : lane-strided partial sums, then the butterfly
-    {
-        const int lane = tid & 63, wave = tid >> 6;
-        const int z0 = opaque_zero();
-        const double *pp = prev_partials + z0;
-        constexpr int PB = MAX_G / 64;
-        constexpr int VPW = (NV + NW - 1) / NW; // values per wave
-        double pv[VPW][PB];
-#pragma unroll
-        for (int q = 0; q < VPW; ++q)
-        {
-            const int v = wave + q * NW;
-#pragma unroll
-            for (int j = 0; j < PB; ++j)
-            {
-                const int b = lane + 64 * j;
-                pv[q][j] = (v < NV && b < G) ? pp[(size_t)v * G + b] : 0.0;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < VPW; ++q)
-        {
-            const int v = wave + q * NW;
-            double a = pv[q][0];
-#pragma unroll
-            for (int j = 1; j < PB; ++j)
-                a += pv[q][j];
-            a = wave_sum(a);
-            if (lane == 0 && v < NV)
-                lds_tot[v] = a;
-        }
-    }
-    __syncthreads();
     if (tid < 64)
     {
         const bool fresh = s.bad_steps < 0; // host marks a brand-new state with bad_steps = -1
@@ -353,43 +395,63 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
 
     Sums acc;
     pass_zero<P>(acc);
-    auto do_row = [&](const double *xr, double y, double sw) {
-        double Jrow[P];
-        if (phase == PH_FVV)
-        {
-            const double fv = row_fvv<M, JAC>(th, vel, delta, ctx.prm.h_fvv, ctx.prm.fvv_analytic != 0, xr, y, sw,
-                                              Jrow, &acc.badj);
+    // Rows beyond n were prefetched from row n-1 (clamped index) and are switched off through their weight:
+    // sw = 0 zeroes the Jacobian row, a select zeroes f.  No branch per row, so the accumulators stay plain
+    // FMA chains (a predicated row costs a zero-fill + add per accumulator).  The phase is uniform: one
+    // loop nest per kind of pass.
+    if (phase == PH_FVV)
+    {
+        auto do_row = [&](const double *xr, double y, double sw, bool live) {
+            double Jrow[P];
+            double fv = row_fvv<M, JAC>(th, vel, delta, ctx.prm.h_fvv, ctx.prm.fvv_analytic != 0, xr, y, sw, Jrow,
+                                        &acc.badj);
+            fv = live ? fv : 0.0;
 #pragma unroll
             for (int k = 0; k < P; ++k)
                 acc.g[k] += Jrow[k] * fv;
-        }
-        else
+        };
+#pragma unroll
+        for (int k = 0; k < R; ++k)
         {
-            const double f = row_fj<M, JAC>(th, delta, xr, y, sw, Jrow, &acc.badj);
-            acc_fj<P>(acc, f, Jrow);
+            const bool live = i0 + k * stride < n;
+            do_row(px[k], py[k], live ? pw[k] : 0.0, live);
         }
-    };
+        for (long long i = i0 + R * stride; i < n; i += stride)
+        {
+            double xr[NX];
 #pragma unroll
-    for (int k = 0; k < R; ++k)
-    {
-        if (i0 + k * stride < n)
-            do_row(px[k], py[k], pw[k]);
+            for (int c = 0; c < NX; ++c)
+                xr[c] = x0[(size_t)c * n + i];
+            do_row(xr, yv[i], swv ? swv[i] : 1.0, true);
+        }
     }
-    for (long long i = i0 + R * stride; i < n; i += stride)
+    else
     {
-        double xr[NX];
+        auto do_row = [&](const double *xr, double y, double sw, bool live) {
+            double Jrow[P];
+            double f = row_fj<M, JAC>(th, delta, xr, y, sw, Jrow, &acc.badj);
+            f = live ? f : 0.0;
+            acc_fj<P>(acc, f, Jrow);
+        };
 #pragma unroll
-        for (int c = 0; c < NX; ++c)
-            xr[c] = x0[(size_t)c * n + i];
-        do_row(xr, yv[i], swv ? swv[i] : 1.0);
+        for (int k = 0; k < R; ++k)
+        {
+            const bool live = i0 + k * stride < n;
+            do_row(px[k], py[k], live ? pw[k] : 0.0, live);
+        }
+        for (long long i = i0 + R * stride; i < n; i += stride)
+        {
+            double xr[NX];
+#pragma unroll
+            for (int c = 0; c < NX; ++c)
+                xr[c] = x0[(size_t)c * n + i];
+            do_row(xr, yv[i], swv ? swv[i] : 1.0, true);
+        }
     }
 
     GSLNLS_STAMP(5);
     // ---------------- workgroup reduction -> one partial set ---------------------------------
-    block_sum_to<NV, T>(reinterpret_cast<const double *>(&acc), lds_red, lds_tot);
-    __syncthreads();
-    if (tid < NV)
-        ctx.partials[parity][(size_t)tid * G + blockIdx.x] = lds_tot[tid];
+    block_sum_to<NV, T>(reinterpret_cast<const double *>(&acc), lds_red, ctx.partials[parity] + blockIdx.x, (size_t)G);
     GSLNLS_STAMP(6);
 }
 

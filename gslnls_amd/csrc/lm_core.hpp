@@ -78,7 +78,7 @@ struct PassSums
     static constexpr int NA = P * (P + 1) / 2;
     static constexpr int NV = 2 + NA + P;
     double ssr;   // sum f_i^2
-    double badj;  // number of non-finite Jacobian entries seen (src/nls.c:899-907)
+    double badj;  // 0, or NaN when a non-finite analytic Jacobian entry was seen (src/nls.c:899-907)
     double A[NA]; // lower triangle of J^T J, packed row by row: (i,j), j<=i -> i(i+1)/2+j
     double g[P];  // J^T f   (PH_FVV: J^T fvv)
 };
@@ -549,7 +549,7 @@ GSLNLS_HD void lm_advance(LmState<P> &s, const PassSums<P> &r, const LmParams &p
         if (prm.jac_analytic)
         {
             s.nevaldf += 1;
-            if (r.badj > 0.0)
+            if (!(r.badj == 0.0))
             {
                 // gsl_df returned GSL_EBADFUNC (src/nls.c:899-907): init fails, driver sees it at once
                 lm_take_point(s, r);
@@ -591,7 +591,7 @@ GSLNLS_HD void lm_advance(LmState<P> &s, const PassSums<P> &r, const LmParams &p
             s.nevalfvv += 1;
         else
             s.nevalf += 1;
-        if (prm.fvv_analytic && r.badj > 0.0)
+        if (prm.fvv_analytic && !(r.badj == 0.0))
         {
             // gsl_fvv returned GSL_EBADFUNC (src/nls.c:963-970): trust_iterate returns the
             // step status, which the iterator treats as a failed step (rho = -1)
@@ -661,7 +661,7 @@ GSLNLS_HD void lm_advance(LmState<P> &s, const PassSums<P> &r, const LmParams &p
         if (prm.jac_analytic)
         {
             s.nevaldf += 1;
-            if (r.badj > 0.0)
+            if (!(r.badj == 0.0))
             {
                 lm_end_iteration(s, prm, ST_EBADFUNC);
                 return;

@@ -11,6 +11,7 @@
 // Registry ids are part of the C ABI (include/gslnls_core.h, GSLNLS_MODEL_*).
 #pragma once
 #include "lm_core.hpp"
+#include "devmath.hpp"
 
 namespace gslnls
 {
@@ -22,11 +23,11 @@ struct ModelExpDecay
     static constexpr bool HAS_FVV = true;
     GSLNLS_HD static double value(const double *th, const double *xr)
     {
-        return th[0] * exp(-th[1] * xr[0]) + th[2];
+        return th[0] * gexp(-th[1] * xr[0]) + th[2];
     }
     GSLNLS_HD static double value_grad(const double *th, const double *xr, double *g)
     {
-        const double e = exp(-th[1] * xr[0]);
+        const double e = gexp(-th[1] * xr[0]);
         g[0] = e;
         g[1] = -th[0] * xr[0] * e;
         g[2] = 1.0;
@@ -34,7 +35,7 @@ struct ModelExpDecay
     }
     GSLNLS_HD static double fvv(const double *th, const double *v, const double *xr)
     {
-        const double x = xr[0], e = exp(-th[1] * x);
+        const double x = xr[0], e = gexp(-th[1] * x);
         return 2.0 * v[0] * v[1] * (-x * e) + v[1] * v[1] * th[0] * x * x * e;
     }
 };
@@ -46,18 +47,18 @@ struct ModelMisra1a
     static constexpr bool HAS_FVV = true;
     GSLNLS_HD static double value(const double *th, const double *xr)
     {
-        return th[0] * (1.0 - exp(-th[1] * xr[0]));
+        return th[0] * (1.0 - gexp(-th[1] * xr[0]));
     }
     GSLNLS_HD static double value_grad(const double *th, const double *xr, double *g)
     {
-        const double e = exp(-th[1] * xr[0]);
+        const double e = gexp(-th[1] * xr[0]);
         g[0] = 1.0 - e;
         g[1] = th[0] * xr[0] * e;
         return th[0] * (1.0 - e);
     }
     GSLNLS_HD static double fvv(const double *th, const double *v, const double *xr)
     {
-        const double x = xr[0], e = exp(-th[1] * x);
+        const double x = xr[0], e = gexp(-th[1] * x);
         return 2.0 * v[0] * v[1] * (x * e) + v[1] * v[1] * (-th[0] * x * x * e);
     }
 };
@@ -70,12 +71,12 @@ struct ModelGaussPeak
     GSLNLS_HD static double value(const double *th, const double *xr)
     {
         const double u = xr[0] - th[1];
-        return th[0] * exp(-(u * u) / (2.0 * th[2] * th[2]));
+        return th[0] * gexp(-(u * u) / (2.0 * th[2] * th[2]));
     }
     GSLNLS_HD static double value_grad(const double *th, const double *xr, double *g)
     {
         const double u = xr[0] - th[1], c2 = th[2] * th[2];
-        const double e = exp(-(u * u) / (2.0 * c2));
+        const double e = gexp(-(u * u) / (2.0 * c2));
         g[0] = e;
         g[1] = th[0] * e * u / c2;
         g[2] = th[0] * e * u * u / (c2 * th[2]);
@@ -84,7 +85,7 @@ struct ModelGaussPeak
     GSLNLS_HD static double fvv(const double *th, const double *v, const double *xr)
     {
         const double a = th[0], c = th[2], u = xr[0] - th[1], c2 = c * c;
-        const double e = exp(-(u * u) / (2.0 * c2));
+        const double e = gexp(-(u * u) / (2.0 * c2));
         const double fab = e * u / c2;
         const double fac = e * u * u / (c2 * c);
         const double fbb = a * e * (u * u / (c2 * c2) - 1.0 / c2);
@@ -104,15 +105,15 @@ struct ModelGauss1
     GSLNLS_HD static double value(const double *th, const double *xr)
     {
         const double x = xr[0], u1 = x - th[3], u2 = x - th[6];
-        return th[0] * exp(-th[1] * x) + th[2] * exp(-(u1 * u1) / (th[4] * th[4])) +
-               th[5] * exp(-(u2 * u2) / (th[7] * th[7]));
+        return th[0] * gexp(-th[1] * x) + th[2] * gexp(-(u1 * u1) / (th[4] * th[4])) +
+               th[5] * gexp(-(u2 * u2) / (th[7] * th[7]));
     }
     GSLNLS_HD static double value_grad(const double *th, const double *xr, double *g)
     {
         const double x = xr[0], u1 = x - th[3], u2 = x - th[6];
-        const double e0 = exp(-th[1] * x);
-        const double e1 = exp(-(u1 * u1) / (th[4] * th[4]));
-        const double e2 = exp(-(u2 * u2) / (th[7] * th[7]));
+        const double e0 = gexp(-th[1] * x);
+        const double e1 = gexp(-(u1 * u1) / (th[4] * th[4]));
+        const double e2 = gexp(-(u2 * u2) / (th[7] * th[7]));
         g[0] = e0;
         g[1] = -th[0] * x * e0;
         g[2] = e1;

@@ -45,8 +45,10 @@ GSLNLS_HD void fd_deltas(const double *th, double h, double *delta)
     }
 }
 
-// f_i and row i of the (weighted) Jacobian at th.  Returns f_i; *nbad counts non-finite
-// analytic Jacobian entries (only the analytic path is checked by the reference).
+// f_i and row i of the (weighted) Jacobian at th.  Returns f_i; *nbad becomes non-zero (NaN) when an
+// analytic Jacobian entry is not finite (only the analytic path is checked by the reference, which
+// then returns GSL_EBADFUNC, src/nls.c:899-907).  The flag is accumulated as sum_j 0 * J_ij -- one FMA per
+// entry instead of a class compare + select + add; consumers test `!(badj == 0)`.
 template <class M, int JAC>
 GSLNLS_HD double row_fj(const double *th, const double *delta, const double *xr, double y, double sw,
                         double *Jrow, double *nbad)
@@ -57,15 +59,14 @@ GSLNLS_HD double row_fj(const double *th, const double *delta, const double *xr,
         double gr[P];
         const double m = M::value_grad(th, xr, gr);
         const double f = (isfinite(m) ? m - y : INFINITY) * sw;
-        double bad = 0.0;
+        double bad = *nbad;
 #pragma unroll
         for (int j = 0; j < P; ++j)
         {
-            if (!isfinite(gr[j]))
-                bad += 1.0;
+            bad = fma(gr[j], 0.0, bad);
             Jrow[j] = gr[j] * sw;
         }
-        *nbad += bad;
+        *nbad = bad;
         return f;
     }
     else if (JAC == JAC_FORWARD)
@@ -132,8 +133,7 @@ GSLNLS_HD double row_fvv(const double *th, const double *v, const double *delta,
     if (analytic)
     {
         const double r = M::fvv(th, v, xr);
-        if (!isfinite(r))
-            *nbad += 1.0;
+        *nbad = fma(r, 0.0, *nbad);
         return r * sw;
     }
     double tp[P];

@@ -13,6 +13,7 @@
 // then one slot per instruction (instruction i writes slot base + i).
 #pragma once
 #include "lm_core.hpp"
+#include "devmath.hpp"
 
 namespace gslnls
 {
@@ -63,7 +64,7 @@ GSLNLS_HD double vm_apply(unsigned char op, double x, double y)
     case VM_DIV: return x / y;
     case VM_NEG: return -x;
     case VM_POW: return pow(x, y);
-    case VM_EXP: return exp(x);
+    case VM_EXP: return gexp(x);
     case VM_LOG: return log(x);
     case VM_SIN: return sin(x);
     case VM_COS: return cos(x);

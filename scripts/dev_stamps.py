@@ -21,7 +21,7 @@ for jac in (1, 0):
     wpb = nrows.value // 256 if nrows.value >= 256 else nrows.value
     t0 = st[:, 0].min()
     rel = st - t0
-    names = ["entry", "prefetch issued", "state+partials reduced", "advance done", "after barrier", "rows done", "kernel end"]
+    names = ["entry", "prefetch issued", "state+partials reduced", "advance done", "after barrier", "rows done", "kernel end", "partials published"]
     w0 = rel[0::wpb]       # wave 0 of each block
     wo = np.delete(rel, np.arange(0, nrows.value, wpb), axis=0)
     print("jac=%d rows=%d (100 MHz-ish s_memtime ticks are shader cycles)" % (jac, nrows.value))
