@@ -245,7 +245,7 @@ def main():
                                   cd.ctypes.data_as(_lib.DP), args.chunk, C.byref(res))
         if rc != 0:
             raise SystemExit("fit failed: %s" % _lib.strerror(rc))
-        return res.niter, res.n_launches, res.loop_ms
+        return res.niter, res.n_launches, res.loop_ms, res.neval[0] + res.neval[1]
 
     def barrier():
         if dist is not None:
@@ -256,13 +256,14 @@ def main():
         one_fit()
     barrier()
     t0 = time.perf_counter()
-    iters = launches = 0
+    iters = launches = ref_passes = 0
     loop_ms = 0.0
     for _ in range(args.steps):
-        a, b, c = one_fit()
+        a, b, c, d = one_fit()
         iters += a
         launches += b
         loop_ms += c
+        ref_passes += d
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -276,12 +277,21 @@ def main():
         dist.all_reduce(it, op=dist.ReduceOp.SUM)
         tot_iters = float(it.item())
 
-    # dominant kernel: HIP events on the library's stream around back-to-back launches that each do the
-    # full prologue + one full pass over (x, y)
+    # Dominant kernel lm_step_kernel, HIP events on the library's own stream.
+    # (1) over the timed region: device time of each fit's launch loop (events around it, summed by the
+    #     library: loop_ms) / its launches.  Algorithmic bytes by SURVEY.md 8(d): the reference reads x and y once
+    #     per f evaluation and once per Jacobian evaluation (16n B each) = 32n per LM iteration with one trial,
+    #     +16n per extra rejected trial, 32n for the initial point; "a speculative single fused pass is allowed
+    #     but the reported denominator stays 32n".  neval.f + neval.J is exactly that count of passes.
+    # (2) streamed view: back-to-back launches that each do the full prologue + one full fused pass
+    #     (gslnls_dense_time_pass), 16n B actually read per launch -- what the PMC traffic is compared with.
+    alg_bytes_fit = 16.0 * n * ref_passes / args.steps
+    ms_loop_fit = loop_ms / args.steps
+    launches_fit = launches / args.steps
+    achieved = alg_bytes_fit / (ms_loop_fit * 1e-3) / 1e9
     th = np.array([4.0, 1.2, 0.8])
     ms_launch = float(L.gslnls_dense_time_pass(h, jac, th.ctypes.data_as(_lib.DP), 2000))
-    alg_bytes = 16.0 * n  # one pass reads x and y once (8 B each), nothing n-sized is written
-    achieved = alg_bytes / (ms_launch * 1e-3) / 1e9
+    streamed = 16.0 * n / (ms_launch * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(tpath):
@@ -313,8 +323,13 @@ def main():
                    "parallelism": "replicas only (x%d)" % world, "par": [float(v) for v in par]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "lm_step_kernel<ModelExpDecay>", "bytes_per_launch": alg_bytes,
-                     "ms_per_launch": ms_launch},
+                     "kernel": "lm_step_kernel<ModelExpDecay>",
+                     "bytes_per_launch": alg_bytes_fit / launches_fit, "ms_per_launch": ms_loop_fit / launches_fit,
+                     "accounting": "SURVEY 8(d): 16n B per reference pass (f or J evaluation); %.0f passes per fit "
+                                   "done in %.0f launches, timed region" % (ref_passes / args.steps, launches_fit),
+                     "streamed": {"bytes_per_launch": 16.0 * n, "ms_per_full_launch": ms_launch, "GBs": streamed,
+                                  "frac": streamed / HBM_PEAK_GBS,
+                                  "note": "bytes actually read by one fused launch (x and y once); compare traffic"}},
     }
     line["multistart"] = multistart_bench(L, _lib, torch, dist, rank, world, max(5, args.steps // 4), 3)
     if not args.headline_only:

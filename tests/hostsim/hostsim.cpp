@@ -4,6 +4,8 @@
 // with g++ and replaces the GPU's parallel pass by a serial loop, so the device state
 // machine and row functions can be checked against the oracle on a CPU-only box.  This
 // exercises "host logic" only; GPU parity proper is tests/test_gpu_*.py through the C ABI.
+#include <cstdlib>
+#include <cstdio>
 #include <math.h>
 #include <string.h>
 #include "lm_core.hpp"
@@ -88,6 +90,9 @@ static int fit(int n, const double *x, const double *y, const double *sw, const 
             pass<M, JAC_CENTER>(s, prm, n, x, y, sw, acc);
         const int nb = s.niter, pb = s.phase;
         lm_advance<P>(s, acc, prm);
+        if (getenv("GSLNLS_HOSTSIM_TRACE"))
+            fprintf(stderr, "pass %ld: phase %d -> %d niter %d -> %d mu %.3e bad_steps %d\n", launches, pb, s.phase, nb,
+                    s.niter, s.mu, s.bad_steps);
         if (ssrtrace)
         {
             if (pb == PH_INIT)
