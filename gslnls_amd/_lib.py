@@ -38,6 +38,17 @@ def set_expr(m, expr, parnames, xnames, lowering="auto"):
     return e, pn, xn
 
 
+class Sparse(C.Structure):
+    """gslnls_sparse: dgRMatrix (format 0) / dgCMatrix (1) / dgTMatrix (2) as the Matrix package stores them"""
+    _fields_ = [("format", C.c_int), ("nrow", C.c_int), ("ncol", C.c_int), ("nnz", C.c_long),
+                ("p", C.POINTER(C.c_int)), ("i", C.POINTER(C.c_int)), ("j", C.POINTER(C.c_int)),
+                ("x", C.POINTER(C.c_double))]
+
+
+LARGE_F_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_void_p)
+LARGE_JAC_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(Sparse), C.c_void_p)
+
+
 class Result(C.Structure):
     _fields_ = [("par", DP), ("covar", DP), ("resid", DP), ("grad", DP), ("niter", C.c_int), ("conv", C.c_int),
                 ("ssr", C.c_double), ("ssrtol", C.c_double), ("neval", C.c_int * 3), ("info", C.c_int),
@@ -73,6 +84,8 @@ _SIGNATURES = {
     "gslnls_nls_large": (C.c_int, [C.POINTER(Model), C.c_void_p, C.c_int, DP, C.c_void_p, IP, DP,
                                    C.POINTER(LargeResult)]),
     "gslnls_large_create": (C.c_void_p, [C.POINTER(Model), C.c_void_p, C.c_int, C.c_void_p, IP]),
+    "gslnls_large_create_sparse": (C.c_void_p, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, LARGE_F_CB, LARGE_JAC_CB,
+                                                C.c_void_p, IP]),
     "gslnls_large_destroy": (None, [C.c_void_p]),
     "gslnls_large_solve": (C.c_int, [C.c_void_p, DP, IP, DP, C.POINTER(LargeResult)]),
     "gslnls_large_time_pass": (C.c_float, [C.c_void_p, C.c_int, DP, DP, C.c_int]),

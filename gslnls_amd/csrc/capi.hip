@@ -13,6 +13,7 @@
 #include "formula.hpp"
 #include "irls_host.hpp"
 #include "large_host.hpp"
+#include "sparse_large.hpp"
 #include "irls_batch.hpp"
 #include "robust_host.hpp"
 
@@ -375,6 +376,39 @@ int gslnls_large_solve(gslnls_large *h, const double *start, const int *control_
     return R.status;
 }
 
+gslnls_large *gslnls_large_create_sparse(int n, int p, const double *y, const double *weights, gslnls_large_f_cb f,
+                                         gslnls_large_jac_cb jac, void *user, int *err)
+{
+    int e = GSLNLS_SUCCESS;
+    gslnls_large *h = nullptr;
+    if (n < 1 || p < 1 || !y || !f || !jac)
+        e = GSLNLS_EINVAL;
+    else
+    {
+        std::vector<double> sw;
+        if (weights)
+        {
+            sw.resize(n);
+            for (int i = 0; i < n; ++i)
+                sw[i] = sqrt(weights[i]);
+        }
+        auto *ops = new SparseCbOps();
+        e = ops->init(n, p, y, weights ? sw.data() : nullptr, f, jac, user);
+        if (e == GSLNLS_SUCCESS)
+        {
+            h = new gslnls_large;
+            h->ops = ops;
+            h->n = n;
+            h->p = p;
+        }
+        else
+            delete ops;
+    }
+    if (err)
+        *err = e;
+    return h;
+}
+
 int gslnls_nls_large(const gslnls_model *fn, const double *y, int n, const double *start, const double *weights,
                      const int *control_int, const double *control_dbl, gslnls_large_result *out)
 {
@@ -394,6 +428,8 @@ float gslnls_large_time_pass(gslnls_large *h, int mode, const double *x, const d
     std::vector<double> g(h->p), d(h->p);
     double ssr, bad, nw2;
     if (h->ops->eval(x, &ssr, g.data(), d.data(), nullptr, &bad))
+        return -1.f;
+    if (h->ops->lazy_jac && h->ops->eval_jac(g.data(), d.data(), nullptr))
         return -1.f;
     h->ops->accept();
     double tot = 0.0;

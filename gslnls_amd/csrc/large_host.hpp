@@ -29,6 +29,11 @@ struct LargeOps
     // EVAL pass at x (trial buffers): ssr, g = J^T f, diag(J^T J) [and full J^T J when jtj != nullptr]
     virtual int eval(const double *x, double *ssr, double *g, double *diag, double *jtj, double *bad) = 0;
     virtual void accept() = 0; // the last EVAL point becomes the current point
+    // Operators whose Jacobian is expensive to obtain (host callbacks) set lazy_jac: eval() then returns ssr only
+    // and eval_jac() completes g, diag [, J^T J] for the same point once the step is accepted -- the reference's
+    // own order (f at every trial, df only after acceptance).
+    bool lazy_jac = false;
+    virtual int eval_jac(double *, double *, double *) { return GSLNLS_E_UNSUPPORTED; }
     // JTJV pass at the current point xcur: ||J u||^2 and J^T J u
     virtual int jtjv(const double *xcur, const double *u, double *normw2, double *out) = 0;
     virtual int full_jtj(const double *xcur, double *jtj) = 0;          // p x p row-major (symmetric)
@@ -219,6 +224,8 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
     int rc = ops.eval(x.data(), &fnorm2, g.data(), dJ.data(), need_jtj ? JTJ.data() : nullptr, &bad);
     if (rc)
         return rc;
+    if (ops.lazy_jac && (rc = ops.eval_jac(g.data(), dJ.data(), need_jtj ? JTJ.data() : nullptr)))
+        return rc;
     ops.accept();
     ops.nevalf += 1;
     ops.nevaldfu += 1;
@@ -385,7 +392,9 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
                 delta /= factor_down;
             if (found)
             {
-                // accepted: g, J^T J (diag) at x_trial came with the same EVAL pass
+                // accepted: g, J^T J (diag) at x_trial came with the same EVAL pass (or are completed now)
+                if (ops.lazy_jac && (rc = ops.eval_jac(gt.data(), dJt.data(), need_jtj ? JTJt.data() : nullptr)))
+                    return rc;
                 ops.accept();
                 ops.nevaldfu += 1;
                 ops.nevaldf2 += 1;

@@ -93,15 +93,116 @@ class LargeProblem:
                                                        int(reps)))
 
 
-def gsl_nls_large(fn, data=None, start=None, algorithm="lm", control=None, trace=False, weights=None, y=None, A=None):
+class SparseLargeProblem(LargeProblem):
+    """gsl_nls_large(fn = function, jac = function returning a sparse matrix): the callables stay on the host (as the
+    R closures do in the reference, src/nls_large.c:426-653), all products with J run on the device.
+
+    fn(theta) -> model values [n]; jac(theta) -> scipy.sparse csr (dgRMatrix) / csc (dgCMatrix) / coo (dgTMatrix)
+    matrix or a dense n x p array (dgeMatrix / base matrix)."""
+
+    def __init__(self, fn, jac, y, p, weights=None):
+        import scipy.sparse as sp
+        self.n, self.p = int(len(y)), int(p)
+        self._y = np.ascontiguousarray(y, dtype=np.float64)
+        self._w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        self._keep = None
+        self.error = None
+        n, pp = self.n, self.p
+
+        def f_cb(theta, p_, out, n_, _user):
+            try:
+                th = np.ctypeslib.as_array(theta, shape=(p_,)).copy()
+                val = np.asarray(fn(th), dtype=np.float64).reshape(-1)
+                if val.shape[0] != n_:
+                    raise ValueError("fn returned %d values, expected %d" % (val.shape[0], n_))
+                np.ctypeslib.as_array(out, shape=(n_,))[:] = val
+                return 0
+            except Exception as e:  # noqa: the error crosses the C boundary as a status
+                self.error = e
+                return 1
+
+        def jac_cb(theta, p_, J, _user):
+            try:
+                th = np.ctypeslib.as_array(theta, shape=(p_,)).copy()
+                M = jac(th)
+                if not sp.issparse(M):
+                    M = sp.csr_matrix(np.asarray(M, dtype=np.float64).reshape(n, pp))
+                if M.shape != (n, pp):
+                    raise ValueError("jac returned a %s matrix, expected %s" % (M.shape, (n, pp)))
+                fmt = M.getformat()
+                if fmt not in ("csr", "csc", "coo"):
+                    M = M.tocsr()
+                    fmt = "csr"
+                x = np.ascontiguousarray(M.data, dtype=np.float64)
+                s = J.contents
+                s.nrow, s.ncol, s.nnz = n, pp, x.shape[0]
+                s.x = x.ctypes.data_as(DP)
+                if fmt == "coo":
+                    a = np.ascontiguousarray(M.row, dtype=np.int32)
+                    b = np.ascontiguousarray(M.col, dtype=np.int32)
+                    s.format, s.i, s.j = 2, a.ctypes.data_as(IP), b.ctypes.data_as(IP)
+                else:
+                    a = np.ascontiguousarray(M.indptr, dtype=np.int32)
+                    b = np.ascontiguousarray(M.indices, dtype=np.int32)
+                    s.p = a.ctypes.data_as(IP)
+                    if fmt == "csr":
+                        s.format, s.j = 0, b.ctypes.data_as(IP)
+                    else:
+                        s.format, s.i = 1, b.ctypes.data_as(IP)
+                self._keep = (x, a, b)  # valid until the next call, as the header asks
+                return 0
+            except Exception as e:  # noqa
+                self.error = e
+                return 1
+
+        self._f_cb, self._jac_cb = _lib.LARGE_F_CB(f_cb), _lib.LARGE_JAC_CB(jac_cb)
+        err = C.c_int(0)
+        self._h = _lib.lib().gslnls_large_create_sparse(
+            self.n, self.p, self._y.ctypes.data_as(C.c_void_p),
+            None if self._w is None else self._w.ctypes.data_as(C.c_void_p), self._f_cb, self._jac_cb, None,
+            C.byref(err))
+        if not self._h:
+            _lib.check(err.value)
+            raise RuntimeError("gslnls_large_create_sparse failed: %s" % _lib.strerror(err.value))
+
+    def solve(self, *a, **k):
+        self.error = None
+        fit = super().solve(*a, **k)
+        if self.error is not None:  # an exception inside fn / jac aborted the fit (status EINVAL)
+            raise self.error
+        return fit
+
+
+def gsl_nls_large(fn, data=None, start=None, algorithm="lm", control=None, trace=False, weights=None, y=None, A=None,
+                  jac=None):
     """gsl_nls_large(fn = y ~ f(x, theta), data, start, algorithm = c("lm", ..., "cgst"), ...)  (R/nls_large.R:124)
 
-    fn: formula string lowering to a registered row model, or "glmexp" with A (n x p) and y.
+    fn: formula string lowering to a registered row model; "glmexp" with A (n x p) and y; or a callable
+    fn(theta) -> model values together with jac(theta) -> sparse / dense Jacobian and the response y
+    (gsl_nls_large.function, R/nls_large.R:420-627).
     """
     if start is None:
         raise ValueError("starting values 'start' are required")
     if weights is not None and np.any(~(np.asarray(weights) > 0)):
         raise ValueError("missing or non-positive weights not allowed")
+    if callable(fn):
+        if jac is None or not callable(jac):
+            raise NotImplementedError("gsl_nls_large(fn = function) needs jac = function (no finite differences on "
+                                      "the large path, R/nls_large.R:470-480 requires it as well)")
+        if y is None:
+            raise ValueError("response 'y' is required with a function model")
+        if isinstance(start, dict):
+            names, st = list(start.keys()), np.array([float(np.atleast_1d(v)[0]) for v in start.values()])
+        else:
+            st = np.asarray(start, dtype=np.float64)
+            names = ["par%d" % (i + 1) for i in range(st.shape[0])]
+        prob = SparseLargeProblem(fn, jac, y, st.shape[0], weights)
+        try:
+            fit = prob.solve(st, algorithm, control, trace)
+        finally:
+            prob.close()
+        fit["parnames"] = names
+        return fit
     if fn == "glmexp":
         A = np.asarray(A, dtype=np.float64)
         st = np.asarray(start, dtype=np.float64)

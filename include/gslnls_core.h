@@ -220,6 +220,29 @@ int gslnls_large_solve(gslnls_large *h, const double *start, const int *control_
  * 2 = full J^T J (p = 64: MFMA kernel + reduction + readback, host clock) */
 float gslnls_large_time_pass(gslnls_large *h, int mode, const double *x, const double *u, int reps);
 
+/* ---- gsl_nls_large with a sparse Jacobian supplied by the caller ---------------------------------------
+ * The model and its Jacobian stay host callbacks, as the R closures fn / jac are in the reference
+ * (gsl_f_large, gsl_df_large: src/nls_large.c:426-653); J arrives as a Matrix-package style sparse matrix
+ * (dgRMatrix / dgCMatrix / dgTMatrix, match_dg_class src/nls_large.c:16-49).  Everything after the callbacks
+ * -- weighting, ssr, J^T f, diag(J^T J), the CG products J^T (J u), dense J^T J for `lm`, covariance -- runs
+ * on the device (csrc/sparse_large.hpp).  f is called at every trial point, jac once per accepted point. */
+#define GSLNLS_SPARSE_CSR 0 /* dgRMatrix: p = row pointers [nrow+1], j = column indices [nnz] */
+#define GSLNLS_SPARSE_CSC 1 /* dgCMatrix: p = column pointers [ncol+1], i = row indices [nnz] */
+#define GSLNLS_SPARSE_COO 2 /* dgTMatrix: i, j triplets [nnz]; duplicates are summed */
+typedef struct gslnls_sparse
+{
+    int format, nrow, ncol;
+    long nnz;
+    const int *p, *i, *j; /* 0-based, as the Matrix package stores them */
+    const double *x;      /* [nnz] */
+} gslnls_sparse;
+/* model values m(theta) (NOT residuals; the core subtracts y) into fval[n]; non-zero return aborts the fit */
+typedef int (*gslnls_large_f_cb)(const double *theta, int p, double *fval, int n, void *user);
+/* fill *J with pointers to host arrays that stay valid until the next call of the same callback */
+typedef int (*gslnls_large_jac_cb)(const double *theta, int p, gslnls_sparse *J, void *user);
+gslnls_large *gslnls_large_create_sparse(int n, int p, const double *y, const double *weights, gslnls_large_f_cb f,
+                                         gslnls_large_jac_cb jac, void *user, int *err);
+
 /* ---- introspection ---------------------------------------------------------------------- */
 const char *gslnls_strerror(int code);     /* gsl_strerror strings, App. C.4 */
 const char *gslnls_algorithm_name(int trs); /* gsl_multifit_nlinear_trs_name */

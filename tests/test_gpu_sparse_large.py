@@ -1,0 +1,127 @@
+"""GPU tests of gsl_nls_large with a caller-supplied sparse Jacobian (csrc/sparse_large.hpp), through the C ABI.
+
+The reference's own sparse example and pin: penalty function I with p = 500 (README.md:1040-1146: model
+c(sqrt(1e-5) (theta - 1), sum(theta^2) - 1/4), Jacobian rbind(Diagonal(sqrt(1e-5)), 2 t(theta)) as dgCMatrix),
+residual sum of squares 0.004778845 for both lm and cgst."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import gslnls_amd
+    from gslnls_amd import _lib
+    assert _lib.lib().gslnls_device_count() >= 1, "no MI355X visible: the HIP path cannot be tested"
+    return gslnls_amd
+
+
+def penalty(p, fmt):
+    a = np.sqrt(1e-5)
+
+    def fn(th):
+        return np.concatenate([a * (th - 1.0), [np.sum(th ** 2) - 0.25]])
+
+    def jac(th):
+        J = sp.vstack([sp.identity(p, format="csr") * a, sp.csr_matrix(2.0 * th.reshape(1, -1))])
+        if fmt == "dense":
+            return J.toarray()
+        if fmt == "coo_dup":
+            # triplets with duplicates that must be summed (dgTMatrix semantics): split every entry in two halves
+            c = J.tocoo()
+            return sp.coo_matrix((np.concatenate([c.data / 2, c.data / 2]),
+                                  (np.concatenate([c.row, c.row]), np.concatenate([c.col, c.col]))), shape=c.shape)
+        return J.asformat(fmt)
+    return fn, jac
+
+
+def oracle_penalty(gslref, p, algorithm, ctrl=None):
+    a = np.sqrt(1e-5)
+
+    def fn(th):
+        return np.concatenate([a * (th - 1.0), [np.sum(th ** 2) - 0.25]])
+
+    def dfl(trans, th, u, want_v, want_jtj):
+        J = np.vstack([a * np.eye(p), 2.0 * th.reshape(1, -1)])
+        v = (J.T @ u if trans else J @ u) if want_v else None
+        return v, (J.T @ J if want_jtj else None)
+    return gslref.nls_large(p + 1, p, np.arange(1.0, p + 1), fn=fn, dfl=dfl, algorithm=algorithm, ctrl=ctrl)
+
+
+@pytest.mark.parametrize("fmt", ["csc", "csr", "coo", "coo_dup", "dense"])
+def test_penalty_p500_cgst_readme_pin(amd, gslref, pins, fmt):
+    p = 500
+    fn, jac = penalty(p, fmt)
+    fit = amd.gsl_nls_large(fn, y=np.zeros(p + 1), start=np.arange(1.0, p + 1), algorithm="cgst", jac=jac,
+                            control=dict(maxiter=500))
+    ref = oracle_penalty(gslref, p, "cgst", gslref.control(maxiter=500))
+    assert fit["conv"] == 0 and ref["conv"] == 0
+    assert abs(fit["ssr"] - 0.004778845) < 5e-10          # README.md:1100-1101
+    assert abs(fit["ssr"] - ref["ssr"]) <= 1e-10 * ref["ssr"]
+    assert np.allclose(fit["par"], ref["par"], rtol=1e-6, atol=1e-9)
+    assert fit["niter"] == ref["niter"]
+
+
+def test_penalty_p500_lm_sparse_jtj(amd, gslref):
+    p = 500
+    fn, jac = penalty(p, "csc")
+    fit = amd.gsl_nls_large(fn, y=np.zeros(p + 1), start=np.arange(1.0, p + 1), algorithm="lm", jac=jac,
+                            control=dict(maxiter=500))
+    ref = oracle_penalty(gslref, p, "lm", gslref.control(maxiter=500))
+    assert fit["conv"] == 0 and ref["conv"] == 0
+    assert abs(fit["ssr"] - 0.004778845) < 5e-10          # README.md:1068-1069
+    assert abs(fit["ssr"] - ref["ssr"]) <= 1e-9 * ref["ssr"]
+    # the valley is flat (singular values sqrt(1e-5) against 2|theta|): both stop by xtol at points whose ssr
+    # agree to 1e-9 while the coordinates still differ in the 4th digit (the true minimiser has all theta_i equal)
+    assert np.allclose(fit["par"], ref["par"], rtol=2e-3)
+    assert abs(fit["niter"] - ref["niter"]) <= 0.05 * ref["niter"]  # ~230 iterations creeping along the valley
+    # covariance = (J^T J)^-1 from the dense J^T J assembled on the device
+    th = fit["par"]
+    J = np.vstack([np.sqrt(1e-5) * np.eye(p), 2.0 * th.reshape(1, -1)])
+    assert np.allclose(np.asarray(fit["covar"]), np.linalg.inv(J.T @ J), rtol=1e-6)
+
+
+def test_penalty_p5_small(amd, gslref):
+    """the same model at the size of the reference's large-path unit tests (unit_tests_gslnls.R:109-131: n, p ~ 5)"""
+    p = 5
+    fn, jac = penalty(p, "csc")
+    fit = amd.gsl_nls_large(fn, y=np.zeros(p + 1), start=np.arange(1.0, p + 1), algorithm="cgst", jac=jac)
+    ref = oracle_penalty(gslref, p, "cgst")
+    assert fit["conv"] == ref["conv"] == 0
+    assert np.allclose(fit["par"], ref["par"], rtol=1e-6)
+    assert fit["niter"] == ref["niter"]
+
+
+def test_weighted_banded_problem_long_rows_and_columns(amd):
+    """a random banded + one dense row + one dense column Jacobian (exercises the thread-per-segment kernel, the
+    long-segment list and row weighting): linear model, so the answer is the weighted least-squares solution"""
+    rng = np.random.Generator(np.random.PCG64(7))
+    n, p = 4000, 600
+    A = sp.diags([rng.standard_normal(n), rng.standard_normal(n - 1), rng.standard_normal(n - 2)], [0, -1, -2],
+                 shape=(n, p), format="lil")
+    A[n - 1, :] = rng.standard_normal(p)          # dense row (600 entries > SP_LONG)
+    A[:, 3] = rng.standard_normal((n, 1))         # dense column (4000 entries)
+    for k in range(p):                            # make sure every column is hit below the band as well
+        A[p + (k * 5) % (n - p), k] = 1.0 + rng.random()
+    A = A.tocsr()
+    truth = rng.standard_normal(p)
+    w = 0.5 + rng.random(n)
+    y = A @ truth + 0.01 * rng.standard_normal(n)
+    fit = amd.gsl_nls_large(lambda th: A @ th, y=y, start=np.zeros(p), algorithm="cgst", jac=lambda th: A, weights=w,
+                            control=dict(maxiter=200))
+    W = sp.diags(w)
+    sol = np.linalg.solve((A.T @ W @ A).toarray(), A.T @ (w * y))
+    assert fit["conv"] == 0
+    assert np.allclose(fit["par"], sol, rtol=1e-5, atol=1e-7)
+    r = np.sqrt(w) * (A @ fit["par"] - y)
+    assert np.allclose(np.asarray(fit["resid"]), r, rtol=1e-9, atol=1e-12)
+    assert abs(fit["ssr"] - r @ r) <= 1e-10 * (r @ r)
+
+
+def test_callback_errors_surface(amd):
+    def bad_fn(th):
+        raise RuntimeError("model blew up")
+    with pytest.raises(RuntimeError, match="model blew up"):
+        amd.gsl_nls_large(bad_fn, y=np.zeros(3), start=np.ones(2), algorithm="cgst", jac=lambda th: np.ones((3, 2)))
