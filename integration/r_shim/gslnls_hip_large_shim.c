@@ -1,0 +1,181 @@
+/*
+ * gslnls_hip_large_shim.c -- reference-side binding for .Call(C_nls_large, ...) (src/init.c:16,
+ * src/nls_large.c:66-75): gsl_nls_large() with `fn` / `jac` R closures, the Jacobian dense or a Matrix-package
+ * sparse matrix.  NOT compiled in this repository's image (no R.h).  A maintainer registers
+ *     {"C_nls_large", (DL_FUNC) &C_nls_large_hip, 9}
+ * in src/init.c in place of C_nls_large; algorithms other than lm / cgst fall through to the original.
+ *
+ * The closures are evaluated on the R main thread exactly as gsl_f_large / gsl_df_large do
+ * (src/nls_large.c:426-472, :474-653) -- but f once per trial point and J once per accepted point instead
+ * of once per matrix-vector product; every product with J then runs on the device
+ * (gslnls_amd/csrc/sparse_large.hpp).
+ */
+#define R_NO_REMAP
+#include <R.h>
+#include <Rinternals.h>
+#include <string.h>
+#include "gslnls_core.h"
+
+SEXP C_nls_large(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP weights, SEXP control_int,
+                 SEXP control_dbl); /* original entry, kept for what is not lowered */
+
+typedef struct
+{
+    SEXP fn, jac, env, parnames;
+    SEXP keep;   /* last Jacobian object: its slots must stay valid until the next callback */
+    int n, p, failed;
+    double *dense; /* scratch for base-matrix / dgeMatrix Jacobians turned into CSR */
+    int *dp, *dj;
+} shim_state;
+
+static SEXP named_par(const double *theta, shim_state *s)
+{
+    SEXP par = PROTECT(Rf_allocVector(REALSXP, s->p));
+    memcpy(REAL(par), theta, sizeof(double) * s->p);
+    Rf_setAttrib(par, R_NamesSymbol, s->parnames); /* src/nls_large.c:436-441 */
+    UNPROTECT(1);
+    return par;
+}
+
+static int shim_f(const double *theta, int p, double *fval, int n, void *user)
+{
+    shim_state *s = (shim_state *)user;
+    SEXP par = PROTECT(named_par(theta, s));
+    SEXP call = PROTECT(Rf_lang2(s->fn, par));
+    SEXP val = PROTECT(Rf_eval(call, s->env));
+    int ok = Rf_isReal(val) && Rf_length(val) == n; /* src/nls_large.c:449-455 */
+    if (ok)
+        memcpy(fval, REAL(val), sizeof(double) * n); /* non-finite values are mapped to +Inf by the core */
+    else
+        s->failed = 1;
+    UNPROTECT(3);
+    return ok ? 0 : 1;
+}
+
+/* same classification as match_dg_class, src/nls_large.c:16-49 */
+static int dg_class(SEXP obj)
+{
+    if (Rf_inherits(obj, "dgTMatrix"))
+        return GSLNLS_SPARSE_COO;
+    if (Rf_inherits(obj, "dgCMatrix"))
+        return GSLNLS_SPARSE_CSC;
+    if (Rf_inherits(obj, "dgRMatrix"))
+        return GSLNLS_SPARSE_CSR;
+    return -1; /* dgeMatrix or base matrix: dense */
+}
+
+static int shim_jac(const double *theta, int p, gslnls_sparse *J, void *user)
+{
+    shim_state *s = (shim_state *)user;
+    SEXP par = PROTECT(named_par(theta, s));
+    SEXP call = PROTECT(Rf_lang2(s->jac, par));
+    SEXP val = PROTECT(Rf_eval(call, s->env));
+    R_ReleaseObject(s->keep);
+    R_PreserveObject(val); /* slots stay valid until the next call, as gslnls_large_jac_cb asks */
+    s->keep = val;
+    UNPROTECT(3);
+    J->nrow = s->n;
+    J->ncol = s->p;
+    const int cls = dg_class(val);
+    if (cls >= 0)
+    {
+        SEXP x = R_do_slot(val, Rf_install("x"));
+        J->format = cls;
+        J->nnz = Rf_length(x);
+        J->x = REAL(x);
+        if (cls != GSLNLS_SPARSE_COO)
+            J->p = INTEGER(R_do_slot(val, Rf_install("p")));
+        if (cls != GSLNLS_SPARSE_CSR)
+            J->i = INTEGER(R_do_slot(val, Rf_install("i")));
+        if (cls != GSLNLS_SPARSE_CSC)
+            J->j = INTEGER(R_do_slot(val, Rf_install("j")));
+        return 0;
+    }
+    /* dense n x p (column-major): every entry becomes a stored CSC entry; the index arrays are built once */
+    SEXP dx = Rf_inherits(val, "dgeMatrix") ? R_do_slot(val, Rf_install("x")) : val;
+    if (!Rf_isReal(dx) || Rf_length(dx) != s->n * s->p)
+    {
+        s->failed = 1;
+        return 1;
+    }
+    if (!s->dp)
+    {
+        s->dp = (int *)R_alloc(s->p + 1, sizeof(int));
+        s->dj = (int *)R_alloc((size_t)s->n * s->p, sizeof(int));
+        for (int c = 0; c <= s->p; c++)
+            s->dp[c] = c * s->n;
+        for (int c = 0; c < s->p; c++)
+            for (int r = 0; r < s->n; r++)
+                s->dj[(size_t)c * s->n + r] = r;
+    }
+    J->format = GSLNLS_SPARSE_CSC;
+    J->nnz = (long)s->n * s->p;
+    J->p = s->dp;
+    J->i = s->dj;
+    J->x = REAL(dx);
+    return 0;
+}
+
+SEXP C_nls_large_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP weights, SEXP control_int,
+                     SEXP control_dbl)
+{
+    const int trs = INTEGER(control_int)[2];
+    if ((trs != 0 && trs != 5) || !Rf_isFunction(jac) || gslnls_device_count() < 1)
+        return C_nls_large(fn, y, jac, fvv, env, start, weights, control_int, control_dbl);
+
+    SEXP startvec = PROTECT(Rf_coerceVector(start, REALSXP));
+    const int p = Rf_length(startvec), n = Rf_length(y);
+    shim_state s = {fn, jac, env, Rf_getAttrib(start, R_NamesSymbol), R_NilValue, n, p, 0, NULL, NULL, NULL};
+    int err = 0;
+    gslnls_large *h = gslnls_large_create_sparse(n, p, REAL(y), Rf_isNull(weights) ? NULL : REAL(weights), shim_f,
+                                                 shim_jac, &s, &err);
+    if (!h)
+    {
+        UNPROTECT(1);
+        return C_nls_large(fn, y, jac, fvv, env, start, weights, control_int, control_dbl);
+    }
+    const int maxiter = INTEGER(control_int)[0], verbose = INTEGER(control_int)[1];
+    /* result list of src/nls_large.c:275-416: par, covar, resid, grad (NULL here: J is never densified), niter,
+     * status, conv, ssr, ssrtol, algorithm, neval [, partrace, ssrtrace] */
+    SEXP ans = PROTECT(Rf_allocVector(VECSXP, verbose ? 13 : 11));
+    SEXP par = PROTECT(Rf_allocVector(REALSXP, p)), covar = PROTECT(Rf_allocMatrix(REALSXP, p, p)),
+         resid = PROTECT(Rf_allocVector(REALSXP, n));
+    gslnls_large_result out;
+    memset(&out, 0, sizeof out);
+    out.par = REAL(par);
+    out.covar = REAL(covar);
+    out.resid = REAL(resid);
+    int nprot = 5;
+    if (verbose)
+    {
+        SEXP pt = PROTECT(Rf_allocMatrix(REALSXP, maxiter + 1, p)), st = PROTECT(Rf_allocVector(REALSXP, maxiter + 1));
+        nprot += 2;
+        out.partrace = REAL(pt);
+        out.ssrtrace = REAL(st);
+        SET_VECTOR_ELT(ans, 11, pt);
+        SET_VECTOR_ELT(ans, 12, st);
+    }
+    const int rc = gslnls_large_solve(h, REAL(startvec), INTEGER(control_int), REAL(control_dbl), &out);
+    gslnls_large_destroy(h);
+    R_ReleaseObject(s.keep);
+    if (rc == GSLNLS_E_UNSUPPORTED || rc == GSLNLS_E_NODEVICE)
+    {
+        UNPROTECT(nprot);
+        return C_nls_large(fn, y, jac, fvv, env, start, weights, control_int, control_dbl);
+    }
+    Rf_setAttrib(par, R_NamesSymbol, s.parnames);
+    SET_VECTOR_ELT(ans, 0, par);
+    SET_VECTOR_ELT(ans, 1, covar);
+    SET_VECTOR_ELT(ans, 2, resid);
+    SET_VECTOR_ELT(ans, 4, Rf_ScalarInteger(out.niter));
+    SET_VECTOR_ELT(ans, 5, Rf_mkString(gslnls_strerror(out.conv)));
+    SET_VECTOR_ELT(ans, 6, Rf_ScalarInteger(out.conv));
+    SET_VECTOR_ELT(ans, 7, Rf_ScalarReal(out.ssr));
+    SET_VECTOR_ELT(ans, 8, Rf_ScalarReal(out.ssrtol));
+    SET_VECTOR_ELT(ans, 9, Rf_mkString(gslnls_algorithm_name(trs)));
+    SEXP neval = PROTECT(Rf_allocVector(INTSXP, 4));
+    memcpy(INTEGER(neval), out.neval, sizeof(int) * 4); /* f, dfu, df2, fvv: src/nls_large.c:395-401 */
+    SET_VECTOR_ELT(ans, 10, neval);
+    UNPROTECT(nprot + 1);
+    return ans;
+}
