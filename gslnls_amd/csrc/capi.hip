@@ -144,6 +144,16 @@ static int batch_irls_run(gslnls_batch *h, int lo, int hi, int jac, int fvv, con
     a.par = h->d_par;
     a.scal = h->d_scal;
     a.ints = h->d_ints;
+    a.prof = nullptr;
+    unsigned long long *d_prof = nullptr;
+    if (getenv("GSLNLS_BATCH_PROF")) // developer diagnostic: per-phase shader cycles of every data set
+    {
+        if (hipMalloc(&d_prof, sizeof(unsigned long long) * 8 * (size_t)h->B) == hipSuccess)
+        {
+            (void)hipMemset(d_prof, 0, sizeof(unsigned long long) * 8 * (size_t)h->B);
+            a.prof = d_prof;
+        }
+    }
     const int jacmode = jac ? JAC_ANALYTIC : (ci[5] ? JAC_CENTER : JAC_FORWARD);
     hipEventRecord(h->e0, h->st);
     switch (jacmode)
@@ -162,6 +172,20 @@ static int batch_irls_run(gslnls_batch *h, int lo, int hi, int jac, int fvv, con
     GSLNLS_HIP_OK(hipStreamSynchronize(h->st));
     if (kernel_ms)
         hipEventElapsedTime(kernel_ms, h->e0, h->e1);
+    if (d_prof)
+    {
+        std::vector<unsigned long long> hp(8 * (size_t)h->B);
+        (void)hipMemcpy(hp.data(), d_prof, sizeof(unsigned long long) * hp.size(), hipMemcpyDeviceToHost);
+        (void)hipFree(d_prof);
+        double tot[8] = {0};
+        for (int d = lo; d < hi; ++d)
+            for (int k = 0; k < 8; ++k)
+                tot[k] += (double)hp[(size_t)d * 8 + k];
+        const double nd = hi - lo;
+        fprintf(stderr, "[batch prof] per data set (kcycles): rows %.0f  reduce %.0f  advance %.0f  reweight %.0f  total %.0f "
+                        "| passes %.1f\n",
+                tot[0] / nd / 1e3, tot[1] / nd / 1e3, tot[2] / nd / 1e3, tot[3] / nd / 1e3, tot[4] / nd / 1e3, tot[5] / nd);
+    }
     return GSLNLS_SUCCESS;
 }
 

@@ -42,10 +42,18 @@ struct IrlsBatchArgs
     double *par;          // [B][P]
     double *scal;         // [B][4]: sigma, ssr (weighted), irls_tol, chisq_init
     int *ints;            // [B][4]: conv, irls_status, irls_niter, niter
+    unsigned long long *prof; // developer diagnostic (GSLNLS_BATCH_PROF): [B][8] cycle totals, or nullptr
 };
 
+// out-of-line on purpose: its own register allocation, nothing of the row loop live across it
+template <int P>
+__device__ __attribute__((noinline)) void lm_advance_lds(LmState<P> *s, const PassSums<P> *r, const LmParams *prm)
+{
+    lm_advance<P>(*s, *r, *prm);
+}
+
 template <class M, int JAC, int T>
-__global__ __launch_bounds__(T) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
+__global__ __launch_bounds__(T, 2) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
 {
     constexpr int P = M::P, NX = M::NX;
     using Sums = PassSums<P>;
@@ -54,13 +62,17 @@ __global__ __launch_bounds__(T) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
     __shared__ double lds_tot[NV];
     __shared__ LmState<P> lds_state;
     __shared__ unsigned int hist[256];
-    __shared__ unsigned long long sel_prefix, sel_mask, sel_k;
+    __shared__ unsigned long long sel_prefix, sel_mask, sel_k, sel_lo, sel_hi;
+    __shared__ unsigned int sel_cnt_le;
     __shared__ double sh_val[2], sh_sigma, sh_scale;
     __shared__ int sh_flag;
 
     const int d = a.lo + blockIdx.x;
     if (d >= a.hi)
         return;
+    unsigned long long pf[6] = {0, 0, 0, 0, 0, 0};
+    auto now = [&]() -> unsigned long long { return a.prof ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull; };
+    const unsigned long long t_begin = now();
     const int n = a.n, tid = threadIdx.x;
     const double *xd = a.x + (size_t)d * NX * n;
     const double *yd = a.y + (size_t)d * n;
@@ -86,11 +98,7 @@ __global__ __launch_bounds__(T) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
         irls_iter += 1;
         // ---------------- cold LM solve from the original start with the current weights ----------------
         if (tid == 0)
-        {
-            LmState<P> s;
-            lm_state_reset<P>(s, a.start, a.has_lu ? a.lu : nullptr);
-            lds_state = s;
-        }
+            lm_state_reset<P>(lds_state, a.start, a.has_lu ? a.lu : nullptr);
         prm.chisq_in = (irls_iter > 1) ? chisq_carry : NAN;
         __syncthreads();
         for (int guard = 0; guard < 1000000; ++guard)
@@ -106,46 +114,77 @@ __global__ __launch_bounds__(T) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
                 vel[k] = lds_state.vel[k];
             }
             fd_deltas<P>(th, prm.h_df, delta);
+            const unsigned long long t0 = now();
             Sums acc;
             pass_zero<P>(acc);
-            for (int i = tid; i < n; i += T)
+            // the phase is uniform: one loop per kind of pass (both bodies inside one loop cost registers)
+            if (phase == PH_FVV)
             {
-                double xr[NX];
-#pragma unroll
-                for (int c = 0; c < NX; ++c)
-                    xr[c] = xd[(size_t)c * n + i];
-                double Jrow[P];
-                if (phase == PH_FVV)
+                for (int i = tid; i < n; i += T)
                 {
+                    double xr[NX];
+#pragma unroll
+                    for (int c = 0; c < NX; ++c)
+                        xr[c] = xd[(size_t)c * n + i];
+                    double Jrow[P];
                     const double fv = row_fvv<M, JAC>(th, vel, delta, prm.h_fvv, prm.fvv_analytic != 0, xr, yd[i],
                                                       swd[i], Jrow, &acc.badj);
 #pragma unroll
                     for (int k = 0; k < P; ++k)
                         acc.g[k] += Jrow[k] * fv;
                 }
-                else
+            }
+            else
+            {
+                // software pipeline: the next row's x, y, sqrt(w) are requested before this row is evaluated
+                double nx[NX], ny = 0.0, nw = 0.0;
+                if (tid < n)
                 {
-                    const double f = row_fj<M, JAC>(th, delta, xr, yd[i], swd[i], Jrow, &acc.badj);
+#pragma unroll
+                    for (int c = 0; c < NX; ++c)
+                        nx[c] = xd[(size_t)c * n + tid];
+                    ny = yd[tid];
+                    nw = swd[tid];
+                }
+#pragma unroll 1
+                for (int i = tid; i < n; i += T)
+                {
+                    double xr[NX];
+#pragma unroll
+                    for (int c = 0; c < NX; ++c)
+                        xr[c] = nx[c];
+                    const double yy = ny, ww = nw;
+                    const int inext = i + T < n ? i + T : i;
+#pragma unroll
+                    for (int c = 0; c < NX; ++c)
+                        nx[c] = xd[(size_t)c * n + inext];
+                    ny = yd[inext];
+                    nw = swd[inext];
+                    double Jrow[P];
+                    const double f = row_fj<M, JAC>(th, delta, xr, yy, ww, Jrow, &acc.badj);
                     acc_fj<P>(acc, f, Jrow);
                 }
             }
+            const unsigned long long t1 = now();
             const double tot = block_sum_slots<NV, T>(reinterpret_cast<const double *>(&acc), lds_red);
             if (tid < NV)
                 lds_tot[tid] = tot;
             __syncthreads();
-            if (tid < 64)
+            const unsigned long long t2 = now();
+            if (tid == 0)
             {
-                LmState<P> s = lds_state;
-                Sums r;
-                double *rf = reinterpret_cast<double *>(&r);
-#pragma unroll
-                for (int v = 0; v < NV; ++v)
-                    rf[v] = lds_tot[v];
-                lm_advance<P>(s, r, prm);
-                if (tid == 0)
-                    lds_state = s;
+                // one lane advances the state IN PLACE in LDS: a register copy of LmState<8> (~115 doubles) plus
+                // the 8 x 8 system of lm_solve pushed the kernel to 256 VGPRs + AGPR/scratch spills = one
+                // wavefront per SIMD; p-sized algebra through LDS costs a few thousand cycles per LM iteration
+                // but lets a second data set share the CU and hide them
+                lm_advance_lds<P>(&lds_state, reinterpret_cast<const Sums *>(lds_tot), &prm);
             }
             __syncthreads();
+            const unsigned long long t3 = now();
+            pf[0] += t1 - t0;
+            pf[1] += t2 - t1;
+            pf[2] += t3 - t2;
+            pf[5] += 1;
         }
         status = lds_state.status;
         if (irls_iter == 1)
@@ -155,6 +194,7 @@ __global__ __launch_bounds__(T) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
             break;
 
         // ---------------- re-weighting ----------------
+        const unsigned long long tw0 = now();
         double th[P];
 #pragma unroll
         for (int k = 0; k < P; ++k)
@@ -168,53 +208,165 @@ __global__ __launch_bounds__(T) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
             kd[i] = (unsigned long long)__double_as_longlong(fabs(row_resid<M>(th, xr, yd[i], 1.0)));
         }
         __syncthreads();
+        // median of |r| (src/nls_utils.c:162-186 sorts; here a radix SELECT on the bit patterns, which order like
+        // the non-negative doubles they encode).  One select for the lower middle order statistic k_lo; for even
+        // n the upper one is the smallest key above it unless the value repeats -- one extra sweep instead of a
+        // second 8-pass select.  Bytes that are equal in the smallest and the largest key are skipped.  The
+        // histogram of a byte is built with wave-aggregated LDS atomics: the keys of one wavefront mostly share
+        // their high bytes, and 64 same-address atomics serialise.
         const unsigned long long k_lo = (unsigned long long)((n - 1) / 2), k_hi = (unsigned long long)(n / 2);
-        const int nsel = (k_lo == k_hi) ? 1 : 2;
-        for (int which = 0; which < nsel; ++which)
         {
+            unsigned long long kmin = ~0ull, kmax = 0ull;
+#pragma unroll 8
+            for (int i = tid; i < n; i += T)
+            {
+                const unsigned long long key = kd[i];
+                kmin = key < kmin ? key : kmin;
+                kmax = key > kmax ? key : kmax;
+            }
+            // wave min / max through the shuffle-free route: LDS atomics on two words
             if (tid == 0)
             {
-                sel_prefix = 0;
-                sel_mask = 0;
-                sel_k = which == 0 ? k_lo : k_hi;
+                sel_lo = ~0ull;
+                sel_hi = 0ull;
             }
-            for (int pass = 7; pass >= 0; --pass)
+            __syncthreads();
+            atomicMin(&sel_lo, kmin);
+            atomicMax(&sel_hi, kmax);
+            __syncthreads();
+        }
+        int first_pass = 7;
+        {
+            const unsigned long long diff = sel_lo ^ sel_hi;
+            while (first_pass > 0 && ((diff >> (8 * first_pass)) & 255ull) == 0ull)
+                --first_pass;
+        }
+        if (tid == 0)
+        {
+            const int sh = 8 * (first_pass + 1);
+            sel_mask = sh >= 64 ? 0ull : ~((1ull << sh) - 1ull); // bytes above first_pass: common to all keys
+            sel_prefix = sel_lo & sel_mask;
+            sel_k = k_lo;
+            sel_cnt_le = 0;
+        }
+        __syncthreads();
+        for (int pass = first_pass; pass >= 0; --pass)
+        {
+            if (tid < 256)
+                hist[tid] = 0;
+            __syncthreads();
+            const unsigned long long prefix = sel_prefix, mask = sel_mask;
+            // the first two bytes examined are shared by most keys of a wavefront: aggregate; later bytes are
+            // spread over the 256 bins and plain atomics rarely collide
+            const bool aggregate = pass > first_pass - 2;
+            constexpr int KU = 8; // keys in flight per thread: the loads overlap instead of exposing 8 latencies
+            for (int i0 = 0; i0 < n; i0 += KU * T)
             {
-                if (tid < 256)
-                    hist[tid] = 0;
-                __syncthreads();
-                const unsigned long long prefix = sel_prefix, mask = sel_mask;
-                for (int i = tid; i < n; i += T)
+                unsigned long long key[KU];
+#pragma unroll
+                for (int u = 0; u < KU; ++u)
                 {
-                    const unsigned long long key = kd[i];
-                    if ((key & mask) == prefix)
-                        atomicAdd(&hist[(key >> (8 * pass)) & 255ull], 1u);
+                    const int i = i0 + u * T + tid;
+                    key[u] = kd[i < n ? i : n - 1];
                 }
-                __syncthreads();
-                if (tid == 0)
+#pragma unroll
+                for (int u = 0; u < KU; ++u)
                 {
-                    unsigned long long k = sel_k, cum = 0;
-                    int bin = 255;
-                    for (int b = 0; b < 256; ++b)
+                    const int i = i0 + u * T + tid;
+                    int bin = -1;
+                    if (i < n && (key[u] & mask) == prefix)
+                        bin = (int)((key[u] >> (8 * pass)) & 255ull);
+                    if (aggregate)
                     {
-                        const unsigned long long c = hist[b];
-                        if (k < cum + c)
+                        // up to 3 rounds of "everyone with the first lane's bin adds once", then plain atomics
+                        unsigned long long todo = __ballot(bin >= 0);
+#pragma unroll 1
+                        for (int round = 0; round < 3 && todo; ++round)
                         {
-                            bin = b;
-                            break;
+                            const int leader = __ffsll((long long)todo) - 1;
+                            const int b = __builtin_amdgcn_readlane(bin, leader);
+                            const unsigned long long same = __ballot(bin == b);
+                            if ((int)(tid & 63) == leader)
+                                atomicAdd(&hist[b], (unsigned int)__popcll(same));
+                            todo &= ~same;
+                            if (bin == b)
+                                bin = -1;
                         }
-                        cum += c;
+                    }
+                    if (bin >= 0)
+                        atomicAdd(&hist[bin], 1u);
+                }
+            }
+            __syncthreads();
+            // which bin holds rank sel_k: wavefront 0, lane l owns bins 4l .. 4l+3, exclusive scan over the lanes
+            if (tid < 64)
+            {
+                const unsigned int c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+                unsigned int incl = c0 + c1 + c2 + c3;
+#pragma unroll
+                for (int dlt = 1; dlt < 64; dlt <<= 1)
+                {
+                    const unsigned int up = __shfl_up(incl, dlt);
+                    if (tid >= dlt)
+                        incl += up;
+                }
+                const unsigned long long k = sel_k;
+                const unsigned long long before = incl - (c0 + c1 + c2 + c3);
+                if (k >= before && k < incl)
+                {
+                    unsigned long long cum = before;
+                    int bin = 4 * tid;
+                    if (k >= cum + c0)
+                    {
+                        cum += c0;
+                        bin += 1;
+                        if (k >= cum + c1)
+                        {
+                            cum += c1;
+                            bin += 1;
+                            if (k >= cum + c2)
+                            {
+                                cum += c2;
+                                bin += 1;
+                            }
+                        }
                     }
                     sel_k = k - cum;
                     sel_prefix = prefix | ((unsigned long long)bin << (8 * pass));
                     sel_mask = mask | (255ull << (8 * pass));
                 }
-                __syncthreads();
             }
-            if (tid == 0)
-                sh_val[which] = __longlong_as_double((long long)sel_prefix);
             __syncthreads();
         }
+        // sel_prefix is the k_lo-th smallest key.  Upper middle (even n): equal to it if enough keys are <= it,
+        // else the smallest key above it.
+        const unsigned long long v_lo = sel_prefix;
+        int nsel = 1;
+        if (k_hi != k_lo)
+        {
+            nsel = 2;
+            unsigned int cnt_le = 0;
+            unsigned long long next = ~0ull;
+#pragma unroll 8
+            for (int i = tid; i < n; i += T)
+            {
+                const unsigned long long key = kd[i];
+                cnt_le += key <= v_lo ? 1u : 0u;
+                if (key > v_lo && key < next)
+                    next = key;
+            }
+            if (tid == 0)
+                sel_lo = ~0ull;
+            __syncthreads();
+            atomicAdd(&sel_cnt_le, cnt_le);
+            atomicMin(&sel_lo, next);
+            __syncthreads();
+            if (tid == 0)
+                sh_val[1] = __longlong_as_double((long long)(((unsigned long long)sel_cnt_le > k_hi) ? v_lo : sel_lo));
+        }
+        if (tid == 0)
+            sh_val[0] = __longlong_as_double((long long)v_lo);
+        __syncthreads();
         if (tid == 0)
             sh_sigma = 1.482602218505602 * (nsel == 1 ? sh_val[0] : (sh_val[0] + sh_val[1]) / 2.0);
         __syncthreads();
@@ -256,6 +408,7 @@ __global__ __launch_bounds__(T) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
         __syncthreads();
         const double scale = sh_scale;
         irls_status = sh_flag;
+        pf[3] += now() - tw0;
         if (irls_status == ST_SUCCESS || irls_iter >= a.irls_maxiter)
             break;
         for (int i = tid; i < n; i += T)
@@ -271,6 +424,12 @@ __global__ __launch_bounds__(T) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
         __syncthreads();
     }
 
+    if (tid == 0 && a.prof)
+    {
+        pf[4] = now() - t_begin;
+        for (int k = 0; k < 6; ++k)
+            a.prof[(size_t)d * 8 + k] = pf[k];
+    }
     if (tid == 0)
     {
         int conv = status;
