@@ -21,6 +21,7 @@ duration from HIP events on the library's stream), "cpu_baseline" (the oracle, s
 """
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import sys
@@ -107,12 +108,16 @@ def multistart_bench(L, _lib, torch, dist, rank, world, steps, warmup):
         torch.cuda.synchronize()
         kms.clear()
         t0 = time.perf_counter()
+        stamps = []
         for _ in range(steps):
             step()
+            stamps.append(time.perf_counter())
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        if os.environ.get("GSLNLS_BENCH_DEBUG"):
+            print(label, ["%.3f" % (1e3 * (b - a)) for a, b in zip([t0] + stamps[:-1], stamps)], file=sys.stderr)
         if dist is not None:
             t = torch.tensor([el], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -224,6 +229,10 @@ def main():
         raise SystemExit("bench.py: no MI355X visible; the HIP path has no CPU fallback")
     _lib.check(L.gslnls_set_device(local_rank))
 
+    # the interpreter's cyclic collector can pause for tens of ms once torch's object graph is loaded (seen: one
+    # 38 ms step among 0.1 ms ones); the timed regions allocate nothing that needs it
+    gc.collect()
+    gc.disable()
     n = args.n
     x, y = c2_data(n, 20250927 + rank)
     X = np.asfortranarray(x.reshape(n, 1))

@@ -22,6 +22,8 @@ struct HipMsEvaluator : MsEvaluator
     SobolTable *d_sobol = nullptr;
     long long *d_draw = nullptr;
     double *d_start = nullptr, *d_rec = nullptr;
+    MsBatch batch_cache;     // reused by DenseFit::mstart_batch
+    double *h_rec = nullptr; // pinned staging for the records: a pageable destination costs ~7x the PCIe time
     int cap = 0;
     float last_kernel_ms = 0.f;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -44,6 +46,8 @@ struct HipMsEvaluator : MsEvaluator
         hipFree(d_draw);
         hipFree(d_start);
         hipFree(d_rec);
+        if (h_rec)
+            (void)hipHostFree(h_rec);
         if (e0)
             hipEventDestroy(e0);
         if (e1)
@@ -57,6 +61,10 @@ struct HipMsEvaluator : MsEvaluator
         hipFree(d_draw);
         hipFree(d_start);
         hipFree(d_rec);
+        if (h_rec)
+            (void)hipHostFree(h_rec);
+        h_rec = nullptr;
+        GSLNLS_HIP_OK(hipHostMalloc(&h_rec, sizeof(double) * (size_t)count * K));
         GSLNLS_HIP_OK(hipMalloc(&d_draw, sizeof(long long) * count));
         GSLNLS_HIP_OK(hipMalloc(&d_start, sizeof(double) * (size_t)count * P));
         GSLNLS_HIP_OK(hipMalloc(&d_rec, sizeof(double) * (size_t)count * K));
@@ -128,8 +136,10 @@ struct HipMsEvaluator : MsEvaluator
         }
         hipEventRecord(e1, st);
         if (!out_on_device)
-            GSLNLS_HIP_OK(hipMemcpyAsync(out, d_rec, sizeof(double) * (size_t)(hi - lo) * K, hipMemcpyDeviceToHost, st));
+            GSLNLS_HIP_OK(hipMemcpyAsync(h_rec, d_rec, sizeof(double) * (size_t)(hi - lo) * K, hipMemcpyDeviceToHost, st));
         GSLNLS_HIP_OK(hipStreamSynchronize(st));
+        if (!out_on_device)
+            memcpy(out, h_rec, sizeof(double) * (size_t)(hi - lo) * K);
         hipEventElapsedTime(&last_kernel_ms, e0, e1);
         return 0;
     }
@@ -235,14 +245,19 @@ int DenseFit<M>::mstart_batch(int jac, const double *ranges, const double *kd, l
     ev.prm = make_params(ci, cd, jac, 0, lupars != nullptr, ctx.sw != nullptr);
     ev.jacmode = jac ? JAC_ANALYTIC : (ci[5] ? JAC_CENTER : JAC_FORWARD);
     ev.lupars = lupars;
-    MsBatch b;
-    b.count = count;
+    // the batch description is kept too: a fresh 1.5 MB of vectors per call (65536 points) costs more host time
+    // in page faults than the kernel takes
+    MsBatch &b = ev.batch_cache;
+    if (b.count != count || b.draw.empty() || b.draw[0] != first_draw)
+    {
+        b.count = count;
+        b.draw.resize(count);
+        for (int i = 0; i < count; ++i)
+            b.draw[i] = first_draw + i;
+        b.start.assign((size_t)count * P, 0.0);
+    }
     b.p = P;
     b.K = MsRecord<P>::K;
-    b.draw.resize(count);
-    for (int i = 0; i < count; ++i)
-        b.draw[i] = first_draw + i;
-    b.start.assign((size_t)count * P, 0.0);
     b.range.assign(ranges, ranges + 2 * P);
     b.kd.resize(P);
     for (int k = 0; k < P; ++k)
