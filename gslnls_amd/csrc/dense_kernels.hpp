@@ -247,39 +247,49 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
         // wave w sums the G partials of values v = w-1, w-1 + RW, ...: lane-strided partial sums, DPP butterfly
         const int z0 = opaque_zero();
         const double *pp = prev_partials + z0;
-        double pv[VPW][PB];
-#pragma unroll
-        for (int q = 0; q < VPW; ++q)
+        // values are taken QC at a time (all of them at once for the usual p <= 6; the chunking only keeps the
+        // register file bounded when one wave owns dozens of values, p >= 9)
+        constexpr int QC = VPW < 8 ? VPW : 8;
+#pragma unroll 1
+        for (int q0 = 0; q0 < VPW; q0 += QC)
         {
-            const int v = (wave - 1) + q * RW;
+            double pv[QC][PB];
 #pragma unroll
-            for (int j = 0; j < PB; ++j)
+            for (int q = 0; q < QC; ++q)
             {
-                const int b = lane + 64 * j;
-                pv[q][j] = (v < NV && b < G) ? pp[(size_t)v * G + b] : 0.0;
+                const int v = (wave - 1) + (q0 + q) * RW;
+#pragma unroll
+                for (int j = 0; j < PB; ++j)
+                {
+                    const int b = lane + 64 * j;
+                    pv[q][j] = (v < NV && b < G) ? pp[(size_t)v * G + b] : 0.0;
+                }
+            }
+            double a[QC];
+#pragma unroll
+            for (int q = 0; q < QC; ++q)
+            {
+                a[q] = pv[q][0];
+#pragma unroll
+                for (int j = 1; j < PB; ++j)
+                    a[q] += pv[q][j];
+            }
+#pragma unroll
+            for (int q = 0; q < QC; ++q)
+                a[q] = wave_sum(a[q]);
+            if (lane == 0)
+            {
+#pragma unroll
+                for (int q = 0; q < QC; ++q)
+                {
+                    const int v = (wave - 1) + (q0 + q) * RW;
+                    if (v < NV)
+                        lds_tot[v] = a[q];
+                }
             }
         }
-        double a[VPW];
-#pragma unroll
-        for (int q = 0; q < VPW; ++q)
-        {
-            a[q] = pv[q][0];
-#pragma unroll
-            for (int j = 1; j < PB; ++j)
-                a[q] += pv[q][j];
-        }
-#pragma unroll
-        for (int q = 0; q < VPW; ++q)
-            a[q] = wave_sum(a[q]);
         if (lane == 0)
         {
-#pragma unroll
-            for (int q = 0; q < VPW; ++q)
-            {
-                const int v = (wave - 1) + q * RW;
-                if (v < NV)
-                    lds_tot[v] = a[q];
-            }
             // LDS operations of one wave complete in order: the totals are visible before the count
             __hip_atomic_fetch_add(&lds_arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }

@@ -139,3 +139,39 @@ def test_native_lowering_c2_full_size(amd):
     assert fit["conv"] == 0 and fit["niter"] == ref["niter"]
     assert np.allclose(fit["par"], ref["par"], rtol=1e-8)
     assert abs(fit["ssr"] - ref["ssr"]) <= 1e-12 * ref["ssr"]
+
+
+def test_native_lowering_p12_four_gaussians(amd, gslref):
+    """p = 12 (beyond the interpreter's instantiations): only the native lowering serves it; checked against the
+    oracle with the same analytic Jacobian (numpy) on noisy synthetic peaks"""
+    rng = np.random.Generator(np.random.PCG64(11))
+    n = 4000
+    x = np.linspace(0.0, 40.0, n)
+    truth = np.array([5.0, 8.0, 1.5, 3.0, 16.0, 2.0, 4.0, 25.0, 1.2, 2.5, 33.0, 2.2])
+    def model(th):
+        return sum(th[3 * k] * np.exp(-(x - th[3 * k + 1]) ** 2 / th[3 * k + 2] ** 2) for k in range(4))
+    y = model(truth) + 0.05 * rng.standard_normal(n)
+    names = ["a1", "m1", "s1", "a2", "m2", "s2", "a3", "m3", "s3", "a4", "m4", "s4"]
+    formula = "y ~ " + " + ".join("a%d*exp(-(x-m%d)^2/s%d^2)" % (k, k, k) for k in (1, 2, 3, 4))
+    start = truth * (1.0 + 0.05 * np.array([1, -1, 1, -1, 1, -1, 1, -1, 1, -1, 1, -1]))
+    with pytest.raises(NotImplementedError):
+        amd.gsl_nls(formula, data=dict(x=x, y=y), start=dict(zip(names, start)), jac=True, lowering="vm")
+    fit = amd.gsl_nls(formula, data=dict(x=x, y=y), start=dict(zip(names, start)), jac=True, lowering="jit",
+                      control=dict(solver="cholesky"))
+
+    def jac(th):
+        J = np.zeros((n, 12))
+        for k in range(4):
+            a, m, s = th[3 * k:3 * k + 3]
+            u = x - m
+            e = np.exp(-u * u / (s * s))
+            J[:, 3 * k] = e
+            J[:, 3 * k + 1] = a * e * 2 * u / (s * s)
+            J[:, 3 * k + 2] = a * e * 2 * u * u / (s ** 3)
+        return J
+    ref = gslref.nls(n, 12, start, fn=lambda th: model(th) - y, jac=jac, ctrl=gslref.control(solver="cholesky"))
+    assert fit["conv"] == 0 and ref["conv"] == 0
+    assert np.allclose(fit["par"], ref["par"], rtol=1e-6)
+    assert np.allclose(fit["par"], truth, rtol=2e-2)
+    assert abs(fit["ssr"] - ref["ssr"]) <= 1e-9 * ref["ssr"]
+    assert fit["niter"] == ref["niter"]
