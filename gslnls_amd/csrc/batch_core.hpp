@@ -86,7 +86,7 @@ GSLNLS_HD void ms_fit_point(const MsParams &mp, const RowSrc &rows, const double
     PassSums<P> acc;
     ms_pass<M, JAC>(s, mp, rows, acc);
     double det0 = det_cholesky<P>(acc.A);
-    if (mp.prm.jac_analytic && acc.badj > 0.0)
+    if (mp.prm.jac_analytic && !(acc.badj == 0.0))
         det0 = 0.0; // eval_df failed (src/nls_utils.c:47-48)
     rec.det0 = det0;
     rec.ssr_start = acc.ssr;

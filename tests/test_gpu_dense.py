@@ -171,3 +171,21 @@ def test_failure_paths(amd, nist):
         amd.gsl_nls(q["formula"], data=q["data"], start=q["start"], algorithm="dogleg")
     with pytest.raises(NotImplementedError):
         amd.gsl_nls(q["formula"], data=q["data"], start=q["start"], weights=np.diag(np.full(14, 100.0)))
+
+
+def test_nonfinite_jacobian_start_fails_loudly_not_silently(amd, gslref):
+    """src/nls.c:899-907 (GSL_EBADFUNC for a non-finite analytic Jacobian), src/nls.c:849-858 (+Inf residuals):
+    the device flags the former through sum_j 0 * J_ij; see tests/test_host_logic.py for the oracle side"""
+    x = np.linspace(0.0, 3.0, 4000)
+    y = 5.0 * np.exp(-1.5 * x) + 1.0
+    prob = amd.DenseProblem(1, 3, x, y)
+    ctrl = amd.gsl_nls_control(solver="cholesky")
+    bad = prob.solve([1.0, -400.0, 0.0], jac=True, control=ctrl)
+    assert bad["conv"] == 9 and np.all(np.asarray(bad["par"]) == [1.0, -400.0, 0.0])
+    fd = prob.solve([1.0, -400.0, 0.0], jac=False, control=ctrl)
+    ref = gslref.nls(4000, 3, [1.0, -400.0, 0.0], rowdata=dict(model=gslref.MODEL_EXPDECAY, x=x, y=y), use_jac=False,
+                     ctrl=gslref.control(solver="cholesky"))
+    assert fd["conv"] == ref["conv"]
+    ok = prob.solve([1.0, 1.0, 0.0], jac=True, control=ctrl)
+    prob.close()
+    assert ok["conv"] == 0 and np.allclose(ok["par"], [5.0, 1.5, 1.0], rtol=1e-6)

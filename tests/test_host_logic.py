@@ -208,3 +208,29 @@ def test_device_psi_functions_match_oracle(gslref, hostsim, rho, cc):
     want = np.array([L.gslref_psi(v, c3.ctypes.data_as(gslref.DP), rho) for v in x])
     wantp = np.array([L.gslref_psip(v, c3.ctypes.data_as(gslref.DP), rho) for v in x])
     assert np.array_equal(ps, want) and np.array_equal(pp, wantp)
+
+
+def test_nonfinite_jacobian_and_residual_rules(gslref, hostsim):
+    """src/nls.c:899-907: a non-finite analytic Jacobian entry makes gsl_df return GSL_EBADFUNC (conv 9);
+    src/nls.c:849-858: non-finite model values become +Inf residuals, so a trial point there is simply rejected.
+    The device path detects the former through sum_j 0 * J_ij (NaN flag) instead of a class test per entry."""
+    from gslnls_amd.control import gsl_nls_control, pack_control
+    x = np.linspace(0.0, 3.0, 40)
+    y = 5.0 * np.exp(-1.5 * x) + 1.0
+    ci, cd = pack_control(gsl_nls_control(solver="cholesky"), "lm", False, True, False)
+    # lam = -400: exp(400 x) overflows for x > 1.77 -> Inf Jacobian entries at the start itself
+    bad = hostsim.fit(1, 3, x, y, [1.0, -400.0, 0.0], ci, cd, jac=1)
+    ref = gslref.nls(40, 3, [1.0, -400.0, 0.0], rowdata=dict(model=gslref.MODEL_EXPDECAY, x=x, y=y), use_jac=True,
+                     ctrl=gslref.control(solver="cholesky"))
+    # The reference ignores winit's status (src/nls.c:541-545): after the failed Jacobian it iterates on an
+    # unset workspace; the oracle (zero-filled workspace) then ends in "no progress" (27).  The device reports the
+    # cause itself (9).  Both are failures for the caller (NA results, par = start); the code differs on purpose.
+    assert bad["conv"] == 9 and ref["conv"] in (9, 27)
+    # same start with the FD Jacobian: no EBADFUNC rule (only the analytic path is checked), both must agree again
+    fd = hostsim.fit(1, 3, x, y, [1.0, -400.0, 0.0], ci, cd, jac=0)
+    ref_fd = gslref.nls(40, 3, [1.0, -400.0, 0.0], rowdata=dict(model=gslref.MODEL_EXPDECAY, x=x, y=y), use_jac=False,
+                        ctrl=gslref.control(solver="cholesky"))
+    assert fd["conv"] == ref_fd["conv"]
+    # a regular start is unaffected by the flag arithmetic
+    ok = hostsim.fit(1, 3, x, y, [1.0, 1.0, 0.0], ci, cd, jac=1)
+    assert ok["conv"] == 0 and np.allclose(ok["par"], [5.0, 1.5, 1.0], rtol=1e-6)
