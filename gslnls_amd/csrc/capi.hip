@@ -638,6 +638,14 @@ int gslnls_dense_set_swts(gslnls_dense *h, const double *swts)
     return h->impl->set_swts(swts);
 }
 
+int gslnls_dense_diagnostics(gslnls_dense *h, int jac, const double *par, const int *control_int,
+                             const double *control_dbl, double *hat, double *cooks)
+{
+    if (!h || !h->impl || !par || !control_int || !control_dbl)
+        return GSLNLS_EINVAL;
+    return h->impl->diagnostics(jac, par, control_int, control_dbl, hat, cooks);
+}
+
 int gslnls_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv, const double *start,
                int start_is_matrix, const double *swts, int swts_is_matrix, const double *lupars,
                const int *control_int, const double *control_dbl, const int *has_start, int loss_rho,

@@ -72,6 +72,7 @@ struct DenseBase
                      int loss_rho, const double *loss_cc, gslnls_result *out) = 0;
     virtual float time_pass(int jac, const double *theta, int reps) = 0;
     virtual int set_swts(const double *swts) = 0;
+    virtual int diagnostics(int jac, const double *theta, const int *ci, const double *cd, double *hat, double *cooks) = 0;
     // multi-start branch of C_nls (src/nls.c:274-532) followed by the final single-start solve
     virtual int mstart(int jac, int fvv, const double *start2p, const double *lupars, const int *ci, const double *cd,
                        const int *has_start, const MsComm &comm, int loss_rho, const double *loss_cc,
@@ -444,6 +445,7 @@ struct DenseFit : DenseBase
              const double *loss_cc, gslnls_result *out) override;
     int sums_at(const double *theta, int jacmode, PassSums<P> &out);
     int robust_weights(int jacmode, const double *mpopt, double *d_sw_robust);
+    int diagnostics(int jac, const double *theta, const int *ci, const double *cd, double *hat, double *cooks) override;
 
     int mstart(int jac, int fvv, const double *start2p, const double *lupars, const int *ci, const double *cd,
                const int *has_start, const MsComm &comm, int loss_rho, const double *loss_cc, gslnls_result *out) override;

@@ -24,7 +24,7 @@ struct CooksArgs
 
 template <class M, int JAC, int T>
 __global__ __launch_bounds__(T) void cooks_kernel(DenseCtx<M::P> ctx, CooksArgs<M::P> a, double *d,
-                                                  unsigned long long *keys)
+                                                  unsigned long long *keys, double *hat = nullptr)
 {
     constexpr int P = M::P, NX = M::NX;
     double th[P], delta[P];
@@ -53,7 +53,10 @@ __global__ __launch_bounds__(T) void cooks_kernel(DenseCtx<M::P> ctx, CooksArgs<
         }
         const double di = (e * e) / (P * a.s2) * (h / ((1 - h) * (1 - h)));
         d[i] = di;
-        keys[i] = (unsigned long long)__double_as_longlong(fabs(di));
+        if (keys)
+            keys[i] = (unsigned long long)__double_as_longlong(fabs(di));
+        if (hat)
+            hat[i] = h;
     }
 }
 
@@ -194,6 +197,61 @@ int DenseFit<M>::robust_weights(int jacmode, const double *mpopt, double *d_sw_r
     if (rc)
         return rc;
     return (noutlier > 0 && noutlier < (n - P)) ? 1 : 0;
+}
+
+// hat values h_i = J_i (J^T J)^-1 J_i^T and Cook's distances at `theta` (src/nls_utils.c:88-150; what the S3
+// methods hatvalues() / cooks.distance() of the reference compute from the n x p gradient on the host)
+template <class M>
+int DenseFit<M>::diagnostics(int jac, const double *theta, const int *ci, const double *cd, double *hat, double *cooks)
+{
+    ctx.prm = make_params(ci, cd, jac, 0, false, ctx.sw != nullptr);
+    const int jacmode = jac ? JAC_ANALYTIC : (ci[5] ? JAC_CENTER : JAC_FORWARD);
+    PassSums<P> s;
+    int rc = sums_at(theta, jacmode, s);
+    if (rc)
+        return rc;
+    std::vector<double> A((size_t)P * P);
+    for (int i = 0; i < P; ++i)
+        for (int j = 0; j <= i; ++j)
+            A[i * P + j] = A[j * P + i] = s.A[tri(i, j)];
+    if (!lg_chol(P, A))
+        return GSLNLS_EINVAL; // singular J^T J: hat_values fails in the reference as well
+    lg_chol_invert(P, A);
+    CooksArgs<P> ca;
+    for (int k = 0; k < P; ++k)
+        ca.theta[k] = theta[k];
+    for (int k = 0; k < P * P; ++k)
+        ca.Cinv[k] = A[k];
+    ca.s2 = s.ssr / (n - P);
+    double *d_d = nullptr, *d_h = nullptr;
+    GSLNLS_HIP_OK(hipMalloc(&d_d, sizeof(double) * (size_t)n));
+    GSLNLS_HIP_OK(hipMalloc(&d_h, sizeof(double) * (size_t)n));
+    const int Gf = std::min(2048, (int)((n + T - 1) / T));
+    switch (jacmode)
+    {
+    case JAC_ANALYTIC:
+        hipLaunchKernelGGL((cooks_kernel<M, JAC_ANALYTIC, T>), dim3(Gf), dim3(T), 0, stream, ctx, ca, d_d,
+                           (unsigned long long *)nullptr, d_h);
+        break;
+    case JAC_FORWARD:
+        hipLaunchKernelGGL((cooks_kernel<M, JAC_FORWARD, T>), dim3(Gf), dim3(T), 0, stream, ctx, ca, d_d,
+                           (unsigned long long *)nullptr, d_h);
+        break;
+    default:
+        hipLaunchKernelGGL((cooks_kernel<M, JAC_CENTER, T>), dim3(Gf), dim3(T), 0, stream, ctx, ca, d_d,
+                           (unsigned long long *)nullptr, d_h);
+        break;
+    }
+    hipError_t e = hipSuccess;
+    if (hat)
+        e = hipMemcpyAsync(hat, d_h, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream);
+    if (cooks && e == hipSuccess)
+        e = hipMemcpyAsync(cooks, d_d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(stream);
+    (void)hipFree(d_d);
+    (void)hipFree(d_h);
+    return e == hipSuccess ? GSLNLS_SUCCESS : GSLNLS_E_NODEVICE;
 }
 
 } // namespace gslnls

@@ -56,6 +56,12 @@ struct VmDenseFit : DenseFit<ModelVM<P>>
         upload();
         return Base::time_pass(jac, theta, reps);
     }
+    int diagnostics(int jac, const double *theta, const int *ci, const double *cd, double *hat, double *cooks) override
+    {
+        if (upload())
+            return GSLNLS_E_NODEVICE;
+        return Base::diagnostics(jac, theta, ci, cd, hat, cooks);
+    }
 };
 
 template <int P>

@@ -139,6 +139,20 @@ class DenseProblem:
             _lib.lib().gslnls_dense_destroy(self._h)
             self._h = None
 
+    def diagnostics(self, par, jac=True, control=None):
+        """hat values and Cook's distances at `par` (hatvalues.gsl_nls / cooks.distance.gsl_nls of the reference,
+        R/nls_methods.R, computed on the device from the resident data): returns (hat[n], cooks[n])"""
+        ctrl = control if (control is not None and len(control) >= 23) else gsl_nls_control(**(control or {}))
+        ci, cd = pack_control(ctrl, "lm", False, True, False)
+        th = np.ascontiguousarray(par, dtype=np.float64)
+        hat, cooks = np.zeros(self.n), np.zeros(self.n)
+        rc = _lib.lib().gslnls_dense_diagnostics(self._h, int(bool(jac)), _dp(th), ci.ctypes.data_as(IP), _dp(cd),
+                                                 _dp(hat), _dp(cooks))
+        _lib.check(rc)
+        if rc != 0:
+            raise RuntimeError("diagnostics failed: %s" % _lib.strerror(rc))
+        return hat, cooks
+
     def __del__(self):
         try:
             self.close()

@@ -148,6 +148,11 @@ int gslnls_dense_solve(gslnls_dense *h, int jac, int fvv, const double *start, c
  * library's stream; returns average milliseconds per launch (negative on error) */
 float gslnls_dense_time_pass(gslnls_dense *h, int jac, const double *theta, int reps);
 /* swap the weights of a resident problem (IRLS) */
+/* Post-fit diagnostics on the resident data: hat values h_i = J_i (J^T J)^-1 J_i^T and Cook's distances
+ * e_i^2 / (p s^2) * h_i / (1 - h_i)^2 at `par` (hat_values / cooks_d, src/nls_utils.c:88-150; the reference's S3 methods
+ * hatvalues() and cooks.distance() build them from the n x p gradient on the host).  Either output may be NULL. */
+int gslnls_dense_diagnostics(gslnls_dense *h, int jac, const double *par, const int *control_int,
+                             const double *control_dbl, double *hat, double *cooks);
 int gslnls_dense_set_swts(gslnls_dense *h, const double *swts);
 
 /* ---- multi-start (src/nls_mstart.c, src/nls.c:274-532) ----------------------------------------

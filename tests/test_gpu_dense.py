@@ -189,3 +189,27 @@ def test_nonfinite_jacobian_start_fails_loudly_not_silently(amd, gslref):
     ok = prob.solve([1.0, 1.0, 0.0], jac=True, control=ctrl)
     prob.close()
     assert ok["conv"] == 0 and np.allclose(ok["par"], [5.0, 1.5, 1.0], rtol=1e-6)
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_hat_values_and_cooks_distance(amd, weighted):
+    """hat_values / cooks_d (src/nls_utils.c:88-150) on the resident data vs a numpy restatement from the n x p
+    gradient (what hatvalues.gsl_nls / cooks.distance.gsl_nls do on the host); sum(h) = p"""
+    x, y = c2_data(20000)
+    w = None
+    if weighted:
+        w = 0.5 + np.random.Generator(np.random.PCG64(1)).random(len(x))
+    prob = amd.DenseProblem(1, 3, x, y, weights=w)
+    fit = prob.solve([1.0, 1.0, 0.0], jac=True, control=amd.gsl_nls_control(solver="cholesky"))
+    hat, cooks = prob.diagnostics(fit["par"], jac=True)
+    hat_fd, cooks_fd = prob.diagnostics(fit["par"], jac=False)
+    prob.close()
+    J, r = np.asarray(fit["grad"]), np.asarray(fit["resid"])          # weighted J and residuals
+    C = np.linalg.inv(J.T @ J)
+    h = np.einsum("ij,jk,ik->i", J, C, J)
+    s2 = (r @ r) / (len(x) - 3)
+    d = r ** 2 / (3 * s2) * h / (1 - h) ** 2
+    assert abs(hat.sum() - 3.0) < 1e-9
+    assert np.allclose(hat, h, rtol=1e-9, atol=1e-15)
+    assert np.allclose(cooks, d, rtol=1e-8, atol=1e-18)
+    assert np.allclose(hat_fd, h, rtol=1e-5) and np.allclose(cooks_fd, d, rtol=1e-5, atol=1e-12)
