@@ -496,6 +496,35 @@ struct DenseFit : DenseBase
             launch_step(jacmode, parity);
             parity ^= 1;
         }
+        if (getenv("GSLNLS_GRAPH_PROBE"))
+        {
+            // developer probe: the same launches replayed from a captured hipGraph (16 kernel nodes per replay)
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess)
+                return -1.f;
+            for (int k = 0; k < 16; ++k)
+            {
+                launch_step(jacmode, parity);
+                parity ^= 1;
+            }
+            if (hipStreamEndCapture(stream, &graph) != hipSuccess ||
+                hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess)
+                return -1.f;
+            const int replays = reps / 16 > 0 ? reps / 16 : 1;
+            (void)hipGraphLaunch(exec, stream);
+            hipEventRecord(ev0, stream);
+            for (int r = 0; r < replays; ++r)
+                (void)hipGraphLaunch(exec, stream);
+            hipEventRecord(ev1, stream);
+            if (hipStreamSynchronize(stream) != hipSuccess)
+                return -1.f;
+            float gms = 0.f;
+            hipEventElapsedTime(&gms, ev0, ev1);
+            (void)hipGraphExecDestroy(exec);
+            (void)hipGraphDestroy(graph);
+            return gms / (float)(replays * 16);
+        }
         hipEventRecord(ev0, stream);
         for (int k = 0; k < reps; ++k)
         {
