@@ -15,6 +15,7 @@ IP = C.POINTER(C.c_int)
 
 E_NODEVICE = -100
 E_UNSUPPORTED = -101
+E_INTERRUPTED = -102
 
 
 MODEL_EXPR = 100
@@ -100,6 +101,7 @@ _SIGNATURES = {
     "gslnls_device_count": (C.c_int, []),
     "gslnls_set_device": (C.c_int, [C.c_int]),
     "gslnls_version": (C.c_char_p, []),
+    "gslnls_set_interrupt_hook": (None, [C.c_void_p]),
     "gslnls_expr_build": (C.c_int, [C.POINTER(Model), C.c_char_p, C.c_int]),
 }
 
@@ -139,4 +141,6 @@ def check(rc):
         raise GslnlsDeviceError("gslnls_amd: no usable HIP device (MI355X path has no CPU fallback)")
     if rc == E_UNSUPPORTED:
         raise NotImplementedError("gslnls_amd: configuration not lowered to the device")
+    if rc == E_INTERRUPTED:
+        raise KeyboardInterrupt("gslnls_amd: fit interrupted through the interrupt hook")
     return rc

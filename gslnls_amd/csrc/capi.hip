@@ -638,6 +638,12 @@ int gslnls_dense_set_swts(gslnls_dense *h, const double *swts)
     return h->impl->set_swts(swts);
 }
 
+void gslnls_set_interrupt_hook(int (*check)(void))
+{
+    g_interrupt_hook = check;
+    ms_interrupt_hook = check;
+}
+
 int gslnls_dense_diagnostics(gslnls_dense *h, int jac, const double *par, const int *control_int,
                              const double *control_dbl, double *hat, double *cooks)
 {
@@ -688,6 +694,8 @@ const char *gslnls_strerror(int code)
         return "iteration is not making progress towards solution";
     case GSLNLS_E_NODEVICE:
         return "no HIP device / HIP runtime failure";
+    case GSLNLS_E_INTERRUPTED:
+        return "interrupted by the caller";
     case GSLNLS_E_UNSUPPORTED:
         return "configuration not lowered to the device";
     default:

@@ -85,6 +85,9 @@ struct DenseBase
     int n = 0, p = 0;
 };
 
+// optional hook polled between launch chunks / passes / multi-start batches (gslnls_set_interrupt_hook)
+inline int (*g_interrupt_hook)(void) = nullptr;
+
 template <class M>
 struct DenseFit : DenseBase
 {
@@ -355,6 +358,12 @@ struct DenseFit : DenseBase
                 break;
             if (launches > max_launches)
                 return GSLNLS_FAILURE;
+            // between chunks: give the embedding application its say (R: R_CheckUserInterrupt)
+            if (g_interrupt_hook && g_interrupt_hook())
+            {
+                (void)hipStreamSynchronize(stream);
+                return GSLNLS_E_INTERRUPTED;
+            }
         }
         __sync_synchronize();
         last_ms = (float)(1e3 * (now_s() - t_begin));

@@ -334,6 +334,8 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
     int status = ST_CONTINUE, iter = 0, info = 0;
     do
     {
+        if (g_interrupt_hook && g_interrupt_hook())
+            return GSLNLS_E_INTERRUPTED;
         R.chisq0 = R.chisq1;
         // ---- trust_iterate ----
         int itstatus = ST_SUCCESS, bad_steps = 0;

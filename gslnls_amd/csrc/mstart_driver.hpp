@@ -31,6 +31,9 @@
 namespace gslnls
 {
 
+// set through gslnls_set_interrupt_hook (capi.hip); polled once per major iteration
+inline int (*ms_interrupt_hook)(void) = nullptr;
+
 struct MsBatch
 {
     int count = 0;
@@ -396,6 +399,8 @@ inline int ms_major_loop(MsState &m, MsEvaluator &ev, const MsComm &comm, const 
 {
     do
     {
+        if (ms_interrupt_hook && ms_interrupt_hook())
+            return -102; // GSLNLS_E_INTERRUPTED
         const int rc = ms_major_iteration(m, ev, comm);
         if (rc)
             return rc;

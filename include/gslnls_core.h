@@ -49,6 +49,7 @@ extern "C" {
 /* library-level errors (never produced by the reference): returned by the entry
  * points themselves, never stored in `conv` */
 #define GSLNLS_E_NODEVICE (-100)   /* no HIP device / HIP runtime failure: the path fails loudly */
+#define GSLNLS_E_INTERRUPTED (-102) /* the interrupt hook asked to stop */
 #define GSLNLS_E_UNSUPPORTED (-101) /* combination not lowered to the device (e.g. GLS weight matrix) */
 
 typedef struct gslnls_model
@@ -247,6 +248,11 @@ typedef int (*gslnls_large_f_cb)(const double *theta, int p, double *fval, int n
 typedef int (*gslnls_large_jac_cb)(const double *theta, int p, gslnls_sparse *J, void *user);
 gslnls_large *gslnls_large_create_sparse(int n, int p, const double *y, const double *weights, gslnls_large_f_cb f,
                                          gslnls_large_jac_cb jac, void *user, int *err);
+
+/* Long device loops poll this hook between launch chunks (dense), passes (large) and multi-start batches; a
+ * non-zero return abandons the fit with GSLNLS_E_INTERRUPTED.  The R shim installs a wrapper around
+ * R_CheckUserInterrupt (the reference relies on R_ExecWithCleanup, src/nls.c:61, NEWS.md 1.1.1). */
+void gslnls_set_interrupt_hook(int (*check)(void));
 
 /* ---- introspection ---------------------------------------------------------------------- */
 const char *gslnls_strerror(int code);     /* gsl_strerror strings, App. C.4 */

@@ -20,6 +20,12 @@
 SEXP C_nls(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP swts, SEXP lupars,
            SEXP control_int, SEXP control_dbl, SEXP has_start, SEXP loss_config);
 
+/* user interrupts (Ctrl-C) while the device loop runs: R_CheckUserInterrupt long-jumps, so it is probed under
+ * R_ToplevelExec and reported to the core as a status; the core abandons the fit and C_nls_hip raises the error
+ * after its own clean-up */
+static void probe_interrupt(void *dummy) { R_CheckUserInterrupt(); }
+static int interrupt_hook(void) { return R_ToplevelExec(probe_interrupt, NULL) == FALSE; }
+
 static SEXP deparse_rhs(SEXP fn)
 {
     /* .fn <- function(par, .data = mf) eval(formula[[3]], ...)  (R/nls.R:565): the closure's
@@ -39,6 +45,7 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
 {
     const int n = Rf_length(y);
     const int mstart = Rf_isMatrix(start);                       /* src/nls.c:79 */
+    gslnls_set_interrupt_hook(interrupt_hook);
     const int p = mstart ? Rf_ncols(start) : Rf_length(start);
     SEXP parnames = mstart ? VECTOR_ELT(Rf_getAttrib(start, R_DimNamesSymbol), 1)
                            : Rf_getAttrib(start, R_NamesSymbol); /* src/nls.c:158-161 */
@@ -184,6 +191,8 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
     const int rc = gslnls_nls(&model, REAL(y), n, !Rf_isNull(jac), !Rf_isNull(fvv), st, mstart,
                               Rf_isNull(swts) ? NULL : REAL(swts), 0, lu, INTEGER(control_int), REAL(control_dbl),
                               hs, wgt_i, REAL(VECTOR_ELT(loss_config, 1)), &res);
+    if (rc == GSLNLS_E_INTERRUPTED)
+        Rf_onintr(); /* does not return: the pending interrupt is re-raised now that the device loop is drained */
     if (rc <= GSLNLS_E_NODEVICE) /* no device / not lowered after all: the GSL path still exists */
     {
         UNPROTECT(verbose ? 8 : 6);

@@ -213,3 +213,29 @@ def test_hat_values_and_cooks_distance(amd, weighted):
     assert np.allclose(hat, h, rtol=1e-9, atol=1e-15)
     assert np.allclose(cooks, d, rtol=1e-8, atol=1e-18)
     assert np.allclose(hat_fd, h, rtol=1e-5) and np.allclose(cooks_fd, d, rtol=1e-5, atol=1e-12)
+
+
+def test_interrupt_hook_abandons_the_fit(amd):
+    """gslnls_set_interrupt_hook: polled between launch chunks; a non-zero answer ends the call with
+    GSLNLS_E_INTERRUPTED (the R shim wires R_CheckUserInterrupt to it)"""
+    import ctypes as C
+    from gslnls_amd import _lib
+    x, y = c2_data(50000)
+    prob = amd.DenseProblem(1, 3, x, y)
+    calls = []
+    HOOK = C.CFUNCTYPE(C.c_int)
+
+    def hook():
+        calls.append(1)
+        return 1
+    cb = HOOK(hook)
+    _lib.lib().gslnls_set_interrupt_hook(C.cast(cb, C.c_void_p))
+    try:
+        with pytest.raises(KeyboardInterrupt):
+            prob.solve([1.0, 1.0, 0.0], jac=True, control=amd.gsl_nls_control(solver="cholesky"), chunk=2)
+        assert calls
+    finally:
+        _lib.lib().gslnls_set_interrupt_hook(None)
+    fit = prob.solve([1.0, 1.0, 0.0], jac=True, control=amd.gsl_nls_control(solver="cholesky"))
+    prob.close()
+    assert fit["conv"] == 0
