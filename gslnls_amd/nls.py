@@ -269,6 +269,24 @@ def gsl_nls(fn, data=None, start=None, algorithm="lm", control=None, jac=None, f
             sw = np.ascontiguousarray(np.sqrt(w))
     lu = _bounds(lower, upper, names)
     if lu is not None:
+        # the reference's checks, R/nls.R:542-557
+        lo_b, up_b = lu.reshape(p, 2)[:, 0], lu.reshape(p, 2)[:, 1]
+        if np.any(lo_b > up_b):
+            raise ValueError("Parameter lower bounds cannot be larger than upper bounds")
+        if mat is not None:
+            if has_start is not None:
+                # missing range ends are moved inside the bounds first (R/nls.R:545-552)
+                m0, m1 = ~has_start[0], ~has_start[1]
+                if m0.any():
+                    old = mat[0, m0].copy()
+                    mat[0, m0] = np.maximum(old, lo_b[m0])
+                    mat[1, m0] = mat[1, m0] + (mat[0, m0] - old)
+                if m1.any():
+                    mat[1, m1] = np.minimum(mat[1, m1], up_b[m1])
+            if np.any(mat[0] < lo_b) or np.any(mat[1] > up_b):
+                raise ValueError("Starting parameter ranges must be contained within 'lower' and 'upper' bounds")
+        elif np.any(vec < lo_b) or np.any(vec > up_b):
+            raise ValueError("Starting parameters must be contained within 'lower' and/or 'upper' bounds")
         lu = np.ascontiguousarray(lu.reshape(p, 2)[order].reshape(-1))
 
     any_missing = bool(has_start is not None and not np.all(has_start))

@@ -175,3 +175,42 @@ def test_native_lowering_p12_four_gaussians(amd, gslref):
     assert np.allclose(fit["par"], truth, rtol=2e-2)
     assert abs(fit["ssr"] - ref["ssr"]) <= 1e-9 * ref["ssr"]
     assert fit["niter"] == ref["niter"]
+
+
+def _misra1b(nist):
+    q = nist["Misra1b"]
+    data = {k: np.asarray(v, dtype=np.float64) for k, v in q["data"].items()}
+    lhs, rhs = F.parse_formula(q["formula"])
+    names = list(q["start"].keys())
+    y = np.asarray(F.evaluate(lhs, data), dtype=np.float64)
+
+    def fn(th):
+        env = dict(data)
+        env.update(zip(names, th))
+        return np.asarray(F.evaluate(rhs, env), dtype=np.float64) - y
+    return q, data, fn
+
+
+@pytest.mark.parametrize("jac", [True, False])
+def test_expression_model_weights_bounds_lmaccel(amd, gslref, nist, jac):
+    """unit_tests_gslnls.R 2.1.3-2.1.8 style options on a compiled expression: weights vector, lower/upper
+    bounds (one of them active), lmaccel with finite-difference fvv -- each against the oracle"""
+    q, data, fn = _misra1b(nist)
+    n, start = q["n"], list(q["start"].values())
+    w = 0.5 + np.random.Generator(np.random.PCG64(2)).random(n)
+    fit = amd.gsl_nls(q["formula"], data=data, start=q["start"], jac=jac, weights=w, lowering="vm")
+    ref = gslref.nls(n, 2, start, fn=fn, weights=w)
+    assert fit["conv"] == ref["conv"] == 0 and _close(fit["par"], ref["par"], rel=1e-6)
+    assert abs(fit["ssr"] - ref["ssr"]) <= 1e-8 * ref["ssr"]
+    # bounds: b1 held above its optimum (338.0) from the feasible start 500: the fit must end on the bound like the
+    # reference's projection (src/trust.c:9-32)
+    fit = amd.gsl_nls(q["formula"], data=data, start=q["start"], jac=jac, lower=dict(b1=400.0), upper=dict(b2=1.0),
+                      lowering="vm")
+    ref = gslref.nls(n, 2, start, fn=fn, lower=[400.0, -np.inf], upper=[np.inf, 1.0])
+    assert fit["conv"] == ref["conv"]
+    assert abs(fit["par"][0] - 400.0) < 1e-6 * 400 and _close(fit["par"], ref["par"], rel=1e-5)
+    # geodesic acceleration with FD second directional derivatives
+    fit = amd.gsl_nls(q["formula"], data=data, start=q["start"], jac=jac, algorithm="lmaccel", lowering="vm")
+    ref = gslref.nls(n, 2, start, fn=fn, algorithm="lmaccel")
+    assert fit["conv"] == ref["conv"] == 0 and _close(fit["par"], ref["par"], rel=1e-6)
+    assert abs(fit["niter"] - ref["niter"]) <= 1

@@ -234,3 +234,16 @@ def test_nonfinite_jacobian_and_residual_rules(gslref, hostsim):
     # a regular start is unaffected by the flag arithmetic
     ok = hostsim.fit(1, 3, x, y, [1.0, 1.0, 0.0], ci, cd, jac=1)
     assert ok["conv"] == 0 and np.allclose(ok["par"], [5.0, 1.5, 1.0], rtol=1e-6)
+
+
+def test_bounds_validation_errors_like_the_reference():
+    """R/nls.R:542-557: the three stop() conditions on bounds are raised before anything reaches the device"""
+    import gslnls_amd as amd
+    d = dict(x=np.arange(1.0, 7.0), y=np.arange(1.0, 7.0))
+    f = "y ~ b1*(1-exp(-b2*x))"
+    with pytest.raises(ValueError, match="lower bounds cannot be larger"):
+        amd.gsl_nls(f, data=d, start=dict(b1=1.0, b2=1.0), lower=dict(b1=2.0), upper=dict(b1=1.0))
+    with pytest.raises(ValueError, match="Starting parameters must be contained"):
+        amd.gsl_nls(f, data=d, start=dict(b1=500.0, b2=1.0), upper=dict(b1=300.0))
+    with pytest.raises(ValueError, match="Starting parameter ranges must be contained"):
+        amd.gsl_nls(f, data=d, start=dict(b1=[1.0, 500.0], b2=[0.0, 1.0]), upper=dict(b1=300.0))
