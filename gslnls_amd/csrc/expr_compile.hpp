@@ -23,6 +23,7 @@ struct ExprCompiler
         K_CONST,
         K_PARAM,
         K_VAR,
+        K_VDIR, // component k of the direction of the second directional derivative
         K_OP
     };
     struct Node
@@ -51,6 +52,7 @@ struct ExprCompiler
     int cst(double v) { return intern(K_CONST, 0, -1, -1, v); }
     int param(int k) { return intern(K_PARAM, 0, k, -1, 0.0); }
     int var(int c) { return intern(K_VAR, 0, c, -1, 0.0); }
+    int vdir(int k) { return intern(K_VDIR, 0, k, -1, 0.0); }
     bool is_const(int n) const { return nodes[n].kind == K_CONST; }
     bool is_val(int n, double v) const { return nodes[n].kind == K_CONST && nodes[n].c == v; }
 
@@ -285,7 +287,8 @@ struct ExprCompiler
     }
 
     // emit: topological order, the value's closure first
-    bool emit(int value, const std::vector<int> &grads, int p, int nx, VmProgram &out)
+    // fvv < 0: no third closure
+    bool emit(int value, const std::vector<int> &grads, int fvv, int p, int nx, VmProgram &out)
     {
         memset(&out, 0, sizeof(out));
         out.p = p;
@@ -338,6 +341,9 @@ struct ExprCompiler
         const int nvalue = (int)order.size();
         for (int g : grads)
             visit(g);
+        const int ngrad = (int)order.size();
+        if (fvv >= 0)
+            visit(fvv);
         if ((int)consts.size() > VM_MAX_CONST || (int)order.size() > VM_MAX_OPS)
         {
             error = "expression too large for the device program";
@@ -346,15 +352,17 @@ struct ExprCompiler
         out.nconst = (int)consts.size();
         for (size_t c = 0; c < consts.size(); ++c)
             out.consts[c] = consts[c];
-        const int base = p + nx + out.nconst;
+        const int base = 2 * p + nx + out.nconst;
         auto slot = [&](int n) -> int {
             const Node &nd = nodes[n];
             if (nd.kind == K_PARAM)
                 return nd.a;
             if (nd.kind == K_VAR)
                 return p + nd.a;
+            if (nd.kind == K_VDIR)
+                return p + nx + nd.a;
             if (nd.kind == K_CONST)
-                return p + nx + (-slot_of[n] - 1);
+                return 2 * p + nx + (-slot_of[n] - 1);
             return slot_of[n];
         };
         for (size_t i = 0; i < order.size(); ++i)
@@ -365,7 +373,9 @@ struct ExprCompiler
             out.b[i] = (unsigned short)slot(nd.b);
             slot_of[order[i]] = base + (int)i;
         }
-        out.nops = (int)order.size();
+        out.nops = ngrad;
+        out.nfvv = fvv >= 0 ? (int)order.size() : 0;
+        out.fvv_slot = fvv >= 0 ? slot(fvv) : 0;
         out.nvalue = nvalue;
         out.value_slot = slot(value);
         for (int k = 0; k < p; ++k)
@@ -397,7 +407,23 @@ inline std::string compile_expression(const char *rhs, const std::vector<std::st
         std::map<int, bool> dep;
         grads.push_back(ec.diff(value, (int)k, dcache, dep));
     }
-    if (!ec.emit(value, grads, (int)parnames.size(), VM_NX, out))
+    // second directional derivative D^2 f[v, v] = sum_j v_j d/dtheta_j ( sum_k v_k df/dtheta_k )
+    const int p = (int)parnames.size();
+    int g = ec.cst(0.0);
+    for (int k = 0; k < p; ++k)
+        g = ec.op2(VM_ADD, g, ec.op2(VM_MUL, ec.vdir(k), grads[k]));
+    int fvv = ec.cst(0.0);
+    for (int j = 0; j < p; ++j)
+    {
+        std::map<int, int> dcache;
+        std::map<int, bool> dep;
+        fvv = ec.op2(VM_ADD, fvv, ec.op2(VM_MUL, ec.vdir(j), ec.diff(g, j, dcache, dep)));
+    }
+    if (ec.emit(value, grads, fvv, p, VM_NX, out))
+        return "";
+    // too large with the third closure: keep value + gradient (fvv then falls back to finite differences)
+    ec.error.clear();
+    if (!ec.emit(value, grads, -1, p, VM_NX, out))
         return ec.error;
     return "";
 }

@@ -19,24 +19,29 @@ template <int P_>
 struct ModelVM
 {
     static constexpr int ID = 100, P = P_, NX = VM_NX;
-    static constexpr bool HAS_FVV = false; // second directional derivatives: finite differences only
+    static constexpr bool HAS_FVV = true; // symbolic, when the program carries the third closure (nfvv > 0)
 #if defined(__HIP_DEVICE_COMPILE__)
     __device__ static double value(const double *th, const double *xr)
     {
         double slot[VM_MAX_SLOTS];
-        vm_run(c_vm_prog, th, xr, c_vm_prog.nvalue, slot);
+        vm_run(c_vm_prog, th, xr, nullptr, c_vm_prog.nvalue, slot);
         return slot[c_vm_prog.value_slot];
     }
     __device__ static double value_grad(const double *th, const double *xr, double *g)
     {
         double slot[VM_MAX_SLOTS];
-        vm_run(c_vm_prog, th, xr, c_vm_prog.nops, slot);
+        vm_run(c_vm_prog, th, xr, nullptr, c_vm_prog.nops, slot);
 #pragma unroll
         for (int k = 0; k < P; ++k)
             g[k] = slot[c_vm_prog.grad_slot[k]];
         return slot[c_vm_prog.value_slot];
     }
-    __device__ static double fvv(const double *, const double *, const double *) { return NAN; }
+    __device__ static double fvv(const double *th, const double *v, const double *xr)
+    {
+        double slot[VM_MAX_SLOTS];
+        vm_run(c_vm_prog, th, xr, v, c_vm_prog.nfvv, slot);
+        return slot[c_vm_prog.fvv_slot];
+    }
 #else
     // host pass of hipcc: never executed (kernels only); keeps the templates well-formed
     static double value(const double *, const double *) { return NAN; }

@@ -33,6 +33,8 @@ struct VmDenseFit : DenseFit<ModelVM<P>>
     int solve(int jac, int fvv, const double *start, const double *lupars, const int *ci, const double *cd, int chunk,
               gslnls_result *out) override
     {
+        if (fvv && prog.nfvv == 0)
+            return GSLNLS_E_UNSUPPORTED; // second derivatives too large for the program: use fvv = FALSE (finite differences)
         if (upload())
             return GSLNLS_E_NODEVICE;
         return Base::solve(jac, fvv, start, lupars, ci, cd, chunk, out);
@@ -40,6 +42,8 @@ struct VmDenseFit : DenseFit<ModelVM<P>>
     int irls(int jac, int fvv, const double *start, const double *lupars, const int *ci, const double *cd, int loss_rho,
              const double *loss_cc, gslnls_result *out) override
     {
+        if (fvv && prog.nfvv == 0)
+            return GSLNLS_E_UNSUPPORTED;
         if (upload())
             return GSLNLS_E_NODEVICE;
         return Base::irls(jac, fvv, start, lupars, ci, cd, loss_rho, loss_cc, out);
@@ -47,6 +51,8 @@ struct VmDenseFit : DenseFit<ModelVM<P>>
     int mstart(int jac, int fvv, const double *start2p, const double *lupars, const int *ci, const double *cd,
                const int *has_start, const MsComm &comm, int loss_rho, const double *loss_cc, gslnls_result *out) override
     {
+        if (fvv && prog.nfvv == 0)
+            return GSLNLS_E_UNSUPPORTED;
         if (upload())
             return GSLNLS_E_NODEVICE;
         return Base::mstart(jac, fvv, start2p, lupars, ci, cd, has_start, comm, loss_rho, loss_cc, out);

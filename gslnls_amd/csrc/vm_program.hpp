@@ -9,8 +9,11 @@
 // and emits one program whose first `nvalue` instructions compute the model value and whose
 // remaining instructions add the P partial derivatives.
 //
-// Slot layout: [0, p) parameters | [p, p+nx) regressors of the row | [p+nx, p+nx+nconst) constants |
-// then one slot per instruction (instruction i writes slot base + i).
+// Slot layout: [0, p) parameters | [p, p+nx) regressors of the row | [p+nx, 2p+nx) direction v of the second
+// directional derivative (lmaccel, fvv = TRUE: the reference differentiates the formula twice with
+// stats::deriv(..., hessian = TRUE), R/nls.R:600-640) | nconst constants | then one slot per instruction
+// (instruction i writes slot base + i).  Three nested closures: [0, nvalue) value, [0, nops) + gradient,
+// [0, nfvv) + D^2 f[v, v].
 #pragma once
 #include "lm_core.hpp"
 #include "devmath.hpp"
@@ -18,11 +21,11 @@
 namespace gslnls
 {
 
-constexpr int VM_MAX_OPS = 160;
+constexpr int VM_MAX_OPS = 256;
 constexpr int VM_MAX_CONST = 32;
 constexpr int VM_MAX_P = 12;
 constexpr int VM_NX = 3; // regressor columns carried per row (unused ones are zero)
-constexpr int VM_MAX_SLOTS = VM_MAX_P + VM_NX + VM_MAX_CONST + VM_MAX_OPS;
+constexpr int VM_MAX_SLOTS = 2 * VM_MAX_P + VM_NX + VM_MAX_CONST + VM_MAX_OPS;
 
 enum VmOp : unsigned char
 {
@@ -46,8 +49,9 @@ enum VmOp : unsigned char
 
 struct VmProgram
 {
-    int p, nx, nconst, nops, nvalue; // nvalue: instructions needed for the value alone
-    int value_slot;
+    int p, nx, nconst, nops, nvalue; // nvalue: instructions needed for the value alone; nops: value + gradient
+    int nfvv;                        // value + gradient + second directional derivative (0: not available)
+    int value_slot, fvv_slot;
     int grad_slot[VM_MAX_P];
     unsigned char op[VM_MAX_OPS];
     unsigned short a[VM_MAX_OPS], b[VM_MAX_OPS];
@@ -79,16 +83,18 @@ GSLNLS_HD double vm_apply(unsigned char op, double x, double y)
 }
 
 // run instructions [0, upto) of the program on one row
-GSLNLS_HD void vm_run(const VmProgram &prog, const double *th, const double *xr, int upto, double *slot)
+GSLNLS_HD void vm_run(const VmProgram &prog, const double *th, const double *xr, const double *v, int upto, double *slot)
 {
     const int p = prog.p, nx = prog.nx, nc = prog.nconst;
     for (int k = 0; k < p; ++k)
         slot[k] = th[k];
     for (int c = 0; c < nx; ++c)
         slot[p + c] = xr[c];
+    for (int k = 0; k < p; ++k)
+        slot[p + nx + k] = v ? v[k] : 0.0;
     for (int c = 0; c < nc; ++c)
-        slot[p + nx + c] = prog.consts[c];
-    const int base = p + nx + nc;
+        slot[2 * p + nx + c] = prog.consts[c];
+    const int base = 2 * p + nx + nc;
     for (int i = 0; i < upto; ++i)
         slot[base + i] = vm_apply(prog.op[i], slot[prog.a[i]], slot[prog.b[i]]);
 }

@@ -375,7 +375,7 @@ extern "C" void hostsim_psi(int rho, const double *cc, int n, const double *x, d
 // expression models: compile (expr_compile.hpp) and interpret (vm_program.hpp) on the host
 extern "C" int hostsim_expr_eval(const char *rhs, int p, const char *const *parnames, int nvars,
                                  const char *const *varnames, const double *theta, int n, const double *X,
-                                 double *value, double *grad, int *stats)
+                                 double *value, double *grad, int *stats, const double *dir, double *fvv)
 {
     std::vector<std::string> pn(parnames, parnames + p), vn(varnames, varnames + nvars);
     VmProgram prog;
@@ -388,11 +388,15 @@ extern "C" int hostsim_expr_eval(const char *rhs, int p, const char *const *parn
         double xr[VM_NX] = {0, 0, 0};
         for (int c = 0; c < nvars; ++c)
             xr[c] = X[i + (size_t)n * c];
-        vm_run(prog, theta, xr, prog.nops, slot.data());
+        const bool want_fvv = dir && fvv && prog.nfvv > 0;
+        vm_run(prog, theta, xr, dir, want_fvv ? prog.nfvv : prog.nops, slot.data());
         value[i] = slot[prog.value_slot];
         for (int k = 0; k < p; ++k)
             grad[i + (size_t)n * k] = slot[prog.grad_slot[k]];
+        if (fvv)
+            fvv[i] = want_fvv ? slot[prog.fvv_slot] : NAN;
     }
+    stats[3] = prog.nfvv;
     stats[0] = prog.nops;
     stats[1] = prog.nvalue;
     stats[2] = prog.nconst;

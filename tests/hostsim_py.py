@@ -118,8 +118,9 @@ def psi(rho, cc, x):
     return a, b
 
 
-def expr_eval(rhs, parnames, varnames, theta, X):
-    """compile the formula RHS to the device program and interpret it on the host: (value[n], grad[n, p], stats)"""
+def expr_eval(rhs, parnames, varnames, theta, X, direction=None):
+    """compile the formula RHS to the device program and interpret it on the host: (value[n], grad[n, p], stats);
+    with `direction` the stats also carry fvv[n] = D^2 f[v, v]"""
     X = np.asfortranarray(np.asarray(X, dtype=np.float64).reshape(-1, max(1, len(varnames))))
     n, p = X.shape[0], len(parnames)
     pn = (C.c_char_p * p)(*[s.encode() for s in parnames])
@@ -129,8 +130,12 @@ def expr_eval(rhs, parnames, varnames, theta, X):
     grad = np.zeros((n, p), order="F")
     stats = np.zeros(4, dtype=np.int32)
     f = lib().hostsim_expr_eval
-    f.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_char_p), DP, C.c_int, DP, DP, DP, IP]
-    rc = f(rhs.encode(), p, pn, len(varnames), vn, _dp(th), n, _dp(X), _dp(val), _dp(grad), stats.ctypes.data_as(IP))
+    f.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_char_p), DP, C.c_int, DP, DP, DP, IP,
+                  DP, DP]
+    dv = None if direction is None else np.ascontiguousarray(direction, dtype=np.float64)
+    fvv = np.zeros(n)
+    rc = f(rhs.encode(), p, pn, len(varnames), vn, _dp(th), n, _dp(X), _dp(val), _dp(grad), stats.ctypes.data_as(IP),
+           _dp(dv), _dp(fvv))
     if rc != 0:
         raise ValueError("expression did not compile: %s" % rhs)
-    return val, grad, dict(nops=int(stats[0]), nvalue=int(stats[1]), nconst=int(stats[2]))
+    return val, grad, dict(nops=int(stats[0]), nvalue=int(stats[1]), nconst=int(stats[2]), nfvv=int(stats[3]), fvv=fvv)

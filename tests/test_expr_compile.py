@@ -30,7 +30,7 @@ def test_program_value_and_gradient(pb):
     X = np.stack([data[c] for c in xnames], axis=1)
     th = np.array([pb["target"][k] for k in names]) * (1.0 + 0.01 * np.arange(1, len(names) + 1))
     val, grad, st = hs.expr_eval(rhs_text, names, xnames, th, X)
-    assert 0 < st["nvalue"] <= st["nops"] <= 160
+    assert 0 < st["nvalue"] <= st["nops"] <= 256
 
     def ev(t):
         env = dict(data)
@@ -104,3 +104,31 @@ def test_native_lowering_builds_without_a_device(tmp_path, monkeypatch):
     bad = _lib.Model(_lib.MODEL_EXPR, 1, 1, None, 0)
     keep2 = _lib.set_expr(bad, "a*foo(x)", ["a"], ["x"], "jit")  # noqa: F841
     assert _lib.lib().gslnls_expr_build(C.byref(bad), buf, 512) == _lib.E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("pb", PROBLEMS, ids=[p["name"] for p in PROBLEMS])
+def test_second_directional_derivative(pb):
+    """fvv = TRUE on a formula: D^2 f[v, v] of the compiled program (third closure) against a central second
+    difference of the numpy evaluation along v (the reference: stats::deriv(hessian = TRUE), R/nls.R:600-640)"""
+    rhs, rhs_text, names, xnames = _split(pb)
+    data = {k: np.asarray(v, dtype=np.float64) for k, v in pb["data"].items()}
+    X = np.stack([data[c] for c in xnames], axis=1)
+    p = len(names)
+    th = np.array([pb["target"][k] for k in names]) * (1.0 + 0.01 * np.arange(1, p + 1))
+    v = th * 0.01 * np.cos(np.arange(1, p + 1))
+    val, grad, st = hs.expr_eval(rhs_text, names, xnames, th, X, direction=v)
+    if st["nfvv"] == 0:
+        pytest.skip("second derivatives of this formula exceed the program size: fvv falls back to finite differences")
+    assert st["nops"] <= st["nfvv"] <= 256
+
+    def ev(t):
+        env = dict(data)
+        env.update({k: t[i] for i, k in enumerate(names)})
+        return np.asarray(F.evaluate(rhs, env), dtype=np.float64) * np.ones(len(X))
+    if pb["name"] == "Lubricant":
+        pytest.skip("values up to 1e10 swamp second differences (see the gradient test)")
+    # Richardson-extrapolated central second difference along v
+    d2 = lambda h: (ev(th + h * v) - 2 * ev(th) + ev(th - h * v)) / (h * h)  # noqa: E731
+    num = (4 * d2(0.5e-2) - d2(1e-2)) / 3
+    scale = np.max(np.abs(num)) + 1e-300
+    assert np.max(np.abs(st["fvv"] - num)) / scale < 2e-5, pb["name"]

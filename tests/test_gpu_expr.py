@@ -214,3 +214,22 @@ def test_expression_model_weights_bounds_lmaccel(amd, gslref, nist, jac):
     ref = gslref.nls(n, 2, start, fn=fn, algorithm="lmaccel")
     assert fit["conv"] == ref["conv"] == 0 and _close(fit["par"], ref["par"], rel=1e-6)
     assert abs(fit["niter"] - ref["niter"]) <= 1
+
+
+@pytest.mark.parametrize("lowering", ["vm", "jit"])
+def test_symbolic_fvv_readme_example2(amd, readme, lowering):
+    """README.md:636-658: example 2 with algorithm = lmaccel and fvv = TRUE needs 12 iterations, 58 function and
+    18 fvv evaluations.  Here the formula is spelled so that it misses the hand-written model: the second
+    directional derivative comes from the compiled program's third closure."""
+    ex = readme["ex2"]
+    formula = "y ~ a / exp((x - b)^2 / (2 * c^2))"
+    assert F.lower(F.parse_formula(formula)[1], ["a", "b", "c"]) is None
+    fit = amd.gsl_nls(formula, data=dict(x=ex["x"], y=ex["y"]), start=dict(a=1, b=0, c=1), algorithm="lmaccel",
+                      fvv=True, trace=True, lowering=lowering)
+    assert fit["conv"] == 0 and fit["niter"] == 12 and fit["neval"] == dict(f=58, J=0, fvv=18)
+    # same trajectory as the hand-written model with its hand-written fvv (the printed README trace belongs to the
+    # finite-difference fvv run and differs in the 4th digit)
+    ref = amd.gsl_nls("y ~ a * exp(-(x - b)^2 / (2 * c^2))", data=dict(x=ex["x"], y=ex["y"]), start=dict(a=1, b=0, c=1),
+                      algorithm="lmaccel", fvv=True, trace=True)
+    assert np.allclose(fit["partrace"], ref["partrace"], rtol=1e-7)
+    assert np.allclose(fit["par"], ex["lmaccel"]["trace"][-1]["par"], rtol=1.2e-5)
