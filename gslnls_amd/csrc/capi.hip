@@ -289,23 +289,7 @@ gslnls_large *gslnls_large_create(const gslnls_model *fn, const double *y, int n
         h->dense = make_dense(fn, y, n, swp, &e);
         if (h->dense)
         {
-            switch (fn->id)
-            {
-            case GSLNLS_MODEL_EXPDECAY:
-                h->ops = make_row_ops<ModelExpDecay>(h->dense);
-                break;
-            case GSLNLS_MODEL_MISRA1A:
-                h->ops = make_row_ops<ModelMisra1a>(h->dense);
-                break;
-            case GSLNLS_MODEL_GAUSSPK:
-                h->ops = make_row_ops<ModelGaussPeak>(h->dense);
-                break;
-            case GSLNLS_MODEL_GAUSS1:
-                h->ops = make_row_ops<ModelGauss1>(h->dense);
-                break;
-            default:
-                e = GSLNLS_E_UNSUPPORTED;
-            }
+            h->ops = h->dense->make_large_ops();
         }
     }
     if (err)
@@ -337,6 +321,8 @@ int gslnls_large_solve(gslnls_large *h, const double *start, const int *control_
         return GSLNLS_EINVAL;
     const int p = h->p, n = h->n;
     LargeOps &ops = *h->ops;
+    if (h->dense && h->dense->prepare_device())
+        return GSLNLS_E_NODEVICE;
     ops.nevalf = ops.nevaldfu = ops.nevaldf2 = 0;
     ops.npass = 0;
     LargeResult R;
@@ -448,6 +434,8 @@ int gslnls_nls_large(const gslnls_model *fn, const double *y, int n, const doubl
 float gslnls_large_time_pass(gslnls_large *h, int mode, const double *x, const double *u, int reps)
 {
     if (!h || !h->ops || reps < 1)
+        return -1.f;
+    if (h->dense && h->dense->prepare_device())
         return -1.f;
     std::vector<double> g(h->p), d(h->p);
     double ssr, bad, nw2;

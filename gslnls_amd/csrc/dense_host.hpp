@@ -62,6 +62,8 @@ inline LmParams make_params(const int *ci, const double *cd, int jac, int fvv, b
     return prm;
 }
 
+struct LargeOps; // large_host.hpp
+
 struct DenseBase
 {
     virtual ~DenseBase() {}
@@ -72,6 +74,10 @@ struct DenseBase
                      int loss_rho, const double *loss_cc, gslnls_result *out) = 0;
     virtual float time_pass(int jac, const double *theta, int reps) = 0;
     virtual int set_swts(const double *swts) = 0;
+    // the matrix-free operator of gsl_nls_large over this problem's resident data (large_host.hpp)
+    virtual LargeOps *make_large_ops() = 0;
+    // whatever must be on the device before kernels of this problem run (expression models: their program)
+    virtual int prepare_device() { return 0; }
     virtual int diagnostics(int jac, const double *theta, const int *ci, const double *cd, double *hat, double *cooks) = 0;
     // multi-start branch of C_nls (src/nls.c:274-532) followed by the final single-start solve
     virtual int mstart(int jac, int fvv, const double *start2p, const double *lupars, const int *ci, const double *cd,
@@ -454,6 +460,7 @@ struct DenseFit : DenseBase
              const double *loss_cc, gslnls_result *out) override;
     int sums_at(const double *theta, int jacmode, PassSums<P> &out);
     int robust_weights(int jacmode, const double *mpopt, double *d_sw_robust);
+    LargeOps *make_large_ops() override;
     int diagnostics(int jac, const double *theta, const int *ci, const double *cd, double *hat, double *cooks) override;
 
     int mstart(int jac, int fvv, const double *start2p, const double *lupars, const int *ci, const double *cd,

@@ -565,6 +565,12 @@ struct RowLargeOps : LargeOps
 };
 
 // dense GLM family with A resident in HBM
+template <class M>
+LargeOps *DenseFit<M>::make_large_ops()
+{
+    return new RowLargeOps<M>(*this);
+}
+
 template <int P>
 struct GlmLargeOps : LargeOps
 {

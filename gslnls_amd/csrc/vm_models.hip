@@ -9,6 +9,7 @@
 #include "mstart_host.hpp"
 #include "irls_host.hpp"
 #include "robust_host.hpp"
+#include "large_host.hpp"
 #include "expr_compile.hpp"
 #include "vm_model.hpp"
 #include "jit_host.hpp"
@@ -57,6 +58,7 @@ struct VmDenseFit : DenseFit<ModelVM<P>>
             return GSLNLS_E_NODEVICE;
         return Base::mstart(jac, fvv, start2p, lupars, ci, cd, has_start, comm, loss_rho, loss_cc, out);
     }
+    int prepare_device() override { return upload(); }
     float time_pass(int jac, const double *theta, int reps) override
     {
         upload();

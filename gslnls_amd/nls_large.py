@@ -30,7 +30,8 @@ def pack_control_large(ctrl, algorithm="lm", trace=False):
 class LargeProblem:
     """model + data resident in HBM for gsl_nls_large (gslnls_large_create)"""
 
-    def __init__(self, model_id, p, x, y, weights=None, row_major=False):
+    def __init__(self, model_id, p, x, y, weights=None, row_major=False, expr=None, parnames=None, xnames=None,
+                 lowering="auto"):
         self.n = int(len(y))
         self.p = int(p)
         x = np.asarray(x, dtype=np.float64).reshape(self.n, -1)
@@ -39,6 +40,8 @@ class LargeProblem:
         self._y = np.ascontiguousarray(y, dtype=np.float64)
         self._w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
         m = _lib.Model(int(model_id), self.p, x.shape[1], self._x.ctypes.data_as(C.c_void_p), 0)
+        if int(model_id) == _lib.MODEL_EXPR:
+            keep = _lib.set_expr(m, expr, list(parnames), list(xnames), lowering)  # noqa: F841
         err = C.c_int(0)
         self._h = _lib.lib().gslnls_large_create(C.byref(m), self._y.ctypes.data_as(C.c_void_p), self.n,
                                                  None if self._w is None else self._w.ctypes.data_as(C.c_void_p),
@@ -174,7 +177,7 @@ class SparseLargeProblem(LargeProblem):
 
 
 def gsl_nls_large(fn, data=None, start=None, algorithm="lm", control=None, trace=False, weights=None, y=None, A=None,
-                  jac=None):
+                  jac=None, lowering="auto"):
     """gsl_nls_large(fn = y ~ f(x, theta), data, start, algorithm = c("lm", ..., "cgst"), ...)  (R/nls_large.R:124)
 
     fn: formula string lowering to a registered row model; "glmexp" with A (n x p) and y; or a callable
@@ -216,14 +219,22 @@ def gsl_nls_large(fn, data=None, start=None, algorithm="lm", control=None, trace
         raise ValueError("gsl_nls_large has no multi-start")
     lhs, rhs = F.parse_formula(fn)
     low = F.lower(rhs, names)
+    expr_kw = {}
     if low is None:
-        raise NotImplementedError("formula RHS does not match a registered device model: %s" % fn)
-    mid, order, xnames = low
+        # any other expression: compiled like in gsl_nls() (GSLNLS_MODEL_EXPR)
+        xnames = [v for v in F.symbols(rhs) if v not in names and v != "pi"]
+        if len(names) > 12 or len(xnames) > 3 or any(v not in data for v in xnames):
+            raise NotImplementedError("formula RHS does not lower to the device: %s" % fn)
+        mid, order = _lib.MODEL_EXPR, list(range(len(names)))
+        expr_kw = dict(expr=fn.split("~", 1)[1].strip(), parnames=names, xnames=xnames, lowering=lowering)
+    else:
+        mid, order, xnames = low
     order = np.asarray(order)
     inv = np.argsort(order)
     yv = np.asarray(F.evaluate(lhs, {k: np.asarray(v, dtype=np.float64) for k, v in data.items()}), dtype=np.float64)
-    X = np.stack([np.asarray(data[c], dtype=np.float64) for c in xnames], axis=1)
-    prob = LargeProblem(mid, len(names), X, yv, weights)
+    X = (np.stack([np.asarray(data[c], dtype=np.float64) for c in xnames], axis=1) if xnames
+         else np.zeros((len(yv), 0)))
+    prob = LargeProblem(mid, len(names), X, yv, weights, **expr_kw)
     fit = prob.solve(vec[order], algorithm, control, trace)
     prob.close()
     fit["par"] = fit["par"][inv]

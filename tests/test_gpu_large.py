@@ -94,3 +94,19 @@ def test_unit_tests_3_x_large(amd, gslref, nist):
         assert fit["algorithm"] == ("steihaug-toint" if alg == "cgst" else "levenberg-marquardt")
     with pytest.raises(NotImplementedError):
         amd.gsl_nls_large(q["formula"], data=q["data"], start=q["start"], algorithm="dogleg")
+
+
+@pytest.mark.parametrize("name", ["Misra1b", "Thurber", "Gauss2"])
+@pytest.mark.parametrize("alg", ["lm", "cgst"])
+def test_large_path_on_compiled_expressions(amd, nist, name, alg):
+    """gsl_nls_large(formula) for formulas without a hand-written device model: the matrix-free passes run on the
+    compiled expression (R/nls_large.R:124 formula method); certified NIST values at the reference's tolerance"""
+    q = nist[name]
+    data = {k: np.asarray(v, dtype=np.float64) for k, v in q["data"].items()}
+    fit = amd.gsl_nls_large(q["formula"], data=data, start=q["start"], algorithm=alg, control=dict(maxiter=200))
+    tgt = np.array(list(q["target"].values()))
+    assert fit["conv"] == 0
+    err = np.abs(np.asarray(fit["par"]) - tgt)
+    assert np.all((err <= TOL) | (err <= 2e-5 * np.abs(tgt))), (fit["par"], tgt)
+    dense = amd.gsl_nls(q["formula"], data=data, start=q["start"], jac=True, control=dict(solver="cholesky"))
+    assert abs(fit["ssr"] - dense["ssr"]) <= 1e-7 * dense["ssr"]
