@@ -233,6 +233,10 @@ int gslnls_debug_stamps(gslnls_dense *h, int jac, const double *theta, int warm,
 {
     return h->impl->debug_stamps(jac, theta, warm, out, nrows);
 }
+int gslnls_debug_adv_stamps(unsigned long long *out8)
+{
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(gslnls::g_adv_stamps), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -1;
+}
 #endif
 
 gslnls_large *gslnls_large_create(const gslnls_model *fn, const double *y, int n, const double *weights, int *err)

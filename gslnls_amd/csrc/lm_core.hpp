@@ -35,6 +35,25 @@
 namespace gslnls
 {
 
+#if defined(GSLNLS_STAMPS) && defined(__HIPCC__)
+__device__ unsigned long long g_adv_stamps[8];
+#endif
+#if defined(GSLNLS_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define GSLNLS_ADV_STAMP(k)                                                                  \
+    do                                                                                       \
+    {                                                                                        \
+        unsigned long long t__;                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");          \
+        if (blockIdx.x == 0 && threadIdx.x == 0)                                             \
+            g_adv_stamps[k] = t__;                                                           \
+    } while (0)
+#else
+#define GSLNLS_ADV_STAMP(k) \
+    do                      \
+    {                       \
+    } while (0)
+#endif
+
 // GSL errno values placed in `conv`
 enum
 {
@@ -489,7 +508,9 @@ GSLNLS_HD void lm_end_iteration(LmState<P> &s, const LmParams &prm, int itstatus
     // next driver2 iteration: chisq0 <- chisq1, fresh trust_iterate call
     s.chisq0 = s.chisq1;
     s.bad_steps = 0;
+    GSLNLS_ADV_STAMP(3);
     lm_begin_step(s, prm);
+    GSLNLS_ADV_STAMP(4);
 }
 
 // GSL scaling.c on the diagonal of J^T J
@@ -623,6 +644,7 @@ GSLNLS_HD void lm_advance(LmState<P> &s, const PassSums<P> &r, const LmParams &p
     }
 
     // PH_TRIAL: trust_eval_step + radius/mu updates (src/trust.c:474-545)
+    GSLNLS_ADV_STAMP(0);
     s.nevalf += 1;
     double rho;
     if (!(r.ssr < s.fnorm2))
@@ -647,6 +669,7 @@ GSLNLS_HD void lm_advance(LmState<P> &s, const PassSums<P> &r, const LmParams &p
         const double pred = vAv * finv + 2.0 * s.mu * (Dv2 * finv);
         rho = (pred > 0.0) ? ared / pred : -1.0;
     }
+    GSLNLS_ADV_STAMP(1);
     bool found = rho > 0.0;
     if (prm.trs == 1 && s.avratio > prm.avmax)
         found = false;
@@ -677,7 +700,9 @@ GSLNLS_HD void lm_advance(LmState<P> &s, const PassSums<P> &r, const LmParams &p
         s.nu = 2.0;
         s.mu *= fmax(0.333333333333333, b);
         s.bad_steps = 0;
+        GSLNLS_ADV_STAMP(2);
         lm_end_iteration(s, prm, ST_SUCCESS);
+        GSLNLS_ADV_STAMP(5);
     }
     else
     {

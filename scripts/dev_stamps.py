@@ -36,4 +36,8 @@ for jac in (1, 0):
         a = w0[:, k]; b = wo[:, k]
         print("  %-24s wave0: med=%7d max=%7d | other waves: med=%7d max=%7d" % (nm, np.median(a), a.max(), np.median(b) if k not in (2, 3) else -1, b.max() if k not in (2, 3) else -1))
     print("  total span (max end - min entry): %d cycles" % (st[:, 6].max() - t0))
+    adv = (C.c_ulonglong * 8)()
+    if hasattr(L, "gslnls_debug_adv_stamps") and L.gslnls_debug_adv_stamps(adv) == 0:
+        a = [int(v) for v in adv]
+        print("  lm_advance (block 0): rho %d | accept bookkeeping %d | test %d | solve %d | tail %d" % (a[1] - a[0], a[2] - a[1], a[3] - a[2], a[4] - a[3], a[5] - a[4]))
 prob.close()
