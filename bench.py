@@ -129,6 +129,19 @@ def multistart_bench(L, _lib, torch, dist, rank, world, steps, warmup):
                       "kernel_ms_per_batch_rank0": float(np.mean(kms)), "points_passing_det_filter": int(fitted.sum()),
                       "points_in_global_basin_after_5_iters": good}
     L.gslnls_dense_destroy(h)
+    if world == 1:
+        # the whole multi-start procedure of C4 (sampling, concentration, reduction, local searches, final solve)
+        import gslnls_amd as A
+        d = dict(x=np.array(BOXBOD_X), y=np.array(BOXBOD_Y))
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fit = A.gsl_nls("y ~ b1*(1-exp(-b2*x))", data=d, start=dict(b1=[1.0, 500.0], b2=[0.01, 5.0]), jac=True,
+                            control=dict(mstart_n=8192, mstart_q=819, solver="cholesky"))
+            ts.append(time.perf_counter() - t0)
+        out["full_multistart_fit_8192"] = {"wall_ms": 1e3 * min(ts), "par": [float(v) for v in fit["par"]],
+                                           "ssr": float(fit["ssr"]), "conv": int(fit["conv"]),
+                                           "target": [213.80940889, 0.54723748542, 1168.0088766]}
     out["metric"] = "multi-start concentration fits/s (BoxBOD n=6 p=2, 5 LM iterations each, all-gather of records)"
     out["note"] = ("working set is 96 B per fit: bound by fp64 VALU + exp latency and by launch/collective latency, "
                    "an HBM fraction is not meaningful (SURVEY.md 8(d))")
