@@ -239,3 +239,21 @@ def test_interrupt_hook_abandons_the_fit(amd):
     fit = prob.solve([1.0, 1.0, 0.0], jac=True, control=amd.gsl_nls_control(solver="cholesky"))
     prob.close()
     assert fit["conv"] == 0
+
+
+@pytest.mark.parametrize("jac", [True, False])
+def test_rows_beyond_the_prefetch_window(amd, gslref, jac):
+    """n > 8 * 256 * 512 rows: every thread leaves its 8 prefetched rows and runs the streaming loop of
+    lm_step_kernel as well (BASELINE's n = 1e6 stays inside the prefetch window); weights on, ragged n"""
+    n = 2_500_003
+    x, y = c2_data(n)
+    w = 0.5 + (np.arange(n) % 7) / 7.0
+    ctrl = amd.gsl_nls_control(solver="cholesky")
+    prob = amd.DenseProblem(1, 3, x, y, weights=w)
+    fit = prob.solve([1.0, 1.0, 0.0], jac=jac, control=ctrl, want_vectors=False)
+    prob.close()
+    ref = gslref.nls(n, 3, [1.0, 1.0, 0.0], rowdata=dict(model=gslref.MODEL_EXPDECAY, x=x, y=y), use_jac=jac,
+                     ctrl=gslref.control(solver="cholesky"), weights=w)
+    assert fit["conv"] == 0 and ref["conv"] == 0 and fit["niter"] == ref["niter"]
+    assert _rel(fit["par"], ref["par"]) < 1e-6
+    assert abs(fit["ssr"] - ref["ssr"]) <= 1e-10 * ref["ssr"]
