@@ -426,13 +426,26 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
             const bool live = i0 + k * stride < n;
             do_row(px[k], py[k], live ? pw[k] : 0.0, live);
         }
-        for (long long i = i0 + R * stride; i < n; i += stride)
+        // rows beyond the prefetch window (n > R * G * T): again R rows at a time, loads first
+        for (long long b0 = i0 + R * stride; b0 < n; b0 += R * stride)
         {
-            double xr[NX];
 #pragma unroll
-            for (int c = 0; c < NX; ++c)
-                xr[c] = x0[(size_t)c * n + i];
-            do_row(xr, yv[i], swv ? swv[i] : 1.0, true);
+            for (int k = 0; k < R; ++k)
+            {
+                const long long i = b0 + k * stride;
+                const long long ic = i < n ? i : (n - 1);
+#pragma unroll
+                for (int c = 0; c < NX; ++c)
+                    px[k][c] = x0[(size_t)c * n + ic];
+                py[k] = yv[ic];
+                pw[k] = swv ? swv[ic] : 1.0;
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+            {
+                const bool live = b0 + k * stride < n;
+                do_row(px[k], py[k], live ? pw[k] : 0.0, live);
+            }
         }
     }
     else
@@ -449,13 +462,25 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
             const bool live = i0 + k * stride < n;
             do_row(px[k], py[k], live ? pw[k] : 0.0, live);
         }
-        for (long long i = i0 + R * stride; i < n; i += stride)
+        for (long long b0 = i0 + R * stride; b0 < n; b0 += R * stride)
         {
-            double xr[NX];
 #pragma unroll
-            for (int c = 0; c < NX; ++c)
-                xr[c] = x0[(size_t)c * n + i];
-            do_row(xr, yv[i], swv ? swv[i] : 1.0, true);
+            for (int k = 0; k < R; ++k)
+            {
+                const long long i = b0 + k * stride;
+                const long long ic = i < n ? i : (n - 1);
+#pragma unroll
+                for (int c = 0; c < NX; ++c)
+                    px[k][c] = x0[(size_t)c * n + ic];
+                py[k] = yv[ic];
+                pw[k] = swv ? swv[ic] : 1.0;
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+            {
+                const bool live = b0 + k * stride < n;
+                do_row(px[k], py[k], live ? pw[k] : 0.0, live);
+            }
         }
     }
 
