@@ -22,6 +22,7 @@
 // bit-identical.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include "lm_core.hpp"
 #include "models.hpp"
 #include "rowops.hpp"
@@ -178,6 +179,58 @@ __device__ __forceinline__ int opaque_zero()
     return z;
 }
 
+// make a value opaque to the compiler while it sits in scalar registers (readfirstlane is a no-op for a value
+// that is already scalar; it keeps the constraint legal where the compiler holds the kernel argument in VGPRs)
+__device__ __forceinline__ void pin_sgpr(int &v)
+{
+    v = __builtin_amdgcn_readfirstlane(v);
+    asm volatile("" : "+s"(v));
+}
+__device__ __forceinline__ void pin_sgpr(unsigned int &v)
+{
+    int t = (int)v;
+    pin_sgpr(t);
+    v = (unsigned int)t;
+}
+__device__ __forceinline__ void pin_sgpr(double &v)
+{
+    const long long bits = __double_as_longlong(v);
+    int lo = (int)(bits & 0xffffffffll), hi = (int)(bits >> 32);
+    pin_sgpr(lo);
+    pin_sgpr(hi);
+    v = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <class Q>
+__device__ __forceinline__ void pin_sgpr(Q *&v)
+{
+    const long long bits = (long long)reinterpret_cast<uintptr_t>(v);
+    int lo = (int)(bits & 0xffffffffll), hi = (int)(bits >> 32);
+    pin_sgpr(lo);
+    pin_sgpr(hi);
+    v = reinterpret_cast<Q *>((uintptr_t)(((long long)hi << 32) | (unsigned int)lo));
+}
+__device__ __forceinline__ void pin_params(LmParams &q)
+{
+    pin_sgpr(q.maxiter);
+    pin_sgpr(q.trs);
+    pin_sgpr(q.scale);
+    pin_sgpr(q.fdtype);
+    pin_sgpr(q.jac_analytic);
+    pin_sgpr(q.fvv_analytic);
+    pin_sgpr(q.has_bounds);
+    pin_sgpr(q.has_weights);
+    pin_sgpr(q.bench_hold);
+    pin_sgpr(q.factor_up);
+    pin_sgpr(q.factor_down);
+    pin_sgpr(q.avmax);
+    pin_sgpr(q.h_df);
+    pin_sgpr(q.h_fvv);
+    pin_sgpr(q.xtol);
+    pin_sgpr(q.ftol);
+    pin_sgpr(q.gtol);
+    pin_sgpr(q.chisq_in);
+}
+
 template <int P>
 struct StepBcast
 {
@@ -212,17 +265,16 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
     const int tid = threadIdx.x;
 
     GSLNLS_STAMP(0);
-    __shared__ unsigned int lds_arrived;
-    if (tid == 0)
-        lds_arrived = 0;
-    __syncthreads(); // at entry all waves are in step: this costs a few dozen cycles under the kernarg fetch
-
+    GSLNLS_ADV_STAMP(6);
     // ---------------- loads, in the order their data is needed ---------------------------------
     // Vector-memory results return in issue order and the L1 moves 64 B/clk, so what the critical path waits
-    // for goes first.  Wave 0 owns the state (same address in every lane: one request each) and then
-    // prefetches its rows.  Waves 1.. load the G partial sets of the previous launch, reduce them, publish the
-    // totals through LDS + an arrival counter -- and only then issue their row prefetch (64 KB per CU, 16 MB for
-    // the grid), which streams in under wave 0's lm_advance instead of ahead of the partial sums.
+    // for goes first, and it is issued by the very first instructions of the wave (the pointers are preloaded
+    // kernel arguments): wave 0 owns the state (same address in every lane: one request each), waves 1.. load
+    // the G partial sets of the previous launch.  Everything else -- LDS set-up, the barrier that publishes it,
+    // the scalar loads of the control values -- happens while those loads are in flight (they take ~2700
+    // cycles: the partial sets were written by other XCDs).  The reducing waves then publish the totals through
+    // LDS + an arrival counter and only then issue their row prefetch (64 KB per CU, 16 MB for the grid), which
+    // streams in under wave 0's lm_advance instead of ahead of the partial sums.
     const double *__restrict__ yv = yv_;
     const double *__restrict__ swv = swv_;
     const long long stride = (long long)G * T;
@@ -231,40 +283,98 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
     constexpr int PB = MAX_G / 64;
     constexpr int RW = NW - 1;                 // waves that reduce partials
     constexpr int VPW = (NV + RW - 1) / RW;    // values per reducing wave
+    // values are taken QC at a time (all of them at once for the usual p <= 6; the chunking only keeps the
+    // register file bounded when one wave owns dozens of values, p >= 9)
+    constexpr int QC = VPW < 8 ? VPW : 8;
     const int lane = tid & 63, wave = tid >> 6;
+    const int z0 = opaque_zero();
+    const double *pp = prev_partials + z0;
+    double pv[QC][PB];
+    auto load_partials = [&](int q0) {
+#pragma unroll
+        for (int q = 0; q < QC; ++q)
+        {
+            const int v = (wave - 1) + (q0 + q) * RW;
+#pragma unroll
+            for (int j = 0; j < PB; ++j)
+            {
+                const int b = lane + 64 * j;
+                pv[q][j] = (v < NV && b < G) ? pp[(size_t)v * G + b] : 0.0;
+            }
+        }
+    };
+    // row prefetch into registers: x, y[, sqrt w] of this thread's first R rows
+    double px[R][NX], py[R], pw[R];
+    // rows b0 + k stride, k < R (8-byte requests: 16-byte pairs of consecutive rows were measured and are slower,
+    // 6.6 vs 6.3 us per launch at n = 1e6 and 4.3 vs 5.7 TB/s at n = 6.4e7); rows beyond n are clamped to row n-1
+    auto fetch_rows = [&](long long b0) {
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+        {
+            const long long i = b0 + k * stride;
+            const long long ic = i < n ? i : (n - 1);
+#pragma unroll
+            for (int c = 0; c < NX; ++c)
+                px[k][c] = x0[(size_t)c * n + ic];
+            py[k] = yv[ic];
+            pw[k] = swv ? swv[ic] : 1.0;
+        }
+    };
+    auto row_of = [&](long long b0, int k) { return b0 + k * stride; };
+    double cnt[4];
     if (wave == 0)
     {
-        const int z = opaque_zero();
-        const double *src = reinterpret_cast<const double *>(prev) + z;
+        // Wave 0 has nothing to do until the totals are there, so its own rows are requested right away (one
+        // eighth of the workgroup's prefetch; the other waves hold theirs back until the totals are published,
+        // because 64 KB per CU in front of the partial sums delays them).  The rows go first: the compiler
+        // shuffles a few state registers as soon as they are loaded, and that wait must not sit in front of
+        // anything that still has to be issued.
+        fetch_rows(i0);
+        const double *src = reinterpret_cast<const double *>(prev) + z0;
         double *dst = reinterpret_cast<double *>(&s);
-        static_assert(sizeof(LmState<P>) % 8 == 0, "state is a whole number of doubles");
+        constexpr int ND = (int)(offsetof(LmState<P>, bad_steps) / 8);
+        static_assert(offsetof(LmState<P>, bad_steps) % 8 == 0 && sizeof(LmState<P>) == ND * 8 + 8 * sizeof(int),
+                      "state = ND doubles followed by 8 counters");
 #pragma unroll
-        for (int k = 0; k < (int)(sizeof(LmState<P>) / 8); ++k)
+        for (int k = 0; k < ND; ++k)
             dst[k] = src[k];
+        // the eight counters behind them arrive as four 64-bit words and are unpacked in registers: copied into
+        // the struct as halves of doubles they cannot be promoted out of scratch memory, and every access to them
+        // becomes a scratch round trip behind an s_waitcnt vmcnt(0) in the middle of lm_advance
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            cnt[k] = src[ND + k];
     }
     else
+        load_partials(0);
+
+    // The control values are read here, once, into SGPRs that the compiler may not re-derive from the kernarg
+    // segment: left alone it loads each field where it is first used, i.e. a dozen scalar loads (the first a
+    // cold miss: every launch has a fresh kernarg block) in the middle of wave 0's lm_advance.
+    LmParams prm = ctx.prm;
+    pin_params(prm);
+    LmState<P> *state_out = ctx.state[parity];
+    double *partials_out = ctx.partials[parity];
+    double *ssrtrace = ctx.ssrtrace, *partrace = ctx.partrace;
+    LmState<P> *host_mirror = ctx.host_mirror;
+    unsigned int *done_seq = ctx.done_seq;
+    unsigned int seq = ctx.seq;
+    pin_sgpr(state_out);
+    pin_sgpr(partials_out);
+    pin_sgpr(ssrtrace);
+    pin_sgpr(partrace);
+    pin_sgpr(host_mirror);
+    pin_sgpr(done_seq);
+    pin_sgpr(seq);
+
+    if (wave != 0)
     {
         // wave w sums the G partials of values v = w-1, w-1 + RW, ...: lane-strided partial sums, DPP butterfly
-        const int z0 = opaque_zero();
-        const double *pp = prev_partials + z0;
-        // values are taken QC at a time (all of them at once for the usual p <= 6; the chunking only keeps the
-        // register file bounded when one wave owns dozens of values, p >= 9)
-        constexpr int QC = VPW < 8 ? VPW : 8;
 #pragma unroll 1
         for (int q0 = 0; q0 < VPW; q0 += QC)
         {
-            double pv[QC][PB];
-#pragma unroll
-            for (int q = 0; q < QC; ++q)
-            {
-                const int v = (wave - 1) + (q0 + q) * RW;
-#pragma unroll
-                for (int j = 0; j < PB; ++j)
-                {
-                    const int b = lane + 64 * j;
-                    pv[q][j] = (v < NV && b < G) ? pp[(size_t)v * G + b] : 0.0;
-                }
-            }
+            if (q0 > 0)
+                load_partials(q0);
             double a[QC];
 #pragma unroll
             for (int q = 0; q < QC; ++q)
@@ -288,32 +398,27 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
                 }
             }
         }
-        if (lane == 0)
-        {
-            // LDS operations of one wave complete in order: the totals are visible before the count
-            __hip_atomic_fetch_add(&lds_arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
     }
+    // The barrier is the signal: wave 0 leaves it when every reducing wave has parked its totals in LDS.
+    __syncthreads();
+    GSLNLS_ADV_STAMP(7);
     GSLNLS_STAMP(7);
-    double px[R][NX], py[R], pw[R];
-#pragma unroll
-    for (int k = 0; k < R; ++k)
-    {
-        const long long i = i0 + k * stride;
-        const long long ic = i < n ? i : (n - 1);
-#pragma unroll
-        for (int c = 0; c < NX; ++c)
-            px[k][c] = x0[(size_t)c * n + ic];
-        py[k] = yv[ic];
-        pw[k] = swv ? swv[ic] : 1.0;
-    }
+    if (wave != 0)
+        fetch_rows(i0);
 
     GSLNLS_STAMP(1);
-    // ---------------- wave 0: wait for the RW totals (every reducing wave reaches its increment) ----
     if (wave == 0)
     {
-        while (__hip_atomic_load(&lds_arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)RW)
-            __builtin_amdgcn_s_sleep(1);
+        auto lo32 = [](double d) { return (int)(__double_as_longlong(d) & 0xffffffffll); };
+        auto hi32 = [](double d) { return (int)(__double_as_longlong(d) >> 32); };
+        s.bad_steps = lo32(cnt[0]);
+        s.niter = hi32(cnt[0]);
+        s.phase = lo32(cnt[1]);
+        s.status = hi32(cnt[1]);
+        s.info = lo32(cnt[2]);
+        s.nevalf = hi32(cnt[2]);
+        s.nevaldf = lo32(cnt[3]);
+        s.nevalfvv = hi32(cnt[3]);
     }
     if (tid < 64)
     {
@@ -334,8 +439,8 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
             const int niter_before = s.niter;
             const int phase_before = s.phase;
             GSLNLS_STAMP(2);
-            lm_advance<P>(s, r, ctx.prm);
-            if (ctx.prm.bench_hold && s.phase == PH_DONE)
+            lm_advance<P>(s, r, prm);
+            if (prm.bench_hold && s.phase == PH_DONE)
             {
                 // timing mode: never finish, so that every launch pays the full prologue and a full pass
                 s.phase = PH_TRIAL;
@@ -345,21 +450,21 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
                 s.bad_steps = 0;
             }
             GSLNLS_STAMP(3);
-            if (blockIdx.x == 0 && tid == 0 && ctx.ssrtrace)
+            if (blockIdx.x == 0 && tid == 0 && ssrtrace)
             {
                 // callback (src/nls.c:980-995): trace row 0 after init, row niter after each iteration
                 if (phase_before == PH_INIT)
                 {
-                    ctx.ssrtrace[0] = s.chisq_init;
+                    ssrtrace[0] = s.chisq_init;
                     for (int k = 0; k < P; ++k)
-                        ctx.partrace[(size_t)(ctx.prm.maxiter + 1) * k] = s.x[k];
+                        partrace[(size_t)(prm.maxiter + 1) * k] = s.x[k];
                 }
                 else if (s.niter != niter_before && s.status != ST_EBADFUNC &&
                          !(s.status == ST_ENOPROG && niter_before == 0))
                 {
-                    ctx.ssrtrace[s.niter] = s.chisq1;
+                    ssrtrace[s.niter] = s.chisq1;
                     for (int k = 0; k < P; ++k)
-                        ctx.partrace[s.niter + (size_t)(ctx.prm.maxiter + 1) * k] = s.x[k];
+                        partrace[s.niter + (size_t)(prm.maxiter + 1) * k] = s.x[k];
                 }
             }
         }
@@ -374,14 +479,14 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
             }
             if (blockIdx.x == 0)
             {
-                *ctx.state[parity] = s;
+                *state_out = s;
                 if (s.phase == PH_DONE)
                 {
                     // final state to pinned host memory, then the fit's sequence number with system-scope
                     // release: the host polls the sequence word and can return without draining the stream
-                    *ctx.host_mirror = s;
+                    *host_mirror = s;
                     __threadfence_system();
-                    __hip_atomic_store(ctx.done_seq, ctx.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(done_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
         }
@@ -401,7 +506,7 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
         th[k] = lds_bc.th[k];
         vel[k] = lds_bc.vel[k];
     }
-    fd_deltas<P>(th, ctx.prm.h_df, delta);
+    fd_deltas<P>(th, prm.h_df, delta);
 
     Sums acc;
     pass_zero<P>(acc);
@@ -413,7 +518,7 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
     {
         auto do_row = [&](const double *xr, double y, double sw, bool live) {
             double Jrow[P];
-            double fv = row_fvv<M, JAC>(th, vel, delta, ctx.prm.h_fvv, ctx.prm.fvv_analytic != 0, xr, y, sw, Jrow,
+            double fv = row_fvv<M, JAC>(th, vel, delta, prm.h_fvv, prm.fvv_analytic != 0, xr, y, sw, Jrow,
                                         &acc.badj);
             fv = live ? fv : 0.0;
 #pragma unroll
@@ -423,27 +528,17 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
 #pragma unroll
         for (int k = 0; k < R; ++k)
         {
-            const bool live = i0 + k * stride < n;
+            const bool live = row_of(i0, k) < n;
             do_row(px[k], py[k], live ? pw[k] : 0.0, live);
         }
         // rows beyond the prefetch window (n > R * G * T): again R rows at a time, loads first
         for (long long b0 = i0 + R * stride; b0 < n; b0 += R * stride)
         {
+            fetch_rows(b0);
 #pragma unroll
             for (int k = 0; k < R; ++k)
             {
-                const long long i = b0 + k * stride;
-                const long long ic = i < n ? i : (n - 1);
-#pragma unroll
-                for (int c = 0; c < NX; ++c)
-                    px[k][c] = x0[(size_t)c * n + ic];
-                py[k] = yv[ic];
-                pw[k] = swv ? swv[ic] : 1.0;
-            }
-#pragma unroll
-            for (int k = 0; k < R; ++k)
-            {
-                const bool live = b0 + k * stride < n;
+                const bool live = row_of(b0, k) < n;
                 do_row(px[k], py[k], live ? pw[k] : 0.0, live);
             }
         }
@@ -459,26 +554,16 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
 #pragma unroll
         for (int k = 0; k < R; ++k)
         {
-            const bool live = i0 + k * stride < n;
+            const bool live = row_of(i0, k) < n;
             do_row(px[k], py[k], live ? pw[k] : 0.0, live);
         }
         for (long long b0 = i0 + R * stride; b0 < n; b0 += R * stride)
         {
+            fetch_rows(b0);
 #pragma unroll
             for (int k = 0; k < R; ++k)
             {
-                const long long i = b0 + k * stride;
-                const long long ic = i < n ? i : (n - 1);
-#pragma unroll
-                for (int c = 0; c < NX; ++c)
-                    px[k][c] = x0[(size_t)c * n + ic];
-                py[k] = yv[ic];
-                pw[k] = swv ? swv[ic] : 1.0;
-            }
-#pragma unroll
-            for (int k = 0; k < R; ++k)
-            {
-                const bool live = b0 + k * stride < n;
+                const bool live = row_of(b0, k) < n;
                 do_row(px[k], py[k], live ? pw[k] : 0.0, live);
             }
         }
@@ -486,7 +571,7 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
 
     GSLNLS_STAMP(5);
     // ---------------- workgroup reduction -> one partial set ---------------------------------
-    block_sum_to<NV, T>(reinterpret_cast<const double *>(&acc), lds_red, ctx.partials[parity] + blockIdx.x, (size_t)G);
+    block_sum_to<NV, T>(reinterpret_cast<const double *>(&acc), lds_red, partials_out + blockIdx.x, (size_t)G);
     GSLNLS_STAMP(6);
 }
 

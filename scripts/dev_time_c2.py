@@ -4,6 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from conftest import c2_data
+from gslnls_amd import _lib
+if os.environ.get('GSLNLS_LIB'):
+    _lib.LIB_PATH = os.environ['GSLNLS_LIB']  # developer variants of the library
 import gslnls_amd as A
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
