@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgslnls_hip.so")
+# GSLNLS_LIB: another build of the same library (developer variants, e.g. the stamps build)
+LIB_PATH = os.environ.get("GSLNLS_LIB") or os.path.join(_HERE, "libgslnls_hip.so")
 
 DP = C.POINTER(C.c_double)
 IP = C.POINTER(C.c_int)

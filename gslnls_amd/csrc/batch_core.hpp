@@ -84,25 +84,34 @@ GSLNLS_HD void ms_fit_point(const MsParams &mp, const RowSrc &rows, const double
     LmState<P> s;
     lm_state_reset<P>(s, start, lupars);
     PassSums<P> acc;
-    ms_pass<M, JAC>(s, mp, rows, acc);
-    double det0 = det_cholesky<P>(acc.A);
-    if (mp.prm.jac_analytic && !(acc.badj == 0.0))
-        det0 = 0.0; // eval_df failed (src/nls_utils.c:47-48)
-    rec.det0 = det0;
-    rec.ssr_start = acc.ssr;
+    // One call site for the pass and one for the state machine (the first trip doubles as det_eval_jtj at the
+    // sampled point): the lanes of a wavefront hold different fits, and every extra inlined copy is both code
+    // the instruction cache has to hold and a place where lanes in different states wait for each other.
+    bool fitted = false;
+    double det0 = 0.0;
+    for (int guard = 0; guard < 100000; ++guard)
+    {
+        ms_pass<M, JAC>(s, mp, rows, acc);
+        if (guard == 0)
+        {
+            det0 = det_cholesky<P>(acc.A);
+            if (mp.prm.jac_analytic && !(acc.badj == 0.0))
+                det0 = 0.0; // eval_df failed (src/nls_utils.c:47-48)
+            rec.det0 = det0;
+            rec.ssr_start = acc.ssr;
+            if (!(mp.always_fit || det0 > mp.dtol))
+                break;
+            fitted = true;
+        }
+        lm_advance<P>(s, acc, mp.prm);
+        if (s.phase == PH_DONE)
+            break;
+    }
 #pragma unroll
     for (int k = 0; k < P; ++k)
         rec.x0[k] = start[k];
-    if (mp.always_fit || det0 > mp.dtol)
+    if (fitted)
     {
-        lm_advance<P>(s, acc, mp.prm);
-        int guard = 0;
-        while (s.phase != PH_DONE && guard < 100000)
-        {
-            ms_pass<M, JAC>(s, mp, rows, acc);
-            lm_advance<P>(s, acc, mp.prm);
-            ++guard;
-        }
         rec.det1 = det_cholesky<P>(s.A);
         rec.chisq0 = s.chisq0;
         rec.chisq1 = s.chisq1;

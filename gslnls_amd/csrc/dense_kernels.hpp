@@ -231,6 +231,15 @@ __device__ __forceinline__ void pin_params(LmParams &q)
     pin_sgpr(q.chisq_in);
 }
 
+// lm_advance out of line: its own register allocation, nothing of the caller's row loop live across it.
+// Used where the caller is already short of registers -- the workgroup-per-dataset kernel (irls_batch.hpp) and the
+// step kernel of the interpreted expression models.
+template <int P>
+__device__ __attribute__((noinline)) void lm_advance_lds(LmState<P> *s, const PassSums<P> *r, const LmParams *prm)
+{
+    lm_advance<P>(*s, *r, *prm);
+}
+
 template <int P>
 struct StepBcast
 {
@@ -351,21 +360,29 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
     // The control values are read here, once, into SGPRs that the compiler may not re-derive from the kernarg
     // segment: left alone it loads each field where it is first used, i.e. a dozen scalar loads (the first a
     // cold miss: every launch has a fresh kernarg block) in the middle of wave 0's lm_advance.
+    // (Not for the interpreted expression models, M::ID == 100: their kernels already spill scalar registers
+    // into vector lanes by the hundred, and 44 more that are live from here to the end made the compiler hand
+    // lm_scale a wrong `scale` -- seen on Roszman1 with forward differences.  Those launches are bound by the
+    // interpreter's slot file, not by this.)
+    constexpr bool PIN = (M::ID != 100);
     LmParams prm = ctx.prm;
-    pin_params(prm);
     LmState<P> *state_out = ctx.state[parity];
     double *partials_out = ctx.partials[parity];
     double *ssrtrace = ctx.ssrtrace, *partrace = ctx.partrace;
     LmState<P> *host_mirror = ctx.host_mirror;
     unsigned int *done_seq = ctx.done_seq;
     unsigned int seq = ctx.seq;
-    pin_sgpr(state_out);
-    pin_sgpr(partials_out);
-    pin_sgpr(ssrtrace);
-    pin_sgpr(partrace);
-    pin_sgpr(host_mirror);
-    pin_sgpr(done_seq);
-    pin_sgpr(seq);
+    if constexpr (PIN)
+    {
+        pin_params(prm);
+        pin_sgpr(state_out);
+        pin_sgpr(partials_out);
+        pin_sgpr(ssrtrace);
+        pin_sgpr(partrace);
+        pin_sgpr(host_mirror);
+        pin_sgpr(done_seq);
+        pin_sgpr(seq);
+    }
 
     if (wave != 0)
     {
@@ -420,6 +437,8 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
         s.nevaldf = lo32(cnt[3]);
         s.nevalfvv = hi32(cnt[3]);
     }
+    int niter_before = 0, phase_before = PH_DONE;
+    bool advanced = false;
     if (tid < 64)
     {
         const bool fresh = s.bad_steps < 0; // host marks a brand-new state with bad_steps = -1
@@ -436,10 +455,20 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
 #pragma unroll
             for (int v = 0; v < NV; ++v)
                 rf[v] = lds_tot[v];
-            const int niter_before = s.niter;
-            const int phase_before = s.phase;
+            niter_before = s.niter;
+            phase_before = s.phase;
+            advanced = true;
             GSLNLS_STAMP(2);
-            lm_advance<P>(s, r, prm);
+            if constexpr (M::ID == 100)
+            {
+                // Interpreted expression model: the kernel around this call spills registers by the kilobyte, and with
+                // lm_advance inlined into it the forward-difference instance for p = 4 took its first step with the
+                // damping parameter of the reset state (mu = 0) instead of the one just computed -- seen on Roszman1,
+                // gone with the state machine compiled on its own.
+                lm_advance_lds<P>(&s, &r, &prm);
+            }
+            else
+                lm_advance<P>(s, r, prm);
             if (prm.bench_hold && s.phase == PH_DONE)
             {
                 // timing mode: never finish, so that every launch pays the full prologue and a full pass
@@ -450,23 +479,6 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
                 s.bad_steps = 0;
             }
             GSLNLS_STAMP(3);
-            if (blockIdx.x == 0 && tid == 0 && ssrtrace)
-            {
-                // callback (src/nls.c:980-995): trace row 0 after init, row niter after each iteration
-                if (phase_before == PH_INIT)
-                {
-                    ssrtrace[0] = s.chisq_init;
-                    for (int k = 0; k < P; ++k)
-                        partrace[(size_t)(prm.maxiter + 1) * k] = s.x[k];
-                }
-                else if (s.niter != niter_before && s.status != ST_EBADFUNC &&
-                         !(s.status == ST_ENOPROG && niter_before == 0))
-                {
-                    ssrtrace[s.niter] = s.chisq1;
-                    for (int k = 0; k < P; ++k)
-                        partrace[s.niter + (size_t)(prm.maxiter + 1) * k] = s.x[k];
-                }
-            }
         }
         if (tid == 0)
         {
@@ -477,22 +489,67 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
                 lds_bc.th[k] = (s.phase == PH_FVV) ? s.x[k] : s.xt[k];
                 lds_bc.vel[k] = s.vel[k];
             }
-            if (blockIdx.x == 0)
-            {
-                *state_out = s;
-                if (s.phase == PH_DONE)
-                {
-                    // final state to pinned host memory, then the fit's sequence number with system-scope
-                    // release: the host polls the sequence word and can return without draining the stream
-                    *host_mirror = s;
-                    __threadfence_system();
-                    __hip_atomic_store(done_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-            }
         }
     }
     __syncthreads();
     GSLNLS_STAMP(4);
+
+    // Workgroup 0 keeps the record: state for the next launch, trace rows, and -- when the fit has ended -- the
+    // copy in pinned host memory.  All of it after the barrier (the other waves are already on their rows) and
+    // as global stores: a flat store also counts as an LDS operation, and the wait in front of the barrier would
+    // hold the whole workgroup until the 23 stores of the state had completed.
+    if (blockIdx.x == 0 && tid == 0)
+    {
+        typedef __attribute__((address_space(1))) double GDouble;
+        // the state as ND doubles + the eight counters packed in four 64-bit words (the mirror image of the load)
+        constexpr int ND = (int)(offsetof(LmState<P>, bad_steps) / 8);
+        double img[ND + 4];
+        {
+            const double *src = reinterpret_cast<const double *>(&s);
+#pragma unroll
+            for (int k = 0; k < ND; ++k)
+                img[k] = src[k];
+            auto pack = [](int lo, int hi) { return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo); };
+            img[ND + 0] = pack(s.bad_steps, s.niter);
+            img[ND + 1] = pack(s.phase, s.status);
+            img[ND + 2] = pack(s.info, s.nevalf);
+            img[ND + 3] = pack(s.nevaldf, s.nevalfvv);
+        }
+        auto store_state = [&](LmState<P> *where) {
+            GDouble *dst = (GDouble *)reinterpret_cast<double *>(where);
+#pragma unroll
+            for (int k = 0; k < ND + 4; ++k)
+                dst[k] = img[k];
+        };
+        if (advanced && ssrtrace)
+        {
+            GDouble *st = (GDouble *)ssrtrace;
+            GDouble *pt = (GDouble *)partrace;
+            // callback (src/nls.c:980-995): trace row 0 after init, row niter after each iteration
+            if (phase_before == PH_INIT)
+            {
+                st[0] = s.chisq_init;
+                for (int k = 0; k < P; ++k)
+                    pt[(size_t)(prm.maxiter + 1) * k] = s.x[k];
+            }
+            else if (s.niter != niter_before && s.status != ST_EBADFUNC &&
+                     !(s.status == ST_ENOPROG && niter_before == 0))
+            {
+                st[s.niter] = s.chisq1;
+                for (int k = 0; k < P; ++k)
+                    pt[s.niter + (size_t)(prm.maxiter + 1) * k] = s.x[k];
+            }
+        }
+        store_state(state_out);
+        if (s.phase == PH_DONE)
+        {
+            // final state to pinned host memory, then the fit's sequence number with system-scope
+            // release: the host polls the sequence word and can return without draining the stream
+            store_state(host_mirror);
+            __threadfence_system();
+            __hip_atomic_store(done_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 
     const int phase = lds_bc.phase;
     if (phase == PH_DONE)

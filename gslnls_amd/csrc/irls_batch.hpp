@@ -45,13 +45,6 @@ struct IrlsBatchArgs
     unsigned long long *prof; // developer diagnostic (GSLNLS_BATCH_PROF): [B][8] cycle totals, or nullptr
 };
 
-// out-of-line on purpose: its own register allocation, nothing of the row loop live across it
-template <int P>
-__device__ __attribute__((noinline)) void lm_advance_lds(LmState<P> *s, const PassSums<P> *r, const LmParams *prm)
-{
-    lm_advance<P>(*s, *r, *prm);
-}
-
 template <class M, int JAC, int T>
 __global__ __launch_bounds__(T, 2) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
 {

@@ -476,9 +476,9 @@ GSLNLS_HD int lm_test(const LmState<P> &s, const LmParams &prm, int *info)
 }
 
 // bookkeeping at the end of one driver2 iteration (src/nls_fit.c:73-103).
-// Returns true when an iteration was completed (caller may record a trace row).
+// Returns true when the driver goes round again, i.e. the caller has to start the next step.
 template <int P>
-GSLNLS_HD void lm_end_iteration(LmState<P> &s, const LmParams &prm, int itstatus)
+GSLNLS_HD bool lm_end_iteration(LmState<P> &s, const LmParams &prm, int itstatus)
 {
     const int iter = s.niter; // driver2's `iter` before ++
     s.niter += 1;
@@ -488,7 +488,7 @@ GSLNLS_HD void lm_end_iteration(LmState<P> &s, const LmParams &prm, int itstatus
         s.info = itstatus;
         s.status = itstatus;
         s.phase = PH_DONE;
-        return;
+        return false;
     }
     int info = 0;
     const int t = lm_test(s, prm, &info);
@@ -497,20 +497,18 @@ GSLNLS_HD void lm_end_iteration(LmState<P> &s, const LmParams &prm, int itstatus
     {
         s.status = ST_SUCCESS;
         s.phase = PH_DONE;
-        return;
+        return false;
     }
     if (s.niter >= prm.maxiter)
     {
         s.status = ST_EMAXITER;
         s.phase = PH_DONE;
-        return;
+        return false;
     }
     // next driver2 iteration: chisq0 <- chisq1, fresh trust_iterate call
     s.chisq0 = s.chisq1;
     s.bad_steps = 0;
-    GSLNLS_ADV_STAMP(3);
-    lm_begin_step(s, prm);
-    GSLNLS_ADV_STAMP(4);
+    return true;
 }
 
 // GSL scaling.c on the diagonal of J^T J
@@ -557,16 +555,22 @@ GSLNLS_HD void lm_take_point(LmState<P> &s, const PassSums<P> &r)
 GSLNLS_HD int lm_fd_cost(const LmParams &prm, int p) { return prm.fdtype ? 2 * p : p; }
 
 // The state machine.  `r` holds the sums of the pass that `s.phase` asked for.
+// Every path that continues with a new step (initialisation, accepted step, rejected step) only decides so and
+// falls through to ONE lm_begin_step at the end: the damped solve is the bulk of this function, and where lanes
+// of a wavefront hold different fits (multi-start) they would otherwise run one copy of it per path, one after
+// the other.
 template <int P>
 GSLNLS_HD void lm_advance(LmState<P> &s, const PassSums<P> &r, const LmParams &prm)
 {
     if (s.phase == PH_DONE)
         return;
 
+    bool step = false;
     if (s.phase == PH_INIT)
     {
         // trust_init_LD (src/trust.c:311-372): f, J, g, D, delta, mu0
         s.nevalf += 1;
+        bool ok = true;
         if (prm.jac_analytic)
         {
             s.nevaldf += 1;
@@ -578,34 +582,35 @@ GSLNLS_HD void lm_advance(LmState<P> &s, const PassSums<P> &r, const LmParams &p
                 s.status = ST_EBADFUNC;
                 s.info = ST_EBADFUNC;
                 s.phase = PH_DONE;
-                return;
+                ok = false;
             }
         }
         else
             s.nevalf += lm_fd_cost(prm, P);
-        lm_take_point(s, r);
-        lm_scale(s, prm, true);
-        double Dx2 = 0.0, mx = -1.0;
-#pragma unroll
-        for (int j = 0; j < P; ++j)
+        if (ok)
         {
-            const double u = s.diag[j] * s.x[j];
-            Dx2 += u * u;
-            mx = fmax(mx, sqrt(s.A[tri(j, j)]) / s.diag[j]);
+            lm_take_point(s, r);
+            lm_scale(s, prm, true);
+            double Dx2 = 0.0, mx = -1.0;
+#pragma unroll
+            for (int j = 0; j < P; ++j)
+            {
+                const double u = s.diag[j] * s.x[j];
+                Dx2 += u * u;
+                mx = fmax(mx, sqrt(s.A[tri(j, j)]) / s.diag[j]);
+            }
+            s.delta = 0.3 * fmax(1.0, sqrt(Dx2));
+            s.mu = 1.0e-3 * mx * mx;
+            s.nu = 2.0;
+            s.avratio = 0.0;
+            s.chisq_init = r.ssr;
+            s.chisq0 = s.chisq1 = (prm.chisq_in == prm.chisq_in) ? prm.chisq_in : r.ssr;
+            s.niter = 0;
+            s.bad_steps = 0;
+            step = true;
         }
-        s.delta = 0.3 * fmax(1.0, sqrt(Dx2));
-        s.mu = 1.0e-3 * mx * mx;
-        s.nu = 2.0;
-        s.avratio = 0.0;
-        s.chisq_init = r.ssr;
-        s.chisq0 = s.chisq1 = (prm.chisq_in == prm.chisq_in) ? prm.chisq_in : r.ssr;
-        s.niter = 0;
-        s.bad_steps = 0;
-        lm_begin_step(s, prm);
-        return;
     }
-
-    if (s.phase == PH_FVV)
+    else if (s.phase == PH_FVV)
     {
         // acceleration solve (src/trust.c:252-289): rhs = -J^T fvv, same damped matrix
         if (prm.fvv_analytic)
@@ -642,78 +647,83 @@ GSLNLS_HD void lm_advance(LmState<P> &s, const PassSums<P> &r, const LmParams &p
         s.phase = PH_TRIAL;
         return;
     }
-
-    // PH_TRIAL: trust_eval_step + radius/mu updates (src/trust.c:474-545)
-    GSLNLS_ADV_STAMP(0);
-    s.nevalf += 1;
-    double rho;
-    if (!(r.ssr < s.fnorm2))
-        rho = -1.0; // ||f_trial|| >= ||f|| (also catches +Inf residuals and NaN)
     else
     {
-        const double finv = 1.0 / s.fnorm2;
-        const double ared = 1.0 - r.ssr * finv;
-        // lm_preduction: (||J v||/||f||)^2 + 2 mu (||D v||/||f||)^2 with v the velocity
-        double vAv = 0.0, Dv2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < P; ++i)
+        // PH_TRIAL: trust_eval_step + radius/mu updates (src/trust.c:474-545)
+        GSLNLS_ADV_STAMP(0);
+        s.nevalf += 1;
+        double rho;
+        if (!(r.ssr < s.fnorm2))
+            rho = -1.0; // ||f_trial|| >= ||f|| (also catches +Inf residuals and NaN)
+        else
         {
-            double row = 0.0;
+            const double finv = 1.0 / s.fnorm2;
+            const double ared = 1.0 - r.ssr * finv;
+            // lm_preduction: (||J v||/||f||)^2 + 2 mu (||D v||/||f||)^2 with v the velocity
+            double vAv = 0.0, Dv2 = 0.0;
 #pragma unroll
-            for (int j = 0; j < P; ++j)
-                row += s.A[j <= i ? tri(i, j) : tri(j, i)] * s.vel[j];
-            vAv += row * s.vel[i];
-            const double u = s.diag[i] * s.vel[i];
-            Dv2 += u * u;
-        }
-        const double pred = vAv * finv + 2.0 * s.mu * (Dv2 * finv);
-        rho = (pred > 0.0) ? ared / pred : -1.0;
-    }
-    GSLNLS_ADV_STAMP(1);
-    bool found = rho > 0.0;
-    if (prm.trs == 1 && s.avratio > prm.avmax)
-        found = false;
-
-    if (rho > 0.75)
-        s.delta *= prm.factor_up;
-    else if (rho < 0.25)
-        s.delta /= prm.factor_down;
-
-    if (found)
-    {
-        if (prm.jac_analytic)
-        {
-            s.nevaldf += 1;
-            if (!(r.badj == 0.0))
+            for (int i = 0; i < P; ++i)
             {
-                lm_end_iteration(s, prm, ST_EBADFUNC);
-                return;
+                double row = 0.0;
+#pragma unroll
+                for (int j = 0; j < P; ++j)
+                    row += s.A[j <= i ? tri(i, j) : tri(j, i)] * s.vel[j];
+                vAv += row * s.vel[i];
+                const double u = s.diag[i] * s.vel[i];
+                Dv2 += u * u;
+            }
+            const double pred = vAv * finv + 2.0 * s.mu * (Dv2 * finv);
+            rho = (pred > 0.0) ? ared / pred : -1.0;
+        }
+        GSLNLS_ADV_STAMP(1);
+        bool found = rho > 0.0;
+        if (prm.trs == 1 && s.avratio > prm.avmax)
+            found = false;
+
+        if (rho > 0.75)
+            s.delta *= prm.factor_up;
+        else if (rho < 0.25)
+            s.delta /= prm.factor_down;
+
+        int itstatus = ST_CONTINUE; // CONTINUE = the iteration is not over (rejected step, another trial follows)
+        if (found)
+        {
+            itstatus = ST_SUCCESS;
+            if (prm.jac_analytic)
+            {
+                s.nevaldf += 1;
+                if (!(r.badj == 0.0))
+                    itstatus = ST_EBADFUNC;
+            }
+            else
+                s.nevalf += lm_fd_cost(prm, P);
+            if (itstatus == ST_SUCCESS)
+            {
+                lm_take_point(s, r);
+                lm_scale(s, prm, false);
+                // nielsen_accept (src/trust.c:175-188)
+                double b = 2.0 * rho - 1.0;
+                b = 1.0 - b * b * b;
+                s.nu = 2.0;
+                s.mu *= fmax(0.333333333333333, b);
+                s.bad_steps = 0;
             }
         }
         else
-            s.nevalf += lm_fd_cost(prm, P);
-        lm_take_point(s, r);
-        lm_scale(s, prm, false);
-        // nielsen_accept (src/trust.c:175-188)
-        double b = 2.0 * rho - 1.0;
-        b = 1.0 - b * b * b;
-        s.nu = 2.0;
-        s.mu *= fmax(0.333333333333333, b);
-        s.bad_steps = 0;
+        {
+            // nielsen_reject (src/trust.c:190-199)
+            s.mu *= s.nu;
+            s.nu *= 2.0;
+            if (++s.bad_steps > 15)
+                itstatus = ST_ENOPROG;
+        }
         GSLNLS_ADV_STAMP(2);
-        lm_end_iteration(s, prm, ST_SUCCESS);
-        GSLNLS_ADV_STAMP(5);
+        step = (itstatus == ST_CONTINUE) ? true : lm_end_iteration(s, prm, itstatus);
+        GSLNLS_ADV_STAMP(3);
     }
-    else
-    {
-        // nielsen_reject (src/trust.c:190-199)
-        s.mu *= s.nu;
-        s.nu *= 2.0;
-        if (++s.bad_steps > 15)
-            lm_end_iteration(s, prm, ST_ENOPROG);
-        else
-            lm_begin_step(s, prm);
-    }
+    if (step)
+        lm_begin_step(s, prm);
+    GSLNLS_ADV_STAMP(4);
 }
 
 } // namespace gslnls

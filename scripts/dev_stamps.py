@@ -40,5 +40,5 @@ for jac in (1, 0):
     if hasattr(L, "gslnls_debug_adv_stamps") and L.gslnls_debug_adv_stamps(adv) == 0:
         a = [int(v) for v in adv]
         print("  block 0 wave 0, cycles after kernel entry: entry barrier passed %d | advance starts %d" % (a[7] - a[6], a[0] - a[6]))
-        print("  lm_advance (block 0): rho %d | accept bookkeeping + test %d | solve %d | tail %d | whole %d" % (a[1] - a[0], a[3] - a[1], a[4] - a[3], a[5] - a[4], a[5] - a[0]))
+        print("  lm_advance (block 0): rho %d | accept/reject bookkeeping %d | end of iteration + test %d | begin step (solve) %d | whole %d" % (a[1] - a[0], a[2] - a[1], a[3] - a[2], a[4] - a[3], a[4] - a[0]))
 prob.close()
