@@ -55,10 +55,7 @@ GSLNLS_HD void ms_pass(const LmState<M::P> &s, const MsParams &mp, const RowSrc 
         th[k] = (s.phase == PH_FVV) ? s.x[k] : s.xt[k];
     fd_deltas<P>(th, mp.prm.h_df, delta);
     pass_zero<P>(acc);
-    for (int i = 0; i < mp.n; ++i)
-    {
-        double xr[M::NX], y, sw;
-        rows(i, xr, y, sw);
+    auto do_row = [&](const double *xr, double y, double sw) {
         double Jrow[P];
         if (s.phase == PH_FVV)
         {
@@ -72,6 +69,26 @@ GSLNLS_HD void ms_pass(const LmState<M::P> &s, const MsParams &mp, const RowSrc 
         {
             const double f = row_fj<M, JAC>(th, delta, xr, y, sw, Jrow, &acc.badj);
             acc_fj<P>(acc, f, Jrow);
+        }
+    };
+    if constexpr (RowSrc::STATIC_N > 0)
+    {
+        // tiny data sets held in registers: the loop is unrolled so that every row is a fixed register, and
+        // the (uniform) row count only switches whole rows off
+#pragma unroll
+        for (int i = 0; i < RowSrc::STATIC_N; ++i)
+        {
+            if (i < mp.n)
+                do_row(rows.x[i], rows.y[i], rows.sw[i]);
+        }
+    }
+    else
+    {
+        for (int i = 0; i < mp.n; ++i)
+        {
+            double xr[M::NX], y, sw;
+            rows(i, xr, y, sw);
+            do_row(xr, y, sw);
         }
     }
 }

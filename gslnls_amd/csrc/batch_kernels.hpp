@@ -37,9 +37,20 @@ struct MsKernelArgs
     MsParams mp;
 };
 
+// rows of a tiny data set (BoxBOD: 6) in registers: the LDS round trip in front of every row is a third of a
+// pass when a row costs ~50 instructions
+constexpr int MS_REG_ROWS = 8;
+template <int NX>
+struct RowsReg
+{
+    static constexpr int STATIC_N = MS_REG_ROWS;
+    double x[MS_REG_ROWS][NX], y[MS_REG_ROWS], sw[MS_REG_ROWS];
+};
+
 template <int NX>
 struct RowsLds
 {
+    static constexpr int STATIC_N = 0;
     const double *base;
     int n;
     __device__ void operator()(int i, double *xr, double &y, double &sw) const
@@ -55,6 +66,7 @@ struct RowsLds
 template <int NX>
 struct RowsGlobal
 {
+    static constexpr int STATIC_N = 0;
     const double *x[4];
     const double *y;
     const double *sw;
@@ -87,6 +99,16 @@ __global__ __launch_bounds__(MS_T) void ms_fit_kernel(MsKernelArgs<M::P> a)
         }
         __syncthreads();
     }
+    // The P columns of the direction-number table go through LDS as well: read from global memory inside
+    // sobol_coord's bit loop they are up to 30 dependent cold loads per coordinate, ~10 us in front of every fit.
+    __shared__ unsigned int lds_sobol[SOBOL_BITS][P];
+    const bool halton = a.sobol->halton != 0;
+    if (!halton)
+    {
+        for (int e = threadIdx.x; e < SOBOL_BITS * P; e += MS_T)
+            lds_sobol[e / P][e % P] = a.sobol->v[e / P][e % P];
+        __syncthreads();
+    }
     const int idx = a.lo + blockIdx.x * MS_T + threadIdx.x;
     if (idx >= a.hi)
         return;
@@ -96,12 +118,44 @@ __global__ __launch_bounds__(MS_T) void ms_fit_kernel(MsKernelArgs<M::P> a)
     for (int k = 0; k < P; ++k)
     {
         if (d >= 0)
-            start[k] = sobol_to_range(sobol_coord(*a.sobol, (unsigned int)d, k), a.l0[k], a.l1[k], a.kd[k]);
+        {
+            double u;
+            if (halton)
+                u = sobol_coord(*a.sobol, (unsigned int)d, k);
+            else
+            {
+                // same XOR as sobol_coord, over all 30 bits with the unset ones masked out: 30 independent
+                // broadcast reads instead of a data-dependent loop
+                const unsigned int kk = (unsigned int)d + 1u;
+                const unsigned int g = kk ^ (kk >> 1);
+                unsigned int num = 0;
+#pragma unroll
+                for (int b = 0; b < SOBOL_BITS; ++b)
+                    num ^= lds_sobol[b][k] & (0u - ((g >> b) & 1u));
+                u = (double)num * (1.0 / 1073741824.0); // 2^-30
+            }
+            start[k] = sobol_to_range(u, a.l0[k], a.l1[k], a.kd[k]);
+        }
         else
             start[k] = a.start[(size_t)idx * P + k];
     }
     MsRecord<P> rec;
-    if (staged)
+    if (staged && n <= MS_REG_ROWS)
+    {
+        RowsReg<NX> rows;
+#pragma unroll
+        for (int i = 0; i < MS_REG_ROWS; ++i)
+        {
+            const int ic = i < n ? i : 0;
+#pragma unroll
+            for (int c = 0; c < NX; ++c)
+                rows.x[i][c] = lds_rows[c * n + ic];
+            rows.y[i] = lds_rows[NX * n + ic];
+            rows.sw[i] = lds_rows[(NX + 1) * n + ic];
+        }
+        ms_fit_point<M, JAC>(a.mp, rows, start, a.has_lu ? a.lu : nullptr, rec);
+    }
+    else if (staged)
     {
         RowsLds<NX> rows{lds_rows, n};
         ms_fit_point<M, JAC>(a.mp, rows, start, a.has_lu ? a.lu : nullptr, rec);
