@@ -223,9 +223,12 @@ struct DenseFit : DenseBase
         return GSLNLS_SUCCESS;
     }
 
-    void launch_step(int jacmode, int parity)
+    // fresh: first launch of a fit -- the kernel builds the start state from ctx.sa instead of reading a previous one
+    void launch_step(int jacmode, int parity, bool fresh = false)
     {
         const dim3 grid(ctx.G), block(T);
+        if (fresh)
+            parity |= FRESH_LAUNCH;
         const LmState<P> *prev = ctx.state[parity ^ 1];
         const double *pp = ctx.partials[parity ^ 1];
         switch (jacmode)
@@ -327,7 +330,7 @@ struct DenseFit : DenseBase
                 sa.up[k] = lupars ? lupars[2 * k + 1] : INFINITY;
             }
             h_state[0].phase = PH_INIT;
-            hipLaunchKernelGGL((lm_reset_kernel<P>), dim3(1), dim3(64), 0, stream, ctx, sa);
+            ctx.sa = sa;
         }
         if (chunk <= 0)
             chunk = 16;
@@ -339,7 +342,7 @@ struct DenseFit : DenseBase
         {
             for (int k = 0; k < chunk; ++k)
             {
-                launch_step(jacmode, parity);
+                launch_step(jacmode, parity, launches == 0 && k == 0);
                 parity ^= 1;
             }
             launches += chunk;
@@ -504,12 +507,12 @@ struct DenseFit : DenseBase
                 sa.lo[k] = -INFINITY;
                 sa.up[k] = INFINITY;
             }
-            hipLaunchKernelGGL((lm_reset_kernel<P>), dim3(1), dim3(64), 0, stream, ctx, sa);
+            ctx.sa = sa;
         }
         int parity = 0;
         for (int k = 0; k < 4; ++k)
         {
-            launch_step(jacmode, parity);
+            launch_step(jacmode, parity, k == 0);
             parity ^= 1;
         }
         if (getenv("GSLNLS_GRAPH_PROBE"))

@@ -51,6 +51,16 @@ namespace gslnls
 constexpr int NX_MAX = 4;
 constexpr int MAX_G = 256; // workgroups per fit == partial sets (one per CU)
 
+// Start of a fit: the brand-new state is built on device from kernel arguments (no H2D copy, no reset launch):
+// the first step launch of a fit carries FRESH_LAUNCH in its parity argument and takes the start from ctx.sa.
+template <int P>
+struct StartArgs
+{
+    double start[P];
+    double lo[P], up[P];
+};
+constexpr int FRESH_LAUNCH = 2;
+
 template <int P>
 struct DenseCtx
 {
@@ -69,6 +79,7 @@ struct DenseCtx
     unsigned long long *stamps; // diagnostic builds only
     unsigned int *done_seq;      // pinned host word: sequence number of the last finished fit
     unsigned int seq;            // sequence number of this fit
+    StartArgs<P> sa;             // read by the first launch of a fit only
 };
 
 // Cross-lane move of a double through DPP (VALU, ~8 cycles) instead of ds_bpermute (LDS, ~100
@@ -258,11 +269,13 @@ constexpr int ROWS_AHEAD = 8;
 template <class M, int JAC, int T>
 __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, const double *prev_partials,
                                                     const double *x0, const double *yv_, const double *swv_,
-                                                    long long n, int G, int parity, DenseCtx<M::P> ctx)
+                                                    long long n, int G, int parity_and_flags, DenseCtx<M::P> ctx)
 {
     constexpr int P = M::P;
     constexpr int NX = M::NX;
     using Sums = PassSums<P>;
+    const int parity = parity_and_flags & 1;
+    const bool fresh_launch = (parity_and_flags & FRESH_LAUNCH) != 0; // first launch of a fit: no previous state
     constexpr int NV = Sums::NV;
     constexpr int NW = T / 64;
     constexpr int R = ROWS_AHEAD;
@@ -331,7 +344,11 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
     };
     auto row_of = [&](long long b0, int k) { return b0 + k * stride; };
     double cnt[4];
-    if (wave == 0)
+    if (fresh_launch)
+    {
+        // nothing to wait for: the state comes from the kernel arguments after the barrier
+    }
+    else if (wave == 0)
     {
         // Wave 0 has nothing to do until the totals are there, so its own rows are requested right away (one
         // eighth of the workgroup's prefetch; the other waves hold theirs back until the totals are published,
@@ -384,7 +401,7 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
         pin_sgpr(seq);
     }
 
-    if (wave != 0)
+    if (wave != 0 && !fresh_launch)
     {
         // wave w sums the G partials of values v = w-1, w-1 + RW, ...: lane-strided partial sums, DPP butterfly
 #pragma unroll 1
@@ -420,11 +437,26 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
     __syncthreads();
     GSLNLS_ADV_STAMP(7);
     GSLNLS_STAMP(7);
-    if (wave != 0)
+    if (wave != 0 || fresh_launch)
         fetch_rows(i0);
 
     GSLNLS_STAMP(1);
-    if (wave == 0)
+    if (fresh_launch)
+    {
+        if (wave == 0)
+        {
+            double lu[2 * P];
+#pragma unroll
+            for (int k = 0; k < P; ++k)
+            {
+                lu[2 * k] = ctx.sa.lo[k];
+                lu[2 * k + 1] = ctx.sa.up[k];
+            }
+            lm_state_reset<P>(s, ctx.sa.start, lu);
+            s.bad_steps = -1; // "fresh": this launch skips the advance
+        }
+    }
+    else if (wave == 0)
     {
         auto lo32 = [](double d) { return (int)(__double_as_longlong(d) & 0xffffffffll); };
         auto hi32 = [](double d) { return (int)(__double_as_longlong(d) >> 32); };
@@ -630,32 +662,6 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
     // ---------------- workgroup reduction -> one partial set ---------------------------------
     block_sum_to<NV, T>(reinterpret_cast<const double *>(&acc), lds_red, partials_out + blockIdx.x, (size_t)G);
     GSLNLS_STAMP(6);
-}
-
-// Start of a fit: the brand-new state is built on device from kernel arguments (no H2D copy).
-template <int P>
-struct StartArgs
-{
-    double start[P];
-    double lo[P], up[P];
-};
-
-template <int P>
-__global__ void lm_reset_kernel(DenseCtx<P> ctx, StartArgs<P> a)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0)
-        return;
-    LmState<P> s;
-    double lu[2 * P];
-    for (int k = 0; k < P; ++k)
-    {
-        lu[2 * k] = a.lo[k];
-        lu[2 * k + 1] = a.up[k];
-    }
-    lm_state_reset<P>(s, a.start, lu);
-    s.bad_steps = -1; // "fresh": the first step launch (parity 0) skips the advance
-    *ctx.state[1] = s;
-    ctx.host_mirror->phase = PH_INIT;
 }
 
 // After the fit: weighted residual and Jacobian at the final point, in the layout C_nls

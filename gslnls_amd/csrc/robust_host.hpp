@@ -118,8 +118,8 @@ int DenseFit<M>::sums_at(const double *theta, int jacmode, PassSums<P> &out)
         sa.up[k] = INFINITY;
     }
     const unsigned int seq_keep = ctx.seq;
-    hipLaunchKernelGGL((lm_reset_kernel<P>), dim3(1), dim3(64), 0, stream, ctx, sa);
-    launch_step(jacmode, 0);
+    ctx.sa = sa;
+    launch_step(jacmode, 0, true);
     double *d_tot = nullptr;
     GSLNLS_HIP_OK(hipMalloc(&d_tot, sizeof(double) * NV));
     hipLaunchKernelGGL(large_reduce_kernel, dim3(NV), dim3(64), 0, stream, ctx.partials[0], NV, ctx.G, d_tot);
