@@ -277,6 +277,7 @@ def main():
     for _ in range(args.warmup):
         one_fit()
     barrier()
+    L.gslnls_dense_loop_event_stats(h, None, None, 1)  # HIP-event totals of the launch loops: start from zero
     t0 = time.perf_counter()
     iters = launches = ref_passes = 0
     loop_ms = 0.0
@@ -288,6 +289,8 @@ def main():
         ref_passes += d
     barrier()
     elapsed = time.perf_counter() - t0
+    ev_ms, ev_launches = C.c_double(0.0), C.c_longlong(0)
+    L.gslnls_dense_loop_event_stats(h, C.byref(ev_ms), C.byref(ev_launches), 0)
 
     tot_iters = float(iters)
     tmax = elapsed
@@ -300,15 +303,18 @@ def main():
         tot_iters = float(it.item())
 
     # Dominant kernel lm_step_kernel, HIP events on the library's own stream.
-    # (1) over the timed region: device time of each fit's launch loop (events around it, summed by the
-    #     library: loop_ms) / its launches.  Algorithmic bytes by SURVEY.md 8(d): the reference reads x and y once
-    #     per f evaluation and once per Jacobian evaluation (16n B each) = 32n per LM iteration with one trial,
-    #     +16n per extra rejected trial, 32n for the initial point; "a speculative single fused pass is allowed
-    #     but the reported denominator stays 32n".  neval.f + neval.J is exactly that count of passes.
+    # (1) over the timed region: every fit brackets its launch loop with an event pair on that stream (first step
+    #     launch ... last launch of the last chunk; read back lazily, gslnls_dense_loop_event_stats); their sum is the
+    #     device time of all step launches of the timed region, trailing ones and the gaps between launches included.
+    #     Algorithmic bytes by SURVEY.md 8(d): the reference reads x and y once per f evaluation and once per Jacobian
+    #     evaluation (16n B each) = 32n per LM iteration with one trial, +16n per extra rejected trial, 32n for the
+    #     initial point; "a speculative single fused pass is allowed but the reported denominator stays 32n".
+    #     neval.f + neval.J is exactly that count of passes.
     # (2) streamed view: back-to-back launches that each do the full prologue + one full fused pass
     #     (gslnls_dense_time_pass), 16n B actually read per launch -- what the PMC traffic is compared with.
+    assert ev_launches.value == launches, (ev_launches.value, launches)
     alg_bytes_fit = 16.0 * n * ref_passes / args.steps
-    ms_loop_fit = loop_ms / args.steps
+    ms_loop_fit = ev_ms.value / args.steps
     launches_fit = launches / args.steps
     achieved = alg_bytes_fit / (ms_loop_fit * 1e-3) / 1e9
     th = np.array([4.0, 1.2, 0.8])
@@ -341,14 +347,15 @@ def main():
         "config": {"workload": "C2: exponential model n=%d p=3, LM normal equations (cholesky), %s Jacobian, "
                                "one step = one complete fit from (1,1,0)" % (n, "forward-FD" if args.fd else "analytic"),
                    "niter_per_fit": iters / args.steps, "launches_per_fit": launches / args.steps,
-                   "device_loop_ms_per_fit": loop_ms / args.steps,
+                   "device_loop_ms_per_fit": ev_ms.value / args.steps, "host_loop_ms_per_fit": loop_ms / args.steps,
                    "parallelism": "replicas only (x%d)" % world, "par": [float(v) for v in par]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "lm_step_kernel<ModelExpDecay>",
                      "bytes_per_launch": alg_bytes_fit / launches_fit, "ms_per_launch": ms_loop_fit / launches_fit,
                      "accounting": "SURVEY 8(d): 16n B per reference pass (f or J evaluation); %.0f passes per fit "
-                                   "done in %.0f launches, timed region" % (ref_passes / args.steps, launches_fit),
+                                   "done in %.0f launches; device time = HIP event pair around every fit's launch loop on the "
+                                   "library's stream, summed over the timed region" % (ref_passes / args.steps, launches_fit),
                      "streamed": {"bytes_per_launch": 16.0 * n, "ms_per_full_launch": ms_launch, "GBs": streamed,
                                   "frac": streamed / HBM_PEAK_GBS,
                                   "note": "bytes actually read by one fused launch (x and y once); compare traffic"}},

@@ -228,6 +228,13 @@ float gslnls_dense_time_pass(gslnls_dense *h, int jac, const double *theta, int 
     return h->impl->time_pass(jac, theta, reps);
 }
 
+int gslnls_dense_loop_event_stats(gslnls_dense *h, double *ms_total, long long *launches_total, int reset)
+{
+    if (!h || !h->impl)
+        return GSLNLS_EINVAL;
+    return h->impl->loop_event_stats(ms_total, launches_total, reset);
+}
+
 #ifdef GSLNLS_STAMPS
 int gslnls_debug_stamps(gslnls_dense *h, int jac, const double *theta, int warm, unsigned long long *out, int *nrows)
 {

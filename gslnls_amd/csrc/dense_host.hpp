@@ -73,6 +73,7 @@ struct DenseBase
     virtual int irls(int jac, int fvv, const double *start, const double *lupars, const int *ci, const double *cd,
                      int loss_rho, const double *loss_cc, gslnls_result *out) = 0;
     virtual float time_pass(int jac, const double *theta, int reps) = 0;
+    virtual int loop_event_stats(double *ms_total, long long *launches_total, int reset) = 0;
     virtual int set_swts(const double *swts) = 0;
     // the matrix-free operator of gsl_nls_large over this problem's resident data (large_host.hpp)
     virtual LargeOps *make_large_ops() = 0;
@@ -113,7 +114,16 @@ struct DenseFit : DenseBase
     int trace_cap = 0;
     double *d_resid = nullptr, *d_grad = nullptr, *d_covar = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_chunk = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // device time of the launch loops: one event pair per fit on the library's stream, read back lazily (at the
+    // next fit or when the totals are asked for) so that no fit waits for its own trailing launches
+    static constexpr int EV_RING = 32;
+    hipEvent_t ev_fit0[EV_RING] = {}, ev_fit1[EV_RING] = {};
+    bool ev_pending[EV_RING] = {};
+    long long ev_launches[EV_RING] = {};
+    int ev_head = 0; // slot of the fit in progress / the most recent fit
+    double ev_ms_total = 0.0;
+    long long ev_launches_total = 0;
     MsEvaluator *ms_eval = nullptr; // cached batch evaluator (Sobol table, device buffers)
 
     int init(const gslnls_model *fn, const double *y, int n_, const double *swts)
@@ -124,7 +134,11 @@ struct DenseFit : DenseBase
         GSLNLS_HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         GSLNLS_HIP_OK(hipEventCreate(&ev0));
         GSLNLS_HIP_OK(hipEventCreate(&ev1));
-        GSLNLS_HIP_OK(hipEventCreateWithFlags(&ev_chunk, hipEventDisableTiming));
+        for (int k = 0; k < EV_RING; ++k)
+        {
+            GSLNLS_HIP_OK(hipEventCreate(&ev_fit0[k]));
+            GSLNLS_HIP_OK(hipEventCreate(&ev_fit1[k]));
+        }
         const size_t nb = sizeof(double) * (size_t)n;
         if (fn->x_on_device)
         {
@@ -200,8 +214,13 @@ struct DenseFit : DenseBase
             hipEventDestroy(ev0);
         if (ev1)
             hipEventDestroy(ev1);
-        if (ev_chunk)
-            hipEventDestroy(ev_chunk);
+        for (int k = 0; k < EV_RING; ++k)
+        {
+            if (ev_fit0[k])
+                hipEventDestroy(ev_fit0[k]);
+            if (ev_fit1[k])
+                hipEventDestroy(ev_fit1[k]);
+        }
         if (stream)
             hipStreamDestroy(stream);
     }
@@ -307,6 +326,36 @@ struct DenseFit : DenseBase
         return GSLNLS_SUCCESS;
     }
 
+    // read back one slot of the ring (waits for the fit's trailing launches if they have not drained yet)
+    void collect_fit_events(int slot)
+    {
+        if (!ev_pending[slot])
+            return;
+        float ms = 0.f;
+        if (hipEventSynchronize(ev_fit1[slot]) == hipSuccess &&
+            hipEventElapsedTime(&ms, ev_fit0[slot], ev_fit1[slot]) == hipSuccess)
+        {
+            ev_ms_total += ms;
+            ev_launches_total += ev_launches[slot];
+        }
+        ev_pending[slot] = false;
+    }
+    int loop_event_stats(double *ms_total, long long *launches_total, int reset) override
+    {
+        for (int k = 0; k < EV_RING; ++k)
+            collect_fit_events(k);
+        if (ms_total)
+            *ms_total = ev_ms_total;
+        if (launches_total)
+            *launches_total = ev_launches_total;
+        if (reset)
+        {
+            ev_ms_total = 0.0;
+            ev_launches_total = 0;
+        }
+        return 0;
+    }
+
     // device-resident LM loop from `start` with the current ctx (prm, sw, traces); on return the final
     // state is in h_state[0] (written by the device through the mapped mirror) and in ctx.state[last_parity]
     int run_loop(int jacmode, const double *start, const double *lupars, int chunk)
@@ -318,7 +367,10 @@ struct DenseFit : DenseBase
             GSLNLS_HIP_OK(hipMemsetAsync(d_ssrtrace, 0xFF, sizeof(double) * (maxiter + 1), stream));
             GSLNLS_HIP_OK(hipMemsetAsync(d_partrace, 0xFF, sizeof(double) * (size_t)(maxiter + 1) * P, stream));
         }
+        ev_head = (ev_head + 1) % EV_RING;
+        collect_fit_events(ev_head); // the slot's previous tenant finished EV_RING fits ago: no wait in practice
         const double t_begin = now_s();
+        hipEventRecord(ev_fit0[ev_head], stream);
         ctx.seq += 1; // this fit's sequence number (0 is never used)
         // brand-new state is built on device in slot 1; the first step launch has parity 0 and reads slot 1
         {
@@ -349,6 +401,8 @@ struct DenseFit : DenseBase
             // the device stamps the fit's sequence number into pinned host memory when it ends; poll that word
             // (bounded) instead of draining the stream, so trailing launches overlap with the caller
             bool done = false;
+            // (the same event closes the fit's timing interval: re-recorded after every chunk, the last one counts)
+            hipEvent_t ev_chunk = ev_fit1[ev_head];
             hipEventRecord(ev_chunk, stream);
             for (;;)
             {
@@ -375,6 +429,8 @@ struct DenseFit : DenseBase
             }
         }
         __sync_synchronize();
+        ev_pending[ev_head] = true;
+        ev_launches[ev_head] = launches;
         last_ms = (float)(1e3 * (now_s() - t_begin));
         last_parity = parity ^ 1;
         last_launches = launches;

@@ -101,7 +101,8 @@ typedef struct gslnls_result
     /* multi-start bookkeeping (not part of the R list; exposed for tests) */
     int mstart_nsp, mstart_nwsp, mstart_iters, mstart_stop;
     double mstart_ssropt;
-    /* device-side timing of the solve loop, milliseconds (HIP events on the library's stream) */
+    /* host wall clock of the solve loop, milliseconds: first launch enqueued ... completion word seen (the device
+     * time of the same loop, by HIP events, accumulates in gslnls_dense_loop_event_stats) */
     float loop_ms;
     int n_launches;   /* step-kernel launches issued for this call */
 } gslnls_result;
@@ -148,6 +149,11 @@ int gslnls_dense_solve(gslnls_dense *h, int jac, int fvv, const double *start, c
 /* time `reps` back-to-back launches of the pass kernel at `theta` with HIP events on the
  * library's stream; returns average milliseconds per launch (negative on error) */
 float gslnls_dense_time_pass(gslnls_dense *h, int jac, const double *theta, int reps);
+/* Device time of the solve loops run on this handle since the last reset: every fit brackets its step launches with a
+ * pair of HIP events on the library's stream (first launch ... last launch of the last chunk, trailing launches
+ * included); the pairs sit in a ring and are read back when it wraps or when the totals are asked for, so that no fit
+ * waits for its own trailing launches.  ms_total / launches_total may be NULL. */
+int gslnls_dense_loop_event_stats(gslnls_dense *h, double *ms_total, long long *launches_total, int reset);
 /* swap the weights of a resident problem (IRLS) */
 /* Post-fit diagnostics on the resident data: hat values h_i = J_i (J^T J)^-1 J_i^T and Cook's distances
  * e_i^2 / (p s^2) * h_i / (1 - h_i)^2 at `par` (hat_values / cooks_d, src/nls_utils.c:88-150; the reference's S3 methods
