@@ -216,7 +216,7 @@ def main():
     ap.add_argument("--n", type=int, default=N_OBS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fd", action="store_true", help="forward finite-difference Jacobian instead of analytic")
-    ap.add_argument("--chunk", type=int, default=16)
+    ap.add_argument("--chunk", type=int, default=0, help="step launches per host check; 0 = library default (adaptive)")
     ap.add_argument("--headline-only", action="store_true", help="skip the C3 / C5 side measurements")
     args = ap.parse_args()
 

@@ -184,7 +184,8 @@ struct DenseFit : DenseBase
             GSLNLS_HIP_OK(hipHostGetDevicePointer(&dptr, h_state, 0));
             ctx.host_mirror = reinterpret_cast<LmState<P> *>(dptr);
             h_done = reinterpret_cast<volatile unsigned int *>(reinterpret_cast<char *>(h_state) + sizeof(LmState<P>) * 2);
-            *h_done = 0;
+            h_done[0] = 0;
+            h_done[1] = 0;
             ctx.done_seq = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(dptr) + sizeof(LmState<P>) * 2);
             ctx.seq = 0;
         }
@@ -243,13 +244,14 @@ struct DenseFit : DenseBase
     }
 
     // fresh: first launch of a fit -- the kernel builds the start state from ctx.sa instead of reading a previous one
-    void launch_step(int jacmode, int parity, bool fresh = false)
+    void launch_step(int jacmode, int parity, bool fresh = false, long long index = 0)
     {
         const dim3 grid(ctx.G), block(T);
-        if (fresh)
-            parity |= FRESH_LAUNCH;
         const LmState<P> *prev = ctx.state[parity ^ 1];
         const double *pp = ctx.partials[parity ^ 1];
+        if (fresh)
+            parity |= FRESH_LAUNCH;
+        parity |= (int)((index & 0x0fffffff) << 2);
         switch (jacmode)
         {
         case JAC_ANALYTIC:
@@ -295,6 +297,7 @@ struct DenseFit : DenseBase
     // ---- pieces of one fit -------------------------------------------------------------------
     int last_parity = 0;
     long long last_launches = 0;
+    int pred_kind = -1, pred_launches = 0; // launches the previous fit of this kind needed (adaptive first chunk)
     float last_ms = 0.f;
 
     int prepare(int jac, int fvv, const double *lupars, const int *ci, const double *cd, bool trace)
@@ -384,20 +387,33 @@ struct DenseFit : DenseBase
             h_state[0].phase = PH_INIT;
             ctx.sa = sa;
         }
-        if (chunk <= 0)
-            chunk = 16;
+        // Launches are enqueued in chunks and the completion word is polled between them; what is enqueued beyond the
+        // launch that ends the fit still runs (as ~2.7 us no-ops).  With the default chunking the first chunk is sized
+        // by the previous fit of the same kind on this handle (repeated fits -- IRLS re-solves, bootstrap, a benchmark
+        // loop -- end where the last one did), followed by small top-ups; an explicit chunk is taken as given.
+        const int kind = jacmode * 8 + ctx.prm.trs * 2 + (ctx.sw ? 1 : 0);
+        const bool adaptive = chunk <= 0;
+        int next_chunk = 16;
+        if (adaptive)
+        {
+            chunk = (pred_kind == kind && pred_launches > 0) ? pred_launches : 16;
+            next_chunk = (pred_kind == kind && pred_launches > 0) ? 4 : 16;
+        }
+        else
+            next_chunk = chunk;
         // upper bound on launches: every iteration may take 16 trials (x2 passes with acceleration) + init
-        const long long max_launches = ((long long)maxiter * 17 + 2) * (ctx.prm.trs ? 2 : 1) + chunk;
+        const long long max_launches = ((long long)maxiter * 17 + 2) * (ctx.prm.trs ? 2 : 1) + chunk + next_chunk;
         long long launches = 0;
         int parity = 0;
         for (;;)
         {
             for (int k = 0; k < chunk; ++k)
             {
-                launch_step(jacmode, parity, launches == 0 && k == 0);
+                launch_step(jacmode, parity, launches == 0 && k == 0, launches + k);
                 parity ^= 1;
             }
             launches += chunk;
+            chunk = next_chunk;
             // the device stamps the fit's sequence number into pinned host memory when it ends; poll that word
             // (bounded) instead of draining the stream, so trailing launches overlap with the caller
             bool done = false;
@@ -429,6 +445,10 @@ struct DenseFit : DenseBase
             }
         }
         __sync_synchronize();
+        pred_kind = kind;
+        pred_launches = (int)h_done[1] + 1;
+        if (pred_launches < 1 || pred_launches > 4096)
+            pred_launches = 0;
         ev_pending[ev_head] = true;
         ev_launches[ev_head] = launches;
         last_ms = (float)(1e3 * (now_s() - t_begin));

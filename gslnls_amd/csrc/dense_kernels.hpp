@@ -59,7 +59,7 @@ struct StartArgs
     double start[P];
     double lo[P], up[P];
 };
-constexpr int FRESH_LAUNCH = 2;
+constexpr int FRESH_LAUNCH = 2; // bits 2.. of the same argument: index of the launch within its fit
 
 template <int P>
 struct DenseCtx
@@ -275,6 +275,7 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
     constexpr int NX = M::NX;
     using Sums = PassSums<P>;
     const int parity = parity_and_flags & 1;
+    const unsigned int launch_idx = (unsigned int)parity_and_flags >> 2; // position of this launch in its fit
     const bool fresh_launch = (parity_and_flags & FRESH_LAUNCH) != 0; // first launch of a fit: no previous state
     constexpr int NV = Sums::NV;
     constexpr int NW = T / 64;
@@ -578,6 +579,8 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
             // final state to pinned host memory, then the fit's sequence number with system-scope
             // release: the host polls the sequence word and can return without draining the stream
             store_state(host_mirror);
+            if (advanced)
+                done_seq[1] = launch_idx; // the launch that ended the fit (the host sizes the next fit's first chunk by it)
             __threadfence_system();
             __hip_atomic_store(done_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
