@@ -262,9 +262,12 @@ def main():
     jac = 0 if args.fd else 1
     st = START.copy()
 
+    # argument pointers built once: numpy's .ctypes.data_as costs ~1 us per call, which is harness, not the path
+    st_p, ci_p, cd_p, res_p = st.ctypes.data_as(_lib.DP), ci.ctypes.data_as(_lib.IP), cd.ctypes.data_as(_lib.DP), C.byref(res)
+    solve = L.gslnls_dense_solve
+
     def one_fit():
-        rc = L.gslnls_dense_solve(h, jac, 0, st.ctypes.data_as(_lib.DP), None, ci.ctypes.data_as(_lib.IP),
-                                  cd.ctypes.data_as(_lib.DP), args.chunk, C.byref(res))
+        rc = solve(h, jac, 0, st_p, None, ci_p, cd_p, args.chunk, res_p)
         if rc != 0:
             raise SystemExit("fit failed: %s" % _lib.strerror(rc))
         return res.niter, res.n_launches, res.loop_ms, res.neval[0] + res.neval[1]
