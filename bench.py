@@ -92,10 +92,13 @@ def multistart_bench(L, _lib, torch, dist, rank, world, steps, warmup):
         ms = C.c_float(0)
         kms = []
 
+        # argument pointers built once (numpy's .ctypes.data_as costs ~1 us per call: harness, not the path)
+        rg_p, kd_p, ci_p, cd_p = (ranges.ctypes.data_as(_lib.DP), kd.ctypes.data_as(_lib.DP), ci.ctypes.data_as(_lib.IP),
+                                  cd.ctypes.data_as(_lib.DP))
+        out_p, ms_p = C.c_void_p(shard.data_ptr()), C.byref(ms)
+
         def step():
-            rc = L.gslnls_mstart_batch(h, 1, ranges.ctypes.data_as(_lib.DP), kd.ctypes.data_as(_lib.DP), 0, total,
-                                       lo, hi, 5, 1e-6, ci.ctypes.data_as(_lib.IP), cd.ctypes.data_as(_lib.DP), None,
-                                       C.c_void_p(shard.data_ptr()), 1, C.byref(ms))
+            rc = L.gslnls_mstart_batch(h, 1, rg_p, kd_p, 0, total, lo, hi, 5, 1e-6, ci_p, cd_p, None, out_p, 1, ms_p)
             if rc != 0:
                 raise SystemExit("mstart batch failed: %d" % rc)
             kms.append(ms.value)

@@ -46,6 +46,7 @@ struct MsBatch
     int maxiter = 0;
     double dtol = 0.0;
     int always_fit = 0;
+    int consecutive = -1;            // 1: draw[i] == draw[0] + i is known to hold, 0: known not to, -1: look
     std::vector<double> records;     // count x K, filled by the evaluator (+ all-gather)
 };
 
