@@ -123,6 +123,8 @@ GSLNLS_HD int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 template <int P>
 GSLNLS_HD void lm_solve(const double *Ap, const double *diag, double mu, const double *rhs, double *sol)
 {
+    // only the lower triangle M[i][j], j <= i, is kept (the matrix is symmetric and stays so): no mirrored copies
+    // to maintain, and a symmetric interchange touches each stored element once
     double M[P][P];
     int perm[P];
 #pragma unroll
@@ -136,7 +138,6 @@ GSLNLS_HD void lm_solve(const double *Ap, const double *diag, double mu, const d
             if (i == j)
                 v += mu * diag[i] * diag[i];
             M[i][j] = v;
-            M[j][i] = v;
         }
     }
     double b[P];
@@ -174,24 +175,39 @@ GSLNLS_HD void lm_solve(const double *Ap, const double *diag, double mu, const d
                 q = i;
             }
         }
+        // symmetric interchange of rows/columns j and q (q > j), written for each candidate q = i with static
+        // indices; in the lower triangle:  (j,j) <-> (i,i);  (j,k) <-> (i,k) for k < j;  (k,j) <-> (i,k) for
+        // j < k < i;  (k,j) <-> (k,i) for k > i;  (i,j) stays
 #pragma unroll
         for (int i = j + 1; i < P; ++i)
         {
             if (i == q)
             {
-#pragma unroll
-                for (int c = 0; c < P; ++c)
                 {
-                    const double t = M[j][c];
-                    M[j][c] = M[i][c];
-                    M[i][c] = t;
+                    const double t = M[j][j];
+                    M[j][j] = M[i][i];
+                    M[i][i] = t;
                 }
 #pragma unroll
-                for (int c = 0; c < P; ++c)
+                for (int k = 0; k < j; ++k)
                 {
-                    const double t = M[c][j];
-                    M[c][j] = M[c][i];
-                    M[c][i] = t;
+                    const double t = M[j][k];
+                    M[j][k] = M[i][k];
+                    M[i][k] = t;
+                }
+#pragma unroll
+                for (int k = j + 1; k < i; ++k)
+                {
+                    const double t = M[k][j];
+                    M[k][j] = M[i][k];
+                    M[i][k] = t;
+                }
+#pragma unroll
+                for (int k = i + 1; k < P; ++k)
+                {
+                    const double t = M[k][j];
+                    M[k][j] = M[k][i];
+                    M[k][i] = t;
                 }
                 const double tb = b[j];
                 b[j] = b[i];
@@ -215,10 +231,7 @@ GSLNLS_HD void lm_solve(const double *Ap, const double *diag, double mu, const d
             const double vi = M[i][j];
 #pragma unroll
             for (int k = j + 1; k <= i; ++k)
-            {
                 M[i][k] -= ainv * vi * M[k][j];
-                M[k][i] = M[i][k];
-            }
         }
 #pragma unroll
         for (int i = j + 1; i < P; ++i)

@@ -257,3 +257,34 @@ def test_rows_beyond_the_prefetch_window(amd, gslref, jac):
     assert fit["conv"] == 0 and ref["conv"] == 0 and fit["niter"] == ref["niter"]
     assert _rel(fit["par"], ref["par"]) < 1e-6
     assert abs(fit["ssr"] - ref["ssr"]) <= 1e-10 * ref["ssr"]
+
+
+def test_chunking_and_event_timing_do_not_change_the_fit(amd):
+    """The host only decides how many step launches it enqueues ahead (explicit chunk, or the default sized by the
+    previous fit of the same kind on the handle) and brackets them with HIP events: results must be bit-identical
+    whatever the chunking, repeated default fits must stop enqueuing beyond the launch that ends the fit, and the
+    event totals must cover exactly the launches issued."""
+    import ctypes as C
+    from gslnls_amd import _lib
+    L = _lib.lib()
+    n = 50_000
+    x, y = c2_data(n)
+    ctrl = amd.gsl_nls_control(solver="cholesky", xtol=1.49e-8, gtol=1.49e-8)
+    prob = amd.DenseProblem(1, 3, x, y)
+    L.gslnls_dense_loop_event_stats(prob._h, None, None, 1)
+    fits = [prob.solve([1.0, 1.0, 0.0], jac=True, control=ctrl, want_vectors=False, chunk=c) for c in (3, 16, 64, 0, 0, 0)]
+    ms, nl = C.c_double(0.0), C.c_longlong(0)
+    assert L.gslnls_dense_loop_event_stats(prob._h, C.byref(ms), C.byref(nl), 0) == 0
+    prob.close()
+    ref = fits[0]
+    for f in fits[1:]:
+        assert np.array_equal(f["par"], ref["par"]) and f["ssr"] == ref["ssr"]
+        assert f["niter"] == ref["niter"] and f["neval"] == ref["neval"] and f["conv"] == 0
+    # with chunk = 3 the loop stops within 3 launches of the one that ended the fit: an upper bound on what is needed
+    needed_at_most = fits[0]["n_launches"]
+    assert fits[1]["n_launches"] == 16 * ((needed_at_most - 3) // 16 + 1) or fits[1]["n_launches"] >= needed_at_most - 2
+    # default chunking after a fit of the same kind: exactly the launches the previous one needed
+    assert fits[4]["n_launches"] == fits[5]["n_launches"] <= needed_at_most
+    assert fits[5]["n_launches"] >= needed_at_most - 2
+    assert nl.value == sum(f["n_launches"] for f in fits)
+    assert 0.0 < ms.value < 1e3
