@@ -66,3 +66,24 @@ def test_batch_shards_are_independent(amd):
     prob.close()
     assert np.array_equal(np.vstack([a["par"], b["par"]]), full["par"])
     assert np.array_equal(np.concatenate([a["irls_niter"], b["irls_niter"]]), full["irls_niter"])
+
+
+def test_c5_full_size_properties(amd):
+    """BASELINE configs[4] at full size (4096 data sets x n = 1e4, p = 8, bisquare): properties that need no CPU
+    reference -- every robust fit converges and recovers its generating parameters in spite of the 2 % outliers,
+    a data set fitted inside the full batch comes out bitwise as in a small batch of its own, and a second run
+    of the whole batch is bitwise identical."""
+    B, n = 4096, 10000
+    X, Y, TH = c5_data(B, n)
+    prob = amd.BatchProblem(4, 8, X, Y)
+    full = prob.irls(GAUSS1_START, loss="bisquare", jac=True, control=dict(solver="cholesky"))
+    again = prob.irls(GAUSS1_START, loss="bisquare", jac=True, control=dict(solver="cholesky"))
+    part = prob.irls(GAUSS1_START, loss="bisquare", jac=True, control=dict(solver="cholesky"), lo=1000, hi=1064)
+    prob.close()
+    assert int((full["conv"] == 0).sum()) == B and int((full["irls_status"] == 0).sum()) == B
+    assert np.array_equal(full["par"], again["par"]) and np.array_equal(full["irls_niter"], again["irls_niter"])
+    assert np.array_equal(part["par"], full["par"][1000:1064])
+    assert np.array_equal(part["sigma"], full["sigma"][1000:1064])
+    assert np.max(np.abs(full["par"] / TH - 1.0)) < 0.02
+    # sigma = 1.4826 median|r| of N(0, 2.5^2) noise with 2 % gross outliers
+    assert np.all(np.abs(full["sigma"] / 2.5 - 1.0) < 0.1)

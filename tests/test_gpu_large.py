@@ -110,3 +110,27 @@ def test_large_path_on_compiled_expressions(amd, nist, name, alg):
     assert np.all((err <= TOL) | (err <= 2e-5 * np.abs(tgt))), (fit["par"], tgt)
     dense = amd.gsl_nls(q["formula"], data=data, start=q["start"], jac=True, control=dict(solver="cholesky"))
     assert abs(fit["ssr"] - dense["ssr"]) <= 1e-7 * dense["ssr"]
+
+
+def test_c3_full_size_properties(amd):
+    """BASELINE configs[2] at full size (n = 1e7, p = 64, A = 5.12 GB resident): properties that need no CPU
+    reference -- the cgst fit recovers the generating parameters, a second run is bitwise identical (fixed-shape
+    reductions), and lm (full J^T J through the fp64 MFMA SYRK + host Cholesky) lands on the same optimum as the
+    matrix-free Steihaug-Toint path."""
+    n, p = 10_000_000, 64
+    A, y, th = glm_data(n, p)
+    prob = amd.LargeProblem(5, p, A, y)
+    del A
+    x0 = np.zeros(p)
+    a = prob.solve(x0, "cgst", want_resid=False)
+    b = prob.solve(x0, "cgst", want_resid=False)
+    c = prob.solve(x0, "lm", want_resid=False)
+    prob.close()
+    assert a["conv"] == 0 and c["conv"] == 0
+    assert np.array_equal(a["par"], b["par"]) and a["ssr"] == b["ssr"] and a["niter"] == b["niter"]
+    # y = f(theta*) (1 + 0.01 N(0,1)): the estimate sits within a few standard errors (~ 0.01 / sqrt(n / p)) of theta*
+    assert np.max(np.abs(a["par"] - th)) < 1e-3
+    assert np.max(np.abs(c["par"] - a["par"])) < 1e-6
+    assert abs(c["ssr"] - a["ssr"]) <= 1e-9 * a["ssr"]
+    # relative residual variance 0.01^2 on responses exp(a.theta) = O(1)
+    assert 0.5e-4 < a["ssr"] / n < 2e-4
