@@ -143,7 +143,9 @@ typedef struct gslnls_dense gslnls_dense;
 gslnls_dense *gslnls_dense_create(const gslnls_model *fn, const double *y, int n, const double *swts,
                                   int *err);
 void gslnls_dense_destroy(gslnls_dense *h);
-/* single-start solve (default loss) on resident data; chunk = step launches per host check (0 = default) */
+/* single-start solve (default loss) on resident data; chunk = step launches enqueued per host check of the
+ * device's completion word.  0 = default: 16, or -- after a fit of the same kind on this handle -- as many launches as
+ * that fit needed, then top-ups of 4 (launches enqueued beyond the one that ends a fit still run, as no-ops) */
 int gslnls_dense_solve(gslnls_dense *h, int jac, int fvv, const double *start, const double *lupars,
                        const int *control_int, const double *control_dbl, int chunk, gslnls_result *out);
 /* time `reps` back-to-back launches of the pass kernel at `theta` with HIP events on the
