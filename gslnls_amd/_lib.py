@@ -74,6 +74,7 @@ _SIGNATURES = {
     "gslnls_dense_create": (C.c_void_p, [C.POINTER(Model), C.c_void_p, C.c_int, C.c_void_p, IP]),
     "gslnls_dense_destroy": (None, [C.c_void_p]),
     "gslnls_dense_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, DP, DP, IP, DP, C.c_int, C.POINTER(Result)]),
+    "gslnls_trim_cache": (None, []),
     "gslnls_dense_time_pass": (C.c_float, [C.c_void_p, C.c_int, DP, C.c_int]),
     "gslnls_dense_loop_event_stats": (C.c_int, [C.c_void_p, DP, C.POINTER(C.c_longlong), C.c_int]),
     "gslnls_dense_set_swts": (C.c_int, [C.c_void_p, DP]),

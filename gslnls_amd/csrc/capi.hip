@@ -32,6 +32,13 @@ namespace gslnls
 DenseBase *make_dense_expr(const gslnls_model *fn, const double *y, int n, const double *swts, int *err); // vm_models.hip
 }
 
+// destroyed problems of the hand-written models are parked for the next create of the same model (dense_host.hpp)
+static void release_dense(DenseBase *b)
+{
+    if (b && !b->park())
+        delete b;
+}
+
 static DenseBase *make_dense(const gslnls_model *fn, const double *y, int n, const double *swts, int *err)
 {
     int ndev = 0;
@@ -50,7 +57,9 @@ static DenseBase *make_dense(const gslnls_model *fn, const double *y, int n, con
             *err = GSLNLS_EINVAL;                                   \
             return nullptr;                                         \
         }                                                           \
-        auto *d = new DenseFit<MODEL>();                            \
+        auto *d = fn->x_on_device ? nullptr : DenseFit<MODEL>::acquire(); \
+        if (!d)                                                     \
+            d = new DenseFit<MODEL>();                              \
         rc = d->init(fn, y, n, swts);                               \
         b = d;                                                      \
     }
@@ -208,7 +217,7 @@ void gslnls_dense_destroy(gslnls_dense *h)
 {
     if (h)
     {
-        delete h->impl;
+        release_dense(h->impl);
         delete h;
     }
 }
@@ -308,7 +317,7 @@ gslnls_large *gslnls_large_create(const gslnls_model *fn, const double *y, int n
     if (e != GSLNLS_SUCCESS || !h->ops)
     {
         delete h->ops;
-        delete h->dense;
+        release_dense(h->dense);
         delete h;
         return nullptr;
     }
@@ -320,7 +329,7 @@ void gslnls_large_destroy(gslnls_large *h)
     if (h)
     {
         delete h->ops;
-        delete h->dense;
+        release_dense(h->dense);
         delete h;
     }
 }
@@ -669,7 +678,7 @@ int gslnls_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv,
         rc = b->irls(jac, fvv, start, lupars, control_int, control_dbl, loss_rho, loss_cc, out);
     else
         rc = b->solve(jac, fvv, start, lupars, control_int, control_dbl, 0, out);
-    delete b;
+    release_dense(b);
     return rc;
 }
 
@@ -721,6 +730,14 @@ int gslnls_device_count(void)
     if (hipGetDeviceCount(&n) != hipSuccess)
         return 0;
     return n;
+}
+
+void gslnls_trim_cache(void)
+{
+    DenseFit<ModelExpDecay>::trim_pool();
+    DenseFit<ModelMisra1a>::trim_pool();
+    DenseFit<ModelGaussPeak>::trim_pool();
+    DenseFit<ModelGauss1>::trim_pool();
 }
 
 int gslnls_set_device(int ordinal)

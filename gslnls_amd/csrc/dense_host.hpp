@@ -74,6 +74,10 @@ struct DenseBase
                      int loss_rho, const double *loss_cc, gslnls_result *out) = 0;
     virtual float time_pass(int jac, const double *theta, int reps) = 0;
     virtual int loop_event_stats(double *ms_total, long long *launches_total, int reset) = 0;
+    // Give the object back instead of destroying it: true = it went into its type's pool of parked problems (stream,
+    // events, workspaces, pinned mirror, cached multi-start evaluator stay allocated for the next create of the same
+    // model), false = the caller deletes it.
+    virtual bool park() { return false; }
     virtual int set_swts(const double *swts) = 0;
     // the matrix-free operator of gsl_nls_large over this problem's resident data (large_host.hpp)
     virtual LargeOps *make_large_ops() = 0;
@@ -117,7 +121,7 @@ struct DenseFit : DenseBase
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // device time of the launch loops: one event pair per fit on the library's stream, read back lazily (at the
     // next fit or when the totals are asked for) so that no fit waits for its own trailing launches
-    static constexpr int EV_RING = 32;
+    static constexpr int EV_RING = 4;
     hipEvent_t ev_fit0[EV_RING] = {}, ev_fit1[EV_RING] = {};
     bool ev_pending[EV_RING] = {};
     long long ev_launches[EV_RING] = {};
@@ -125,44 +129,144 @@ struct DenseFit : DenseBase
     double ev_ms_total = 0.0;
     long long ev_launches_total = 0;
     MsEvaluator *ms_eval = nullptr; // cached batch evaluator (Sobol table, device buffers)
+    long long cap_rows = 0;         // rows the owned data buffers hold
+    bool sw_owned = false;
+    int device_ordinal = -1;
+
+    // One-shot calls (gslnls_nls == C_nls: create, fit, destroy) on small problems used to spend ~3 ms in
+    // hipMalloc / hipHostMalloc / hipFree / stream and event creation around a fit of ~0.1 ms.  A destroyed problem
+    // that owns its data is parked instead (at most POOL_MAX per model type and process) and the next create of
+    // that model re-binds it: data re-uploaded into the buffers it has (re-allocated only when they are too small).
+    static constexpr int POOL_MAX = 2;
+    static std::vector<DenseFit<M> *> &pool()
+    {
+        static std::vector<DenseFit<M> *> v;
+        return v;
+    }
+    static DenseFit<M> *acquire()
+    {
+        int dev = -1;
+        (void)hipGetDevice(&dev);
+        auto &v = pool();
+        for (size_t k = 0; k < v.size(); ++k)
+            if (v[k]->device_ordinal == dev)
+            {
+                DenseFit<M> *d = v[k];
+                v.erase(v.begin() + (long)k);
+                return d;
+            }
+        return nullptr;
+    }
+    bool park() override
+    {
+        if (M::ID >= 100 || !owns_data || !stream || (int)pool().size() >= POOL_MAX)
+            return false; // (expression models are created elsewhere and not re-bound)
+        (void)hipStreamSynchronize(stream); // trailing launches of the last fit
+        pool().push_back(this);
+        return true;
+    }
+    static void trim_pool()
+    {
+        for (DenseFit<M> *d : pool())
+            delete d;
+        pool().clear();
+    }
 
     int init(const gslnls_model *fn, const double *y, int n_, const double *swts)
     {
-        n = n_;
         p = P;
-        memset(&ctx, 0, sizeof(ctx));
-        GSLNLS_HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        GSLNLS_HIP_OK(hipEventCreate(&ev0));
-        GSLNLS_HIP_OK(hipEventCreate(&ev1));
-        for (int k = 0; k < EV_RING; ++k)
+        const bool first = (stream == nullptr);
+        if (first)
         {
-            GSLNLS_HIP_OK(hipEventCreate(&ev_fit0[k]));
-            GSLNLS_HIP_OK(hipEventCreate(&ev_fit1[k]));
+            memset(&ctx, 0, sizeof(ctx));
+            (void)hipGetDevice(&device_ordinal);
+            GSLNLS_HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+            GSLNLS_HIP_OK(hipEventCreate(&ev0));
+            GSLNLS_HIP_OK(hipEventCreate(&ev1));
+            for (int k = 0; k < EV_RING; ++k)
+            {
+                GSLNLS_HIP_OK(hipEventCreate(&ev_fit0[k]));
+                GSLNLS_HIP_OK(hipEventCreate(&ev_fit1[k]));
+            }
+            // sized for the largest grid: the buffers outlive the problem they were first created for
+            GSLNLS_HIP_OK(hipMalloc(&d_partials, sizeof(double) * 2 * NV * MAX_G));
+            GSLNLS_HIP_OK(hipMalloc(&d_state, sizeof(LmState<P>) * 2));
+            GSLNLS_HIP_OK(hipHostMalloc(&h_state, sizeof(LmState<P>) * 2 + 64, hipHostMallocMapped));
+            GSLNLS_HIP_OK(hipMalloc(&d_covar, sizeof(double) * P * P));
         }
+        else
+        {
+            // a parked problem: nothing of the previous tenant may leak into this one
+            for (int k = 0; k < EV_RING; ++k)
+                ev_pending[k] = false;
+            ev_ms_total = 0.0;
+            ev_launches_total = 0;
+            pred_kind = -1;
+            pred_launches = 0;
+            last_parity = 0;
+            last_launches = 0;
+            last_ms = 0.f;
+            if (n_ != n)
+            {
+                // result vectors are allocated on demand for the current n
+                hipFree(d_resid);
+                hipFree(d_grad);
+                d_resid = d_grad = nullptr;
+            }
+            const unsigned int keep_seq = ctx.seq; // the completion word keeps counting upwards
+            memset(&ctx, 0, sizeof(ctx));
+            ctx.seq = keep_seq;
+        }
+        n = n_;
         const size_t nb = sizeof(double) * (size_t)n;
         if (fn->x_on_device)
         {
+            if (owns_data)
+            {
+                hipFree(d_x);
+                hipFree(d_y);
+                hipFree(d_sw);
+                cap_rows = 0;
+                sw_owned = false;
+            }
+            owns_data = false;
             d_x = const_cast<double *>(fn->x);
             d_y = const_cast<double *>(y);
             d_sw = const_cast<double *>(swts);
         }
         else
         {
+            if (!owns_data || cap_rows < n)
+            {
+                if (owns_data)
+                {
+                    hipFree(d_x);
+                    hipFree(d_y);
+                    hipFree(d_sw);
+                }
+                d_x = d_y = d_sw = nullptr;
+                sw_owned = false;
+                GSLNLS_HIP_OK(hipMalloc(&d_x, nb * M::NX));
+                GSLNLS_HIP_OK(hipMalloc(&d_y, nb));
+                cap_rows = n;
+            }
             owns_data = true;
-            GSLNLS_HIP_OK(hipMalloc(&d_x, nb * M::NX));
-            GSLNLS_HIP_OK(hipMalloc(&d_y, nb));
             GSLNLS_HIP_OK(hipMemcpy(d_x, fn->x, nb * M::NX, hipMemcpyHostToDevice));
             GSLNLS_HIP_OK(hipMemcpy(d_y, y, nb, hipMemcpyHostToDevice));
             if (swts)
             {
-                GSLNLS_HIP_OK(hipMalloc(&d_sw, nb));
+                if (!sw_owned)
+                {
+                    GSLNLS_HIP_OK(hipMalloc(&d_sw, sizeof(double) * (size_t)cap_rows));
+                    sw_owned = true;
+                }
                 GSLNLS_HIP_OK(hipMemcpy(d_sw, swts, nb, hipMemcpyHostToDevice));
             }
         }
         for (int c = 0; c < M::NX; ++c)
             ctx.x[c] = d_x + (size_t)c * n;
         ctx.y = d_y;
-        ctx.sw = d_sw;
+        ctx.sw = swts ? d_sw : nullptr;
         ctx.n = n;
         // one workgroup per CU at most; fewer when the problem is small (>= 2 rows per thread)
         int G = (int)(((long long)n + 2LL * T - 1) / (2LL * T));
@@ -171,25 +275,23 @@ struct DenseFit : DenseBase
         if (G > MAX_G)
             G = MAX_G;
         ctx.G = G;
-        GSLNLS_HIP_OK(hipMalloc(&d_partials, sizeof(double) * 2 * NV * G));
-        GSLNLS_HIP_OK(hipMemset(d_partials, 0, sizeof(double) * 2 * NV * G));
         ctx.partials[0] = d_partials;
         ctx.partials[1] = d_partials + (size_t)NV * G;
-        GSLNLS_HIP_OK(hipMalloc(&d_state, sizeof(LmState<P>) * 2));
         ctx.state[0] = d_state;
         ctx.state[1] = d_state + 1;
-        GSLNLS_HIP_OK(hipHostMalloc(&h_state, sizeof(LmState<P>) * 2 + 64, hipHostMallocMapped));
         {
             void *dptr = nullptr;
             GSLNLS_HIP_OK(hipHostGetDevicePointer(&dptr, h_state, 0));
             ctx.host_mirror = reinterpret_cast<LmState<P> *>(dptr);
             h_done = reinterpret_cast<volatile unsigned int *>(reinterpret_cast<char *>(h_state) + sizeof(LmState<P>) * 2);
-            h_done[0] = 0;
-            h_done[1] = 0;
             ctx.done_seq = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(dptr) + sizeof(LmState<P>) * 2);
-            ctx.seq = 0;
+            if (first)
+            {
+                h_done[0] = 0;
+                h_done[1] = 0;
+                ctx.seq = 0;
+            }
         }
-        GSLNLS_HIP_OK(hipMalloc(&d_covar, sizeof(double) * P * P));
         return GSLNLS_SUCCESS;
     }
 
@@ -236,8 +338,11 @@ struct DenseFit : DenseBase
             ctx.sw = nullptr;
             return GSLNLS_SUCCESS;
         }
-        if (!d_sw)
-            GSLNLS_HIP_OK(hipMalloc(&d_sw, nb));
+        if (!sw_owned)
+        {
+            GSLNLS_HIP_OK(hipMalloc(&d_sw, sizeof(double) * (size_t)cap_rows));
+            sw_owned = true;
+        }
         GSLNLS_HIP_OK(hipMemcpy(d_sw, swts, nb, hipMemcpyHostToDevice));
         ctx.sw = d_sw;
         return GSLNLS_SUCCESS;

@@ -28,11 +28,18 @@ struct HipMsEvaluator : MsEvaluator
     float last_kernel_ms = 0.f;
     hipEvent_t e0 = nullptr, e1 = nullptr;
 
+    // settings of one call (the object itself -- Sobol table, staging buffers -- is kept by the problem)
+    void configure(const int *ci, const double *cd, int jac, int fvv, const double *lu)
+    {
+        lupars = lu;
+        prm = make_params(ci, cd, jac, fvv, lu != nullptr, fit.ctx.sw != nullptr);
+        jacmode = jac ? JAC_ANALYTIC : (ci[5] ? JAC_CENTER : JAC_FORWARD);
+    }
+
     HipMsEvaluator(DenseFit<M> &f, const int *ci, const double *cd, int jac, int fvv, const double *lu)
         : fit(f), lupars(lu)
     {
-        prm = make_params(ci, cd, jac, fvv, lu != nullptr, f.ctx.sw != nullptr);
-        jacmode = jac ? JAC_ANALYTIC : (ci[5] ? JAC_CENTER : JAC_FORWARD);
+        configure(ci, cd, jac, fvv, lu);
         SobolTable t;
         sobol_build(t, P);
         hipMalloc(&d_sobol, sizeof(SobolTable));
@@ -168,7 +175,11 @@ int DenseFit<M>::mstart(int jac, int fvv, const double *start2p, const double *l
         return GSLNLS_E_UNSUPPORTED;
     MsState m;
     ms_init(m, P, ci, cd, start2p, has_start, lupars);
-    HipMsEvaluator<M> ev(*this, ci, cd, jac, fvv, lupars);
+    if (!ms_eval)
+        ms_eval = new HipMsEvaluator<M>(*this, ci, cd, jac, fvv, lupars);
+    HipMsEvaluator<M> &ev = *static_cast<HipMsEvaluator<M> *>(ms_eval);
+    ev.configure(ci, cd, jac, fvv, lupars);
+    ev.batch_cache.consecutive = -1;
     int rc = ms_major_loop(m, ev, comm, start2p);
     if (rc)
         return rc < 0 && rc > -100 ? GSLNLS_FAILURE : rc;

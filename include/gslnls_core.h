@@ -143,6 +143,10 @@ typedef struct gslnls_dense gslnls_dense;
 gslnls_dense *gslnls_dense_create(const gslnls_model *fn, const double *y, int n, const double *swts,
                                   int *err);
 void gslnls_dense_destroy(gslnls_dense *h);
+/* Destroyed problems of the built-in models that own their data are parked (at most two per model and process) and
+ * re-bound by the next create of the same model -- a one-shot gslnls_nls() on a small problem is otherwise dominated by
+ * ~3 ms of device allocation around ~0.1 ms of fitting.  gslnls_trim_cache() frees what is parked. */
+void gslnls_trim_cache(void);
 /* single-start solve (default loss) on resident data; chunk = step launches enqueued per host check of the
  * device's completion word.  0 = default: 16, or -- after a fit of the same kind on this handle -- as many launches as
  * that fit needed, then top-ups of 4 (launches enqueued beyond the one that ends a fit still run, as no-ops) */

@@ -288,3 +288,42 @@ def test_chunking_and_event_timing_do_not_change_the_fit(amd):
     assert fits[5]["n_launches"] >= needed_at_most - 2
     assert nl.value == sum(f["n_launches"] for f in fits)
     assert 0.0 < ms.value < 1e3
+
+
+def test_parked_problems_rebind_cleanly(amd):
+    """gslnls_dense_destroy parks a problem of a built-in model and the next create of that model re-binds it (stream,
+    workspaces, pinned mirror, data buffers if large enough).  Nothing of the previous tenant may show: a sequence of
+    different problems through the pool (n growing and shrinking, weights appearing and disappearing, vectors requested
+    or not) must give bit-for-bit what each problem gives on a freshly allocated object."""
+    from gslnls_amd import _lib
+    L = _lib.lib()
+    ctrl = amd.gsl_nls_control(solver="cholesky")
+    rng = np.random.default_rng(5)
+    cases = []
+    for n, weighted in ((1000, False), (5000, True), (300, False), (5000, False), (301, True)):
+        x, y = c2_data(n)
+        w = rng.uniform(0.5, 2.0, n) if weighted else None
+        cases.append((x, y, w))
+
+    def run(case, want_vectors):
+        x, y, w = case
+        prob = amd.DenseProblem(1, 3, x, y, weights=w)
+        fit = prob.solve([1.0, 1.0, 0.0], jac=True, control=ctrl, want_vectors=want_vectors)
+        prob.close()
+        return fit
+
+    fresh = []
+    for k, c in enumerate(cases):
+        L.gslnls_trim_cache()  # nothing parked: a newly allocated object
+        fresh.append(run(c, k % 2 == 0))
+    L.gslnls_trim_cache()
+    for rep in range(2):
+        for k, c in enumerate(cases):
+            got = run(c, k % 2 == 0)
+            ref = fresh[k]
+            assert got["conv"] == ref["conv"] == 0 and got["niter"] == ref["niter"] and got["neval"] == ref["neval"]
+            assert np.array_equal(got["par"], ref["par"]) and got["ssr"] == ref["ssr"]
+            if k % 2 == 0:
+                assert np.array_equal(got["resid"], ref["resid"]) and np.array_equal(got["grad"], ref["grad"])
+                assert np.array_equal(got["covar"], ref["covar"])
+    L.gslnls_trim_cache()
