@@ -30,6 +30,7 @@ static MsComm g_comm;
 namespace gslnls
 {
 DenseBase *make_dense_expr(const gslnls_model *fn, const double *y, int n, const double *swts, int *err); // vm_models.hip
+void trim_dense_expr();                                                                                         // vm_models.hip
 }
 
 // destroyed problems of the hand-written models are parked for the next create of the same model (dense_host.hpp)
@@ -738,6 +739,9 @@ void gslnls_trim_cache(void)
     DenseFit<ModelMisra1a>::trim_pool();
     DenseFit<ModelGaussPeak>::trim_pool();
     DenseFit<ModelGauss1>::trim_pool();
+#ifndef GSLNLS_NO_EXPR
+    trim_dense_expr();
+#endif
 }
 
 int gslnls_set_device(int ordinal)

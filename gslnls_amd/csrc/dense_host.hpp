@@ -159,8 +159,8 @@ struct DenseFit : DenseBase
     }
     bool park() override
     {
-        if (M::ID >= 100 || !owns_data || !stream || (int)pool().size() >= POOL_MAX)
-            return false; // (expression models are created elsewhere and not re-bound)
+        if (M::ID > 100 || !owns_data || !stream || (int)pool().size() >= POOL_MAX)
+            return false; // (natively lowered expression models live in their own shared objects: not re-bound)
         (void)hipStreamSynchronize(stream); // trailing launches of the last fit
         pool().push_back(this);
         return true;

@@ -76,7 +76,11 @@ template <int P>
 static DenseBase *make_vm_impl(const VmProgram &prog, const gslnls_model *fn, const double *y, int n, const double *swts,
                           int *err)
 {
-    auto *d = new VmDenseFit<P>();
+    // interpreted expression problems are containers for any program with P parameters: parked ones are re-bound
+    // (every DenseFit<ModelVM<P>> that exists is a VmDenseFit<P>: they are only created here)
+    auto *d = fn->x_on_device ? nullptr : static_cast<VmDenseFit<P> *>(DenseFit<ModelVM<P>>::acquire());
+    if (!d)
+        d = new VmDenseFit<P>();
     d->prog = prog;
     // the expression always sees VM_NX regressor columns; pad the missing ones with zeros
     gslnls_model padded = *fn;
@@ -113,12 +117,22 @@ DenseBase *GSLNLS_CAT(make_vm_p, GSLNLS_VM_P)(const VmProgram &prog, const gslnl
     return make_vm_impl<GSLNLS_VM_P>(prog, fn, y, n, swts, err);
 }
 
+void GSLNLS_CAT(trim_vm_p, GSLNLS_VM_P)() { DenseFit<ModelVM<GSLNLS_VM_P>>::trim_pool(); }
+
 #else // dispatcher
 
 #define GSLNLS_VM_DECL(k)                                                                                              \
     DenseBase *make_vm_p##k(const VmProgram &, const gslnls_model *, const double *, int, const double *, int *);
 GSLNLS_VM_DECL(1) GSLNLS_VM_DECL(2) GSLNLS_VM_DECL(3) GSLNLS_VM_DECL(4) GSLNLS_VM_DECL(5) GSLNLS_VM_DECL(6)
 GSLNLS_VM_DECL(7) GSLNLS_VM_DECL(8) GSLNLS_VM_DECL(9)
+
+#define GSLNLS_VM_TRIM_DECL(k) void trim_vm_p##k();
+GSLNLS_VM_TRIM_DECL(1) GSLNLS_VM_TRIM_DECL(2) GSLNLS_VM_TRIM_DECL(3) GSLNLS_VM_TRIM_DECL(4) GSLNLS_VM_TRIM_DECL(5)
+GSLNLS_VM_TRIM_DECL(6) GSLNLS_VM_TRIM_DECL(7) GSLNLS_VM_TRIM_DECL(8) GSLNLS_VM_TRIM_DECL(9)
+void trim_dense_expr()
+{
+    trim_vm_p1(); trim_vm_p2(); trim_vm_p3(); trim_vm_p4(); trim_vm_p5(); trim_vm_p6(); trim_vm_p7(); trim_vm_p8(); trim_vm_p9();
+}
 
 DenseBase *make_dense_expr(const gslnls_model *fn, const double *y, int n, const double *swts, int *err)
 {

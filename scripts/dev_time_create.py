@@ -22,3 +22,9 @@ for kw in (dict(start=dict(b1=100.0, b2=0.75)), dict(start=dict(b1=[1.0, 500.0],
         t0 = time.perf_counter()
         fit = A.gsl_nls("y ~ b1*(1-exp(-b2*x))", data=d, jac=True, **kw)
         print("gsl_nls %s: %.3f ms conv %d" % ("single" if "control" not in kw else "mstart 8192", 1e3 * (time.perf_counter() - t0), fit["conv"]))
+# an expression (interpreted) model: the same one-shot call
+xx = np.linspace(0.0, 3.0, 200); yy = 5.0 * np.exp(-1.5 * xx) + 1.0 + 0.01 * np.sin(37.0 * xx)
+for rep in range(4):
+    t0 = time.perf_counter()
+    fit = A.gsl_nls("y ~ A * exp(-lam * x) + b + 0 * x", data=dict(x=xx, y=yy), start=dict(A=1.0, lam=1.0, b=0.0), lowering="vm")
+    print("gsl_nls interpreted expression: %.3f ms conv %d" % (1e3 * (time.perf_counter() - t0), fit["conv"]))
