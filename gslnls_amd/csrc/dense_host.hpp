@@ -129,6 +129,8 @@ struct DenseFit : DenseBase
     double ev_ms_total = 0.0;
     long long ev_launches_total = 0;
     MsEvaluator *ms_eval = nullptr; // cached batch evaluator (Sobol table, device buffers)
+    void *irls_arena = nullptr;     // work arrays of the robust re-weighting (irls_host.hpp), kept between calls
+    size_t irls_arena_bytes = 0;
     long long cap_rows = 0;         // rows the owned data buffers hold
     bool sw_owned = false;
     int device_ordinal = -1;
@@ -298,6 +300,7 @@ struct DenseFit : DenseBase
     ~DenseFit() override
     {
         delete ms_eval;
+        hipFree(irls_arena);
         if (owns_data)
         {
             hipFree(d_x);

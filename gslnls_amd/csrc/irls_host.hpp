@@ -40,29 +40,38 @@ int DenseFit<M>::irls(int jac, int fvv, const double *start, const double *lupar
     int nblk = (int)((n + TW - 1) / TW);
     if (nblk > 1024)
         nblk = 1024;
-    GSLNLS_HIP_OK(hipMalloc(&d_r, nb));
-    GSLNLS_HIP_OK(hipMalloc(&d_wt, nb));
-    GSLNLS_HIP_OK(hipMalloc(&d_psi, nb));
-    GSLNLS_HIP_OK(hipMalloc(&d_psip, nb));
-    GSLNLS_HIP_OK(hipMalloc(&d_swA, nb));
-    GSLNLS_HIP_OK(hipMalloc(&d_swB, nb));
-    GSLNLS_HIP_OK(hipMalloc(&d_keys, sizeof(unsigned long long) * (size_t)n));
-    GSLNLS_HIP_OK(hipMalloc(&d_part, sizeof(double) * nblk));
-    GSLNLS_HIP_OK(hipMalloc(&d_sel, sizeof(SelectState) * 2));
-    GSLNLS_HIP_OK(hipMalloc(&d_sc, sizeof(IrlsScalars)));
-    auto cleanup = [&]() {
-        hipFree(d_r);
-        hipFree(d_wt);
-        hipFree(d_psi);
-        hipFree(d_psip);
-        hipFree(d_swA);
-        hipFree(d_swB);
-        hipFree(d_keys);
-        hipFree(d_part);
-        hipFree(d_sel);
-        hipFree(d_sc);
-        ctx.sw = user_sw;
-    };
+    // one arena kept by the problem (and, through the pool of parked problems, by the next one-shot call): ten
+    // hipMalloc / hipFree pairs per robust fit cost ~3 ms, more than the fit of a small data set
+    {
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t need = 6 * up(nb) + up(sizeof(unsigned long long) * (size_t)n) + up(sizeof(double) * nblk) +
+                            up(sizeof(SelectState) * 2) + up(sizeof(IrlsScalars));
+        if (irls_arena_bytes < need)
+        {
+            hipFree(irls_arena);
+            irls_arena = nullptr;
+            irls_arena_bytes = 0;
+            GSLNLS_HIP_OK(hipMalloc(&irls_arena, need));
+            irls_arena_bytes = need;
+        }
+        char *q = static_cast<char *>(irls_arena);
+        auto take = [&](size_t b) {
+            char *r = q;
+            q += up(b);
+            return r;
+        };
+        d_r = reinterpret_cast<double *>(take(nb));
+        d_wt = reinterpret_cast<double *>(take(nb));
+        d_psi = reinterpret_cast<double *>(take(nb));
+        d_psip = reinterpret_cast<double *>(take(nb));
+        d_swA = reinterpret_cast<double *>(take(nb));
+        d_swB = reinterpret_cast<double *>(take(nb));
+        d_keys = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * (size_t)n));
+        d_part = reinterpret_cast<double *>(take(sizeof(double) * nblk));
+        d_sel = reinterpret_cast<SelectState *>(take(sizeof(SelectState) * 2));
+        d_sc = reinterpret_cast<IrlsScalars *>(take(sizeof(IrlsScalars)));
+    }
+    auto cleanup = [&]() { ctx.sw = user_sw; };
 
     // the solver always runs weighted under a robust loss (gsl_multifit_nlinear_winit, src/nls.c:542-543):
     // first solve with the user weights (or ones)

@@ -28,3 +28,8 @@ for rep in range(4):
     t0 = time.perf_counter()
     fit = A.gsl_nls("y ~ A * exp(-lam * x) + b + 0 * x", data=dict(x=xx, y=yy), start=dict(A=1.0, lam=1.0, b=0.0), lowering="vm")
     print("gsl_nls interpreted expression: %.3f ms conv %d" % (1e3 * (time.perf_counter() - t0), fit["conv"]))
+# robust (IRLS) one-shot call on a registered model
+for rep in range(4):
+    t0 = time.perf_counter()
+    fit = A.gsl_nls("y ~ A * exp(-lam * x) + b", data=dict(x=xx, y=yy), start=dict(A=1.0, lam=1.0, b=0.0), loss="huber", jac=True)
+    print("gsl_nls huber IRLS: %.3f ms conv %d irls_niter %s" % (1e3 * (time.perf_counter() - t0), fit["conv"], fit.get("irls", {}).get("irls_niter")))
