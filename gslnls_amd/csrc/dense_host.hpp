@@ -163,6 +163,8 @@ struct DenseFit : DenseBase
     {
         if (M::ID > 100 || !owns_data || !stream || (int)pool().size() >= POOL_MAX)
             return false; // (natively lowered expression models live in their own shared objects: not re-bound)
+        if ((size_t)cap_rows * (M::NX + 2) * sizeof(double) > ((size_t)256 << 20))
+            return false; // parking is for the small problems whose cost is allocation; big buffers go back at once
         (void)hipStreamSynchronize(stream); // trailing launches of the last fit
         pool().push_back(this);
         return true;
