@@ -71,7 +71,54 @@ GSLNLS_HD void ms_pass(const LmState<M::P> &s, const MsParams &mp, const RowSrc 
             acc_fj<P>(acc, f, Jrow);
         }
     };
-    if constexpr (RowSrc::STATIC_N > 0)
+    if constexpr (RowSrc::STATIC_N > 0 && RowSrc::LPF > 1)
+    {
+        // tiny data set in registers, LPF lanes per fit: lane `sub` of a group takes rows sub, sub + LPF, ... (every
+        // lane runs the same instructions on its own row of the step), then the groups add their sums up (lane
+        // exchange inside quads: every lane of a group ends with the same bits) and all of them run lm_advance
+        constexpr int LPF = RowSrc::LPF;
+#pragma unroll
+        for (int k = 0; k < RowSrc::STATIC_N / LPF; ++k)
+        {
+            if (k * LPF < mp.n)
+            {
+                double xr[M::NX], y = rows.y[k * LPF], sw = rows.sw[k * LPF];
+#pragma unroll
+                for (int c = 0; c < M::NX; ++c)
+                    xr[c] = rows.x[k * LPF][c];
+#pragma unroll
+                for (int t = 1; t < LPF; ++t)
+                {
+                    const bool mine = rows.sub == t;
+#pragma unroll
+                    for (int c = 0; c < M::NX; ++c)
+                        xr[c] = mine ? rows.x[k * LPF + t][c] : xr[c];
+                    y = mine ? rows.y[k * LPF + t] : y;
+                    sw = mine ? rows.sw[k * LPF + t] : sw;
+                }
+                // a row beyond n (odd n) is switched off through its weight, as in the grid-per-fit pass
+                const bool live = k * LPF + rows.sub < mp.n;
+                double Jrow[P];
+                if (s.phase == PH_FVV)
+                {
+                    double fv = row_fvv<M, JAC>(th, s.vel, delta, mp.prm.h_fvv, mp.prm.fvv_analytic != 0, xr, y,
+                                                live ? sw : 0.0, Jrow, &acc.badj);
+                    fv = live ? fv : 0.0;
+#pragma unroll
+                    for (int q = 0; q < P; ++q)
+                        acc.g[q] += Jrow[q] * fv;
+                }
+                else
+                {
+                    double f = row_fj<M, JAC>(th, delta, xr, y, live ? sw : 0.0, Jrow, &acc.badj);
+                    f = live ? f : 0.0;
+                    acc_fj<P>(acc, f, Jrow);
+                }
+            }
+        }
+        rows.combine(acc);
+    }
+    else if constexpr (RowSrc::STATIC_N > 0)
     {
         // tiny data sets held in registers: the loop is unrolled so that every row is a fixed register, and
         // the (uniform) row count only switches whole rows off

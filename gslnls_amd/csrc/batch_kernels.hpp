@@ -40,17 +40,45 @@ struct MsKernelArgs
 // rows of a tiny data set (BoxBOD: 6) in registers: the LDS round trip in front of every row is a third of a
 // pass when a row costs ~50 instructions
 constexpr int MS_REG_ROWS = 8;
-template <int NX>
+
+// lane exchange inside a quad (DPP quad_perm: a VALU move, no LDS)
+template <int CTRL>
+__device__ __forceinline__ double ms_dpp_mov(double v)
+{
+    const long long bits = __double_as_longlong(v);
+    int lo = (int)(bits & 0xffffffffll), hi = (int)(bits >> 32);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// LPF lanes (1, 2 or 4; groups are aligned inside quads) share one fit: see ms_pass
+template <int NX, int LPF_>
 struct RowsReg
 {
     static constexpr int STATIC_N = MS_REG_ROWS;
+    static constexpr int LPF = LPF_;
     double x[MS_REG_ROWS][NX], y[MS_REG_ROWS], sw[MS_REG_ROWS];
+    int sub; // this lane's place in its group
+    template <int P>
+    __device__ void combine(PassSums<P> &acc) const
+    {
+        double *v = reinterpret_cast<double *>(&acc);
+#pragma unroll
+        for (int k = 0; k < PassSums<P>::NV; ++k)
+        {
+            if (LPF >= 2)
+                v[k] += ms_dpp_mov<0xB1>(v[k]); // quad_perm [1,0,3,2]
+            if (LPF >= 4)
+                v[k] += ms_dpp_mov<0x4E>(v[k]); // quad_perm [2,3,0,1]
+        }
+    }
 };
 
 template <int NX>
 struct RowsLds
 {
-    static constexpr int STATIC_N = 0;
+    static constexpr int STATIC_N = 0, LPF = 1;
     const double *base;
     int n;
     __device__ void operator()(int i, double *xr, double &y, double &sw) const
@@ -66,7 +94,7 @@ struct RowsLds
 template <int NX>
 struct RowsGlobal
 {
-    static constexpr int STATIC_N = 0;
+    static constexpr int STATIC_N = 0, LPF = 1;
     const double *x[4];
     const double *y;
     const double *sw;
@@ -80,7 +108,8 @@ struct RowsGlobal
     }
 };
 
-template <class M, int JAC>
+// LPF > 1 (small batches of tiny data sets, chosen by the host): LPF lanes per fit, the workgroup covers MS_T / LPF points
+template <class M, int JAC, int LPF = 1>
 __global__ __launch_bounds__(MS_T) void ms_fit_kernel(MsKernelArgs<M::P> a)
 {
     constexpr int P = M::P, NX = M::NX;
@@ -109,9 +138,9 @@ __global__ __launch_bounds__(MS_T) void ms_fit_kernel(MsKernelArgs<M::P> a)
             lds_sobol[e / P][e % P] = a.sobol->v[e / P][e % P];
         __syncthreads();
     }
-    const int idx = a.lo + blockIdx.x * MS_T + threadIdx.x;
+    const int idx = a.lo + (blockIdx.x * MS_T + threadIdx.x) / LPF;
     if (idx >= a.hi)
-        return;
+        return; // (whole groups: idx is the same for the LPF lanes of a group)
     double start[P];
     const long long d = a.draw ? a.draw[idx] : a.first_draw + idx;
 #pragma unroll
@@ -142,7 +171,8 @@ __global__ __launch_bounds__(MS_T) void ms_fit_kernel(MsKernelArgs<M::P> a)
     MsRecord<P> rec;
     if (staged && n <= MS_REG_ROWS)
     {
-        RowsReg<NX> rows;
+        RowsReg<NX, LPF> rows;
+        rows.sub = threadIdx.x % LPF;
 #pragma unroll
         for (int i = 0; i < MS_REG_ROWS; ++i)
         {
@@ -170,6 +200,8 @@ __global__ __launch_bounds__(MS_T) void ms_fit_kernel(MsKernelArgs<M::P> a)
         rows.sw = a.sw;
         ms_fit_point<M, JAC>(a.mp, rows, start, a.has_lu ? a.lu : nullptr, rec);
     }
+    if (LPF > 1 && threadIdx.x % LPF != 0)
+        return; // every lane of the group holds the same record
     double *out = a.records + (size_t)idx * MsRecord<P>::K;
     const double *src = reinterpret_cast<const double *>(&rec);
 #pragma unroll

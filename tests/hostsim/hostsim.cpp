@@ -165,7 +165,7 @@ extern "C" void hostsim_lm_solve8(const double *Ap, const double *diag, double m
 template <int NX>
 struct RowsHost
 {
-    static constexpr int STATIC_N = 0;
+    static constexpr int STATIC_N = 0, LPF = 1;
     const double *x, *y, *sw;
     int n;
     void operator()(int i, double *xr, double &yy, double &w) const
