@@ -94,3 +94,49 @@ def test_c4_full_multistart_matches_oracle(amd, gslref, nist):
     assert (m["nsp"], m["nwsp"], m["iters"], m["stop"]) == (mo["nsp"], mo["nwsp"], mo["iters"], mo["stop"])
     assert abs(m["ssropt"] - mo["ssropt"]) <= 1e-7 * mo["ssropt"]
     assert np.max(np.abs(fit["par"] - o["par"]) / np.abs(o["par"])) < 1e-6
+
+
+def test_lanes_per_fit_do_not_change_the_records(amd, nist):
+    """Small batches of tiny data sets run two or four lanes per fit (rows split over the lanes of a group, sums
+    exchanged inside quads), large ones one lane per fit: the first 8192 draws fitted in a batch of 8192 (four lanes),
+    of 20000 (two lanes) and of 40000 (one lane) must tell the same story -- same det-filter decisions, iteration
+    counts and status codes, end points equal up to what the re-association of six-term sums grows to in five
+    iterations."""
+    from gslnls_amd import _lib
+    from gslnls_amd.control import gsl_nls_control, pack_control
+    q, x, y, tgt = _boxbod(nist)
+    ci, cd = pack_control(gsl_nls_control(solver="cholesky"), "lm")
+    prob = amd.DenseProblem(2, 2, x, y)
+    ranges = np.array([1.0, 500.0, 0.01, 5.0])
+    kd = np.array([0.75, 0.75])
+    K = _lib.lib().gslnls_mstart_record_size(2)
+    recs = []
+    for N in (8192, 20000, 40000):
+        rec = np.zeros((N, K))
+        ms = C.c_float(0)
+        for jac in (1, 0):
+            rc = _lib.lib().gslnls_mstart_batch(prob._h, jac, ranges.ctypes.data_as(_lib.DP), kd.ctypes.data_as(_lib.DP), 0,
+                                                N, 0, N, 5, 1e-6, ci.ctypes.data_as(_lib.IP), cd.ctypes.data_as(_lib.DP),
+                                                None, rec.ctypes.data_as(C.c_void_p), 0, C.byref(ms))
+            assert rc == 0
+            recs.append(rec[:8192].copy())
+    prob.close()
+    for jac in (0, 1):
+        four, two, one = recs[jac], recs[2 + jac], recs[4 + jac]
+        for other in (four, two):
+            assert np.array_equal(other[:, 4:6], one[:, 4:6])                    # the sampled points themselves
+            assert np.array_equal(other[:, 8] > 1e-6, one[:, 8] > 1e-6)          # det filter
+            assert np.array_equal(other[:, 11], one[:, 11]) and np.array_equal(other[:, 12], one[:, 12])
+            sel = (one[:, 8] > 1e-6) & np.isfinite(one[:, 7])
+            if jac == 0:
+                # recs[0::2] are the analytic-Jacobian runs: re-associated six-term sums, nothing else (measured 2e-12)
+                assert np.allclose(other[sel, 0:2], one[sel, 0:2], rtol=1e-9, atol=1e-12)
+                assert np.allclose(other[sel, 7], one[sel, 7], rtol=1e-9)
+            else:
+                # forward differences turn a last-bit change of a trial point into a ~1e-9 relative change of the
+                # Jacobian (rounding noise eps f / delta is not smooth in the point), and five iterations from a random
+                # start grow that to ~1e-4 for a few dozen of the 8192 points -- for any evaluation order, the
+                # reference's included; iteration counts and status codes above are unaffected
+                assert np.allclose(other[sel, 0:2], one[sel, 0:2], rtol=2e-3, atol=1e-9)
+                assert np.allclose(other[sel, 7], one[sel, 7], rtol=2e-3)
+                assert np.sum(np.abs(other[sel, 7] / one[sel, 7] - 1.0) > 1e-6) < 200
