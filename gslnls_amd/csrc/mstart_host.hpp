@@ -134,9 +134,10 @@ struct HipMsEvaluator : MsEvaluator
         // A batch that leaves most SIMDs empty anyway runs two or four lanes per fit when the data set sits in
         // registers: its duration is the latency of the slowest fit, and the pass over the rows is split between the
         // lanes of a group (8192 BoxBOD points, 5 iterations: 43.9 us with one lane, 37.4 with two, 36.3 with four).
-        // (not instantiated for natively lowered expression models, M::ID == 101: every extra instantiation is
-        // seconds of hipcc in front of the first fit)
-        constexpr bool MULTI_LANE = M::ID <= 100;
+        // (hand-written models only: for the expression models every extra instantiation is seconds of hipcc -- in
+        // front of the first fit of a natively lowered formula, and minutes over the nine interpreter units of the
+        // library build)
+        constexpr bool MULTI_LANE = M::ID < 100;
         int lpf = 1;
         if (MULTI_LANE && fit.n <= MS_REG_ROWS)
         {
