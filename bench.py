@@ -211,6 +211,51 @@ def batch_irls_bench(_lib, rank, world, B=4096, n=10000):
             "irls_converged": int((out["irls_status"] == 0).sum()), "mean_irls_iterations": float(out["irls_niter"].mean())}
 
 
+def spawn_ranks(n_ranks):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this script (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would set), relay rank 0's one
+    JSON line, return the worst exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def plumbing_only(args):
+    """The launch path without a GPU: rendezvous, one all-gather of (rank, pid), barrier, one line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    ranks, pids = [rank], [os.getpid()]
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("GSLNLS_BENCH_BACKEND", "gloo"), rank=rank, world_size=world)
+        mine = torch.tensor([rank, os.getpid()], dtype=torch.int64)
+        allv = torch.zeros(2 * world, dtype=torch.int64)
+        dist.all_gather_into_tensor(allv, mine)
+        dist.barrier()
+        ranks, pids = [int(v) for v in allv[0::2]], [int(v) for v in allv[1::2]]
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"plumbing_only": True, "n_gpus": world, "gpus_flag": args.gpus, "ranks": ranks, "pids": pids,
+                          "steps": args.steps, "warmup": args.warmup}))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -221,7 +266,19 @@ def main():
     ap.add_argument("--fd", action="store_true", help="forward finite-difference Jacobian instead of analytic")
     ap.add_argument("--chunk", type=int, default=0, help="step launches per host check; 0 = library default (adaptive)")
     ap.add_argument("--headline-only", action="store_true", help="skip the C3 / C5 side measurements")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="GPU-free check of the N-rank launch: spawn, rendezvous, one all-gather of rank ids, one line")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # launched as plain `python bench.py --gpus N`: become a launcher.  Nothing in this process has touched the
+        # GPU (torch is not even imported yet); the ranks are fresh child processes, never a re-exec of this one.
+        raise SystemExit(spawn_ranks(args.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s: refusing to report an N-GPU line from a different "
+                         "number of ranks" % (args.gpus, os.environ.get("WORLD_SIZE")))
+    if args.plumbing_only:
+        raise SystemExit(plumbing_only(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -58,7 +58,8 @@ class Result(C.Structure):
                 ("irls_sigma", C.c_double), ("irls_tol", C.c_double), ("irls_status", C.c_int),
                 ("irls_niter", C.c_int), ("partrace", DP), ("ssrtrace", DP), ("mstart_nsp", C.c_int),
                 ("mstart_nwsp", C.c_int), ("mstart_iters", C.c_int), ("mstart_stop", C.c_int),
-                ("mstart_ssropt", C.c_double), ("loop_ms", C.c_float), ("n_launches", C.c_int)]
+                ("mstart_ssropt", C.c_double), ("loop_ms", C.c_float), ("n_launches", C.c_int),
+                ("jtj_cond", C.c_double)]
 
 
 class LargeResult(C.Structure):
@@ -71,6 +72,7 @@ class LargeResult(C.Structure):
 _SIGNATURES = {
     "gslnls_nls": (C.c_int, [C.POINTER(Model), C.c_void_p, C.c_int, C.c_int, C.c_int, DP, C.c_int, C.c_void_p,
                              C.c_int, DP, IP, DP, IP, C.c_int, DP, C.POINTER(Result)]),
+    "gslnls_solver_served": (C.c_int, [IP, C.POINTER(Result)]),
     "gslnls_dense_create": (C.c_void_p, [C.POINTER(Model), C.c_void_p, C.c_int, C.c_void_p, IP]),
     "gslnls_dense_destroy": (None, [C.c_void_p]),
     "gslnls_dense_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, DP, DP, IP, DP, C.c_int, C.POINTER(Result)]),

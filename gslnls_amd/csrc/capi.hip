@@ -683,6 +683,15 @@ int gslnls_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv,
     return rc;
 }
 
+int gslnls_solver_served(const int *control_int, const gslnls_result *res)
+{
+    if (!control_int || !res)
+        return 0;
+    if (control_int[4] == 1)
+        return 1; // cholesky: exactly what the device path does
+    return (res->jtj_cond <= GSLNLS_COND_LIMIT) ? 1 : 0; // qr / svd: NaN (failed fit) compares false
+}
+
 const char *gslnls_strerror(int code)
 {
     switch (code)

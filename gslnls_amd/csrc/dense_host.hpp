@@ -62,6 +62,62 @@ inline LmParams make_params(const int *ci, const double *cd, int jac, int fvv, b
     return prm;
 }
 
+// 2-norm condition number of C = S A S, S = diag(A)^-1/2, A the packed lower triangle of J^T J at the final point:
+// cyclic Jacobi rotations on the p x p matrix (p <= 12).  A diagnostic of the boundary (gslnls_result::jtj_cond,
+// gslnls_solver_served), not a step of the algorithm.
+inline double scaled_jtj_cond(const double *Ap, int P)
+{
+    std::vector<double> C((size_t)P * P);
+    for (int i = 0; i < P; ++i)
+        for (int j = 0; j <= i; ++j)
+        {
+            const double di = Ap[i * (i + 1) / 2 + i], dj = Ap[j * (j + 1) / 2 + j];
+            if (!(di > 0.0) || !(dj > 0.0) || !std::isfinite(di) || !std::isfinite(dj))
+                return INFINITY; // a zero column: singular
+            const double v = Ap[i * (i + 1) / 2 + j] / (sqrt(di) * sqrt(dj));
+            C[(size_t)i * P + j] = C[(size_t)j * P + i] = v;
+        }
+    for (int sweep = 0; sweep < 60; ++sweep)
+    {
+        double off = 0.0;
+        for (int i = 0; i < P; ++i)
+            for (int j = 0; j < i; ++j)
+                off += C[(size_t)i * P + j] * C[(size_t)i * P + j];
+        if (off < 1e-30)
+            break;
+        for (int q = 1; q < P; ++q)
+            for (int r = 0; r < q; ++r)
+            {
+                const double apq = C[(size_t)q * P + r];
+                if (apq == 0.0)
+                    continue;
+                const double theta = (C[(size_t)q * P + q] - C[(size_t)r * P + r]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < P; ++k)
+                {
+                    const double akr = C[(size_t)k * P + r], akq = C[(size_t)k * P + q];
+                    C[(size_t)k * P + r] = c * akr - sn * akq;
+                    C[(size_t)k * P + q] = sn * akr + c * akq;
+                }
+                for (int k = 0; k < P; ++k)
+                {
+                    const double ark = C[(size_t)r * P + k], aqk = C[(size_t)q * P + k];
+                    C[(size_t)r * P + k] = c * ark - sn * aqk;
+                    C[(size_t)q * P + k] = sn * ark + c * aqk;
+                }
+            }
+    }
+    double emin = INFINITY, emax = 0.0;
+    for (int i = 0; i < P; ++i)
+    {
+        const double e = C[(size_t)i * P + i];
+        emin = fmin(emin, e);
+        emax = fmax(emax, e);
+    }
+    return (emin > 0.0) ? emax / emin : INFINITY;
+}
+
 struct LargeOps; // large_host.hpp
 
 struct DenseBase
@@ -627,6 +683,7 @@ struct DenseFit : DenseBase
         out->chisq_init = s.chisq_init;
         out->loop_ms = last_ms;
         out->n_launches = (int)last_launches;
+        out->jtj_cond = ok ? scaled_jtj_cond(s.A, P) : NAN;
         return s.status;
     }
 

@@ -192,6 +192,7 @@ def _finish(out, res, trace, algorithm, n):
                algorithm=_lib.lib().gslnls_algorithm_name(ALGORITHMS.index(algorithm)).decode(),
                neval=dict(f=res.neval[0], J=res.neval[1], fvv=res.neval[2]), info=res.info,
                chisq_init=res.chisq_init, loop_ms=res.loop_ms, n_launches=res.n_launches, n=n,
+               jtj_cond=res.jtj_cond,
                irls=dict(irls_sigma=res.irls_sigma, irls_tol=res.irls_tol, irls_status=res.irls_status,
                          irls_niter=res.irls_niter, irls_conv=res.irls_status),
                mstart=dict(nsp=res.mstart_nsp, nwsp=res.mstart_nwsp, iters=res.mstart_iters,
@@ -324,6 +325,15 @@ def gsl_nls(fn, data=None, start=None, algorithm="lm", control=None, jac=None, f
                                LOSSES.index(loss_cfg["rho"]), _dp(cc), C.byref(res))
     _lib.check(rc)
     fit = _finish(out, res, trace, algorithm, n)
+    # solver routing rule of the boundary (include/gslnls_core.h): a "qr" / "svd" request is served on the normal
+    # equations only while the scaled condition number allows it; the R shim re-runs such a fit through GSL, this
+    # mirror has no GSL to fall back to and says so
+    fit["solver_served"] = bool(_lib.lib().gslnls_solver_served(ci.ctypes.data_as(IP), C.byref(res)))
+    if not fit["solver_served"] and res.conv in (0, 11):
+        import warnings
+        warnings.warn("solver=%r requested but kappa(S J'J S) = %.3g exceeds %.0e: the normal-equations result may "
+                      "carry fewer than 6 digits (the R binding falls through to GSL here)"
+                      % (ctrl["solver"], res.jtj_cond, 1e10))
     # back to the caller's parameter order
     fit["par"] = fit["par"][inv]
     fit["covar"] = np.asarray(fit["covar"])[np.ix_(inv, inv)]

@@ -105,7 +105,20 @@ typedef struct gslnls_result
      * time of the same loop, by HIP events, accumulates in gslnls_dense_loop_event_stats) */
     float loop_ms;
     int n_launches;   /* step-kernel launches issued for this call */
+    /* 2-norm condition number of the column-scaled normal matrix C = S J^T J S, S = diag(J^T J)^-1/2, at the final
+     * point (NaN when the fit failed).  The device path always solves the normal equations (control_int[4] ==
+     * cholesky in the reference's encoding, R/nls.R:1186); a caller that asked for "qr" or "svd" compares this with
+     * GSLNLS_COND_LIMIT and keeps its own QR path beyond it -- see gslnls_solver_served(). */
+    double jtj_cond;
 } gslnls_result;
+
+/* Solver routing rule of the boundary.  control_int[4]: 0 qr (the R default), 1 cholesky, 2 svd (R/nls.R:702).
+ * cholesky requests are always served.  qr / svd requests are served on the normal equations as long as
+ * kappa_2(C) <= GSLNLS_COND_LIMIT: the normal equations lose about log10(kappa(C))/2 more digits than a QR of J, so
+ * below 1e10 the coefficients keep >= 6 significant digits (the reference's own tests compare at eps^(1/4) = 1.22e-4).
+ * Beyond the limit gslnls_solver_served() returns 0 and the R shim re-runs the fit through the unchanged GSL path. */
+#define GSLNLS_COND_LIMIT 1e10
+int gslnls_solver_served(const int *control_int, const gslnls_result *res);
 
 /*
  * gslnls_nls -- replaces C_nls (src/nls.c:54-813).

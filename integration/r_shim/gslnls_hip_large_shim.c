@@ -1,7 +1,8 @@
 /*
  * gslnls_hip_large_shim.c -- reference-side binding for .Call(C_nls_large, ...) (src/init.c:16,
  * src/nls_large.c:66-75): gsl_nls_large() with `fn` / `jac` R closures, the Jacobian dense or a Matrix-package
- * sparse matrix.  NOT compiled in this repository's image (no R.h).  A maintainer registers
+ * sparse matrix.  Not linked in this repository's image (no R); syntax-checked by build() against tests/r_stub/.
+ * A maintainer registers
  *     {"C_nls_large", (DL_FUNC) &C_nls_large_hip, 9}
  * in src/init.c in place of C_nls_large; algorithms other than lm / cgst fall through to the original.
  *
@@ -40,6 +41,7 @@ static SEXP named_par(const double *theta, shim_state *s)
 static int shim_f(const double *theta, int p, double *fval, int n, void *user)
 {
     shim_state *s = (shim_state *)user;
+    (void)p;
     SEXP par = PROTECT(named_par(theta, s));
     SEXP call = PROTECT(Rf_lang2(s->fn, par));
     SEXP val = PROTECT(Rf_eval(call, s->env));
@@ -67,6 +69,7 @@ static int dg_class(SEXP obj)
 static int shim_jac(const double *theta, int p, gslnls_sparse *J, void *user)
 {
     shim_state *s = (shim_state *)user;
+    (void)p;
     SEXP par = PROTECT(named_par(theta, s));
     SEXP call = PROTECT(Rf_lang2(s->jac, par));
     SEXP val = PROTECT(Rf_eval(call, s->env));
@@ -135,9 +138,13 @@ SEXP C_nls_large_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, 
         return C_nls_large(fn, y, jac, fvv, env, start, weights, control_int, control_dbl);
     }
     const int maxiter = INTEGER(control_int)[0], verbose = INTEGER(control_int)[1];
-    /* result list of src/nls_large.c:275-416: par, covar, resid, grad (NULL here: J is never densified), niter,
-     * status, conv, ssr, ssrtol, algorithm, neval [, partrace, ssrtrace] */
-    SEXP ans = PROTECT(Rf_allocVector(VECSXP, verbose ? 13 : 11));
+    /* result list of src/nls_large.c:275-416: par, covar, resid, grad, niter, status, conv, ssr, ssrtol, algorithm,
+     * neval [, partrace, ssrtrace] */
+    const char *nms13[] = {"par", "covar", "resid", "grad", "niter", "status", "conv", "ssr", "ssrtol", "algorithm",
+                           "neval", "partrace", "ssrtrace", ""};
+    const char *nms11[] = {"par", "covar", "resid", "grad", "niter", "status", "conv", "ssr", "ssrtol", "algorithm",
+                           "neval", ""};
+    SEXP ans = PROTECT(Rf_mkNamed(VECSXP, verbose ? nms13 : nms11));
     SEXP par = PROTECT(Rf_allocVector(REALSXP, p)), covar = PROTECT(Rf_allocMatrix(REALSXP, p, p)),
          resid = PROTECT(Rf_allocVector(REALSXP, n));
     gslnls_large_result out;
@@ -146,9 +153,11 @@ SEXP C_nls_large_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, 
     out.covar = REAL(covar);
     out.resid = REAL(resid);
     int nprot = 5;
+    SEXP pt = R_NilValue;
     if (verbose)
     {
-        SEXP pt = PROTECT(Rf_allocMatrix(REALSXP, maxiter + 1, p)), st = PROTECT(Rf_allocVector(REALSXP, maxiter + 1));
+        pt = PROTECT(Rf_allocMatrix(REALSXP, maxiter + 1, p));
+        SEXP st = PROTECT(Rf_allocVector(REALSXP, maxiter + 1));
         nprot += 2;
         out.partrace = REAL(pt);
         out.ssrtrace = REAL(st);
@@ -157,25 +166,75 @@ SEXP C_nls_large_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, 
     }
     const int rc = gslnls_large_solve(h, REAL(startvec), INTEGER(control_int), REAL(control_dbl), &out);
     gslnls_large_destroy(h);
-    R_ReleaseObject(s.keep);
     if (rc == GSLNLS_E_UNSUPPORTED || rc == GSLNLS_E_NODEVICE)
     {
+        R_ReleaseObject(s.keep);
         UNPROTECT(nprot);
         return C_nls_large(fn, y, jac, fvv, env, start, weights, control_int, control_dbl);
     }
+    const int ok = (out.conv == GSLNLS_SUCCESS || out.conv == GSLNLS_EMAXITER);
     Rf_setAttrib(par, R_NamesSymbol, s.parnames);
     SET_VECTOR_ELT(ans, 0, par);
+    if (!Rf_isNull(s.parnames))
+    {
+        SEXP dn = PROTECT(Rf_allocVector(VECSXP, 2)); /* src/nls_large.c:327-334 */
+        SET_VECTOR_ELT(dn, 0, s.parnames);
+        SET_VECTOR_ELT(dn, 1, s.parnames);
+        Rf_setAttrib(covar, R_DimNamesSymbol, dn);
+        UNPROTECT(1);
+    }
     SET_VECTOR_ELT(ans, 1, covar);
     SET_VECTOR_ELT(ans, 2, resid);
+    {
+        /* grad: the reference returns the dense n x p copy of the Jacobian it evaluated last (src/nls_large.c:353-384).
+         * The device never densifies J; the last Jacobian object the closure returned (evaluated at the last accepted
+         * point = the returned par) is still held, so R's own as.matrix() produces the same matrix. */
+        SEXP g = R_NilValue;
+        if (ok && s.keep != R_NilValue)
+            g = Rf_eval(Rf_lang2(Rf_install("as.matrix"), s.keep), R_BaseEnv);
+        g = PROTECT(g == R_NilValue ? Rf_allocMatrix(REALSXP, n, p) : Rf_coerceVector(g, REALSXP));
+        if (!ok || s.keep == R_NilValue)
+            for (size_t i = 0; i < (size_t)n * p; i++)
+                REAL(g)[i] = NA_REAL;
+        if (!Rf_isNull(s.parnames))
+        {
+            SEXP dn = PROTECT(Rf_allocVector(VECSXP, 2));
+            SET_VECTOR_ELT(dn, 1, s.parnames);
+            Rf_setAttrib(g, R_DimNamesSymbol, dn);
+            UNPROTECT(1);
+        }
+        SET_VECTOR_ELT(ans, 3, g);
+        UNPROTECT(1);
+    }
+    R_ReleaseObject(s.keep);
+    if (!ok)
+    {
+        for (int k = 0; k < p * p; k++)
+            REAL(covar)[k] = NA_REAL;
+        for (int i = 0; i < n; i++)
+            REAL(resid)[i] = NA_REAL;
+    }
     SET_VECTOR_ELT(ans, 4, Rf_ScalarInteger(out.niter));
     SET_VECTOR_ELT(ans, 5, Rf_mkString(gslnls_strerror(out.conv)));
     SET_VECTOR_ELT(ans, 6, Rf_ScalarInteger(out.conv));
     SET_VECTOR_ELT(ans, 7, Rf_ScalarReal(out.ssr));
     SET_VECTOR_ELT(ans, 8, Rf_ScalarReal(out.ssrtol));
     SET_VECTOR_ELT(ans, 9, Rf_mkString(gslnls_algorithm_name(trs)));
-    SEXP neval = PROTECT(Rf_allocVector(INTSXP, 4));
-    memcpy(INTEGER(neval), out.neval, sizeof(int) * 4); /* f, dfu, df2, fvv: src/nls_large.c:395-401 */
-    SET_VECTOR_ELT(ans, 10, neval);
-    UNPROTECT(nprot + 1);
+    {
+        const char *en[] = {"f", "dfu", "df2", "fvv", ""}; /* src/nls_large.c:395-401 */
+        SEXP neval = PROTECT(Rf_mkNamed(INTSXP, en));
+        memcpy(INTEGER(neval), out.neval, sizeof(int) * 4);
+        SET_VECTOR_ELT(ans, 10, neval);
+        UNPROTECT(1);
+    }
+    if (verbose && !Rf_isNull(s.parnames))
+    {
+        SEXP dn = PROTECT(Rf_allocVector(VECSXP, 2));
+        SET_VECTOR_ELT(dn, 0, R_NilValue);
+        SET_VECTOR_ELT(dn, 1, s.parnames);
+        Rf_setAttrib(pt, R_DimNamesSymbol, dn);
+        UNPROTECT(1);
+    }
+    UNPROTECT(nprot);
     return ans;
 }

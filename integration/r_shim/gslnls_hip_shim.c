@@ -2,9 +2,10 @@
  * gslnls_hip_shim.c -- the reference-side binding: what a gslnls maintainer adds to src/ so
  * that .Call(C_nls, ...) runs on the MI355X core instead of GSL.
  *
- * NOT compiled in this repository's image (no R.h / Rinternals.h here).  It is the
- * complete translation unit a maintainer would drop next to src/nls.c and register in src/init.c
- * in place of C_nls:    {"C_nls", (DL_FUNC) &C_nls_hip, 12}
+ * Not linked in this repository's image (no R here); __graft_entry__.build() and
+ * tests/test_abi.py syntax-check it with gcc -fsyntax-only -Wall against the declaration-only R API
+ * stand-in under tests/r_stub/.  It is the complete translation unit a maintainer would drop next to
+ * src/nls.c and register in src/init.c in place of C_nls:    {"C_nls", (DL_FUNC) &C_nls_hip, 12}
  * Everything it does is SEXP <-> plain-pointer translation, in the order src/nls.c:66-263 unpacks
  * and src/nls.c:632-812 packs; no numerics.
  *
@@ -23,21 +24,70 @@ SEXP C_nls(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP swts,
 /* user interrupts (Ctrl-C) while the device loop runs: R_CheckUserInterrupt long-jumps, so it is probed under
  * R_ToplevelExec and reported to the core as a status; the core abandons the fit and C_nls_hip raises the error
  * after its own clean-up */
-static void probe_interrupt(void *dummy) { R_CheckUserInterrupt(); }
+static void probe_interrupt(void *dummy)
+{
+    (void)dummy;
+    R_CheckUserInterrupt();
+}
 static int interrupt_hook(void) { return R_ToplevelExec(probe_interrupt, NULL) == FALSE; }
 
-static SEXP deparse_rhs(SEXP fn)
+/* `formula` as the closure .fn sees it: .fn <- function(par, .data = mf) eval(formula[[3]], ...) is created inside
+ * gsl_nls.formula (R/nls.R:565), so its enclosure is that call's frame, which binds `formula` and `mf`.  Only that
+ * frame is searched (Rf_findVarInFrame): a plain `function` passed as fn must not pick up some unrelated `formula`
+ * further up its enclosing environments. */
+static SEXP closure_formula(SEXP fn)
 {
-    /* .fn <- function(par, .data = mf) eval(formula[[3]], ...)  (R/nls.R:565): the closure's
-     * environment holds `formula` and the model frame `mf` */
-    SEXP cloenv = CLOENV(fn);
-    SEXP formula = Rf_findVar(Rf_install("formula"), cloenv);
-    if (formula == R_UnboundValue || Rf_length(formula) < 3)
+    if (TYPEOF(fn) != CLOSXP)
         return R_NilValue;
+    SEXP formula = Rf_findVarInFrame(CLOENV(fn), Rf_install("formula"));
+    if (formula == R_UnboundValue || TYPEOF(formula) != LANGSXP || Rf_length(formula) < 3)
+        return R_NilValue;
+    return formula;
+}
+
+static SEXP deparse_rhs(SEXP formula)
+{
     SEXP call = PROTECT(Rf_lang2(Rf_install("deparse1"), Rf_lang2(Rf_install("quote"), CADDR(formula))));
     SEXP txt = PROTECT(Rf_eval(call, R_BaseEnv));
     UNPROTECT(2);
     return txt;
+}
+
+/* one data column by name: `mf` is a list (R/nls.R:481 as.list(mf), or the user's `data` list, :448) -- or, for
+ * robustness, an environment.  R_NilValue when the name is not a numeric column of length n. */
+static SEXP frame_column(SEXP mf, const char *name, int n)
+{
+    SEXP col = R_NilValue;
+    if (TYPEOF(mf) == ENVSXP)
+    {
+        col = Rf_findVarInFrame(mf, Rf_install(name));
+        if (col == R_UnboundValue)
+            col = R_NilValue;
+    }
+    else if (TYPEOF(mf) == VECSXP)
+    {
+        SEXP nms = Rf_getAttrib(mf, R_NamesSymbol);
+        for (int k = 0; !Rf_isNull(nms) && k < Rf_length(mf); k++)
+            if (!strcmp(CHAR(STRING_ELT(nms, k)), name))
+            {
+                col = VECTOR_ELT(mf, k);
+                break;
+            }
+    }
+    if (col == R_NilValue || !(TYPEOF(col) == REALSXP || TYPEOF(col) == INTSXP || TYPEOF(col) == LGLSXP) ||
+        Rf_length(col) != n)
+        return R_NilValue;
+    return col;
+}
+
+/* NA-filled REALSXP of length n (src/nls.c:774-780) */
+static SEXP na_vector(int n)
+{
+    SEXP v = PROTECT(Rf_allocVector(REALSXP, n));
+    for (int i = 0; i < n; i++)
+        REAL(v)[i] = NA_REAL;
+    UNPROTECT(1);
+    return v;
 }
 
 SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP swts, SEXP lupars,
@@ -51,7 +101,8 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
                            : Rf_getAttrib(start, R_NamesSymbol); /* src/nls.c:158-161 */
 
     /* ---- model lowering: formula RHS -> registry id, parameter order, data columns ---- */
-    SEXP rhs = deparse_rhs(fn);
+    SEXP formula = closure_formula(fn);
+    SEXP rhs = PROTECT(formula == R_NilValue ? R_NilValue : deparse_rhs(formula));
     const char *pn[64];
     int order[64];
     char cols[256];
@@ -68,8 +119,8 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
         /* not a hand-written device model: hand the expression itself to the core (GSLNLS_MODEL_EXPR), which
          * compiles it with its symbolic gradient -- the analogue of R/nls.R:565,588-599.  Data columns are the
          * variables of the RHS that are not parameters: all.vars(formula[[3]]) minus names(start). */
-        SEXP vars = PROTECT(Rf_eval(Rf_lang2(Rf_install("all.vars"), Rf_lang2(Rf_install("quote"),
-                            CADDR(Rf_findVar(Rf_install("formula"), CLOENV(fn))))), R_BaseEnv));
+        SEXP vars = PROTECT(Rf_eval(Rf_lang2(Rf_install("all.vars"), Rf_lang2(Rf_install("quote"), CADDR(formula))),
+                                    R_BaseEnv));
         int nxe = 0, ok = 1;
         cols[0] = 0;
         for (int v = 0; v < Rf_length(vars) && ok; v++)
@@ -100,21 +151,34 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
     }
     if (model_id <= 0 || Rf_isMatrix(swts) ||                    /* does not lower, or GLS weights */
         INTEGER(control_int)[2] > 1)                             /* dogleg / ddogleg / subspace2D */
+    {
+        UNPROTECT(1);
         return C_nls(fn, y, jac, fvv, env, start, swts, lupars, control_int, control_dbl, has_start, loss_config);
+    }
 
     /* data columns from the model frame, column-major n x nx in device regressor order */
-    SEXP mf = Rf_findVar(Rf_install("mf"), CLOENV(fn));
+    SEXP mf = Rf_findVarInFrame(CLOENV(fn), Rf_install("mf"));
     int nx = 1;
     for (const char *c = cols; *c; c++)
         nx += (*c == ',');
     double *X = (double *)R_alloc((size_t)n * nx, sizeof(double));
     {
         char buf[256];
-        strncpy(buf, cols, sizeof(buf));
+        strncpy(buf, cols, sizeof(buf) - 1);
+        buf[sizeof(buf) - 1] = 0;
         int c = 0;
         for (char *tok = strtok(buf, ","); tok; tok = strtok(NULL, ","), c++)
         {
-            SEXP col = PROTECT(Rf_coerceVector(Rf_eval(Rf_install(tok), mf == R_UnboundValue ? env : mf), REALSXP));
+            SEXP raw = (mf == R_UnboundValue) ? R_NilValue : frame_column(mf, tok, n);
+            if (raw == R_NilValue)
+            {
+                /* the symbol is not a column of the model frame (a global, a length-1 constant, ...): the closure
+                 * would still evaluate it through its enclosure, the device cannot -> the GSL path */
+                UNPROTECT(1);
+                return C_nls(fn, y, jac, fvv, env, start, swts, lupars, control_int, control_dbl, has_start,
+                             loss_config);
+            }
+            SEXP col = PROTECT(Rf_coerceVector(raw, REALSXP));
             memcpy(X + (size_t)c * n, REAL(col), sizeof(double) * n);
             UNPROTECT(1);
         }
@@ -177,12 +241,26 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
     res.covar = cov_d;
     res.resid = REAL(resid);
     res.grad = grad_d;
+    /* robust loss: the irls slot's three n-vectors (src/nls.c:756-762) are filled by the core */
+    SEXP irlswts = R_NilValue, irlspsi = R_NilValue, irlspsip = R_NilValue;
+    int nprot = 7; /* rhs, startvec, ans, par, cov, resid, grad */
+    if (wgt_i)
+    {
+        irlswts = PROTECT(Rf_allocVector(REALSXP, n));
+        irlspsi = PROTECT(Rf_allocVector(REALSXP, n));
+        irlspsip = PROTECT(Rf_allocVector(REALSXP, n));
+        nprot += 3;
+        res.irls_weights = REAL(irlswts);
+        res.irls_psi = REAL(irlspsi);
+        res.irls_dpsi = REAL(irlspsip);
+    }
     SEXP ptrace = R_NilValue, strace = R_NilValue;
     double *ptrace_d = NULL;
     if (verbose)
     {
         ptrace = PROTECT(Rf_allocMatrix(REALSXP, niter + 1, p));
         strace = PROTECT(Rf_allocVector(REALSXP, niter + 1));
+        nprot += 2;
         ptrace_d = (double *)R_alloc((size_t)(niter + 1) * p, sizeof(double));
         res.partrace = ptrace_d;
         res.ssrtrace = REAL(strace);
@@ -193,11 +271,14 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
                               hs, wgt_i, REAL(VECTOR_ELT(loss_config, 1)), &res);
     if (rc == GSLNLS_E_INTERRUPTED)
         Rf_onintr(); /* does not return: the pending interrupt is re-raised now that the device loop is drained */
-    if (rc <= GSLNLS_E_NODEVICE) /* no device / not lowered after all: the GSL path still exists */
+    /* no device / not lowered after all, or a qr / svd request on a problem too ill-conditioned for the normal
+     * equations (gslnls_solver_served, include/gslnls_core.h): the GSL path still exists */
+    if (rc <= GSLNLS_E_NODEVICE || !gslnls_solver_served(INTEGER(control_int), &res))
     {
-        UNPROTECT(verbose ? 8 : 6);
+        UNPROTECT(nprot);
         return C_nls(fn, y, jac, fvv, env, start, swts, lupars, control_int, control_dbl, has_start, loss_config);
     }
+    const int ok = (res.conv == GSLNLS_SUCCESS || res.conv == GSLNLS_EMAXITER);
 
     /* back to the caller's parameter order */
     for (int k = 0; k < p; k++)
@@ -212,8 +293,21 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
     }
     Rf_setAttrib(par, R_NamesSymbol, parnames);
     SET_VECTOR_ELT(ans, 0, par);
+    {
+        SEXP dn = PROTECT(Rf_allocVector(VECSXP, 2)); /* src/nls.c:686-693 */
+        SET_VECTOR_ELT(dn, 0, parnames);
+        SET_VECTOR_ELT(dn, 1, parnames);
+        Rf_setAttrib(cov, R_DimNamesSymbol, dn);
+        UNPROTECT(1);
+    }
     SET_VECTOR_ELT(ans, 1, cov);
     SET_VECTOR_ELT(ans, 2, resid);
+    {
+        SEXP dn = PROTECT(Rf_allocVector(VECSXP, 2)); /* column names only, src/nls.c:728-734 */
+        SET_VECTOR_ELT(dn, 1, parnames);
+        Rf_setAttrib(grad, R_DimNamesSymbol, dn);
+        UNPROTECT(1);
+    }
     SET_VECTOR_ELT(ans, 3, grad);
     SET_VECTOR_ELT(ans, 4, Rf_ScalarInteger(res.niter));
     SET_VECTOR_ELT(ans, 5, Rf_mkString(gslnls_strerror(res.conv)));
@@ -229,11 +323,45 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
         SET_VECTOR_ELT(ans, 10, ne);
         UNPROTECT(1);
     }
+    if (wgt_i)
+    {
+        /* the irls slot, element for element as src/nls.c:756-791 builds it (gslModel reads all eight,
+         * R/nls.R:1413-1484); NA vectors when the fit failed (the core fills them with NaN in that case too, but R
+         * distinguishes NA_real_ from NaN) */
+        const char *irlsnms[] = {"irls_weights", "irls_psi", "irls_dpsi", "irls_sigma", "irls_status", "irls_niter",
+                                 "irls_tol", "irls_conv", ""};
+        SEXP ansirls = PROTECT(Rf_mkNamed(VECSXP, irlsnms));
+        SET_VECTOR_ELT(ansirls, 0, ok ? irlswts : na_vector(n));
+        SET_VECTOR_ELT(ansirls, 1, ok ? irlspsi : na_vector(n));
+        SET_VECTOR_ELT(ansirls, 2, ok ? irlspsip : na_vector(n));
+        SET_VECTOR_ELT(ansirls, 3, Rf_ScalarReal(res.irls_sigma));
+        SET_VECTOR_ELT(ansirls, 4, Rf_mkString(gslnls_strerror(res.irls_status)));
+        SET_VECTOR_ELT(ansirls, 5, Rf_ScalarInteger(res.irls_niter));
+        SET_VECTOR_ELT(ansirls, 6, Rf_ScalarReal(res.irls_tol));
+        SET_VECTOR_ELT(ansirls, 7, Rf_ScalarInteger(res.irls_status));
+        SET_VECTOR_ELT(ans, 11, ansirls);
+        UNPROTECT(1);
+    }
     if (verbose)
     {
+        SEXP dn = PROTECT(Rf_allocVector(VECSXP, 2)); /* src/nls.c:793-803 */
+        SET_VECTOR_ELT(dn, 0, R_NilValue);
+        SET_VECTOR_ELT(dn, 1, parnames);
+        Rf_setAttrib(ptrace, R_DimNamesSymbol, dn);
+        UNPROTECT(1);
         SET_VECTOR_ELT(ans, 12, ptrace);
         SET_VECTOR_ELT(ans, 13, strace);
     }
-    UNPROTECT(verbose ? 8 : 6);
+    if (!ok)
+    {
+        /* src/nls.c:667-737: NA (not NaN) fills on failure */
+        for (int k = 0; k < p * p; k++)
+            REAL(cov)[k] = NA_REAL;
+        for (int i = 0; i < n; i++)
+            REAL(resid)[i] = NA_REAL;
+        for (size_t i = 0; i < (size_t)n * p; i++)
+            REAL(grad)[i] = NA_REAL;
+    }
+    UNPROTECT(nprot);
     return ans;
 }

@@ -46,3 +46,35 @@ def test_product_never_touches_the_oracle():
                     if re.search(r"gslref|oracle/|libgslref", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_r_shims_parse_against_the_header():
+    """the reference-side bindings (integration/r_shim) type-check against include/gslnls_core.h and the
+    declaration-only R API stand-in (tests/r_stub): every field and entry point they use exists with that type"""
+    import __graft_entry__ as G
+    G.check_r_shims()
+    src = open(os.path.join(ROOT, "integration", "r_shim", "gslnls_hip_shim.c")).read()
+    # the irls slot of the returned list (src/nls.c:756-791) is filled, with the reference's eight names
+    for nm in ("irls_weights", "irls_psi", "irls_dpsi", "irls_sigma", "irls_status", "irls_niter", "irls_tol", "irls_conv"):
+        assert '"%s"' % nm in src, nm
+    assert "SET_VECTOR_ELT(ans, 11, ansirls)" in src and "gslnls_solver_served" in src
+    assert "Rf_findVarInFrame(CLOENV(fn)" in src and "Rf_findVar(" not in src
+
+
+def test_bench_gpus_flag_spawns_that_many_ranks():
+    """`python bench.py --gpus 2` with no launcher starts two rank processes itself (gloo here, no GPU), and a
+    --gpus that disagrees with WORLD_SIZE is refused instead of mislabelled"""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"] == [0, 1] and len(set(d["pids"])) == 2
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--plumbing-only"],
+                         capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="2", RANK="0"))
+    assert bad.returncode != 0 and "refusing" in bad.stderr

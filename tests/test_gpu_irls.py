@@ -121,3 +121,63 @@ def test_robust_multistart_second_pass(amd, gslref, nist, loss, start, outlier):
     assert (m["nsp"], m["nwsp"], m["iters"], m["stop"]) == (mo["nsp"], mo["nwsp"], mo["iters"], mo["stop"])
     assert fit["irls"]["irls_niter"] == o["irls"]["irls_niter"]
     assert np.allclose(fit["par"], o["par"], rtol=1e-5)
+
+
+def test_boundary_fills_the_whole_irls_slot(amd, gslref, nist):
+    """the contract the R shim relies on (src/nls.c:756-791): a robust gslnls_nls() call fills irls_weights / psi / dpsi
+    and the four scalars; a default-loss call leaves the arrays untouched"""
+    import ctypes as C
+    from gslnls_amd import _lib
+    from gslnls_amd.control import gsl_nls_control, pack_control
+    q = nist["Misra1a"]
+    x, y = np.array(q["data"]["x"]), np.array(q["data"]["y"]).copy()
+    y[0] = 25.0
+    n, p = len(y), 2
+    X = np.asfortranarray(x.reshape(n, 1))
+    m = _lib.Model(2, p, 1, X.ctypes.data_as(C.c_void_p), 0)
+    ci, cd = pack_control(gsl_nls_control(solver="cholesky"), "lm")
+    st = np.array([500.0, 1e-4])
+    cc = np.array([4.685061])
+    hs = np.ones(4, dtype=np.int32)
+    for rho in (3, 0):
+        par, w, psi, dpsi = np.zeros(p), np.full(n, -7.0), np.full(n, -7.0), np.full(n, -7.0)
+        res = _lib.Result()
+        res.par = par.ctypes.data_as(_lib.DP)
+        res.irls_weights, res.irls_psi, res.irls_dpsi = (a.ctypes.data_as(_lib.DP) for a in (w, psi, dpsi))
+        rc = _lib.lib().gslnls_nls(C.byref(m), y.ctypes.data_as(C.c_void_p), n, 0, 0, st.ctypes.data_as(_lib.DP), 0, None,
+                                   0, None, ci.ctypes.data_as(_lib.IP), cd.ctypes.data_as(_lib.DP),
+                                   hs.ctypes.data_as(_lib.IP), rho, cc.ctypes.data_as(_lib.DP), C.byref(res))
+        assert rc == 0 and res.conv == 0
+        if rho:
+            o = gslref.nls(n, p, st, rowdata=dict(model=gslref.MODEL_MISRA1A, x=x, y=y), use_jac=False,
+                           ctrl=gslref.control(solver="cholesky"), loss="bisquare")
+            assert np.all(w != -7.0) and np.all(psi != -7.0) and np.all(dpsi != -7.0)
+            assert np.allclose(w, o["irls_weights"], rtol=1e-5, atol=1e-9)
+            assert np.allclose(psi, o["irls_psi"], rtol=1e-5, atol=1e-7)
+            assert res.irls_status == 0 and res.irls_niter == o["irls"]["irls_niter"] and res.irls_sigma > 0
+            assert abs(res.irls_tol - o["irls"]["irls_tol"]) < 1e-6
+        else:
+            assert np.all(w == -7.0) and np.all(psi == -7.0)
+        assert np.isfinite(res.jtj_cond) and res.jtj_cond >= 1.0
+        assert _lib.lib().gslnls_solver_served(ci.ctypes.data_as(_lib.IP), C.byref(res)) == 1
+
+
+def test_solver_routing_rule(amd, nist):
+    """include/gslnls_core.h: cholesky is always served; qr / svd requests are served on the normal equations while the
+    scaled condition number stays below GSLNLS_COND_LIMIT, and flagged for the GSL path beyond it"""
+    import warnings
+    q = nist["Misra1a"]
+    d = dict(x=np.array(q["data"]["x"]), y=np.array(q["data"]["y"]))
+    fit = amd.gsl_nls(q["formula"], data=d, start=q["start"])  # default control: solver = "qr"
+    assert fit["conv"] == 0 and fit["solver_served"] and 1.0 <= fit["jtj_cond"] < 1e10
+    # a nearly collinear pair of columns: f = (a + b) x + 1e-7 b x^2
+    x = np.linspace(1.0, 2.0, 50)
+    y = 3.0 * x + 1e-7 * 2.0 * x ** 2
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        bad = amd.gsl_nls("y ~ (a + b) * x + 1e-7 * b * x^2", data=dict(x=x, y=y), start=dict(a=1.0, b=1.0), jac=True)
+    assert bad["jtj_cond"] > 1e10 and not bad["solver_served"]
+    assert any("falls through to GSL" in str(v.message) for v in w)
+    ok = amd.gsl_nls("y ~ (a + b) * x + 1e-7 * b * x^2", data=dict(x=x, y=y), start=dict(a=1.0, b=1.0), jac=True,
+                     control=dict(solver="cholesky"))
+    assert ok["solver_served"]
