@@ -11,10 +11,12 @@ before the timed region; nothing n-sized crosses PCIe inside it.
 
     value = LM iterations (niter summed over all steps and ranks) / wall seconds
 
-N > 1: one process per GPU (torch.distributed, backend nccl == RCCL); a single large fit does
-not shard at BASELINE sizes, so the ranks run independent replicas ("weak"),
-bracketed by barriers, time = max over ranks.  The sharded multi-start path (C4) is reported in
-the extra "multistart" object of the same JSON line.
+N > 1: one process per GPU -- `python bench.py --gpus N` starts the N rank processes itself when no launcher
+did (torch.distributed, backend nccl == RCCL, carries the barriers and the max-over-ranks timing); a single
+large fit does not shard at BASELINE sizes, so the ranks run independent replicas ("weak"),
+bracketed by barriers, time = max over ranks.  The sharded multi-start path (C4: one ncclAllGather per batch,
+issued by libgslnls_hip.so itself) and batched robust fits (C5: one final all-gather) are reported, summed over
+the ranks, in the "multistart" and "batched_irls" objects of the same JSON line.
 
 Extra objects: "roofline" (dominant kernel lm_step_kernel: algorithmic bytes 16 n per launch,
 duration from HIP events on the library's stream), "cpu_baseline" (the oracle, single core).
@@ -44,7 +46,7 @@ def c2_data(n, seed):
     return x, y
 
 
-def cpu_baseline(x, y, budget_s=20.0):
+def cpu_baseline(x, y, budget_s=20.0, max_fits=64):
     """The oracle (oracle/, plain C, J materialised row-major like GSL, solver=cholesky) on the same
     workload, one host core.  Test infrastructure used here only as the reported baseline."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -57,7 +59,7 @@ def cpu_baseline(x, y, budget_s=20.0):
         fits += 1
         iters += out["niter"]
         el = time.perf_counter() - t0
-        if el > budget_s or fits >= 64:
+        if el > budget_s or fits >= max_fits:
             break
     return dict(value=iters / el, unit="LM iterations/s", cores=1, kind="port",
                 sample="%d complete fits of the same n=1e6,p=3 problem (%d iterations) in %.1f s, "
@@ -65,11 +67,59 @@ def cpu_baseline(x, y, budget_s=20.0):
                 niter_per_fit=out["niter"], par=[float(v) for v in out["par"]])
 
 
+def _cpu_worker(args):
+    n, seed, budget_s = args
+    x, y = c2_data(n, seed)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gslref
+    ctrl = gslref.control(solver="cholesky", xtol=1.49e-8, gtol=1.49e-8)
+    rd = dict(model=gslref.MODEL_EXPDECAY, x=x, y=y)
+    iters, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        iters += gslref.nls(n, 3, START, rowdata=rd, use_jac=True, ctrl=ctrl)["niter"]
+    return iters, time.perf_counter() - t0
+
+
+def cpu_baseline_allcores(n, seed, budget_s=8.0):
+    """All host cores: the reference is single-threaded (src/Makevars.in links no OpenMP), so the all-core figure is
+    `cores` independent fits of the same problem side by side -- aggregate iterations/s, cores stated."""
+    import multiprocessing as mp
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    with mp.get_context("spawn").Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(n, seed, budget_s)] * cores)
+    return dict(value=sum(r[0] / r[1] for r in res), unit="LM iterations/s", cores=cores, kind="port",
+                sample="%d processes x complete fits of the n=1e6,p=3 problem for %.0f s each (aggregate)" % (cores, budget_s))
+
+
 BOXBOD_X = [1.0, 2.0, 3.0, 5.0, 7.0, 10.0]          # NIST BoxBOD (R/nls_test.R:790-791)
 BOXBOD_Y = [109.0, 149.0, 149.0, 191.0, 213.0, 224.0]
 
 
-def multistart_bench(L, _lib, torch, dist, rank, world, steps, warmup):
+def bind_library_comm(L, torch, dist, rank, world, backend):
+    """Bootstrap of the in-library RCCL communicator (include/gslnls_core.h): rank 0 makes the 128-byte id, the job's
+    existing process group carries it to the others (bootstrap only -- the all-gathers of the data path are issued by
+    libgslnls_hip.so itself on its own stream).  Returns a label of what the data path uses."""
+    idbuf = C.create_string_buffer(128)
+    ok = torch.zeros(1, dtype=torch.int32)
+    if rank == 0:
+        ok[0] = 1 if L.gslnls_comm_get_unique_id(idbuf) == 0 else 0
+    t = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).clone()
+    dev = "cuda" if backend == "nccl" else "cpu"
+    t, okd = t.to(dev), ok.to(dev)
+    dist.broadcast(t, 0)
+    dist.broadcast(okd, 0)
+    if int(okd.item()) != 1:
+        return None, "RCCL unavailable on rank 0: %s" % L.gslnls_comm_last_error().decode()
+    rc = L.gslnls_comm_init_rank(bytes(t.cpu().numpy().tobytes()), rank, world)
+    flag = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) != 1:
+        L.gslnls_comm_destroy()
+        return None, "ncclCommInitRank failed on some rank: %s" % L.gslnls_comm_last_error().decode()
+    return True, "ncclAllGather issued by libgslnls_hip.so on its own stream (RCCL bound with dlopen)"
+
+
+def multistart_bench(L, _lib, torch, dist, rank, world, steps, warmup, lib_comm):
     """C4: concentration fits/sec of multi-start (src/nls_mstart.c:42-128) on NIST BoxBOD, Sobol starts in
     b1 in [1,500], b2 in [0.01,5], mstart_p = 5 LM iterations each, analytic Jacobian; the points of a batch are
     sharded over the ranks in contiguous blocks and completed with ONE all-gather of the records (RCCL)."""
@@ -87,50 +137,74 @@ def multistart_bench(L, _lib, torch, dist, rank, world, steps, warmup):
     for label, total in (("strong_8192_total", 8192), ("weak_65536_per_gpu", 65536 * world)):
         per = (total + world - 1) // world
         lo, hi = min(total, rank * per), min(total, rank * per + per)
-        shard = torch.zeros(per * K, dtype=torch.float64, device="cuda")
-        allb = torch.zeros(world * per * K, dtype=torch.float64, device="cuda") if world > 1 else shard
+        use_lib = world == 1 or lib_comm
+        shard = allb = None
+        if not use_lib:
+            # fallback: the records are gathered by torch.distributed on torch's stream
+            shard = torch.zeros(per * K, dtype=torch.float64, device="cuda")
+            allb = torch.zeros(world * per * K, dtype=torch.float64, device="cuda")
         ms = C.c_float(0)
         kms = []
+        rec_host = np.zeros((total, K))
 
         # argument pointers built once (numpy's .ctypes.data_as costs ~1 us per call: harness, not the path)
         rg_p, kd_p, ci_p, cd_p = (ranges.ctypes.data_as(_lib.DP), kd.ctypes.data_as(_lib.DP), ci.ctypes.data_as(_lib.IP),
                                   cd.ctypes.data_as(_lib.DP))
-        out_p, ms_p = C.c_void_p(shard.data_ptr()), C.byref(ms)
+        out_p = C.c_void_p(shard.data_ptr()) if shard is not None else None
+        host_p, ms_p = rec_host.ctypes.data_as(C.c_void_p), C.byref(ms)
 
-        def step():
-            rc = L.gslnls_mstart_batch(h, 1, rg_p, kd_p, 0, total, lo, hi, 5, 1e-6, ci_p, cd_p, None, out_p, 1, ms_p)
+        def step(to_host=False):
+            if use_lib:
+                # lo = -1: this rank's block + the library's own all-gather; records stay in HBM unless asked for
+                rc = L.gslnls_mstart_batch(h, 1, rg_p, kd_p, 0, total, -1, 0, 5, 1e-6, ci_p, cd_p, None,
+                                           host_p if to_host else None, 0, ms_p)
+            else:
+                rc = L.gslnls_mstart_batch(h, 1, rg_p, kd_p, 0, total, lo, hi, 5, 1e-6, ci_p, cd_p, None, out_p, 1, ms_p)
             if rc != 0:
                 raise SystemExit("mstart batch failed: %d" % rc)
             kms.append(ms.value)
-            if world > 1:
+            if not use_lib:
                 dist.all_gather_into_tensor(allb, shard)
-        for _ in range(warmup):
-            step()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        kms.clear()
-        t0 = time.perf_counter()
-        stamps = []
-        for _ in range(steps):
-            step()
-            stamps.append(time.perf_counter())
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        if os.environ.get("GSLNLS_BENCH_DEBUG"):
-            print(label, ["%.3f" % (1e3 * (b - a)) for a, b in zip([t0] + stamps[:-1], stamps)], file=sys.stderr)
-        if dist is not None:
-            t = torch.tensor([el], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        rec = allb[:total * K].view(total, K).cpu().numpy()
+
+        def timed(to_host):
+            for _ in range(warmup):
+                step(to_host)
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            kms.clear()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step(to_host)
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([el], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            return el
+        n0 = L.gslnls_comm_allgather_count()
+        el = timed(False)
+        n_coll = L.gslnls_comm_allgather_count() - n0
+        kernel_ms = float(np.mean(kms))
+        el_host = timed(True) if use_lib else None
+        if use_lib:
+            rec = rec_host
+        else:
+            rec = allb[:total * K].view(total, K).cpu().numpy()
         fitted = rec[:, 3 * 2 + 2] > 1e-6
         good = int(np.sum(np.abs(rec[fitted, 3 * 2 + 1] - 1168.0088766) < 1.0))
+        # flops by SURVEY.md 8(d): (p + 2) model sweeps x n = 6 rows x (1 exp + ~12 flop) per LM iteration; an fp64 exp
+        # is ~25 flop in this library (devmath.hpp): 4 x 6 x 37 = 888 flop per iteration, 5 iterations per fit
+        flop_fit = (2 + 2) * 6 * (25 + 12) * 5
         out[label] = {"fits_per_s": total * steps / el, "points_per_batch": total, "ms_per_batch": el / steps * 1e3,
-                      "kernel_ms_per_batch_rank0": float(np.mean(kms)), "points_passing_det_filter": int(fitted.sum()),
-                      "points_in_global_basin_after_5_iters": good}
+                      "kernel_ms_per_batch_rank0": kernel_ms, "points_passing_det_filter": int(fitted.sum()),
+                      "points_in_global_basin_after_5_iters": good,
+                      "allgathers_by_library_in_timed_region": int(n_coll),
+                      "fits_per_s_records_on_host": (total * steps / el_host) if el_host else None,
+                      "achieved_GFLOPs_kernel": (hi - lo) * flop_fit / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None}
     L.gslnls_dense_destroy(h)
     if world == 1:
         # the whole multi-start procedure of C4 (sampling, concentration, reduction, local searches, final solve)
@@ -146,8 +220,11 @@ def multistart_bench(L, _lib, torch, dist, rank, world, steps, warmup):
                                            "ssr": float(fit["ssr"]), "conv": int(fit["conv"]),
                                            "target": [213.80940889, 0.54723748542, 1168.0088766]}
     out["metric"] = "multi-start concentration fits/s (BoxBOD n=6 p=2, 5 LM iterations each, all-gather of records)"
+    out["collective"] = ("none (one rank)" if world == 1 else
+                         (lib_comm if isinstance(lib_comm, str) else "torch.distributed all_gather_into_tensor (fallback)"))
     out["note"] = ("working set is 96 B per fit: bound by fp64 VALU + exp latency and by launch/collective latency, "
-                   "an HBM fraction is not meaningful (SURVEY.md 8(d))")
+                   "an HBM fraction is not meaningful (SURVEY.md 8(d)); fits_per_s leaves the gathered records in HBM, "
+                   "fits_per_s_records_on_host adds the D2H the host-side commit of the real procedure needs")
     return out
 
 
@@ -180,9 +257,10 @@ def large_bench(L, _lib, n=10_000_000, p=64):
                     "max_abs_err_vs_truth": float(np.max(np.abs(fit["par"] - th)))}}
 
 
-def batch_irls_bench(_lib, rank, world, B=4096, n=10000):
+def batch_irls_bench(_lib, torch, dist, rank, world, B=4096, n=10000):
     """C5: B data sets x n rows, NIST Gauss1 family p = 8, 2 % outliers, loss = bisquare; data sets are
-    independent, so rank r fits the contiguous block [r B/W, (r+1) B/W) with no collective"""
+    independent, so rank r fits the contiguous block [r B/W, (r+1) B/W) with no traffic, and ONE all-gather of
+    theta-hat, sigma-hat and the status words completes the result on every rank (gslnls_batch_irls_gather)"""
     from gslnls_amd.batch import BatchProblem
     truth = np.array([98.778210871, 0.010497276517, 100.48990633, 67.481111276, 23.129773360, 71.994503004,
                       178.99805021, 18.389389025])
@@ -200,15 +278,39 @@ def batch_irls_bench(_lib, rank, world, B=4096, n=10000):
         yy[rng.choice(n, n // 50, replace=False)] += 50.0
         Y[d - lo] = yy
     prob = BatchProblem(4, 8, X, Y)
-    prob.irls(start, loss="bisquare", jac=True, control=dict(solver="cholesky"))
+    kw = dict(loss="bisquare", jac=True, control=dict(solver="cholesky"))
+    prob.irls_gathered(B, start, **kw)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = prob.irls(start, loss="bisquare", jac=True, control=dict(solver="cholesky"))
+    out = prob.irls_gathered(B, start, **kw)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
     prob.close()
-    return {"workload": "C5: %d data sets x n=%d, Gauss1 family p=8, bisquare IRLS (this rank: %d)" % (B, n, hi - lo),
-            "datasets_per_s_this_rank": (hi - lo) / el, "irls_iterations_per_s_this_rank": float(out["irls_niter"].sum()) / el,
-            "kernel_ms": out["kernel_ms"], "converged": int((out["conv"] == 0).sum()),
-            "irls_converged": int((out["irls_status"] == 0).sum()), "mean_irls_iterations": float(out["irls_niter"].mean())}
+    # algorithmic bytes by SURVEY.md 8(d): 2 passes x n x 24 B per LM iteration per data set (x, y, w) + per re-weighting
+    # n x 16 B read + n x 8 B written; niter is the LM iteration count of the LAST solve of every data set, the earlier
+    # IRLS rounds are not counted by the kernel -- so this is a lower bound of the bytes, stated as such
+    lm_last = float(out["niter"].sum())
+    rw = float(out["irls_niter"].sum())
+    alg_bytes = lm_last * 2 * n * 24 + rw * n * 24
+    kms = out["kernel_ms"]
+    return {"workload": "C5: %d data sets x n=%d, Gauss1 family p=8, bisquare IRLS, %d rank(s)" % (B, n, world),
+            "datasets_per_s": B / el, "irls_iterations_per_s": rw / el, "wall_ms": el * 1e3,
+            "kernel_ms_rank0": kms, "converged": int((out["conv"] == 0).sum()),
+            "irls_converged": int((out["irls_status"] == 0).sum()), "mean_irls_iterations": float(out["irls_niter"].mean()),
+            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                         "achieved_lower_bound": alg_bytes / world / (kms * 1e-3) / 1e9 if kms > 0 else None,
+                         "frac_lower_bound": alg_bytes / world / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms > 0 else None,
+                         "accounting": "480 KB x LM iterations of the last solve of each data set + 240 KB x IRLS "
+                                       "re-weightings, this rank's data sets / its kernel time; the rows are served "
+                                       "from L2/Infinity Cache and the kernel is bound by fp64 exp, not by HBM"}}
 
 
 def spawn_ranks(n_ranks):
@@ -384,8 +486,11 @@ def main():
     ms_launch = float(L.gslnls_dense_time_pass(h, jac, th.ctypes.data_as(_lib.DP), 2000))
     streamed = 16.0 * n / (ms_launch * 1e-3) / 1e9
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    traffic_source = None
+    tpath = next((os.path.join(ROOT, "profiles", f) for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+                  if os.path.exists(os.path.join(ROOT, "profiles", f))), "")
     if os.path.exists(tpath):
+        traffic_source = "committed profile %s (separate rocprofv3 --pmc passes), NOT measured in this run" % os.path.relpath(tpath, ROOT)
         try:
             # PMC passes (scripts/profile_round.sh): 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE per launch
             pmc = json.load(open(tpath))
@@ -413,7 +518,7 @@ def main():
                    "device_loop_ms_per_fit": ev_ms.value / args.steps, "host_loop_ms_per_fit": loop_ms / args.steps,
                    "parallelism": "replicas only (x%d)" % world, "par": [float(v) for v in par]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "lm_step_kernel<ModelExpDecay>",
                      "bytes_per_launch": alg_bytes_fit / launches_fit, "ms_per_launch": ms_loop_fit / launches_fit,
                      "accounting": "SURVEY 8(d): 16n B per reference pass (f or J evaluation); %.0f passes per fit "
@@ -423,13 +528,60 @@ def main():
                                   "frac": streamed / HBM_PEAK_GBS,
                                   "note": "bytes actually read by one fused launch (x and y once); compare traffic"}},
     }
-    line["multistart"] = multistart_bench(L, _lib, torch, dist, rank, world, max(5, args.steps // 4), 3)
+    if rank == 0 and world == 1:
+        # (a) SURVEY.md 8(d) asks for the forward-difference run beside the analytic one; (b) a fit on a fresh handle
+        # (the launch count of the previous fit is not known yet: 16 launches + top-ups of 16, trailing ones run as no-ops)
+        # beside the repeated-fit loop timed above, whose first chunk is sized by the previous fit
+        other = 1 - jac
+        for _ in range(3):
+            solve(h, other, 0, st_p, None, ci_p, cd_p, args.chunk, res_p)
+        torch.cuda.synchronize()
+        kfd = max(5, min(50, args.steps))
+        t1 = time.perf_counter()
+        it_o = 0
+        for _ in range(kfd):
+            solve(h, other, 0, st_p, None, ci_p, cd_p, args.chunk, res_p)
+            it_o += res.niter
+        torch.cuda.synchronize()
+        el_o = time.perf_counter() - t1
+        line["other_jacobian"] = {"jacobian": "analytic" if other else "forward-FD", "value": it_o / el_o,
+                                  "unit": "LM iterations/s", "fits": kfd, "niter_per_fit": it_o / kfd,
+                                  "launches_per_fit": res.n_launches, "neval_f": res.neval[0], "neval_J": res.neval[1]}
+        h2 = L.gslnls_dense_create(C.byref(model), y.ctypes.data_as(C.c_void_p), n, None, C.byref(err))
+        solve(h2, jac, 0, st_p, None, ci_p, cd_p, args.chunk, res_p)
+        first = {"loop_ms": res.loop_ms, "launches": res.n_launches, "niter": res.niter}
+        solve(h2, jac, 0, st_p, None, ci_p, cd_p, args.chunk, res_p)
+        line["one_shot_vs_repeated"] = {"first_fit_on_a_fresh_handle": first,
+                                        "second_fit_on_it": {"loop_ms": res.loop_ms, "launches": res.n_launches},
+                                        "timed_loop_ms_per_fit": loop_ms / args.steps,
+                                        "note": "value/ms_per_step above are the repeated-fit loop (the best case)"}
+        L.gslnls_dense_destroy(h2)
+    lib_comm = None
+    if world > 1:
+        if os.environ.get("GSLNLS_BENCH_ONE_DEVICE"):
+            lib_comm, why = None, "developer dry run: the ranks share one device, RCCL refuses that"
+        else:
+            lib_comm, why = bind_library_comm(L, torch, dist, rank, world, backend)
+        if lib_comm:
+            lib_comm = why
+        else:
+            # the records are then gathered by torch.distributed (and batched IRLS by the callback form)
+            print("bench.py: in-library RCCL communicator not available (%s); torch.distributed gathers" % why, file=sys.stderr)
+            from gslnls_amd import dist as gdist
+            gdist.init_multistart_comm(65536 * world, 8)
+    line["multistart"] = multistart_bench(L, _lib, torch, dist, rank, world, max(5, args.steps // 4), 3, lib_comm)
     if not args.headline_only:
-        line["batched_irls"] = batch_irls_bench(_lib, rank, world)
+        line["batched_irls"] = batch_irls_bench(_lib, torch, dist, rank, world)
         if world == 1:
             line["large_cgst"] = large_bench(L, _lib)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(x, y)
+    if world > 1:
+        L.gslnls_comm_destroy()
+    if rank == 0 and not args.no_cpu_baseline:
+        # N = 1: the full sample (about 20 s of one core) plus the all-core figure; N > 1: a short sample only, the
+        # other ranks wait at the final barrier meanwhile
+        line["cpu_baseline"] = cpu_baseline(x, y) if world == 1 else cpu_baseline(x, y, budget_s=4.0, max_fits=12)
+        if world == 1 and not args.headline_only:
+            line["cpu_baseline"]["all_cores"] = cpu_baseline_allcores(n, 20250927 + rank)
     elif rank == 0:
         line["cpu_baseline"] = None
     L.gslnls_dense_destroy(h)

@@ -59,7 +59,7 @@ class Result(C.Structure):
                 ("irls_niter", C.c_int), ("partrace", DP), ("ssrtrace", DP), ("mstart_nsp", C.c_int),
                 ("mstart_nwsp", C.c_int), ("mstart_iters", C.c_int), ("mstart_stop", C.c_int),
                 ("mstart_ssropt", C.c_double), ("loop_ms", C.c_float), ("n_launches", C.c_int),
-                ("jtj_cond", C.c_double)]
+                ("jtj_cond", C.c_double), ("n_steps", C.c_int)]
 
 
 class LargeResult(C.Structure):
@@ -84,6 +84,12 @@ _SIGNATURES = {
     "gslnls_lower_formula": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), IP, C.c_char_p, C.c_int]),
     "gslnls_set_comm": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
                                   C.c_int]),
+    "gslnls_comm_get_unique_id": (C.c_int, [C.c_char_p]),
+    "gslnls_comm_init_rank": (C.c_int, [C.c_char_p, C.c_int, C.c_int]),
+    "gslnls_comm_init_file": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int]),
+    "gslnls_comm_destroy": (None, []),
+    "gslnls_comm_allgather_count": (C.c_longlong, []),
+    "gslnls_comm_last_error": (C.c_char_p, []),
     "gslnls_dense_mstart": (C.c_int, [C.c_void_p, C.c_int, C.c_int, DP, DP, IP, DP, IP, C.POINTER(Result)]),
     "gslnls_mstart_batch": (C.c_int, [C.c_void_p, C.c_int, DP, DP, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_double, IP, DP, DP, C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
@@ -100,6 +106,8 @@ _SIGNATURES = {
                                          C.c_int, IP]),
     "gslnls_batch_destroy": (None, [C.c_void_p]),
     "gslnls_batch_irls": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, DP, DP, IP, DP, C.c_int, DP,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    "gslnls_batch_irls_gather": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, DP, DP, IP, DP, C.c_int, DP,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     "gslnls_strerror": (C.c_char_p, [C.c_int]),
     "gslnls_algorithm_name": (C.c_char_p, [C.c_int]),

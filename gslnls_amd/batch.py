@@ -38,15 +38,21 @@ class BatchProblem:
         except Exception:  # noqa
             pass
 
+    def irls_gathered(self, B_total, start, **kw):
+        """One process per GPU: this object holds the calling rank's contiguous block of the B_total data sets
+        (rank r: [r * ceil(B_total / world), ...)); every rank fits its block, one all-gather completes the outputs on
+        every rank (gslnls_batch_irls_gather; communicator: gslnls_amd.dist).  Returns B_total entries."""
+        return self.irls(start, _gather_total=int(B_total), **kw)
+
     def irls(self, start, loss="bisquare", jac=True, fvv=False, algorithm="lm", control=None, lower=None, upper=None,
-             lo=0, hi=None):
+             lo=0, hi=None, _gather_total=None):
         hi = self.B if hi is None else hi
         ctrl = control if (control is not None and len(control) >= 23) else gsl_nls_control(**(control or {}))
         cfg = gsl_nls_loss(loss) if isinstance(loss, str) else gsl_nls_loss(**loss)
         ci, cd = pack_control(ctrl, algorithm)
         st = np.ascontiguousarray(start, dtype=np.float64)
         cc = np.asarray(list(cfg["cc"].values()) + [0.0, 0.0, 0.0], dtype=np.float64)
-        cnt = hi - lo
+        cnt = hi - lo if _gather_total is None else _gather_total
         par = np.zeros((cnt, self.p))
         scal = np.zeros((cnt, 4))
         ints = np.zeros((cnt, 4), dtype=np.int32)
@@ -56,11 +62,19 @@ class BatchProblem:
             lo_ = np.full(self.p, -np.inf) if lower is None else np.asarray(lower, dtype=np.float64)
             up_ = np.full(self.p, np.inf) if upper is None else np.asarray(upper, dtype=np.float64)
             lu = np.ascontiguousarray(np.stack([lo_, up_], axis=1).reshape(-1))
-        rc = _lib.lib().gslnls_batch_irls(self._h, lo, hi, int(bool(jac)), int(bool(fvv)), st.ctypes.data_as(DP),
-                                          None if lu is None else lu.ctypes.data_as(DP), ci.ctypes.data_as(IP),
-                                          cd.ctypes.data_as(DP), LOSSES.index(cfg["rho"]), cc.ctypes.data_as(DP),
-                                          par.ctypes.data_as(C.c_void_p), scal.ctypes.data_as(C.c_void_p),
-                                          ints.ctypes.data_as(C.c_void_p), C.byref(ms))
+        if _gather_total is not None:
+            rc = _lib.lib().gslnls_batch_irls_gather(self._h, _gather_total, int(bool(jac)), int(bool(fvv)),
+                                                     st.ctypes.data_as(DP), None if lu is None else lu.ctypes.data_as(DP),
+                                                     ci.ctypes.data_as(IP), cd.ctypes.data_as(DP), LOSSES.index(cfg["rho"]),
+                                                     cc.ctypes.data_as(DP), par.ctypes.data_as(C.c_void_p),
+                                                     scal.ctypes.data_as(C.c_void_p), ints.ctypes.data_as(C.c_void_p),
+                                                     C.byref(ms))
+        else:
+            rc = _lib.lib().gslnls_batch_irls(self._h, lo, hi, int(bool(jac)), int(bool(fvv)), st.ctypes.data_as(DP),
+                                              None if lu is None else lu.ctypes.data_as(DP), ci.ctypes.data_as(IP),
+                                              cd.ctypes.data_as(DP), LOSSES.index(cfg["rho"]), cc.ctypes.data_as(DP),
+                                              par.ctypes.data_as(C.c_void_p), scal.ctypes.data_as(C.c_void_p),
+                                              ints.ctypes.data_as(C.c_void_p), C.byref(ms))
         _lib.check(rc)
         if rc != 0:
             raise RuntimeError("gslnls_batch_irls failed: %s" % _lib.strerror(rc))

@@ -16,6 +16,7 @@
 #include "sparse_large.hpp"
 #include "irls_batch.hpp"
 #include "robust_host.hpp"
+#include "rccl_comm.hpp"
 
 using namespace gslnls;
 
@@ -26,6 +27,39 @@ struct gslnls_dense
 
 // process-wide communicator of the multi-start sharding (one process per GPU)
 static MsComm g_comm;
+static RcclComm g_rccl;
+
+namespace gslnls
+{
+// the multi-rank form of one batch with the in-library collective: kernel -> ncclAllGather -> D2H, all on the
+// evaluator's stream; the host only enqueues and then waits once
+int ms_rccl_run_batch(MsEvaluator &ev, const MsComm &comm, MsBatch &b, int per, int lo, int hi)
+{
+    RcclComm &rc = *comm.rccl;
+    const size_t shard_doubles = (size_t)per * b.K;
+    int e = rc.ensure(shard_doubles);
+    if (e)
+        return e;
+    const int status_slot = 3 * b.p + 6;
+    int run_rc = 0;
+    if (hi > lo)
+        run_rc = ev.run_async(b, lo, hi, rc.shard);
+    if (run_rc && hi > lo)
+        (void)ev.poke(rc.shard + status_slot, MS_SHARD_FAILED); // fail together, after the collective
+    e = rc.allgather(shard_doubles, (hipStream_t)ev.stream());
+    if (e)
+        return e;
+    if (!b.host_records)
+        return ev.fetch_stream(rc.all, nullptr, 0); // records stay in HBM: only wait for the collective
+    e = ev.fetch_stream(rc.all, b.records.data(), (size_t)b.count * b.K);
+    if (e)
+        return e;
+    for (int r = 0; r < rc.world; ++r)
+        if ((long long)r * per < b.count && b.records[((size_t)r * per) * b.K + status_slot] == MS_SHARD_FAILED)
+            return run_rc ? run_rc : -1;
+    return 0;
+}
+} // namespace gslnls
 
 namespace gslnls
 {
@@ -585,6 +619,123 @@ int gslnls_batch_irls(gslnls_batch *h, int lo, int hi, int jac, int fvv, const d
     return GSLNLS_SUCCESS;
 }
 
+// pack the per-data-set outputs of a batched robust fit into one record of p + 8 doubles: par[p], scal[4], ints[4]
+__global__ void batch_pack_kernel(const double *par, const double *scal, const int *ints, int p, int cnt, double *out)
+{
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= cnt)
+        return;
+    double *o = out + (size_t)d * (p + 8);
+    for (int k = 0; k < p; ++k)
+        o[k] = par[(size_t)d * p + k];
+    for (int k = 0; k < 4; ++k)
+    {
+        o[p + k] = scal[(size_t)d * 4 + k];
+        o[p + 4 + k] = (double)ints[(size_t)d * 4 + k];
+    }
+}
+
+int gslnls_batch_irls_gather(gslnls_batch *h, int B_total, int jac, int fvv, const double *start, const double *lupars,
+                             const int *control_int, const double *control_dbl, int loss_rho, const double *loss_cc,
+                             double *par, double *scal, int *ints, float *kernel_ms)
+{
+    if (!h || B_total < 1)
+        return GSLNLS_EINVAL;
+    const int world = g_comm.world, rank = g_comm.rank;
+    const int per = (B_total + world - 1) / world;
+    const int lo = std::min(B_total, rank * per), hi = std::min(B_total, lo + per);
+    if (h->B != hi - lo)
+        return GSLNLS_EINVAL; // the handle must hold exactly this rank's block
+    const int p = h->p, K = p + 8;
+    int rc = 0;
+    if (hi > lo)
+        rc = gslnls_batch_irls(h, 0, h->B, jac, fvv, start, lupars, control_int, control_dbl, loss_rho, loss_cc, nullptr,
+                               nullptr, nullptr, kernel_ms);
+    std::vector<double> rec((size_t)world * per * K, 0.0);
+    if (world == 1)
+    {
+        if (rc)
+            return rc;
+        GSLNLS_HIP_OK(hipMemcpy(par, h->d_par, sizeof(double) * (size_t)h->B * p, hipMemcpyDeviceToHost));
+        GSLNLS_HIP_OK(hipMemcpy(scal, h->d_scal, sizeof(double) * (size_t)h->B * 4, hipMemcpyDeviceToHost));
+        GSLNLS_HIP_OK(hipMemcpy(ints, h->d_ints, sizeof(int) * (size_t)h->B * 4, hipMemcpyDeviceToHost));
+        return GSLNLS_SUCCESS;
+    }
+    // one all-gather of per x (p + 8) doubles per rank: the final exchange of SURVEY.md 8(e), row "batched IRLS".
+    // A rank that failed still enters it (status slot of its first record = MS_SHARD_FAILED).
+    const size_t shard_doubles = (size_t)per * K;
+    double *d_shard = nullptr, *d_all = nullptr;
+    const bool lib = g_comm.rccl != nullptr;
+    if (lib)
+    {
+        int e = g_rccl.ensure(shard_doubles);
+        if (e)
+            return e;
+        d_shard = g_rccl.shard;
+        d_all = g_rccl.all;
+    }
+    else
+    {
+        if (!g_comm.allgather || !g_comm.shard_buf || !g_comm.all_buf ||
+            (long long)per * K * world > g_comm.cap_points * (long long)gslnls_mstart_record_size(p))
+            return GSLNLS_EINVAL;
+        if (g_comm.buffers_on_device)
+            d_shard = g_comm.shard_buf;
+        else
+            GSLNLS_HIP_OK(hipMalloc(&d_shard, sizeof(double) * shard_doubles));
+    }
+    GSLNLS_HIP_OK(hipMemsetAsync(d_shard, 0, sizeof(double) * shard_doubles, h->st));
+    if (hi > lo && rc == 0)
+        hipLaunchKernelGGL(batch_pack_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->st, h->d_par, h->d_scal, h->d_ints, p,
+                           h->B, d_shard);
+    if (rc)
+    {
+        const double bad = MS_SHARD_FAILED;
+        GSLNLS_HIP_OK(hipMemcpyAsync(d_shard + p + 4, &bad, sizeof(double), hipMemcpyHostToDevice, h->st));
+    }
+    if (lib)
+    {
+        int e = g_rccl.allgather(shard_doubles, h->st);
+        if (e)
+            return e;
+        GSLNLS_HIP_OK(hipMemcpyAsync(rec.data(), d_all, sizeof(double) * rec.size(), hipMemcpyDeviceToHost, h->st));
+        GSLNLS_HIP_OK(hipStreamSynchronize(h->st));
+    }
+    else
+    {
+        if (!g_comm.buffers_on_device)
+        {
+            GSLNLS_HIP_OK(hipMemcpyAsync(g_comm.shard_buf, d_shard, sizeof(double) * shard_doubles, hipMemcpyDeviceToHost, h->st));
+        }
+        GSLNLS_HIP_OK(hipStreamSynchronize(h->st));
+        if (!g_comm.buffers_on_device)
+            hipFree(d_shard);
+        // the callback form counts in records of the multi-start size; hand it the doubles as (per * K) x 1
+        const int e = g_comm.allgather(g_comm.ctx, (int)shard_doubles, 1);
+        if (e)
+            return e;
+        if (g_comm.buffers_on_device)
+            GSLNLS_HIP_OK(hipMemcpy(rec.data(), g_comm.all_buf, sizeof(double) * rec.size(), hipMemcpyDeviceToHost));
+        else
+            memcpy(rec.data(), g_comm.all_buf, sizeof(double) * rec.size());
+    }
+    for (int r = 0; r < world; ++r)
+        if ((long long)r * per < B_total && rec[(size_t)r * per * K + p + 4] == MS_SHARD_FAILED)
+            return rc ? rc : GSLNLS_FAILURE;
+    for (int d = 0; d < B_total; ++d)
+    {
+        const double *o = rec.data() + (size_t)d * K; // block r starts at r * per: contiguous in d
+        for (int k = 0; k < p; ++k)
+            par[(size_t)d * p + k] = o[k];
+        for (int k = 0; k < 4; ++k)
+        {
+            scal[(size_t)d * 4 + k] = o[p + k];
+            ints[(size_t)d * 4 + k] = (int)o[p + 4 + k];
+        }
+    }
+    return GSLNLS_SUCCESS;
+}
+
 int gslnls_lower_formula(const char *rhs, int p, const char *const *parnames, int *par_order, char *varnames_out,
                           int varnames_cap)
 {
@@ -608,6 +759,7 @@ int gslnls_set_comm(int rank, int world, gslnls_allgather_fn fn, void *ctx, doub
 {
     if (world < 1 || rank < 0 || rank >= world)
         return GSLNLS_EINVAL;
+    g_comm = MsComm(); // the callback form replaces an in-library communicator, if one was bound
     g_comm.rank = rank;
     g_comm.world = world;
     g_comm.allgather = fn;
@@ -618,6 +770,53 @@ int gslnls_set_comm(int rank, int world, gslnls_allgather_fn fn, void *ctx, doub
     g_comm.buffers_on_device = buffers_on_device;
     return GSLNLS_SUCCESS;
 }
+
+int gslnls_comm_get_unique_id(char *id128)
+{
+    if (!id128)
+        return GSLNLS_EINVAL;
+    return g_rccl.get_unique_id(id128);
+}
+
+static int comm_bind(int rc)
+{
+    if (rc == GSLNLS_SUCCESS)
+    {
+        g_comm = MsComm();
+        g_comm.rank = g_rccl.rank;
+        g_comm.world = g_rccl.world;
+        g_comm.rccl = &g_rccl;
+        g_comm.rccl_run = ms_rccl_run_batch;
+        g_comm.buffers_on_device = 1;
+        const char *f = getenv("GSLNLS_COMM_FORCE_COLLECTIVE");
+        g_comm.force_collective = (f && f[0] == '1') ? 1 : 0;
+    }
+    return rc;
+}
+
+int gslnls_comm_init_rank(const char *id128, int rank, int world)
+{
+    if (!id128)
+        return GSLNLS_EINVAL;
+    return comm_bind(g_rccl.init_rank(id128, rank, world));
+}
+
+int gslnls_comm_init_file(const char *path, int rank, int world, int timeout_s)
+{
+    if (!path)
+        return GSLNLS_EINVAL;
+    return comm_bind(g_rccl.init_file(path, rank, world, timeout_s > 0 ? timeout_s : 60));
+}
+
+void gslnls_comm_destroy(void)
+{
+    g_rccl.destroy();
+    g_comm = MsComm();
+}
+
+long long gslnls_comm_allgather_count(void) { return g_rccl.n_allgathers; }
+
+const char *gslnls_comm_last_error(void) { return g_rccl.api.err; }
 
 int gslnls_dense_mstart(gslnls_dense *h, int jac, int fvv, const double *start2p, const double *lupars,
                         const int *control_int, const double *control_dbl, const int *has_start, gslnls_result *out)
@@ -632,7 +831,15 @@ int gslnls_mstart_batch(gslnls_dense *h, int jac, const double *ranges, const do
                         const double *control_dbl, const double *lupars, double *records, int records_on_device,
                         float *kernel_ms)
 {
-    if (!h || !h->impl || lo < 0 || hi > count || lo > hi)
+    if (!h || !h->impl || count < 1)
+        return GSLNLS_EINVAL;
+    if (lo < 0)
+    {
+        if (records_on_device)
+            return GSLNLS_EINVAL;
+        h->impl->batch_comm = &g_comm;
+    }
+    else if (hi > count || lo > hi)
         return GSLNLS_EINVAL;
     return h->impl->mstart_batch(jac, ranges, kd, first_draw, count, lo, hi, maxiter, dtol, control_int, control_dbl,
                                  lupars, records, records_on_device, kernel_ms);

@@ -14,6 +14,7 @@
 #include <vector>
 #include "../../include/gslnls_core.h"
 #include "dense_kernels.hpp"
+#include "dense_persist.hpp"
 #include "mstart_driver.hpp"
 
 namespace gslnls
@@ -150,6 +151,7 @@ struct DenseBase
                              double *records, int records_on_device, float *kernel_ms) = 0;
     virtual int debug_stamps(int jac, const double *theta, int warm, unsigned long long *out, int *nrows) = 0;
     int n = 0, p = 0;
+    const MsComm *batch_comm = nullptr; // communicator of mstart_batch's gathered form (set by the C entry point)
 };
 
 // optional hook polled between launch chunks / passes / multi-start batches (gslnls_set_interrupt_hook)
@@ -184,6 +186,10 @@ struct DenseFit : DenseBase
     int ev_head = 0; // slot of the fit in progress / the most recent fit
     double ev_ms_total = 0.0;
     long long ev_launches_total = 0;
+    // one-launch-per-fit path (dense_persist.hpp): granule buffers of the two hops, and whether this handle may use it
+    u64_t *d_pbufs = nullptr;
+    int persist_state = -1; // -1 not decided, 0 off (env, occupancy, or a timed-out fit), 1 on
+    long long last_steps = 0;
     MsEvaluator *ms_eval = nullptr; // cached batch evaluator (Sobol table, device buffers)
     void *irls_arena = nullptr;     // work arrays of the robust re-weighting (irls_host.hpp), kept between calls
     size_t irls_arena_bytes = 0;
@@ -253,6 +259,8 @@ struct DenseFit : DenseBase
             GSLNLS_HIP_OK(hipMalloc(&d_state, sizeof(LmState<P>) * 2));
             GSLNLS_HIP_OK(hipHostMalloc(&h_state, sizeof(LmState<P>) * 2 + 64, hipHostMallocMapped));
             GSLNLS_HIP_OK(hipMalloc(&d_covar, sizeof(double) * P * P));
+            GSLNLS_HIP_OK(hipMalloc(&d_pbufs, sizeof(u64_t) * PersistBufs<P>::WORDS));
+            GSLNLS_HIP_OK(hipMemset(d_pbufs, 0, sizeof(u64_t) * PersistBufs<P>::WORDS));
         }
         else
         {
@@ -263,6 +271,8 @@ struct DenseFit : DenseBase
             ev_launches_total = 0;
             pred_kind = -1;
             pred_launches = 0;
+            persist_state = -1;
+            last_steps = 0;
             last_parity = 0;
             last_launches = 0;
             last_ms = 0.f;
@@ -349,6 +359,8 @@ struct DenseFit : DenseBase
             {
                 h_done[0] = 0;
                 h_done[1] = 0;
+                h_done[2] = 0;
+                h_done[3] = 0;
                 ctx.seq = 0;
             }
         }
@@ -366,6 +378,7 @@ struct DenseFit : DenseBase
             hipFree(d_sw);
         }
         hipFree(d_partials);
+        hipFree(d_pbufs);
         hipFree(d_state);
         if (h_state)
             hipHostFree(h_state);
@@ -460,6 +473,186 @@ struct DenseFit : DenseBase
         }
     }
 
+    // the resident kernel's geometry: PT row threads + one control wave per workgroup, PG workgroups
+    static constexpr int PT = T;
+    int PGrid() const { return ctx.G; }
+    // dynamic LDS a workgroup of the resident kernel may take: 160 KB minus its static arrays
+    static constexpr int persist_lds_budget() { return 160 * 1024 - (NV * PT * 8 + 2048); }
+    // rows per thread that stay in LDS: all of them when the budget allows
+    int PRows() const
+    {
+        const int nc = M::NX + 1 + (ctx.sw ? 1 : 0);
+        const long long need = ((long long)n + (long long)PGrid() * PT - 1) / ((long long)PGrid() * PT);
+        const long long fit = persist_lds_budget() / ((long long)PT * nc * 8);
+        return (int)(need < fit ? need : fit);
+    }
+    bool lds_attr_set[3] = {false, false, false};
+    void launch_fit(int jacmode, PersistArgs pa)
+    {
+        const dim3 grid(PGrid()), block(PT);
+        pa.rows_resident = PRows();
+        {
+            static const int fast_env = getenv("GSLNLS_PERSIST_FAST") ? atoi(getenv("GSLNLS_PERSIST_FAST")) : 1;
+            pa.fast = fast_env;
+        }
+        const size_t dyn = (size_t)pa.rows_resident * PT * (M::NX + 1 + (ctx.sw ? 1 : 0)) * 8;
+        if (!lds_attr_set[jacmode])
+        {
+            // dynamic LDS beyond the default 64 KB has to be announced once per kernel
+            if constexpr (PERSIST_BUILT)
+            {
+                const void *fn = jacmode == JAC_ANALYTIC ? (const void *)lm_fit_kernel<M, JAC_ANALYTIC, PT>
+                               : jacmode == JAC_FORWARD ? (const void *)lm_fit_kernel<M, JAC_FORWARD, PT>
+                                                        : (const void *)lm_fit_kernel<M, JAC_CENTER, PT>;
+                (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, persist_lds_budget());
+            }
+            lds_attr_set[jacmode] = true;
+        }
+        if constexpr (PERSIST_BUILT)
+        switch (jacmode)
+        {
+        case JAC_ANALYTIC:
+            hipLaunchKernelGGL((lm_fit_kernel<M, JAC_ANALYTIC, PT>), grid, block, dyn, stream, ctx.x[0], ctx.y, ctx.sw, ctx.n,
+                               (int)grid.x, pa, ctx);
+            break;
+        case JAC_FORWARD:
+            hipLaunchKernelGGL((lm_fit_kernel<M, JAC_FORWARD, PT>), grid, block, dyn, stream, ctx.x[0], ctx.y, ctx.sw, ctx.n,
+                               (int)grid.x, pa, ctx);
+            break;
+        default:
+            hipLaunchKernelGGL((lm_fit_kernel<M, JAC_CENTER, PT>), grid, block, dyn, stream, ctx.x[0], ctx.y, ctx.sw, ctx.n,
+                               (int)grid.x, pa, ctx);
+            break;
+        }
+    }
+
+    // May this handle run whole fits in one launch?  All G workgroups have to be resident together (one per CU):
+    // decided once per handle from the device's CU count and the kernel's occupancy; GSLNLS_PERSIST=0 turns it off.
+    // interpreted expression models and p > 4 (whose state does not fit the control wave's registers) keep the launch-per-step kernel
+    static constexpr bool PERSIST_BUILT = (M::ID != 100) && (P <= 4);
+    bool persist_ok()
+    {
+        if constexpr (!PERSIST_BUILT)
+            return false;
+        else if (persist_state < 0)
+        {
+            persist_state = 0;
+            // Measured on MI355X (profiles/r02_persist_*.txt): per trial step the resident kernel
+            // takes 2.9 us on one workgroup (launch-per-step: 5.8), 5.9 vs 5.6 us on 8, 7.9 vs 6.3 us on 256 -- the
+            // in-kernel all-reduce (three hops, 2.4-3 us) costs more than the kernel boundary it replaces (about 2.5).
+            // So by default only problems that fit a couple of workgroups take it; GSLNLS_PERSIST=1 forces it for
+            // every grid the device can hold, GSLNLS_PERSIST=0 turns it off.
+            int maxg = 2;
+            if (const char *e = getenv("GSLNLS_PERSIST"))
+            {
+                if (e[0] == '0')
+                    return false;
+                maxg = MAX_G;
+            }
+            int cus = 0, per_cu = 0;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) != hipSuccess)
+                return false;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lm_fit_kernel<M, JAC_ANALYTIC, PT>, PT, 0) != hipSuccess ||
+                per_cu < 1)
+                return false;
+            // one workgroup per CU: the dispatcher deals the workgroups of a launch round-robin over idle CUs, so a
+            // grid of at most `cus` workgroups on an otherwise idle device is resident as a whole; a device that is
+            // busy with something else makes the bounded spins give up, and the fit then takes the other kernel
+            if (PGrid() <= cus && PGrid() <= maxg)
+                persist_state = 1;
+        }
+        return persist_state == 1;
+    }
+
+    static constexpr int PERSIST_CHUNK = 2048; // steps per launch: the host's interrupt hook gets its say in between
+
+    // the whole fit in one launch (dense_persist.hpp); returns 1 when a bounded spin gave up and the caller has to
+    // run the fit through the launch-per-step kernel instead
+    int run_loop_persist(int jacmode, const double *start, const double *lupars, int max_steps_override = 0)
+    {
+        const int maxiter = ctx.prm.maxiter;
+        if (ctx.ssrtrace)
+        {
+            GSLNLS_HIP_OK(hipMemsetAsync(d_ssrtrace, 0xFF, sizeof(double) * (maxiter + 1), stream));
+            GSLNLS_HIP_OK(hipMemsetAsync(d_partrace, 0xFF, sizeof(double) * (size_t)(maxiter + 1) * P, stream));
+        }
+        ev_head = (ev_head + 1) % EV_RING;
+        collect_fit_events(ev_head);
+        const double t_begin = now_s();
+        hipEventRecord(ev_fit0[ev_head], stream);
+        ctx.seq += 1;
+        {
+            StartArgs<P> sa;
+            for (int k = 0; k < P; ++k)
+            {
+                sa.start[k] = start[k];
+                sa.lo[k] = lupars ? lupars[2 * k] : -INFINITY;
+                sa.up[k] = lupars ? lupars[2 * k + 1] : INFINITY;
+            }
+            h_state[0].phase = PH_INIT;
+            ctx.sa = sa;
+        }
+        PersistArgs pa;
+        pa.bufs = d_pbufs;
+        pa.tag_base = ((ctx.seq & 0x7ffffu) | 0x80000u) << 12;
+        pa.step0 = 0;
+        pa.max_steps = max_steps_override > 0 ? max_steps_override : PERSIST_CHUNK;
+        pa.resume = 0;
+        const long long max_steps_total = ((long long)maxiter * 17 + 2) * (ctx.prm.trs ? 2 : 1) + 2;
+        long long launches = 0;
+        for (;;)
+        {
+            launch_fit(jacmode, pa);
+            if (hipGetLastError() != hipSuccess)
+                return GSLNLS_E_NODEVICE;
+            launches += 1;
+            hipEvent_t ev_chunk = ev_fit1[ev_head];
+            hipEventRecord(ev_chunk, stream);
+            bool done = false;
+            for (;;)
+            {
+                if (*h_done == ctx.seq)
+                {
+                    done = true;
+                    break;
+                }
+                const hipError_t q = hipEventQuery(ev_chunk);
+                if (q == hipSuccess)
+                {
+                    done = (*h_done == ctx.seq);
+                    break;
+                }
+                if (q != hipErrorNotReady)
+                    return GSLNLS_E_NODEVICE; // a launch failure or device fault: do not spin on it
+            }
+            if (done)
+                break;
+            __sync_synchronize();
+            if (h_done[2] == ctx.seq)
+            {
+                persist_state = 0; // the device is shared with something that keeps our workgroups apart
+                ev_pending[ev_head] = false;
+                return 1;
+            }
+            if (max_steps_override > 0)
+                break; // timing mode: the requested number of steps has run
+            pa.step0 += pa.max_steps;
+            pa.resume = 1;
+            if (pa.step0 > max_steps_total)
+                return GSLNLS_FAILURE;
+            if (g_interrupt_hook && g_interrupt_hook())
+                return GSLNLS_E_INTERRUPTED;
+        }
+        __sync_synchronize();
+        ev_pending[ev_head] = true;
+        ev_launches[ev_head] = launches;
+        last_ms = (float)(1e3 * (now_s() - t_begin));
+        last_parity = 0;
+        last_launches = launches;
+        last_steps = (long long)h_done[1];
+        return GSLNLS_SUCCESS;
+    }
+
     // ---- pieces of one fit -------------------------------------------------------------------
     int last_parity = 0;
     long long last_launches = 0;
@@ -529,6 +722,13 @@ struct DenseFit : DenseBase
     // state is in h_state[0] (written by the device through the mapped mirror) and in ctx.state[last_parity]
     int run_loop(int jacmode, const double *start, const double *lupars, int chunk)
     {
+        if (chunk == 0 && persist_ok())
+        {
+            const int rc = run_loop_persist(jacmode, start, lupars);
+            if (rc != 1)
+                return rc;
+            // a spin gave up (workgroups not co-resident): same fit, launch-per-step kernel
+        }
         const int maxiter = ctx.prm.maxiter;
         if (ctx.ssrtrace)
         {
@@ -593,11 +793,14 @@ struct DenseFit : DenseBase
                     done = true;
                     break;
                 }
-                if (hipEventQuery(ev_chunk) == hipSuccess)
+                const hipError_t q = hipEventQuery(ev_chunk);
+                if (q == hipSuccess)
                 {
                     done = (*h_done == ctx.seq);
                     break;
                 }
+                if (q != hipErrorNotReady)
+                    return GSLNLS_E_NODEVICE; // a launch failure or device fault: do not spin on it
             }
             if (done)
                 break;
@@ -620,6 +823,7 @@ struct DenseFit : DenseBase
         last_ms = (float)(1e3 * (now_s() - t_begin));
         last_parity = parity ^ 1;
         last_launches = launches;
+        last_steps = launches;
         return GSLNLS_SUCCESS;
     }
 
@@ -683,6 +887,7 @@ struct DenseFit : DenseBase
         out->chisq_init = s.chisq_init;
         out->loop_ms = last_ms;
         out->n_launches = (int)last_launches;
+        out->n_steps = (int)last_steps;
         out->jtj_cond = ok ? scaled_jtj_cond(s.A, P) : NAN;
         return s.status;
     }
@@ -718,6 +923,21 @@ struct DenseFit : DenseBase
     // diagnostic: per-wave s_memtime stamps of one steady-state launch (needs a -DGSLNLS_STAMPS build)
     int debug_stamps(int jac, const double *theta, int warm, unsigned long long *out, int *nrows) override
     {
+        if (warm < 0)
+        {
+            // resident kernel: [workgroup][role][8] stamps of one step in the middle of a 32-step launch
+            const int prow = PGrid() * 2;
+            unsigned long long *dp = nullptr;
+            GSLNLS_HIP_OK(hipMalloc(&dp, sizeof(unsigned long long) * 8 * prow));
+            GSLNLS_HIP_OK(hipMemset(dp, 0, sizeof(unsigned long long) * 8 * prow));
+            ctx.stamps = dp;
+            const float t = time_pass(jac, theta, -32);
+            ctx.stamps = nullptr;
+            GSLNLS_HIP_OK(hipMemcpy(out, dp, sizeof(unsigned long long) * 8 * prow, hipMemcpyDeviceToHost));
+            hipFree(dp);
+            *nrows = prow;
+            return t < 0 ? GSLNLS_FAILURE : GSLNLS_SUCCESS;
+        }
         const int rows = ctx.G * (T / 64);
         unsigned long long *d = nullptr;
         GSLNLS_HIP_OK(hipMalloc(&d, sizeof(unsigned long long) * 8 * rows));
@@ -752,6 +972,27 @@ struct DenseFit : DenseBase
             }
             ctx.sa = sa;
         }
+        if (reps < 0 && persist_ok())
+        {
+            // resident kernel: -reps steps in one launch (bench_hold keeps the fit alive), average per step
+            const double st[P > 0 ? P : 1] = {};
+            (void)st;
+            if (run_loop_persist(jacmode, theta, nullptr, 8) < 0) // warm-up launch
+                return -1.f;
+            (void)hipStreamSynchronize(stream);
+            hipEventRecord(ev0, stream);
+            if (run_loop_persist(jacmode, theta, nullptr, -reps) < 0)
+                return -1.f;
+            hipEventRecord(ev1, stream);
+            if (hipStreamSynchronize(stream) != hipSuccess)
+                return -1.f;
+            float pms = 0.f;
+            hipEventElapsedTime(&pms, ev0, ev1);
+            ev_pending[ev_head] = false;
+            return pms / (float)(-reps);
+        }
+        if (reps < 0)
+            reps = -reps;
         int parity = 0;
         for (int k = 0; k < 4; ++k)
         {

@@ -48,6 +48,7 @@ struct MsBatch
     int always_fit = 0;
     int consecutive = -1;            // 1: draw[i] == draw[0] + i is known to hold, 0: known not to, -1: look
     std::vector<double> records;     // count x K, filled by the evaluator (+ all-gather)
+    bool host_records = true;        // false: leave the (gathered) records in device memory (throughput measurements)
 };
 
 struct MsComm
@@ -61,7 +62,19 @@ struct MsComm
     double *all_buf = nullptr;   // caller-owned, world*per*K doubles
     long long cap_points = 0;    // capacity of all_buf in points (>= world*per)
     int buffers_on_device = 0;
+    // in-library collective (rccl_comm.hpp): when set, the batch kernel writes its shard straight into the
+    // communicator's device buffer and the all-gather is enqueued behind it on the SAME stream -- nothing between
+    // the kernel and the collective runs on the host.  Takes precedence over the callback form above.
+    struct RcclComm *rccl = nullptr;
+    int (*rccl_run)(struct MsEvaluator &ev, const MsComm &comm, struct MsBatch &b, int per, int lo, int hi) = nullptr;
+    // test hook: take the collective path even with one rank (the all-gather of a 1-rank communicator)
+    int force_collective = 0;
 };
+
+// value the status slot of a shard's first record carries when the rank could not compute its shard: every rank
+// still enters the collective (a rank that returned early would leave the others blocked in it) and all of them fail
+// together afterwards
+constexpr double MS_SHARD_FAILED = -424242.0;
 
 struct MsEvaluator
 {
@@ -70,7 +83,15 @@ struct MsEvaluator
     virtual int run(MsBatch &b, int lo, int hi, double *out, bool out_on_device) = 0;
     // copy ndoubles from src (device or host) to host dst
     virtual int fetch(const double *src, bool src_on_device, double *dst, size_t ndoubles) = 0;
+    // stream-ordered form for the in-library collective: run() without the final synchronisation, the stream the
+    // kernel went to, and a fetch enqueued on that stream (synchronises it)
+    virtual int run_async(MsBatch &b, int lo, int hi, double *dev_out) { return run(b, lo, hi, dev_out, true); }
+    virtual void *stream() { return nullptr; }
+    virtual int fetch_stream(const double *dev_src, double *dst, size_t ndoubles) { return fetch(dev_src, true, dst, ndoubles); }
+    // mark a device shard as failed (one double)
+    virtual int poke(double *dev_dst, double value) { (void)dev_dst; (void)value; return -1; }
 };
+
 
 // stable ascending order with NaN last == R_orderVector1(.., nalast = TRUE, decreasing = FALSE)
 inline void ms_order(const std::vector<double> &v, std::vector<int> &ord)
@@ -104,23 +125,39 @@ struct MsState
 
 inline int ms_run_batch(MsEvaluator &ev, const MsComm &comm, MsBatch &b)
 {
-    b.records.assign((size_t)b.count * b.K, 0.0);
-    if (comm.world <= 1)
-        return ev.run(b, 0, b.count, b.records.data(), false);
+    if (b.host_records)
+        b.records.assign((size_t)b.count * b.K, 0.0);
+    if (comm.world <= 1 && !(comm.rccl && comm.force_collective))
+        return b.host_records ? ev.run(b, 0, b.count, b.records.data(), false) : ev.run(b, 0, b.count, nullptr, true);
     // contiguous blocks of ceil(count / world) points per rank; the last block may be short
     const int per = (b.count + comm.world - 1) / comm.world;
     const int lo = std::min(b.count, comm.rank * per), hi = std::min(b.count, lo + per);
+    if (comm.rccl && comm.rccl_run)
+        return comm.rccl_run(ev, comm, b, per, lo, hi);
     if (!comm.allgather || !comm.shard_buf || !comm.all_buf || (long long)per * comm.world > comm.cap_points)
         return -1;
     int rc = 0;
     if (hi > lo)
         rc = ev.run(b, lo, hi, comm.shard_buf, comm.buffers_on_device != 0);
-    if (rc)
-        return rc;
-    rc = comm.allgather(comm.ctx, per, b.K);
-    if (rc)
-        return rc;
-    return ev.fetch(comm.all_buf, comm.buffers_on_device != 0, b.records.data(), (size_t)b.count * b.K);
+    const int status_slot = 3 * b.p + 6; // K = 3p + 8: ..., niter, status, nevalf
+    if (rc && hi > lo)
+    {
+        // this rank failed: say so in its shard and enter the collective anyway
+        if (comm.buffers_on_device)
+            (void)ev.poke(comm.shard_buf + status_slot, MS_SHARD_FAILED);
+        else
+            comm.shard_buf[status_slot] = MS_SHARD_FAILED;
+    }
+    const int rc2 = comm.allgather(comm.ctx, per, b.K);
+    if (rc2)
+        return rc2;
+    const int rc3 = ev.fetch(comm.all_buf, comm.buffers_on_device != 0, b.records.data(), (size_t)b.count * b.K);
+    if (rc3)
+        return rc3;
+    for (int r = 0; r < comm.world; ++r)
+        if ((long long)r * per < b.count && b.records[((size_t)r * per) * b.K + status_slot] == MS_SHARD_FAILED)
+            return rc ? rc : -1;
+    return 0;
 }
 
 // one major iteration == one call of gsl_multistart_driver (src/nls_mstart.c:24-350)

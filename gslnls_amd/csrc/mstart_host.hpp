@@ -79,6 +79,30 @@ struct HipMsEvaluator : MsEvaluator
         return 0;
     }
 
+    bool defer_sync = false; // run_async: leave the stream running, the collective is enqueued behind the kernel
+    int run_async(MsBatch &b, int lo, int hi, double *dev_out) override
+    {
+        defer_sync = true;
+        const int rc = run(b, lo, hi, dev_out, true);
+        defer_sync = false;
+        return rc;
+    }
+    void *stream() override { return (void *)fit.stream; }
+    int fetch_stream(const double *dev_src, double *dst, size_t nd) override
+    {
+        if (nd)
+            GSLNLS_HIP_OK(hipMemcpyAsync(dst, dev_src, sizeof(double) * nd, hipMemcpyDeviceToHost, fit.stream));
+        GSLNLS_HIP_OK(hipStreamSynchronize(fit.stream));
+        if (e0 && e1)
+            hipEventElapsedTime(&last_kernel_ms, e0, e1);
+        return 0;
+    }
+    int poke(double *dev_dst, double value) override
+    {
+        GSLNLS_HIP_OK(hipMemcpyAsync(dev_dst, &value, sizeof(double), hipMemcpyHostToDevice, fit.stream));
+        GSLNLS_HIP_OK(hipStreamSynchronize(fit.stream));
+        return 0;
+    }
     int run(MsBatch &b, int lo, int hi, double *out, bool out_on_device) override
     {
         if (b.p != P || b.K != K)
@@ -109,7 +133,7 @@ struct HipMsEvaluator : MsEvaluator
         a.first_draw = consecutive ? b.draw[0] : 0;
         a.start = d_start;
         // records of point idx land at records + idx*K: shift the base so that point `lo` lands at out[0]
-        double *dev_out = out_on_device ? out : d_rec;
+        double *dev_out = (out_on_device && out) ? out : d_rec; // (device output without a buffer: the evaluator's own)
         a.records = dev_out - (size_t)lo * K;
         a.sobol = d_sobol;
         a.lo = lo;
@@ -173,6 +197,10 @@ struct HipMsEvaluator : MsEvaluator
         }
 #undef GSLNLS_MS_LAUNCH
         hipEventRecord(e1, st);
+        if (hipGetLastError() != hipSuccess)
+            return GSLNLS_E_NODEVICE;
+        if (defer_sync && out_on_device)
+            return 0;
         if (!out_on_device)
             GSLNLS_HIP_OK(hipMemcpyAsync(h_rec, d_rec, sizeof(double) * (size_t)(hi - lo) * K, hipMemcpyDeviceToHost, st));
         GSLNLS_HIP_OK(hipStreamSynchronize(st));
@@ -308,7 +336,21 @@ int DenseFit<M>::mstart_batch(int jac, const double *ranges, const double *kd, l
     b.maxiter = maxiter;
     b.dtol = dtol;
     b.always_fit = 0;
-    const int rc = ev.run(b, lo, hi, records, records_on_device != 0);
+    int rc;
+    if (lo < 0)
+    {
+        // whole batch, sharded over the ranks of the bound communicator and completed by its all-gather -- exactly
+        // what one concentration stage of the multi-start driver does (ms_run_batch); records: host, count x K
+        if (!batch_comm)
+            return GSLNLS_EINVAL;
+        b.host_records = (records != nullptr);
+        rc = ms_run_batch(ev, *batch_comm, b);
+        if (rc == 0 && records)
+            memcpy(records, b.records.data(), sizeof(double) * (size_t)count * b.K);
+        b.host_records = true;
+    }
+    else
+        rc = ev.run(b, lo, hi, records, records_on_device != 0);
     if (kernel_ms)
         *kernel_ms = ev.last_kernel_ms;
     return rc;

@@ -1,9 +1,12 @@
-"""One process per GPU: shard multi-start's sample points over the ranks of a torch.distributed job.
+"""One process per GPU: shard multi-start's sample points (and batched robust fits) over the ranks of a job.
 
-The only exchange step of the path is one all-gather of the per-point records per batch
-(SURVEY.md 8(e)); with backend "nccl" that is an RCCL all-gather over xGMI on device buffers,
-with "gloo" (CPU tests) the same call on host tensors.  The C library writes this rank's shard
-into `shard`, calls back into `_allgather`, then reads the completed `all` buffer.
+The only exchange step of the path is one all-gather of the per-point records per batch.
+
+* init_library_comm(): the production form.  libgslnls_hip.so owns an RCCL communicator and issues the
+  ncclAllGather itself, on its own stream, right behind the batch kernel; Python only carries the 128-byte
+  bootstrap id from rank 0 to the others (any channel would do: an R host uses gslnls_comm_init_file).
+* init_multistart_comm(): the callback form -- the library calls back into torch.distributed.  Used with the
+  "gloo" backend by the CPU tests (world_size 2 on one box), where no RCCL communicator can exist.
 """
 import ctypes as C
 
@@ -50,6 +53,34 @@ def init_multistart_comm(max_points, p, device=None):
     return calls
 
 
+def init_library_comm():
+    """Bind the in-library RCCL communicator to the ranks of the default process group (backend "nccl").
+    Returns the communicator's description; raises when RCCL cannot be bound."""
+    import torch
+    import torch.distributed as dist
+    L = _lib.lib()
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        L.gslnls_comm_destroy()
+        return "one rank"
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    buf = C.create_string_buffer(128)
+    ok = torch.tensor([1 if (rank != 0 or L.gslnls_comm_get_unique_id(buf) == 0) else 0], dtype=torch.int32, device=dev)
+    t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone().to(dev)
+    dist.broadcast(t, 0)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) != 1:
+        raise RuntimeError("RCCL unavailable: %s" % L.gslnls_comm_last_error().decode())
+    rc = L.gslnls_comm_init_rank(bytes(t.cpu().numpy().tobytes()), rank, world)
+    flag = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) != 1:
+        L.gslnls_comm_destroy()
+        raise RuntimeError("ncclCommInitRank failed: %s" % L.gslnls_comm_last_error().decode())
+    return "RCCL communicator inside libgslnls_hip.so, %d ranks" % world
+
+
 def reset_comm():
+    _lib.lib().gslnls_comm_destroy()
     _lib.lib().gslnls_set_comm(0, 1, None, None, None, None, 0, 0)
     _state.clear()

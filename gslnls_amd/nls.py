@@ -191,7 +191,7 @@ def _finish(out, res, trace, algorithm, n):
     out.update(niter=res.niter, conv=res.conv, status=_lib.strerror(res.conv), ssr=res.ssr, ssrtol=res.ssrtol,
                algorithm=_lib.lib().gslnls_algorithm_name(ALGORITHMS.index(algorithm)).decode(),
                neval=dict(f=res.neval[0], J=res.neval[1], fvv=res.neval[2]), info=res.info,
-               chisq_init=res.chisq_init, loop_ms=res.loop_ms, n_launches=res.n_launches, n=n,
+               chisq_init=res.chisq_init, loop_ms=res.loop_ms, n_launches=res.n_launches, n_steps=res.n_steps, n=n,
                jtj_cond=res.jtj_cond,
                irls=dict(irls_sigma=res.irls_sigma, irls_tol=res.irls_tol, irls_status=res.irls_status,
                          irls_niter=res.irls_niter, irls_conv=res.irls_status),

@@ -110,6 +110,8 @@ typedef struct gslnls_result
      * cholesky in the reference's encoding, R/nls.R:1186); a caller that asked for "qr" or "svd" compares this with
      * GSLNLS_COND_LIMIT and keeps its own QR path beyond it -- see gslnls_solver_served(). */
     double jtj_cond;
+    int n_steps;      /* passes over the rows (trial steps incl. the initial point) the device ran for this call; equals
+                         n_launches on the launch-per-step kernel, while the one-launch-per-fit kernel has n_launches = 1 */
 } gslnls_result;
 
 /* Solver routing rule of the boundary.  control_int[4]: 0 qr (the R default), 1 cholesky, 2 svd (R/nls.R:702).
@@ -160,9 +162,11 @@ void gslnls_dense_destroy(gslnls_dense *h);
  * re-bound by the next create of the same model -- a one-shot gslnls_nls() on a small problem is otherwise dominated by
  * ~3 ms of device allocation around ~0.1 ms of fitting.  gslnls_trim_cache() frees what is parked. */
 void gslnls_trim_cache(void);
-/* single-start solve (default loss) on resident data; chunk = step launches enqueued per host check of the
- * device's completion word.  0 = default: 16, or -- after a fit of the same kind on this handle -- as many launches as
- * that fit needed, then top-ups of 4 (launches enqueued beyond the one that ends a fit still run, as no-ops) */
+/* single-start solve (default loss) on resident data.  chunk = 0 (default): the whole fit runs in ONE launch of the
+ * resident kernel (csrc/dense_persist.hpp) when the device can hold the grid, else as below.  chunk > 0 selects the
+ * launch-per-step kernel with that many step launches enqueued per host check of the device's completion word;
+ * chunk < 0 the same kernel with its adaptive chunking: 16, or -- after a fit of the same kind on this handle -- as many
+ * launches as that fit needed, then top-ups of 4 (launches enqueued beyond the one that ends a fit still run, as no-ops) */
 int gslnls_dense_solve(gslnls_dense *h, int jac, int fvv, const double *start, const double *lupars,
                        const int *control_int, const double *control_dbl, int chunk, gslnls_result *out);
 /* time `reps` back-to-back launches of the pass kernel at `theta` with HIP events on the
@@ -195,12 +199,33 @@ typedef int (*gslnls_allgather_fn)(void *ctx, int per_points, int K);
  * memory).  world = 1 (default) disables it. */
 int gslnls_set_comm(int rank, int world, gslnls_allgather_fn fn, void *ctx, double *shard_buf, double *all_buf,
                     long long cap_points, int buffers_on_device);
+/* The same exchange inside the library: an RCCL communicator owned by libgslnls_hip.so.  The batch kernel writes
+ * its shard into the communicator's device buffer and ONE ncclAllGather over xGMI is enqueued right behind it on
+ * the library's stream; the host only waits for the gathered records.  RCCL is bound at run time (dlopen; the copy
+ * the process already holds, if any), so single-GPU hosts need none.
+ * Bootstrap, once per job: rank 0 calls gslnls_comm_get_unique_id (128 bytes, ncclGetUniqueId), the host application
+ * hands the id to the other ranks over whatever channel it has (MPI, a socket, a file), every rank calls
+ * gslnls_comm_init_rank after gslnls_set_device.  gslnls_comm_init_file does both over a file all ranks can see
+ * (rank 0 writes it atomically, the others wait up to timeout_s seconds).  Every gslnls_nls() / gslnls_dense_mstart()
+ * with start ranges is then sharded; all ranks must make the same calls with the same arguments and get identical
+ * results.  Replaces nothing in the reference (its loop over the sample points, src/nls_mstart.c:42-128, is sequential
+ * in one process, src/nls.c:372-399). */
+#define GSLNLS_COMM_ID_BYTES 128
+int gslnls_comm_get_unique_id(char *id128);
+int gslnls_comm_init_rank(const char *id128, int rank, int world);
+int gslnls_comm_init_file(const char *path, int rank, int world, int timeout_s);
+void gslnls_comm_destroy(void);
+long long gslnls_comm_allgather_count(void); /* collectives issued so far (tests, benchmark) */
+const char *gslnls_comm_last_error(void);
 /* multi-start + final solve on resident data; start2p = 2 x p column-major ranges */
 int gslnls_dense_mstart(gslnls_dense *h, int jac, int fvv, const double *start2p, const double *lupars,
                         const int *control_int, const double *control_dbl, const int *has_start, gslnls_result *out);
 /* one concentration batch (src/nls_mstart.c:42-128) of `count` fresh Sobol points with global draw
  * indices first_draw..first_draw+count-1; computes the records of points [lo, hi) into
- * records[0 : (hi-lo)*K) (host or device memory).  kernel_ms: HIP-event time of the batch kernel. */
+ * records[0 : (hi-lo)*K) (host or device memory).  kernel_ms: HIP-event time of the batch kernel.
+ * lo < 0: the whole batch through the bound communicator -- this rank fits its block of ceil(count/world) points, one
+ * all-gather completes the array on every rank, records (host memory, count x K, may be NULL) receives all of it:
+ * one concentration stage exactly as gslnls_nls() runs it. */
 int gslnls_mstart_batch(gslnls_dense *h, int jac, const double *ranges, const double *kd, long long first_draw,
                         int count, int lo, int hi, int maxiter, double dtol, const int *control_int,
                         const double *control_dbl, const double *lupars, double *records, int records_on_device,
@@ -221,6 +246,15 @@ void gslnls_batch_destroy(gslnls_batch *h);
 int gslnls_batch_irls(gslnls_batch *h, int lo, int hi, int jac, int fvv, const double *start, const double *lupars,
                       const int *control_int, const double *control_dbl, int loss_rho, const double *loss_cc,
                       double *par, double *scal, int *ints, float *kernel_ms);
+
+/* One process per GPU (SURVEY.md 8(e), row "batched IRLS"): the B_total data sets are cut into contiguous blocks of
+ * ceil(B_total / world) per rank, `h` holds exactly this rank's block (created from its slice of x / y); every rank
+ * fits its block with no traffic, then ONE all-gather of (p + 8) doubles per data set completes par / scal / ints
+ * (B_total entries each, same layout as above) on every rank -- through the in-library RCCL communicator when one is
+ * bound (gslnls_comm_init_*), else through the gslnls_set_comm callback.  With one rank it is gslnls_batch_irls. */
+int gslnls_batch_irls_gather(gslnls_batch *h, int B_total, int jac, int fvv, const double *start, const double *lupars,
+                             const int *control_int, const double *control_dbl, int loss_rho, const double *loss_cc,
+                             double *par, double *scal, int *ints, float *kernel_ms);
 
 /* ---- gsl_nls_large: replaces C_nls_large (src/init.c:16, src/nls_large.c:66-424) --------------
  * 9 SEXP arguments there: fn, y, jac, fvv, env, start, weights, control_int[7], control_dbl[8]

@@ -87,3 +87,57 @@ def test_c5_full_size_properties(amd):
     assert np.max(np.abs(full["par"] / TH - 1.0)) < 0.02
     # sigma = 1.4826 median|r| of N(0, 2.5^2) noise with 2 % gross outliers
     assert np.all(np.abs(full["sigma"] / 2.5 - 1.0) < 0.1)
+
+
+def _irls_rank_worker(rank, world, port, B, n, q):
+    import os
+    import sys
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import gslnls_amd
+    from gslnls_amd import dist as gdist
+    from test_gpu_batch import c5_data, GAUSS1_START
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    X, Y, _ = c5_data(B, n)
+    per = (B + world - 1) // world
+    lo, hi = min(B, rank * per), min(B, rank * per + per)
+    calls = gdist.init_multistart_comm(max_points=B * 2, p=8)      # callback communicator over gloo (host buffers)
+    prob = gslnls_amd.BatchProblem(4, 8, X[lo:hi], Y[lo:hi])      # this rank's block only
+    out = prob.irls_gathered(B, GAUSS1_START, loss="bisquare", jac=True, control=dict(solver="cholesky"))
+    prob.close()
+    q.put((rank, out["par"].tolist(), out["sigma"].tolist(), out["irls_niter"].tolist(), out["conv"].tolist(), calls["n"]))
+    dist.barrier()
+    gdist.reset_comm()
+    dist.destroy_process_group()
+
+
+def test_batched_irls_world2_gathers_every_data_set(amd):
+    """SURVEY.md 8(e), row 'batched IRLS': two rank processes (sharing the one GPU of the test box) each fit their
+    contiguous block of an uneven split, ONE all-gather completes theta-hat / sigma-hat / status on both ranks --
+    identical on both and bitwise equal to the single-process batch"""
+    import torch.multiprocessing as mp
+    B, n = 7, 500
+    X, Y, _ = c5_data(B, n)
+    prob = amd.BatchProblem(4, 8, X, Y)
+    solo = prob.irls(GAUSS1_START, loss="bisquare", jac=True, control=dict(solver="cholesky"))
+    one = prob.irls_gathered(B, GAUSS1_START, loss="bisquare", jac=True, control=dict(solver="cholesky"))
+    prob.close()
+    assert np.array_equal(one["par"], solo["par"])          # one rank: the gathered form is the plain one
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + int(np.random.default_rng().integers(0, 2000))
+    procs = [ctx.Process(target=_irls_rank_worker, args=(r, 2, port, B, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+    r0, r1 = res
+    assert r0[1:5] == r1[1:5] and r0[5] == r1[5] == 1         # same on both ranks, exactly one collective
+    assert np.array_equal(np.array(r0[1]), solo["par"]) and np.array_equal(np.array(r0[2]), solo["sigma"])
+    assert r0[3] == solo["irls_niter"].tolist() and r0[4] == solo["conv"].tolist()

@@ -155,7 +155,7 @@ def test_boundary_fills_the_whole_irls_slot(amd, gslref, nist):
             assert np.allclose(w, o["irls_weights"], rtol=1e-5, atol=1e-9)
             assert np.allclose(psi, o["irls_psi"], rtol=1e-5, atol=1e-7)
             assert res.irls_status == 0 and res.irls_niter == o["irls"]["irls_niter"] and res.irls_sigma > 0
-            assert abs(res.irls_tol - o["irls"]["irls_tol"]) < 1e-6
+            assert abs(res.irls_tol - o["irls"]["irls_tol"]) < 1e-3 * o["irls"]["irls_tol"]
         else:
             assert np.all(w == -7.0) and np.all(psi == -7.0)
         assert np.isfinite(res.jtj_cond) and res.jtj_cond >= 1.0

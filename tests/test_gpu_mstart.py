@@ -4,6 +4,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from conftest import ROOT
+
 pytestmark = pytest.mark.gpu
 
 TOL = float(np.finfo(float).eps ** 0.25)
@@ -140,3 +142,48 @@ def test_lanes_per_fit_do_not_change_the_records(amd, nist):
                 assert np.allclose(other[sel, 0:2], one[sel, 0:2], rtol=2e-3, atol=1e-9)
                 assert np.allclose(other[sel, 7], one[sel, 7], rtol=2e-3)
                 assert np.sum(np.abs(other[sel, 7] / one[sel, 7] - 1.0) > 1e-6) < 200
+
+
+def test_in_library_rccl_allgather_one_rank(amd, nist):
+    """The collective of the multi-start path is issued by libgslnls_hip.so itself (csrc/rccl_comm.hpp): bind an RCCL
+    communicator of ONE rank through the file bootstrap (the box has one GPU, and RCCL refuses two ranks on one device),
+    force the sharded code path, and the whole procedure -- batch kernel -> ncclAllGather on the library's stream ->
+    host commit -- must give bit for bit what the plain path gives."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = r"""
+import json, os, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+from conftest import load_golden
+import gslnls_amd as A
+from gslnls_amd import _lib
+L = _lib.lib()
+q = {d["name"]: d for d in load_golden("nist_formula_problems.json")}["BoxBOD"]
+d = dict(x=np.array(q["data"]["x"]), y=np.array(q["data"]["y"]))
+kw = dict(data=d, start=dict(b1=[1.0, 500.0], b2=[0.01, 5.0]), jac=True, control=dict(mstart_n=1000, mstart_q=50, solver="cholesky"))
+plain = A.gsl_nls("y ~ b1*(1-exp(-b2*x))", **kw)
+rc = L.gslnls_comm_init_file(sys.argv[1].encode(), 0, 1, 30)
+n0 = L.gslnls_comm_allgather_count()
+coll = A.gsl_nls("y ~ b1*(1-exp(-b2*x))", **kw)
+n1 = L.gslnls_comm_allgather_count()
+L.gslnls_comm_destroy()
+after = A.gsl_nls("y ~ b1*(1-exp(-b2*x))", **kw)
+print(json.dumps(dict(rc=rc, err=L.gslnls_comm_last_error().decode(), collectives=n1 - n0,
+                      plain=[plain["par"].tolist(), plain["ssr"], plain["mstart"]],
+                      coll=[coll["par"].tolist(), coll["ssr"], coll["mstart"]],
+                      after=[after["par"].tolist(), after["ssr"], after["mstart"]])))
+""" % (ROOT, ROOT)
+    with tempfile.TemporaryDirectory() as td:
+        env = dict(os.environ, GSLNLS_COMM_FORCE_COLLECTIVE="1")
+        out = subprocess.run([sys.executable, "-c", code, os.path.join(td, "nccl_id")], capture_output=True, text=True,
+                             timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    import json
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["rc"] == 0, r["err"]
+    assert r["collectives"] >= 1                       # the library issued the all-gathers itself
+    assert r["coll"] == r["plain"] == r["after"]        # and nothing changed, bit for bit
+    tgt = np.array(list(nist["BoxBOD"]["target"].values()))
+    assert np.all(np.abs(np.array(r["coll"][0]) - tgt) < 1.3e-4)
