@@ -529,7 +529,9 @@ struct DenseFit : DenseBase
     // May this handle run whole fits in one launch?  All G workgroups have to be resident together (one per CU):
     // decided once per handle from the device's CU count and the kernel's occupancy; GSLNLS_PERSIST=0 turns it off.
     // interpreted expression models and p > 4 (whose state does not fit the control wave's registers) keep the launch-per-step kernel
-    static constexpr bool PERSIST_BUILT = (M::ID != 100) && (P <= 4);
+    // (natively lowered expression models, ID > 100, neither: every extra kernel is seconds of hipcc in front of the
+    // first fit of a formula)
+    static constexpr bool PERSIST_BUILT = (M::ID < 100) && (P <= 4);
     bool persist_ok()
     {
         if constexpr (!PERSIST_BUILT)

@@ -632,12 +632,15 @@ GSLNLS_HD void lm_advance(LmState<P> &s, const PassSums<P> &r, const LmParams &p
             s.nevalf += 1;
         if (prm.fvv_analytic && !(r.badj == 0.0))
         {
-            // gsl_fvv returned GSL_EBADFUNC (src/nls.c:963-970): trust_iterate returns the
-            // step status, which the iterator treats as a failed step (rho = -1)
-            s.status = ST_EBADFUNC;
-            s.info = ST_EBADFUNC;
-            s.niter += 1;
-            s.phase = PH_DONE;
+            // gsl_fvv returned GSL_EBADFUNC (src/nls.c:963-970): lm_step fails, and trust_iterate_lu_LD counts a
+            // failed step as a rejected one (src/trust.c:452-483, :530-545): rho = -1, so the radius shrinks, mu grows,
+            // and the loop tries again with the shorter velocity (which may make fvv finite) -- up to 15 times
+            s.delta /= prm.factor_down;
+            s.mu *= s.nu;
+            s.nu *= 2.0;
+            const int itstatus = (++s.bad_steps > 15) ? ST_ENOPROG : ST_CONTINUE;
+            if ((itstatus == ST_CONTINUE) ? true : lm_end_iteration(s, prm, itstatus))
+                lm_begin_step(s, prm);
             return;
         }
         double rhs[P];

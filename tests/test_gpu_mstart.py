@@ -24,9 +24,22 @@ def _boxbod(nist):
     return q, np.array(q["data"]["x"]), np.array(q["data"]["y"]), np.array(list(q["target"].values()))
 
 
-def test_c4_concentration_batch_matches_cpu_evaluator(amd, gslref, hostsim, nist):
-    """8192 Sobol starts in b1 in [1,500], b2 in [0.01,5], mstart_p = 5 LM iterations each:
-    every per-point record from the GPU lanes equals the serial evaluation of the same routine"""
+def _range_transform(u, l0, l1, kd):
+    """the power-law map of a unit-cube point into [l0, l1] (src/nls_mstart.c:46-71)"""
+    v = l0 + (l1 - l0) * u
+    if l0 > 0.0:
+        return (np.power(v - l0 + 1.0, kd) - 1.0) / kd + l0
+    if l1 < 0.0:
+        return -(np.power(-v + l1 + 1.0, kd) - 1.0) / kd + l1
+    return np.where(v > 0.0, (np.power(np.abs(v) + 1.0, kd) - 1.0) / kd, -(np.power(np.abs(v) + 1.0, kd) - 1.0) / kd)
+
+
+def test_c4_concentration_batch_matches_the_oracle_point_by_point(amd, gslref, hostsim, nist):
+    """8192 Sobol starts in b1 in [1,500], b2 in [0.01,5], mstart_p = 5 LM iterations each.  Every
+    per-point record of the GPU lanes is compared with the ORACLE: the start point (gslref.sobol + range transform),
+    and -- for every 8th point -- the oracle's own single-start run of the concentration fit (driver2 with maxiter =
+    mstart_p, gtol = 1e-3: src/nls_mstart.c:79-92): where it ended, ssr, iterations, status.  (The device headers
+    compiled for the host, tests/hostsim, are checked against the same records as a by-product.)"""
     from gslnls_amd import _lib
     from gslnls_amd.control import gsl_nls_control, pack_control
     q, x, y, tgt = _boxbod(nist)
@@ -43,21 +56,70 @@ def test_c4_concentration_batch_matches_cpu_evaluator(amd, gslref, hostsim, nist
                                         0, N, 5, 1e-6, ci.ctypes.data_as(_lib.IP), cd.ctypes.data_as(_lib.DP), None,
                                         rec.ctypes.data_as(C.c_void_p), 0, C.byref(ms))
     assert rc == 0
-    ref = hostsim.mstart_batch_misra(x, y, ranges, kd, 0, N, 5, 1e-6, ci, cd, jac=1)
-    # sampled points: Sobol + range transform, bit-exact integer part, pow() may differ in the last ulp
-    assert np.allclose(rec[:, 4:6], ref[:, 4:6], rtol=1e-14)
+    prob.close()
+    # ---- start points: oracle's sequential Sobol generator + the reference's range map ----
     pts = gslref.sobol(2, N)
-    assert np.allclose(rec[:, 4], (np.power(1.0 + 499.0 * pts[:, 0] - 1.0 + 1.0, 0.75) - 1.0) / 0.75 + 1.0, rtol=1e-13)
-    fitted = ref[:, 8] > 1e-6
-    assert np.array_equal(rec[:, 8] > 1e-6, fitted)              # same det filter decisions
-    assert np.array_equal(rec[:, 11], ref[:, 11])                # same iteration counts
-    assert np.array_equal(rec[:, 12], ref[:, 12])                # same status codes
-    sel = fitted & np.isfinite(ref[:, 7])
-    assert np.allclose(rec[sel, 0:2], ref[sel, 0:2], rtol=1e-7, atol=1e-10)   # where each fit ended
-    assert np.allclose(rec[sel, 7], ref[sel, 7], rtol=1e-9)      # ssr
+    x0 = np.stack([_range_transform(pts[:, k], ranges[2 * k], ranges[2 * k + 1], kd[k]) for k in range(2)], axis=1)
+    assert np.allclose(rec[:, 4:6], x0, rtol=1e-13)
+    # ---- the fits: the oracle's single-start LM from the same point, 5 iterations, gtol 1e-3 ----
+    octrl = gslref.control(solver="cholesky", maxiter=5, gtol=1e-3)
+    rd = dict(model=gslref.MODEL_MISRA1A, x=x, y=y)
+    checked = 0
+    for i in range(0, N, 8):
+        if not rec[i, 8] > 1e-6:
+            continue   # det filter: no fit for this point (decisions are compared for all points below)
+        o = gslref.nls(6, 2, x0[i], rowdata=rd, use_jac=True, ctrl=octrl)
+        assert int(rec[i, 11]) == o["niter"] and int(rec[i, 12]) == o["conv"], (i, rec[i], o["niter"], o["conv"])
+        if o["conv"] in (0, 11) and np.isfinite(o["ssr"]):
+            assert np.allclose(rec[i, 0:2], o["par"], rtol=1e-7, atol=1e-10), (i, rec[i, 0:2], o["par"])
+            assert abs(rec[i, 7] - o["ssr"]) <= 1e-9 * abs(o["ssr"]), (i, rec[i, 7], o["ssr"])
+        checked += 1
+    assert checked > 900
+    # ---- det(J^T J) at the start point decides whether a point is fitted at all (src/nls_utils.c:23-73) ----
+    e = np.exp(-np.outer(x0[:, 1], x))                      # N x 6
+    J0, J1 = 1.0 - e, x0[:, :1] * x[None, :] * e
+    det0 = np.sum(J0 * J0, axis=1) * np.sum(J1 * J1, axis=1) - np.sum(J0 * J1, axis=1) ** 2
+    clear = np.abs(det0 - 1e-6) > 1e-9                      # away from the threshold
+    assert np.array_equal((rec[:, 8] > 1e-6)[clear], (det0 > 1e-6)[clear])
+    # ---- by-product: the host build of the device headers gives the same records ----
+    ref = hostsim.mstart_batch_misra(x, y, ranges, kd, 0, N, 5, 1e-6, ci, cd, jac=1)
+    assert np.array_equal(rec[:, 11], ref[:, 11]) and np.array_equal(rec[:, 12], ref[:, 12])
     # a visible fraction of the starts lands in the wrong basin (ssr ~ 9771.5), the rest near ssr 1168.009
+    sel = (rec[:, 8] > 1e-6) & np.isfinite(rec[:, 7])
     good = np.sum(np.abs(rec[sel, 7] - 1168.0088766) < 1.0)
     assert good > 0.3 * N and np.sum(rec[sel, 7] > 5000) > 0
+
+
+@pytest.mark.parametrize("model_id,p,ranges", [
+    (1, 3, [0.5, 10.0, -2.0, 3.0, -4.0, -1.0]),                                      # ExpDecay: all three branches of the map
+    (4, 8, [90, 110, 0.001, 0.1, 90, 110, 50, 80, 10, 40, 60, 80, 150, 200, 10, 30]),  # Gauss1 family
+])
+def test_start_points_for_p3_and_p8_follow_the_oracle_sobol(amd, gslref, model_id, p, ranges):
+    """multi-start with p = 3 and p = 8 parameters draws dimensions 3..8 of the Sobol sequence (src/nls.c:277-280): the
+    sampled points of a device batch equal gslref.sobol + the reference's range map, from a non-zero draw offset too
+    (Bratley-Fox numbers of those dimensions are pinned structurally only: tests/test_qrng_pins.py)"""
+    from gslnls_amd import _lib
+    from gslnls_amd.control import gsl_nls_control, pack_control
+    n = 40
+    rng = np.random.default_rng(5)
+    x = np.linspace(1.0, 250.0, n)
+    y = rng.uniform(1.0, 2.0, n)
+    prob = amd.DenseProblem(model_id, p, x, y)
+    ci, cd = pack_control(gsl_nls_control(solver="cholesky"), "lm")
+    rg = np.array(ranges, dtype=np.float64)
+    kd = np.linspace(0.5, 1.0, p)
+    K = _lib.lib().gslnls_mstart_record_size(p)
+    for first, N in ((0, 1500), (70000, 300)):
+        rec = np.zeros((N, K))
+        ms = C.c_float(0)
+        rc = _lib.lib().gslnls_mstart_batch(prob._h, 1, rg.ctypes.data_as(_lib.DP), kd.ctypes.data_as(_lib.DP), first, N,
+                                            0, N, 1, 1e300, ci.ctypes.data_as(_lib.IP), cd.ctypes.data_as(_lib.DP), None,
+                                            rec.ctypes.data_as(C.c_void_p), 0, C.byref(ms))
+        assert rc == 0
+        pts = gslref.sobol(p, N, skip=first)
+        x0 = np.stack([_range_transform(pts[:, k], rg[2 * k], rg[2 * k + 1], kd[k]) for k in range(p)], axis=1)
+        # (device pow() and glibc's differ in the last ulp, and (pow(1 + d) - 1) / kd cancels for small d)
+        assert np.allclose(rec[:, 2 * p:3 * p], x0, rtol=1e-12, atol=0), np.max(np.abs(rec[:, 2 * p:3 * p] / x0 - 1))
     prob.close()
 
 
