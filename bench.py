@@ -244,6 +244,8 @@ def large_bench(L, _lib, n=10_000_000, p=64):
     byt = 8.0 * n * p + 16.0 * n
     ms_eval = prob.time_pass(0, x0, u, reps=10)
     ms_jtjv = prob.time_pass(1, x0, u, reps=10)
+    prob.time_pass(2, x0, u, reps=1)  # first call allocates the partial sums
+    ms_jtj = prob.time_pass(2, x0, u, reps=10)
     t0 = time.perf_counter()
     fit = prob.solve(x0, "cgst", want_resid=False)
     el = time.perf_counter() - t0
@@ -252,6 +254,12 @@ def large_bench(L, _lib, n=10_000_000, p=64):
             "bytes_per_pass": byt, "eval_pass_ms": ms_eval, "eval_pass_GBs": byt / ms_eval / 1e6,
             "jtju_pass_ms": ms_jtjv, "jtju_pass_GBs": byt / ms_jtjv / 1e6,
             "roofline_frac_jtju": byt / ms_jtjv / 1e6 / HBM_PEAK_GBS,
+            "full_jtj": {"ms_host_clock": ms_jtj, "what": "J^T J for the lm variant: v_mfma_f64_16x16x4 SYRK kernel + reduction of "
+                         "the workgroup partials + 32 KB read-back; the kernel alone is in profiles/r02_c3_kernel_stats.csv "
+                         "(1.17 ms = 43.6 TFLOP/s executed on the 10 lower-triangle blocks, 91 % of the 47.7 TFLOP/s this "
+                         "instruction reaches back to back on the same device, scripts/mfma_probe/rate.hip; it streams A at "
+                         "4.4 TB/s, so the matrix pipe, not HBM, bounds it)",
+                         "effective_TFLOPs_2np2": 2.0 * n * p * p / ms_jtj / 1e9},
             "fit": {"niter": int(fit["niter"]), "conv": int(fit["conv"]), "passes": int(fit["n_passes"]),
                     "wall_s": el, "outer_iterations_per_s": fit["niter"] / el, "ssr": float(fit["ssr"]),
                     "max_abs_err_vs_truth": float(np.max(np.abs(fit["par"] - th)))}}

@@ -722,7 +722,7 @@ struct GlmLargeOps : LargeOps
     }
     int full_jtj(const double *, double *jtj) override
     {
-        const int Gj = 512;
+        const int Gj = (P == 64) ? 1024 : 512; // the MFMA kernel: four 256-thread workgroups per CU
         if (!d_jtjpart)
             GSLNLS_HIP_OK(hipMalloc(&d_jtjpart, sizeof(double) * (size_t)P * P * Gj + sizeof(double) * P * P));
         double *d_out = d_jtjpart + (size_t)P * P * Gj;

@@ -291,61 +291,110 @@ __global__ __launch_bounds__(T) void glm_jtj_kernel(const double *A, const doubl
 // J^T J only when p fills a 16-wide tile").  v_mfma_f64_16x16x4_f64: D(16x16) += A'(16x4) B(4x16), operand
 // layout probed on gfx950 (scripts/mfma_probe): lane l supplies A'[l%16][l/16] and B[l/16][l%16] and holds
 // D[4r + l/16][l%16] in result register r.
-// One wave instruction covers 4 consecutive rows: lane l (k = l/16, i = l%16) loads the 32 contiguous
-// bytes J[row k][4i .. 4i+3] (the 16 lanes of a row read its 512 B back to back) and scales by m[row].
-// With the logical column order (b, i) -> physical column 4i + b the SAME register is the A' operand of
-// block row b and the B operand of block column b, so the 4 loaded values feed all 10 lower-triangle
-// blocks: acc[ba][bb][r] at lane l is J^T J[4(4r + l/16) + ba][4(l%16) + bb].
+// One wave instruction covers 4 consecutive rows: lane l (k = l/16, i = l%16) loads J[row k][2i, 2i+1] and
+// J[row k][32 + 2i, 33 + 2i] (two 16-byte loads, each dense over the wave) and scales by m[row].
+// With the logical column order (b, i) -> physical column c(b, i) = 2i + (b & 1) + 32 (b >> 1) the SAME register is
+// the A' operand of block row b and the B operand of block column b, so the 4 loaded values feed all 10
+// lower-triangle blocks: acc[ba][bb][r] at lane l is J^T J[c(ba, 4r + l/16)][c(bb, l%16)].
 typedef double v4f64_t __attribute__((ext_vector_type(4)));
 
+// Streaming structure: a wave owns the 4-row chunks c, c + S, c + 2S, ...; the 32 B per lane of the NEXT TWO chunks
+// are already in flight (registers) while the ten MFMAs of the current one issue -- one chunk is 640 MFMA cycles
+// against ~900+ cycles of HBM latency, and the matrix pipe of a SIMD runs one chain per wave, so the loads have to be
+// ahead of it; the hot loop has no bounds check (the ragged tail is one extra, masked chunk per wave).  LDS is only
+// the epilogue's scratch (20 KB, the waves add into it one after the other), so that it does not limit residency.
 template <int T>
-__global__ __launch_bounds__(T) void glm_jtj_mfma64_kernel(const double *A, const double *m, long long n,
-                                                           double *partials /* [4096][gridDim.x] */)
+__global__ __launch_bounds__(T, 4) void glm_jtj_mfma64_kernel(const double *__restrict__ A, const double *__restrict__ m,
+                                                           long long n, double *partials /* [4096][gridDim.x] */)
 {
     constexpr int P = 64, NW = T / 64;
-    __shared__ double lds_acc[NW][10 * 4 * 64];
+    __shared__ double lds_acc[10 * 4 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = lane >> 4, i = lane & 15;
     v4f64_t acc[10];
 #pragma unroll
     for (int q = 0; q < 10; ++q)
         acc[q] = (v4f64_t){0.0, 0.0, 0.0, 0.0};
-    const long long nchunk = (n + 3) / 4;
-    const long long wstride = (long long)gridDim.x * NW;
-    for (long long c = (long long)blockIdx.x * NW + wave; c < nchunk; c += wstride)
+    const long long nfull = n / 4; // chunks whose four rows all exist
+    const long long S = (long long)gridDim.x * NW;
+    const long long c0 = (long long)blockIdx.x * NW + wave;
+    struct Chunk
     {
+        double2 lo, hi;
+        double mm;
+    };
+    auto fetch = [&](long long c) {
+        Chunk t;
         const long long row = c * 4 + k;
-        double val[4] = {0.0, 0.0, 0.0, 0.0};
-        if (row < n)
-        {
-            const double2 lo = *reinterpret_cast<const double2 *>(A + row * P + 4 * i);
-            const double2 hi = *reinterpret_cast<const double2 *>(A + row * P + 4 * i + 2);
-            const double mm = m[row];
-            val[0] = lo.x * mm;
-            val[1] = lo.y * mm;
-            val[2] = hi.x * mm;
-            val[3] = hi.y * mm;
-        }
+        // logical column (b, i) lives at physical column 2i + (b & 1) + 32 (b >> 1): the sixteen lanes of a row read
+        // 256 contiguous bytes per load instruction (with 4i + b every instruction touched all four 128-B lines of
+        // the row for half of their bytes, and the kernel ran at half the load rate: 3.2 TB/s)
+        const double *src = A + row * P + 2 * i;
+        typedef double v2f64_t __attribute__((ext_vector_type(2)));
+        const v2f64_t lo = __builtin_nontemporal_load(reinterpret_cast<const v2f64_t *>(src));
+        const v2f64_t hi = __builtin_nontemporal_load(reinterpret_cast<const v2f64_t *>(src + 32));
+        t.lo = make_double2(lo.x, lo.y);
+        t.hi = make_double2(hi.x, hi.y);
+        t.mm = m[row];
+        return t;
+    };
+    auto consume = [&](const Chunk &t) {
+        const double val[4] = {t.lo.x * t.mm, t.lo.y * t.mm, t.hi.x * t.mm, t.hi.y * t.mm};
         int q = 0;
 #pragma unroll
         for (int ba = 0; ba < 4; ++ba)
 #pragma unroll
             for (int bb = 0; bb <= ba; ++bb, ++q)
                 acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(val[ba], val[bb], acc[q], 0, 0, 0);
+    };
+    const Chunk zero = {{0.0, 0.0}, {0.0, 0.0}, 0.0};
+    Chunk b0 = c0 < nfull ? fetch(c0) : zero;
+    Chunk b1 = c0 + S < nfull ? fetch(c0 + S) : zero;
+    long long c = c0;
+    for (; c + 2 * S < nfull; c += S)
+    {
+        const Chunk b2 = fetch(c + 2 * S);
+        consume(b0);
+        b0 = b1;
+        b1 = b2;
     }
-    // waves of the workgroup -> one partial set (fixed order), scattered to J^T J element order
+    if (c < nfull)
+        consume(b0);
+    if (c + S < nfull)
+        consume(b1);
+    // the ragged tail (n not a multiple of 4): one masked chunk, taken by the wave whose turn it would be
+    if ((n & 3) && (nfull % S) == c0 % S && c0 <= nfull)
+    {
+        const long long row = nfull * 4 + k;
+        Chunk t = zero;
+        if (row < n)
+        {
+            const double *src = A + row * P + 2 * i;
+            t.lo = *reinterpret_cast<const double2 *>(src);
+            t.hi = *reinterpret_cast<const double2 *>(src + 32);
+            t.mm = m[row];
+        }
+        consume(t);
+    }
+    // waves of the workgroup -> one partial set (fixed order: wave 0, 1, ...), scattered to J^T J element order
+    for (int w = 0; w < NW; ++w)
+    {
+        if (wave == w)
+        {
 #pragma unroll
-    for (int q = 0; q < 10; ++q)
+            for (int q = 0; q < 10; ++q)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            lds_acc[wave][(q * 4 + r) * 64 + lane] = acc[q][r];
-    __syncthreads();
+                for (int r = 0; r < 4; ++r)
+                {
+                    const int e = (q * 4 + r) * 64 + lane;
+                    lds_acc[e] = (w == 0) ? acc[q][r] : lds_acc[e] + acc[q][r];
+                }
+        }
+        __syncthreads();
+    }
     for (int e = threadIdx.x; e < 10 * 4 * 64; e += T)
     {
-        double t = 0.0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w)
-            t += lds_acc[w][e];
+        const double t = lds_acc[e];
         const int q = e / 256, r = (e / 64) & 3, l = e & 63;
         int ba = 0, bb = 0, cnt = 0;
         for (int a = 0; a < 4; ++a)
@@ -355,7 +404,7 @@ __global__ __launch_bounds__(T) void glm_jtj_mfma64_kernel(const double *A, cons
                     ba = a;
                     bb = b;
                 }
-        const int gi = 4 * (4 * r + (l >> 4)) + ba, gj = 4 * (l & 15) + bb;
+        const int gi = 2 * (4 * r + (l >> 4)) + (ba & 1) + 32 * (ba >> 1), gj = 2 * (l & 15) + (bb & 1) + 32 * (bb >> 1);
         partials[((size_t)gi * P + gj) * gridDim.x + blockIdx.x] = t;
         if (ba != bb)
             partials[((size_t)gj * P + gi) * gridDim.x + blockIdx.x] = t; // mirror block

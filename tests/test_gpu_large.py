@@ -59,7 +59,7 @@ def test_glm_passes_match_numpy(amd, p, n):
 
 
 @pytest.mark.parametrize("alg", ["cgst", "lm"])
-@pytest.mark.parametrize("p,n", [(64, 20000), (16, 3000)])
+@pytest.mark.parametrize("p,n", [(64, 20000), (64, 20003), (64, 131), (16, 3000)])
 def test_glm_fit_matches_oracle(amd, gslref, alg, p, n):
     A, y, th = glm_data(n, p)
     fit = amd.gsl_nls_large("glmexp", A=A, y=y, start=np.zeros(p), algorithm=alg, trace=True)
