@@ -227,8 +227,9 @@ static int batch_irls_run(gslnls_batch *h, int lo, int hi, int jac, int fvv, con
                 tot[k] += (double)hp[(size_t)d * 8 + k];
         const double nd = hi - lo;
         fprintf(stderr, "[batch prof] per data set (kcycles): rows %.0f  reduce %.0f  advance %.0f  reweight %.0f  total %.0f "
-                        "| passes %.1f\n",
-                tot[0] / nd / 1e3, tot[1] / nd / 1e3, tot[2] / nd / 1e3, tot[3] / nd / 1e3, tot[4] / nd / 1e3, tot[5] / nd);
+                        "| passes %.1f | of reweight: radix selects %.0f, bracketed selects %.0f\n",
+                tot[0] / nd / 1e3, tot[1] / nd / 1e3, tot[2] / nd / 1e3, tot[3] / nd / 1e3, tot[4] / nd / 1e3, tot[5] / nd,
+                tot[6] / nd / 1e3, tot[7] / nd / 1e3);
     }
     return GSLNLS_SUCCESS;
 }

@@ -51,19 +51,25 @@ __global__ __launch_bounds__(T, 2) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
     constexpr int P = M::P, NX = M::NX;
     using Sums = PassSums<P>;
     constexpr int NV = Sums::NV, NW = T / 64;
+    constexpr int GV = 3 * NW; // values per group of the workgroup reduction (12 for 256 threads: 24 KB of LDS)
     __shared__ double lds_red[NW * NV];
+    __shared__ double lds_grp[GV * T];
     __shared__ double lds_tot[NV];
     __shared__ LmState<P> lds_state;
     __shared__ unsigned int hist[256];
     __shared__ unsigned long long sel_prefix, sel_mask, sel_k, sel_lo, sel_hi;
-    __shared__ unsigned int sel_cnt_le;
+    __shared__ unsigned int sel_cnt_le, sel_cand;
     __shared__ double sh_val[2], sh_sigma, sh_scale;
     __shared__ int sh_flag;
+    // bracketed median (IRLS iteration >= 2): the keys that fall inside a narrow bracket around the previous median
+    constexpr int BR_CAP = 2048;
+    __shared__ unsigned long long br_list[BR_CAP];
+    __shared__ unsigned int br_n, br_below;
 
     const int d = a.lo + blockIdx.x;
     if (d >= a.hi)
         return;
-    unsigned long long pf[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto now = [&]() -> unsigned long long { return a.prof ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull; };
     const unsigned long long t_begin = now();
     const int n = a.n, tid = threadIdx.x;
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(T, 2) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
     for (int k = 0; k < P; ++k)
         workp[k] = a.start[k];
     int irls_iter = 0, irls_status = ST_FAILURE, status = ST_CONTINUE;
-    double chisq_carry = NAN, chisq_init = NAN, sigma = 1.0;
+    double chisq_carry = NAN, chisq_init = NAN, sigma = 1.0, sigma_change = 1.0;
     LmParams prm = a.prm;
     prm.has_weights = 1;
 
@@ -159,10 +165,48 @@ __global__ __launch_bounds__(T, 2) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
                 }
             }
             const unsigned long long t1 = now();
-            const double tot = block_sum_slots<NV, T>(reinterpret_cast<const double *>(&acc), lds_red);
-            if (tid < NV)
-                lds_tot[tid] = tot;
-            __syncthreads();
+            // Workgroup sums, GV values at a time through an LDS transpose [value][thread]: wave w then owns values
+            // w, w + NW, ... of the group, every lane adds the NW entries of its column and one DPP wave_sum finishes
+            // a value -- GV / NW wave_sums per wave and group instead of one per value (46 DPP chains per wave were
+            // 14 k cycles per pass); fixed order, so results do not depend on how the data sets are scheduled.
+            {
+                constexpr int NGRP = (NV + GV - 1) / GV;
+                const int lane = tid & 63, wave = tid >> 6;
+                const double *av = reinterpret_cast<const double *>(&acc);
+#pragma unroll
+                for (int gq = 0; gq < NGRP; ++gq)
+                {
+#pragma unroll
+                    for (int v = 0; v < GV; ++v)
+                        if (gq * GV + v < NV)
+                            lds_grp[v * T + tid] = av[gq * GV + v];
+                    __syncthreads();
+                    double part[GV / NW];
+#pragma unroll
+                    for (int q = 0; q < GV / NW; ++q)
+                    {
+                        const int v = wave + q * NW;
+                        part[q] = 0.0;
+                        if (gq * GV + v < NV)
+                        {
+#pragma unroll
+                            for (int w = 0; w < NW; ++w)
+                                part[q] += lds_grp[v * T + w * 64 + lane];
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < GV / NW; ++q)
+                        part[q] = wave_sum(part[q]);
+#pragma unroll
+                    for (int q = 0; q < GV / NW; ++q)
+                    {
+                        const int v = gq * GV + wave + q * NW;
+                        if (lane == 0 && v < NV)
+                            lds_tot[v] = part[q];
+                    }
+                    __syncthreads();
+                }
+            }
             const unsigned long long t2 = now();
             if (tid == 0)
             {
@@ -192,14 +236,62 @@ __global__ __launch_bounds__(T, 2) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
 #pragma unroll
         for (int k = 0; k < P; ++k)
             th[k] = lds_state.x[k];
-        for (int i = tid; i < n; i += T)
+        // From the second IRLS iteration on the median of |r| is close to the previous one: while the keys are produced,
+        // the ones inside a bracket around the previous median are collected in LDS and the ones below it are counted.
+        // If both middle order statistics fall inside the bracket the select runs on that short list in LDS -- the same
+        // exact order statistics as a select over all keys; otherwise the select over the global keys runs.
+        const bool have_br = irls_iter > 1 && sigma > 0.0 && sigma < INFINITY;
+        const double med_prev = sigma * (1.0 / 1.482602218505602);
+        // half-width: 12 % after the first re-weighting (the fit itself still moves), then three times the last
+        // relative change of sigma (IRLS contracts), at least 0.5 %
+        const double br_half = (irls_iter == 2) ? 0.12 : fmin(0.12, fmax(0.005, 3.0 * sigma_change));
+        const unsigned long long b_lo = (unsigned long long)__double_as_longlong(med_prev * (1.0 - br_half)),
+                                 b_hi = (unsigned long long)__double_as_longlong(med_prev * (1.0 + br_half));
+        if (tid == 0)
         {
-            double xr[NX];
-#pragma unroll
-            for (int c = 0; c < NX; ++c)
-                xr[c] = xd[(size_t)c * n + i];
-            kd[i] = (unsigned long long)__double_as_longlong(fabs(row_resid<M>(th, xr, yd[i], 1.0)));
+            br_n = 0;
+            br_below = 0;
         }
+        __syncthreads();
+        unsigned int below = 0;
+        // (four rows per trip, their loads first: with two wavefronts per SIMD a one-row loop exposes an L2 round trip
+        // per row -- measured 1.5 k cycles per row against ~0.5 k of arithmetic)
+        constexpr int RU = 4;
+        for (int i0 = tid; i0 < n; i0 += RU * T)
+        {
+            double xr[RU][NX], yy[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u)
+            {
+                const int i = i0 + u * T < n ? i0 + u * T : n - 1;
+#pragma unroll
+                for (int c = 0; c < NX; ++c)
+                    xr[u][c] = xd[(size_t)c * n + i];
+                yy[u] = yd[i];
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u)
+            {
+                const int i = i0 + u * T;
+                if (i >= n)
+                    break;
+                const unsigned long long key =
+                    (unsigned long long)__double_as_longlong(fabs(row_resid<M>(th, xr[u], yy[u], 1.0)));
+                kd[i] = key;
+                if (have_br)
+                {
+                    below += key < b_lo ? 1u : 0u;
+                    if (key >= b_lo && key <= b_hi)
+                    {
+                        const unsigned int pos = atomicAdd(&br_n, 1u);
+                        if (pos < (unsigned int)BR_CAP)
+                            br_list[pos] = key;
+                    }
+                }
+            }
+        }
+        if (have_br)
+            atomicAdd(&br_below, below);
         __syncthreads();
         // median of |r| (src/nls_utils.c:162-186 sorts; here a radix SELECT on the bit patterns, which order like
         // the non-negative doubles they encode).  One select for the lower middle order statistic k_lo; for even
@@ -208,170 +300,246 @@ __global__ __launch_bounds__(T, 2) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
         // histogram of a byte is built with wave-aggregated LDS atomics: the keys of one wavefront mostly share
         // their high bytes, and 64 same-address atomics serialise.
         const unsigned long long k_lo = (unsigned long long)((n - 1) / 2), k_hi = (unsigned long long)(n / 2);
-        {
-            unsigned long long kmin = ~0ull, kmax = 0ull;
-#pragma unroll 8
-            for (int i = tid; i < n; i += T)
+        const int nsel = (k_hi != k_lo) ? 2 : 1;
+        const unsigned long long tw1 = now();
+        // ---- exact order statistics by radix select (src/nls_utils.c:162-186 sorts) -------------------------------
+        // select_rank(src, nk, rank): the key of that rank among src[0 .. nk) ends up in sel_prefix.  Byte-wise
+        // histogram passes from the first byte in which the smallest and the largest key differ; keys order like the
+        // non-negative doubles they encode.  When the source is the global key array and the keys still matching the
+        // prefix are few enough, they are collected into LDS (br_list) and the remaining passes run there.
+        auto select_rank = [&](const unsigned long long *src, int nk, unsigned long long rank, bool may_collect) {
             {
-                const unsigned long long key = kd[i];
-                kmin = key < kmin ? key : kmin;
-                kmax = key > kmax ? key : kmax;
+                unsigned long long kmin = ~0ull, kmax = 0ull;
+#pragma unroll 8
+                for (int i = tid; i < nk; i += T)
+                {
+                    const unsigned long long key = src[i];
+                    kmin = key < kmin ? key : kmin;
+                    kmax = key > kmax ? key : kmax;
+                }
+                if (tid == 0)
+                {
+                    sel_lo = ~0ull;
+                    sel_hi = 0ull;
+                }
+                __syncthreads();
+                atomicMin(&sel_lo, kmin);
+                atomicMax(&sel_hi, kmax);
+                __syncthreads();
             }
-            // wave min / max through the shuffle-free route: LDS atomics on two words
+            int first_pass = 7;
+            {
+                const unsigned long long diff = sel_lo ^ sel_hi;
+                while (first_pass > 0 && ((diff >> (8 * first_pass)) & 255ull) == 0ull)
+                    --first_pass;
+            }
             if (tid == 0)
             {
-                sel_lo = ~0ull;
-                sel_hi = 0ull;
+                const int sh = 8 * (first_pass + 1);
+                sel_mask = sh >= 64 ? 0ull : ~((1ull << sh) - 1ull); // bytes above first_pass: common to all keys
+                sel_prefix = sel_lo & sel_mask;
+                sel_k = rank;
+                sel_cand = (unsigned int)nk;
             }
             __syncthreads();
-            atomicMin(&sel_lo, kmin);
-            atomicMax(&sel_hi, kmax);
-            __syncthreads();
-        }
-        int first_pass = 7;
-        {
-            const unsigned long long diff = sel_lo ^ sel_hi;
-            while (first_pass > 0 && ((diff >> (8 * first_pass)) & 255ull) == 0ull)
-                --first_pass;
-        }
-        if (tid == 0)
-        {
-            const int sh = 8 * (first_pass + 1);
-            sel_mask = sh >= 64 ? 0ull : ~((1ull << sh) - 1ull); // bytes above first_pass: common to all keys
-            sel_prefix = sel_lo & sel_mask;
-            sel_k = k_lo;
-            sel_cnt_le = 0;
-        }
-        __syncthreads();
-        for (int pass = first_pass; pass >= 0; --pass)
-        {
-            if (tid < 256)
-                hist[tid] = 0;
-            __syncthreads();
-            const unsigned long long prefix = sel_prefix, mask = sel_mask;
-            // the first two bytes examined are shared by most keys of a wavefront: aggregate; later bytes are
-            // spread over the 256 bins and plain atomics rarely collide
-            const bool aggregate = pass > first_pass - 2;
-            constexpr int KU = 8; // keys in flight per thread: the loads overlap instead of exposing 8 latencies
-            for (int i0 = 0; i0 < n; i0 += KU * T)
+            for (int pass = first_pass; pass >= 0; --pass)
             {
-                unsigned long long key[KU];
-#pragma unroll
-                for (int u = 0; u < KU; ++u)
+                if (may_collect && sel_cand <= (unsigned int)BR_CAP)
                 {
-                    const int i = i0 + u * T + tid;
-                    key[u] = kd[i < n ? i : n - 1];
-                }
-#pragma unroll
-                for (int u = 0; u < KU; ++u)
-                {
-                    const int i = i0 + u * T + tid;
-                    int bin = -1;
-                    if (i < n && (key[u] & mask) == prefix)
-                        bin = (int)((key[u] >> (8 * pass)) & 255ull);
-                    if (aggregate)
+                    // few candidates left: gather them (one more sweep of the global keys), finish in LDS
+                    const unsigned long long prefix = sel_prefix, mask = sel_mask;
+                    if (tid == 0)
+                        br_n = 0;
+                    __syncthreads();
+                    constexpr int KU = 8;
+                    for (int i0 = 0; i0 < nk; i0 += KU * T)
                     {
-                        // up to 3 rounds of "everyone with the first lane's bin adds once", then plain atomics
-                        unsigned long long todo = __ballot(bin >= 0);
-#pragma unroll 1
-                        for (int round = 0; round < 3 && todo; ++round)
+                        unsigned long long key[KU];
+#pragma unroll
+                        for (int u = 0; u < KU; ++u)
                         {
-                            const int leader = __ffsll((long long)todo) - 1;
-                            const int b = __builtin_amdgcn_readlane(bin, leader);
-                            const unsigned long long same = __ballot(bin == b);
-                            if ((int)(tid & 63) == leader)
-                                atomicAdd(&hist[b], (unsigned int)__popcll(same));
-                            todo &= ~same;
-                            if (bin == b)
-                                bin = -1;
+                            const int i = i0 + u * T + tid;
+                            key[u] = src[i < nk ? i : nk - 1];
+                        }
+#pragma unroll
+                        for (int u = 0; u < KU; ++u)
+                        {
+                            const int i = i0 + u * T + tid;
+                            if (i < nk && (key[u] & mask) == prefix)
+                                br_list[atomicAdd(&br_n, 1u)] = key[u]; // at most sel_cand <= BR_CAP of them
                         }
                     }
-                    if (bin >= 0)
-                        atomicAdd(&hist[bin], 1u);
+                    __syncthreads();
+                    src = br_list;
+                    nk = (int)br_n;
+                    may_collect = false;
+                    // every listed key carries the prefix: the rank within the list is sel_k, the passes go on below
                 }
-            }
-            __syncthreads();
-            // which bin holds rank sel_k: wavefront 0, lane l owns bins 4l .. 4l+3, exclusive scan over the lanes
-            if (tid < 64)
-            {
-                const unsigned int c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
-                unsigned int incl = c0 + c1 + c2 + c3;
+                if (tid < 256)
+                    hist[tid] = 0;
+                __syncthreads();
+                const unsigned long long prefix = sel_prefix, mask = sel_mask;
+                // the first two bytes examined are shared by most keys of a wavefront: aggregate; later bytes are
+                // spread over the 256 bins and plain atomics rarely collide
+                const bool aggregate = pass > first_pass - 2;
+                constexpr int KU = 8; // keys in flight per thread: the loads overlap instead of exposing 8 latencies
+                for (int i0 = 0; i0 < nk; i0 += KU * T)
+                {
+                    unsigned long long key[KU];
 #pragma unroll
-                for (int dlt = 1; dlt < 64; dlt <<= 1)
-                {
-                    const unsigned int up = __shfl_up(incl, dlt);
-                    if (tid >= dlt)
-                        incl += up;
-                }
-                const unsigned long long k = sel_k;
-                const unsigned long long before = incl - (c0 + c1 + c2 + c3);
-                if (k >= before && k < incl)
-                {
-                    unsigned long long cum = before;
-                    int bin = 4 * tid;
-                    if (k >= cum + c0)
+                    for (int u = 0; u < KU; ++u)
                     {
-                        cum += c0;
-                        bin += 1;
-                        if (k >= cum + c1)
+                        const int i = i0 + u * T + tid;
+                        key[u] = src[i < nk ? i : nk - 1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < KU; ++u)
+                    {
+                        const int i = i0 + u * T + tid;
+                        int bin = -1;
+                        if (i < nk && (key[u] & mask) == prefix)
+                            bin = (int)((key[u] >> (8 * pass)) & 255ull);
+                        if (aggregate)
                         {
-                            cum += c1;
-                            bin += 1;
-                            if (k >= cum + c2)
+                            // up to 3 rounds of "everyone with the first lane's bin adds once", then plain atomics
+                            unsigned long long todo = __ballot(bin >= 0);
+#pragma unroll 1
+                            for (int round = 0; round < 3 && todo; ++round)
                             {
-                                cum += c2;
-                                bin += 1;
+                                const int leader = __ffsll((long long)todo) - 1;
+                                const int bb = __builtin_amdgcn_readlane(bin, leader);
+                                const unsigned long long same = __ballot(bin == bb);
+                                if ((int)(tid & 63) == leader)
+                                    atomicAdd(&hist[bb], (unsigned int)__popcll(same));
+                                todo &= ~same;
+                                if (bin == bb)
+                                    bin = -1;
                             }
                         }
+                        if (bin >= 0)
+                            atomicAdd(&hist[bin], 1u);
                     }
-                    sel_k = k - cum;
-                    sel_prefix = prefix | ((unsigned long long)bin << (8 * pass));
-                    sel_mask = mask | (255ull << (8 * pass));
                 }
+                __syncthreads();
+                // which bin holds rank sel_k: wavefront 0, lane l owns bins 4l .. 4l+3, exclusive scan over the lanes
+                if (tid < 64)
+                {
+                    const unsigned int c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+                    unsigned int incl = c0 + c1 + c2 + c3;
+#pragma unroll
+                    for (int dlt = 1; dlt < 64; dlt <<= 1)
+                    {
+                        const unsigned int up = __shfl_up(incl, dlt);
+                        if (tid >= dlt)
+                            incl += up;
+                    }
+                    const unsigned long long k = sel_k;
+                    const unsigned long long before = incl - (c0 + c1 + c2 + c3);
+                    if (k >= before && k < incl)
+                    {
+                        unsigned long long cum = before;
+                        int bin = 4 * tid;
+                        unsigned int cb = c0;
+                        if (k >= cum + c0)
+                        {
+                            cum += c0;
+                            bin += 1;
+                            cb = c1;
+                            if (k >= cum + c1)
+                            {
+                                cum += c1;
+                                bin += 1;
+                                cb = c2;
+                                if (k >= cum + c2)
+                                {
+                                    cum += c2;
+                                    bin += 1;
+                                    cb = c3;
+                                }
+                            }
+                        }
+                        sel_k = k - cum;
+                        sel_cand = cb;
+                        sel_prefix = prefix | ((unsigned long long)bin << (8 * pass));
+                        sel_mask = mask | (255ull << (8 * pass));
+                    }
+                }
+                __syncthreads();
             }
-            __syncthreads();
-        }
-        // sel_prefix is the k_lo-th smallest key.  Upper middle (even n): equal to it if enough keys are <= it,
-        // else the smallest key above it.
-        const unsigned long long v_lo = sel_prefix;
-        int nsel = 1;
-        if (k_hi != k_lo)
-        {
-            nsel = 2;
+        };
+        // upper_middle(src, nk, v_lo, rank_hi): the key of rank rank_hi = rank(v_lo) + 1 among src[0 .. nk): v_lo again if
+        // enough keys are <= it, else the smallest key above it -- one sweep instead of a second select
+        auto upper_middle = [&](const unsigned long long *src, int nk, unsigned long long v_lo, unsigned long long rank_hi) {
             unsigned int cnt_le = 0;
             unsigned long long next = ~0ull;
 #pragma unroll 8
-            for (int i = tid; i < n; i += T)
+            for (int i = tid; i < nk; i += T)
             {
-                const unsigned long long key = kd[i];
+                const unsigned long long key = src[i];
                 cnt_le += key <= v_lo ? 1u : 0u;
                 if (key > v_lo && key < next)
                     next = key;
             }
             if (tid == 0)
+            {
                 sel_lo = ~0ull;
+                sel_cnt_le = 0;
+            }
             __syncthreads();
             atomicAdd(&sel_cnt_le, cnt_le);
             atomicMin(&sel_lo, next);
             __syncthreads();
             if (tid == 0)
-                sh_val[1] = __longlong_as_double((long long)(((unsigned long long)sel_cnt_le > k_hi) ? v_lo : sel_lo));
+                sh_val[1] = __longlong_as_double((long long)(((unsigned long long)sel_cnt_le > rank_hi) ? v_lo : sel_lo));
+        };
+        const unsigned int br_m = br_n, br_b = br_below;
+        const bool br_ok = have_br && br_m <= (unsigned int)BR_CAP && k_lo >= br_b && k_hi < (unsigned long long)br_b + br_m;
+        if (br_ok)
+        {
+            // both middle order statistics are among the br_m listed keys: select inside LDS
+            select_rank(br_list, (int)br_m, k_lo - br_b, false);
+            const unsigned long long v_lo = sel_prefix;
+            if (nsel == 2)
+                upper_middle(br_list, (int)br_m, v_lo, k_hi - br_b);
+            if (tid == 0)
+                sh_val[0] = __longlong_as_double((long long)v_lo);
+            __syncthreads();
         }
-        if (tid == 0)
-            sh_val[0] = __longlong_as_double((long long)v_lo);
-        __syncthreads();
+        else
+        {
+            select_rank(kd, n, k_lo, true);
+            const unsigned long long v_lo = sel_prefix;
+            if (nsel == 2)
+                upper_middle(kd, n, v_lo, k_hi);
+            if (tid == 0)
+                sh_val[0] = __longlong_as_double((long long)v_lo);
+            __syncthreads();
+        }
+        pf[br_ok ? 7 : 6] += now() - tw1;
         if (tid == 0)
             sh_sigma = 1.482602218505602 * (nsel == 1 ? sh_val[0] : (sh_val[0] + sh_val[1]) / 2.0);
         __syncthreads();
+        sigma_change = (sigma > 0.0) ? fabs(sh_sigma - sigma) / sigma : 1.0;
         sigma = sh_sigma;
         // raw weights (even in r: only |r| is needed), their sum in a fixed order, then the normalised sqrt
         double wsum = 0.0;
-        for (int i = tid; i < n; i += T)
+        for (int i0 = tid; i0 < n; i0 += RU * T)
         {
-            const double rs = __longlong_as_double((long long)kd[i]) / sigma;
-            const double w = fmax(irls_psi(rs, a.loss) / rs, DBL_EPSILON);
-            swd[i] = w;
-            wsum += w;
+            unsigned long long kk[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u)
+                kk[u] = kd[i0 + u * T < n ? i0 + u * T : n - 1];
+#pragma unroll
+            for (int u = 0; u < RU; ++u)
+            {
+                const int i = i0 + u * T;
+                if (i >= n)
+                    break;
+                const double rs = __longlong_as_double((long long)kk[u]) / sigma;
+                const double w = fmax(irls_psi(rs, a.loss) / rs, DBL_EPSILON);
+                swd[i] = w;
+                wsum += w; // same order of additions per thread as the one-row loop: rows tid, tid + T, ...
+            }
         }
         wsum = wave_sum(wsum);
         if ((tid & 63) == 0)
@@ -404,12 +572,27 @@ __global__ __launch_bounds__(T, 2) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
         pf[3] += now() - tw0;
         if (irls_status == ST_SUCCESS || irls_iter >= a.irls_maxiter)
             break;
-        for (int i = tid; i < n; i += T)
+        for (int i0 = tid; i0 < n; i0 += RU * T)
         {
-            double w = swd[i] * scale;
-            if (ud)
-                w = (ud[i] * ud[i]) * w;
-            swd[i] = sqrt(w);
+            double ww[RU], uu[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u)
+            {
+                const int i = i0 + u * T < n ? i0 + u * T : n - 1;
+                ww[u] = swd[i];
+                uu[u] = ud ? ud[i] : 1.0;
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u)
+            {
+                const int i = i0 + u * T;
+                if (i >= n)
+                    break;
+                double w = ww[u] * scale;
+                if (ud)
+                    w = (uu[u] * uu[u]) * w;
+                swd[i] = sqrt(w);
+            }
         }
 #pragma unroll
         for (int k = 0; k < P; ++k)
@@ -420,7 +603,7 @@ __global__ __launch_bounds__(T, 2) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
     if (tid == 0 && a.prof)
     {
         pf[4] = now() - t_begin;
-        for (int k = 0; k < 6; ++k)
+        for (int k = 0; k < 8; ++k)
             a.prof[(size_t)d * 8 + k] = pf[k];
     }
     if (tid == 0)
