@@ -107,6 +107,7 @@ _SIGNATURES = {
     "gslnls_batch_destroy": (None, [C.c_void_p]),
     "gslnls_batch_irls": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, DP, DP, IP, DP, C.c_int, DP,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    "gslnls_batch_last_passes": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "gslnls_batch_irls_gather": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, DP, DP, IP, DP, C.c_int, DP,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     "gslnls_strerror": (C.c_char_p, [C.c_int]),

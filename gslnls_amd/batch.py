@@ -78,6 +78,9 @@ class BatchProblem:
         _lib.check(rc)
         if rc != 0:
             raise RuntimeError("gslnls_batch_irls failed: %s" % _lib.strerror(rc))
+        lm_p, rw_p = C.c_longlong(0), C.c_longlong(0)
+        _lib.lib().gslnls_batch_last_passes(self._h, C.byref(lm_p), C.byref(rw_p))
+        self.last_passes = dict(lm=int(lm_p.value), reweight=int(rw_p.value))  # this rank's data sets only
         return dict(par=par, sigma=scal[:, 0], ssr=scal[:, 1], irls_tol=scal[:, 2], chisq_init=scal[:, 3],
                     conv=ints[:, 0], irls_status=ints[:, 1], irls_niter=ints[:, 2], niter=ints[:, 3],
                     kernel_ms=float(ms.value))

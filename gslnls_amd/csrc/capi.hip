@@ -149,6 +149,8 @@ struct gslnls_batch
     int model_id = 0, p = 0, nx = 0, n = 0, B = 0;
     double *d_x = nullptr, *d_y = nullptr, *d_usw = nullptr, *d_sw = nullptr, *d_par = nullptr, *d_scal = nullptr;
     unsigned long long *d_keys = nullptr;
+    unsigned long long *d_passes = nullptr; // [2] device counters of the last call, h_passes their host copy
+    unsigned long long h_passes[2] = {0, 0};
     int *d_ints = nullptr;
     hipStream_t st = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -198,6 +200,10 @@ static int batch_irls_run(gslnls_batch *h, int lo, int hi, int jac, int fvv, con
             a.prof = d_prof;
         }
     }
+    if (!h->d_passes)
+        GSLNLS_HIP_OK(hipMalloc(&h->d_passes, 2 * sizeof(unsigned long long)));
+    GSLNLS_HIP_OK(hipMemsetAsync(h->d_passes, 0, 2 * sizeof(unsigned long long), h->st));
+    a.pass_total = h->d_passes;
     const int jacmode = jac ? JAC_ANALYTIC : (ci[5] ? JAC_CENTER : JAC_FORWARD);
     hipEventRecord(h->e0, h->st);
     switch (jacmode)
@@ -213,6 +219,7 @@ static int batch_irls_run(gslnls_batch *h, int lo, int hi, int jac, int fvv, con
         break;
     }
     hipEventRecord(h->e1, h->st);
+    GSLNLS_HIP_OK(hipMemcpyAsync(h->h_passes, h->d_passes, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->st));
     GSLNLS_HIP_OK(hipStreamSynchronize(h->st));
     if (kernel_ms)
         hipEventElapsedTime(kernel_ms, h->e0, h->e1);
@@ -634,6 +641,17 @@ __global__ void batch_pack_kernel(const double *par, const double *scal, const i
         o[p + k] = scal[(size_t)d * 4 + k];
         o[p + 4 + k] = (double)ints[(size_t)d * 4 + k];
     }
+}
+
+int gslnls_batch_last_passes(gslnls_batch *h, long long *lm_passes, long long *reweightings)
+{
+    if (!h)
+        return GSLNLS_EINVAL;
+    if (lm_passes)
+        *lm_passes = (long long)h->h_passes[0];
+    if (reweightings)
+        *reweightings = (long long)h->h_passes[1];
+    return GSLNLS_SUCCESS;
 }
 
 int gslnls_batch_irls_gather(gslnls_batch *h, int B_total, int jac, int fvv, const double *start, const double *lupars,

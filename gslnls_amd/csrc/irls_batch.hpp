@@ -43,6 +43,8 @@ struct IrlsBatchArgs
     double *scal;         // [B][4]: sigma, ssr (weighted), irls_tol, chisq_init
     int *ints;            // [B][4]: conv, irls_status, irls_niter, niter
     unsigned long long *prof; // developer diagnostic (GSLNLS_BATCH_PROF): [B][8] cycle totals, or nullptr
+    unsigned long long *pass_total; // [2]: passes over the rows by the LM solves / by the re-weightings, summed over the
+                                    // data sets of the call (the roofline accounting of bench.py), or nullptr
 };
 
 template <class M, int JAC, int T>
@@ -88,6 +90,7 @@ __global__ __launch_bounds__(T, 2) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
     for (int k = 0; k < P; ++k)
         workp[k] = a.start[k];
     int irls_iter = 0, irls_status = ST_FAILURE, status = ST_CONTINUE;
+    unsigned int n_lm_pass = 0, n_rw = 0;
     double chisq_carry = NAN, chisq_init = NAN, sigma = 1.0, sigma_change = 1.0;
     LmParams prm = a.prm;
     prm.has_weights = 1;
@@ -222,6 +225,7 @@ __global__ __launch_bounds__(T, 2) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
             pf[1] += t2 - t1;
             pf[2] += t3 - t2;
             pf[5] += 1;
+            n_lm_pass += 1;
         }
         status = lds_state.status;
         if (irls_iter == 1)
@@ -232,6 +236,7 @@ __global__ __launch_bounds__(T, 2) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
 
         // ---------------- re-weighting ----------------
         const unsigned long long tw0 = now();
+        n_rw += 1;
         double th[P];
 #pragma unroll
         for (int k = 0; k < P; ++k)
@@ -600,6 +605,11 @@ __global__ __launch_bounds__(T, 2) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
         __syncthreads();
     }
 
+    if (tid == 0 && a.pass_total)
+    {
+        atomicAdd(a.pass_total, (unsigned long long)n_lm_pass);
+        atomicAdd(a.pass_total + 1, (unsigned long long)n_rw);
+    }
     if (tid == 0 && a.prof)
     {
         pf[4] = now() - t_begin;

@@ -247,6 +247,10 @@ int gslnls_batch_irls(gslnls_batch *h, int lo, int hi, int jac, int fvv, const d
                       const int *control_int, const double *control_dbl, int loss_rho, const double *loss_cc,
                       double *par, double *scal, int *ints, float *kernel_ms);
 
+/* work done by the last gslnls_batch_irls() on this handle, summed over its data sets: passes over the n rows made by
+ * the LM solves (one per trial step + one per initial point) and number of re-weightings (each: one pass for the
+ * residuals, the median select, one pass for the weights) -- the units of SURVEY.md 8(d)'s C5 byte accounting */
+int gslnls_batch_last_passes(gslnls_batch *h, long long *lm_passes, long long *reweightings);
 /* One process per GPU (SURVEY.md 8(e), row "batched IRLS"): the B_total data sets are cut into contiguous blocks of
  * ceil(B_total / world) per rank, `h` holds exactly this rank's block (created from its slice of x / y); every rank
  * fits its block with no traffic, then ONE all-gather of (p + 8) doubles per data set completes par / scal / ints
