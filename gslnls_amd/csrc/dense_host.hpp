@@ -599,6 +599,13 @@ struct DenseFit : DenseBase
         pa.tag_base = ((ctx.seq & 0x7ffffu) | 0x80000u) << 12;
         pa.step0 = 0;
         pa.max_steps = max_steps_override > 0 ? max_steps_override : PERSIST_CHUNK;
+        if (max_steps_override <= 0)
+        {
+            // test hook: a small chunk exercises the leave-and-resume path of the resident kernel
+            static const int chunk_env = getenv("GSLNLS_PERSIST_CHUNK") ? atoi(getenv("GSLNLS_PERSIST_CHUNK")) : 0;
+            if (chunk_env > 0)
+                pa.max_steps = chunk_env;
+        }
         pa.resume = 0;
         const long long max_steps_total = ((long long)maxiter * 17 + 2) * (ctx.prm.trs ? 2 : 1) + 2;
         long long launches = 0;

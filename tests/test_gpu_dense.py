@@ -368,3 +368,65 @@ def test_scaling_rules_and_central_differences_against_the_oracle(amd, gslref, r
     # f-evaluations with traces equal to 5e-14 in every iteration)
     assert fit["niter"] == o["niter"] and fit["neval"]["J"] == o["neval"]["J"] and _rel(fit["par"], o["par"]) < 1e-8
     assert abs(fit["neval"]["f"] - o["neval"]["f"]) <= 16
+
+
+def test_resident_kernel_equals_launch_per_step_kernel(amd):
+    """csrc/dense_persist.hpp against csrc/dense_kernels.hpp, in a child process with the resident kernel forced for
+    every grid (GSLNLS_PERSIST=1) and leaving / resuming every 3 steps (GSLNLS_PERSIST_CHUNK=3): one workgroup, several
+    groups of workgroups (the three-hop all-reduce incl. the on-device XCD check) and the full C2 grid; analytic, forward
+    and central Jacobians, weights, bounds, lmaccel with finite-difference and analytic fvv, traces.  Same iteration
+    counts and evaluation counts; coefficients to 1e-10 (the two kernels add the row sums in different trees)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r"""
+import json, os, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+from conftest import c2_data
+import gslnls_amd as A
+out = []
+ctrl = A.gsl_nls_control(solver="cholesky", xtol=1.49e-8, gtol=1.49e-8)
+for n in (600, 5000, 70000, 1000000):
+    x, y = c2_data(n)
+    w = np.linspace(0.5, 2.0, n)
+    for kw in (dict(jac=True), dict(jac=False), dict(jac=False, control=A.gsl_nls_control(solver="cholesky", fdtype="center")),
+               dict(jac=True, algorithm="lmaccel"), dict(jac=True, fvv=True, algorithm="lmaccel"), dict(jac=True, weights=w),
+               dict(jac=True, lupars=np.array([0.0, 4.5, 0.0, 10.0, -5.0, 5.0])), dict(jac=True, trace=True)):
+        if n == 1000000 and kw.get("algorithm") == "lmaccel" and not kw.get("fvv"):
+            continue
+        kw = dict(kw)
+        kw.setdefault("control", ctrl)
+        weights = kw.pop("weights", None)
+        prob = A.DenseProblem(1, 3, x, y, weights=weights)
+        res = {}
+        for label, chunk in (("resident", 0), ("launch", -1)):
+            f = prob.solve([1.0, 1.0, 0.0], want_vectors=(n <= 5000), chunk=chunk, **kw)
+            res[label] = dict(par=f["par"].tolist(), niter=f["niter"], conv=f["conv"], neval=f["neval"], ssr=f["ssr"],
+                              launches=f["n_launches"], steps=f["n_steps"],
+                              resid=(f["resid"].tolist() if n <= 5000 else None),
+                              ssrtrace=(np.asarray(f["ssrtrace"]).tolist() if kw.get("trace") else None))
+        prob.close()
+        out.append(dict(n=n, kw=sorted(k for k in kw if k != "control"), **res))
+print(json.dumps(out))
+""" % (ROOT, ROOT)
+    env = dict(os.environ, GSLNLS_PERSIST="1", GSLNLS_PERSIST_CHUNK="3")
+    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert run.returncode == 0, run.stderr[-3000:]
+    cases = json.loads([l for l in run.stdout.splitlines() if l.startswith("[")][-1])
+    assert len(cases) >= 30
+    for c in cases:
+        a, b = c["resident"], c["launch"]
+        tag = (c["n"], c["kw"])
+        assert a["conv"] == b["conv"] == 0 or a["conv"] == b["conv"], tag
+        assert a["niter"] == b["niter"], (tag, a["niter"], b["niter"])
+        assert np.allclose(a["par"], b["par"], rtol=1e-10), tag
+        assert abs(a["ssr"] - b["ssr"]) <= 1e-12 * abs(b["ssr"]), tag
+        assert a["launches"] >= 2 and a["launches"] < b["launches"], tag     # left and resumed, yet far fewer launches
+        assert a["neval"]["J"] == b["neval"]["J"] and a["neval"]["fvv"] == b["neval"]["fvv"], tag
+        assert abs(a["neval"]["f"] - b["neval"]["f"]) <= 16, tag                # round-off trials of the last iteration
+        if a["resid"] is not None:
+            assert np.allclose(a["resid"], b["resid"], rtol=1e-9, atol=1e-12), tag
+        if a["ssrtrace"] is not None:
+            assert np.allclose(a["ssrtrace"], b["ssrtrace"], rtol=1e-12), tag
