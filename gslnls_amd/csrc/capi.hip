@@ -51,11 +51,11 @@ int ms_rccl_run_batch(MsEvaluator &ev, const MsComm &comm, MsBatch &b, int per, 
         return e;
     if (!b.host_records)
         return ev.fetch_stream(rc.all, nullptr, 0); // records stay in HBM: only wait for the collective
-    e = ev.fetch_stream(rc.all, b.records.data(), (size_t)b.count * b.K);
+    e = ev.fetch_stream_view(rc.all, (size_t)b.count * b.K, b, &b.rec); // pinned destination, consumed in place
     if (e)
         return e;
     for (int r = 0; r < rc.world; ++r)
-        if ((long long)r * per < b.count && b.records[((size_t)r * per) * b.K + status_slot] == MS_SHARD_FAILED)
+        if ((long long)r * per < b.count && b.rec[((size_t)r * per) * b.K + status_slot] == MS_SHARD_FAILED)
             return run_rc ? run_rc : -1;
     return 0;
 }

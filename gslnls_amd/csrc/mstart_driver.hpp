@@ -47,7 +47,9 @@ struct MsBatch
     double dtol = 0.0;
     int always_fit = 0;
     int consecutive = -1;            // 1: draw[i] == draw[0] + i is known to hold, 0: known not to, -1: look
-    std::vector<double> records;     // count x K, filled by the evaluator (+ all-gather)
+    std::vector<double> records;     // count x K, filled by the evaluator (+ all-gather) when it has no buffer of its own
+    const double *rec = nullptr;     // the finished batch's records: `records`, or the evaluator's pinned staging buffer
+                                     // (valid until the evaluator runs its next batch)
     bool host_records = true;        // false: leave the (gathered) records in device memory (throughput measurements)
 };
 
@@ -88,6 +90,23 @@ struct MsEvaluator
     virtual int run_async(MsBatch &b, int lo, int hi, double *dev_out) { return run(b, lo, hi, dev_out, true); }
     virtual void *stream() { return nullptr; }
     virtual int fetch_stream(const double *dev_src, double *dst, size_t ndoubles) { return fetch(dev_src, true, dst, ndoubles); }
+    // whole batch on this rank with the records left where the evaluator's copy engine put them (pinned host
+    // memory): 8192 records are 0.9 MB, and zero-filling a vector plus one more memcpy of them cost more than the
+    // batch kernel
+    virtual int run_view(MsBatch &b, const double **view)
+    {
+        b.records.resize((size_t)b.count * b.K);
+        const int rc = run(b, 0, b.count, b.records.data(), false);
+        *view = b.records.data();
+        return rc;
+    }
+    virtual int fetch_stream_view(const double *dev_src, size_t ndoubles, MsBatch &b, const double **view)
+    {
+        b.records.resize(ndoubles);
+        const int rc = fetch_stream(dev_src, b.records.data(), ndoubles);
+        *view = b.records.data();
+        return rc;
+    }
     // mark a device shard as failed (one double)
     virtual int poke(double *dev_dst, double value) { (void)dev_dst; (void)value; return -1; }
 };
@@ -125,10 +144,11 @@ struct MsState
 
 inline int ms_run_batch(MsEvaluator &ev, const MsComm &comm, MsBatch &b)
 {
+    b.rec = nullptr;
+    if (comm.world <= 1 && !(comm.rccl && comm.force_collective))
+        return b.host_records ? ev.run_view(b, &b.rec) : ev.run(b, 0, b.count, nullptr, true);
     if (b.host_records)
         b.records.assign((size_t)b.count * b.K, 0.0);
-    if (comm.world <= 1 && !(comm.rccl && comm.force_collective))
-        return b.host_records ? ev.run(b, 0, b.count, b.records.data(), false) : ev.run(b, 0, b.count, nullptr, true);
     // contiguous blocks of ceil(count / world) points per rank; the last block may be short
     const int per = (b.count + comm.world - 1) / comm.world;
     const int lo = std::min(b.count, comm.rank * per), hi = std::min(b.count, lo + per);
@@ -157,6 +177,7 @@ inline int ms_run_batch(MsEvaluator &ev, const MsComm &comm, MsBatch &b)
     for (int r = 0; r < comm.world; ++r)
         if ((long long)r * per < b.count && b.records[((size_t)r * per) * b.K + status_slot] == MS_SHARD_FAILED)
             return rc ? rc : -1;
+    b.rec = b.records.data();
     return 0;
 }
 
@@ -187,7 +208,7 @@ inline int ms_major_iteration(MsState &m, MsEvaluator &ev, const MsComm &comm)
 
     for (int nn = 0; nn < N; ++nn)
     {
-        const double *rec = &b.records[(size_t)nn * K];
+        const double *rec = b.rec + (size_t)nn * K;
         const double *rx = rec, *rdiag = rec + p;
         (void)rdiag;
         const double *rx0 = rec + 2 * p, *sc = rec + 3 * p;
@@ -367,7 +388,7 @@ inline int ms_major_iteration(MsState &m, MsEvaluator &ev, const MsComm &comm)
         for (int c = 0; c < lb.count; ++c)
         {
             const int nn = cand[c];
-            const double *rec = &lb.records[(size_t)c * K];
+            const double *rec = lb.rec + (size_t)c * K;
             const double *rx = rec, *rdiag = rec + p;
             m.ntix[nn] = 0;
             m.nwsp += 1;

@@ -204,10 +204,28 @@ struct HipMsEvaluator : MsEvaluator
         if (!out_on_device)
             GSLNLS_HIP_OK(hipMemcpyAsync(h_rec, d_rec, sizeof(double) * (size_t)(hi - lo) * K, hipMemcpyDeviceToHost, st));
         GSLNLS_HIP_OK(hipStreamSynchronize(st));
-        if (!out_on_device)
+        if (!out_on_device && out)
             memcpy(out, h_rec, sizeof(double) * (size_t)(hi - lo) * K);
         hipEventElapsedTime(&last_kernel_ms, e0, e1);
         return 0;
+    }
+    // the records of a whole batch, consumed by the driver where the copy engine wrote them
+    int run_view(MsBatch &b, const double **view) override
+    {
+        const int rc = run(b, 0, b.count, nullptr, false);
+        *view = h_rec;
+        return rc;
+    }
+    int fetch_stream_view(const double *dev_src, size_t nd, MsBatch &b, const double **view) override
+    {
+        int rc = ensure(b.count);
+        if (rc)
+            return rc;
+        if (nd > (size_t)cap * K)
+            return GSLNLS_EINVAL;
+        rc = fetch_stream(dev_src, h_rec, nd);
+        *view = h_rec;
+        return rc;
     }
 
     int fetch(const double *src, bool src_on_device, double *dst, size_t nd) override
@@ -346,7 +364,7 @@ int DenseFit<M>::mstart_batch(int jac, const double *ranges, const double *kd, l
         b.host_records = (records != nullptr);
         rc = ms_run_batch(ev, *batch_comm, b);
         if (rc == 0 && records)
-            memcpy(records, b.records.data(), sizeof(double) * (size_t)count * b.K);
+            memcpy(records, b.rec, sizeof(double) * (size_t)count * b.K);
         b.host_records = true;
     }
     else

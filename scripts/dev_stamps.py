@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import c2_data
 from gslnls_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, "gslnls_amd", "libgslnls_hip_stamps.so")
+_lib.LIB_PATH = os.path.join(ROOT, "gslnls_amd", os.environ.get("GSLNLS_STAMPS_LIB", "libgslnls_hip_stamps.so"))
 import gslnls_amd as A
 L = _lib.lib()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
