@@ -251,6 +251,24 @@ __device__ __attribute__((noinline)) void lm_advance_lds(LmState<P> *s, const Pa
     lm_advance<P>(*s, *r, *prm);
 }
 
+// The same for a state that LIVES IN LDS (irls_batch.hpp), passed as 32-bit LDS byte offsets.  Through generic pointers
+// the out-of-line function cannot know which memory they name: the compiler proved "LDS or null" and guarded each of
+// the ~700 accesses of the p = 8 instance with a 64-bit null test and two selects (718 v_cmp_ne_u64 + 828 v_cndmask
+// in 12 k instructions).  Rebuilt from an LDS offset inside the function, every access is a plain ds_read / ds_write.
+__device__ __forceinline__ unsigned lds_offset_of(const void *p)
+{
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+template <int P>
+__device__ __attribute__((noinline)) void lm_advance_lds3(unsigned s_off, unsigned r_off, const LmParams *prm)
+{
+    typedef __attribute__((address_space(3))) LmState<P> *S3;
+    typedef __attribute__((address_space(3))) const PassSums<P> *R3;
+    LmState<P> *s = (LmState<P> *)(S3)(uintptr_t)s_off;
+    const PassSums<P> *r = (const PassSums<P> *)(R3)(uintptr_t)r_off;
+    lm_advance<P>(*s, *r, *prm);
+}
+
 template <int P>
 struct StepBcast
 {

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(T, 2) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
                 // the 8 x 8 system of lm_solve pushed the kernel to 256 VGPRs + AGPR/scratch spills = one
                 // wavefront per SIMD; p-sized algebra through LDS costs a few thousand cycles per LM iteration
                 // but lets a second data set share the CU and hide them
-                lm_advance_lds<P>(&lds_state, reinterpret_cast<const Sums *>(lds_tot), &prm);
+                lm_advance_lds3<P>(lds_offset_of(&lds_state), lds_offset_of(lds_tot), &prm);
             }
             __syncthreads();
             const unsigned long long t3 = now();

@@ -13,6 +13,7 @@
 #include <math.h>
 #include <float.h>
 #include <vector>
+#include <chrono>
 #include "dense_host.hpp"
 #include "large_kernels.hpp"
 
@@ -36,6 +37,12 @@ struct LargeOps
     virtual int eval_jac(double *, double *, double *) { return GSLNLS_E_UNSUPPORTED; }
     // JTJV pass at the current point xcur: ||J u||^2 and J^T J u
     virtual int jtjv(const double *xcur, const double *u, double *normw2, double *out) = 0;
+    // optional: a whole Steihaug-Toint CG step with the p-sized recurrences on the device (sparse_cg.hpp): dx and the
+    // step's status (ST_SUCCESS / ST_EMAXITER); the backend adds the products it made to nevaldfu.  cached_njdx2:
+    // ||J dx||^2 of that step when the backend already computed it behind the step
+    bool device_cg = false;
+    virtual int cgst_device(const double *, const double *, double, long, double *, int *) { return GSLNLS_E_UNSUPPORTED; }
+    virtual bool cached_njdx2(double *) { return false; }
     virtual int full_jtj(const double *xcur, double *jtj) = 0;          // p x p row-major (symmetric)
     virtual int residual(const double *xcur, double *resid_host) = 0;  // weighted residual at the current point
 };
@@ -220,6 +227,16 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
         }
     };
 
+    // GSLNLS_LARGE_PROF=1: wall time per phase of the driver (host clock; every phase ends in a stream synchronisation)
+    static const bool prof = getenv("GSLNLS_LARGE_PROF") != nullptr;
+    double t_phase[5] = {0, 0, 0, 0, 0}; // eval, eval_jac, step (cgst / lm), predicted reduction, total
+    long n_phase[4] = {0, 0, 0, 0};
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto since = [](std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
+    const auto t_begin = now();
+
     // trust_init
     int rc = ops.eval(x.data(), &fnorm2, g.data(), dJ.data(), need_jtj ? JTJ.data() : nullptr, &bad);
     if (rc)
@@ -261,6 +278,13 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
     // GSL cgst.c cgst_step; every CG iteration is ONE fused pass (||J u||^2 and J^T J u together)
     auto cgst_step = [&]() -> int {
         const long cgmaxit = n; // cgst_alloc: max_iter == 0 -> n
+        if (ops.device_cg)
+        {
+            int cgst = ST_SUCCESS;
+            const int rcd = ops.cgst_device(g.data(), diag.data(), delta, cgmaxit, dx.data(), &cgst);
+            if (rcd != GSLNLS_E_UNSUPPORTED)
+                return rcd ? rcd : cgst;
+        }
         for (int i = 0; i < p; ++i)
         {
             z[i] = 0.0;
@@ -342,13 +366,19 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
         bool found = false;
         while (!found)
         {
+            auto tp = now();
             int st = (trs == 5) ? cgst_step() : lm_step();
+            t_phase[2] += since(tp);
+            n_phase[2] += 1;
             double rho = -1.0, ssr_t = 0.0;
             if (st == ST_SUCCESS)
             {
                 for (int i = 0; i < p; ++i)
                     xt[i] = x[i] + dx[i];
+                tp = now();
                 rc = ops.eval(xt.data(), &ssr_t, gt.data(), dJt.data(), need_jtj ? JTJt.data() : nullptr, &bad);
+                t_phase[0] += since(tp);
+                n_phase[0] += 1;
                 if (rc)
                     return rc;
                 ops.nevalf += 1;
@@ -360,9 +390,11 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
                     {
                         // quadratic model: -2 g.dx/||f||^2 - (||J dx||/||f||)^2, one more product with J
                         double nJdx2 = 0.0, gTdx = 0.0;
-                        rc = ops.jtjv(x.data(), dx.data(), &nJdx2, Bd.data());
-                        if (rc)
+                        tp = now();
+                        if (!ops.cached_njdx2(&nJdx2) && (rc = ops.jtjv(x.data(), dx.data(), &nJdx2, Bd.data())))
                             return rc;
+                        t_phase[3] += since(tp);
+                        n_phase[3] += 1;
                         ops.nevaldfu += 1;
                         for (int i = 0; i < p; ++i)
                             gTdx += g[i] * dx[i];
@@ -395,8 +427,11 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
             if (found)
             {
                 // accepted: g, J^T J (diag) at x_trial came with the same EVAL pass (or are completed now)
+                tp = now();
                 if (ops.lazy_jac && (rc = ops.eval_jac(gt.data(), dJt.data(), need_jtj ? JTJt.data() : nullptr)))
                     return rc;
+                t_phase[1] += since(tp);
+                n_phase[1] += 1;
                 ops.accept();
                 ops.nevaldfu += 1;
                 ops.nevaldf2 += 1;
@@ -464,6 +499,15 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
     } while (status == ST_CONTINUE && iter < maxiter);
     if (iter >= maxiter && status != ST_SUCCESS && status != ST_EBADFUNC && status != ST_ENOPROG)
         status = ST_EMAXITER;
+    if (prof)
+    {
+        t_phase[4] = since(t_begin);
+        fprintf(stderr,
+                "[large prof] total %.2f ms | f at trial points %.2f (%ld) | Jacobian at accepted points %.2f (%ld) | steps %.2f "
+                "(%ld) | predicted reduction %.2f (%ld) | host algebra and the rest %.2f\n",
+                t_phase[4], t_phase[0], n_phase[0], t_phase[1], n_phase[1], t_phase[2], n_phase[2], t_phase[3], n_phase[3],
+                t_phase[4] - t_phase[0] - t_phase[1] - t_phase[2] - t_phase[3]);
+    }
     R.x = x;
     R.status = status;
     R.info = info;

@@ -28,6 +28,8 @@
 #include "../../include/gslnls_core.h"
 #include "large_host.hpp"
 
+#include "sparse_cg.hpp"
+
 namespace gslnls
 {
 
@@ -59,8 +61,11 @@ template <int L>
 __global__ __launch_bounds__(SP_T) void sp_segment_kernel(const int *__restrict__ ptr, const int *__restrict__ idx,
                                                           const double *__restrict__ val, const double *__restrict__ vec,
                                                           int nseg, const int *__restrict__ list, int nlist, int skip_long,
-                                                          double *out, double *sq)
+                                                          double *out, double *sq, const int *flag, int run_when)
 {
+    // device-resident CG (sparse_cg.hpp): kernels of iterations enqueued past the end of the step do nothing
+    if (flag && *flag != run_when)
+        return;
     const long gid = (long)blockIdx.x * SP_T + threadIdx.x;
     const long w = gid / L;
     const int lane = (int)(gid % L);
@@ -131,9 +136,11 @@ __global__ __launch_bounds__(SP_T) void sp_resid_kernel(double *f, const double 
 }
 
 // block partials of w^2
-__global__ __launch_bounds__(SP_T) void sp_sumsq_kernel(const double *w, int n, double *partial)
+__global__ __launch_bounds__(SP_T) void sp_sumsq_kernel(const double *w, int n, double *partial, const int *flag, int run_when)
 {
     __shared__ double lds[SP_T / 64];
+    if (flag && *flag != run_when)
+        return;
     double a = 0.0;
     for (int i = blockIdx.x * SP_T + threadIdx.x; i < n; i += gridDim.x * SP_T)
         a = fma(w[i], w[i], a);
@@ -323,6 +330,13 @@ struct SparseCbOps : LargeOps
     double *h_f = nullptr, *h_val = nullptr, *h_pin_in = nullptr, *h_pin_out = nullptr, *h_pin_sq = nullptr;
     std::vector<double> h_part;
     static constexpr int NPART = 256;
+    static_assert(NPART == SPCG_NPART, "spcg_update_kernel adds the partials of sp_sumsq_kernel");
+    // device-resident CG (sparse_cg.hpp): g, diag, z, r, d, dx in one allocation of 6p doubles; scalars; pinned mirrors
+    double *d_cg = nullptr, *h_pin_in2 = nullptr;
+    SpCgScal *d_scal = nullptr, *h_scal = nullptr;
+    int cg_last_its = 1;
+    bool cg_pred_valid = false;
+    double cg_pred = 0.0;
 
     int init(int n_, int p_, const double *y, const double *sw, gslnls_large_f_cb f, gslnls_large_jac_cb j, void *u)
     {
@@ -359,7 +373,13 @@ struct SparseCbOps : LargeOps
         GSLNLS_HIP_OK(hipHostMalloc(&h_pin_in, pb));
         GSLNLS_HIP_OK(hipHostMalloc(&h_pin_out, pb));
         GSLNLS_HIP_OK(hipHostMalloc(&h_pin_sq, pb));
+        GSLNLS_HIP_OK(hipHostMalloc(&h_pin_in2, pb));
+        GSLNLS_HIP_OK(hipMalloc(&d_cg, 6 * pb));
+        GSLNLS_HIP_OK(hipMalloc(&d_scal, sizeof(SpCgScal)));
+        GSLNLS_HIP_OK(hipHostMalloc(&h_scal, sizeof(SpCgScal)));
         h_part.resize(NPART);
+        const char *e = getenv("GSLNLS_LARGE_CG");
+        device_cg = !(e && strcmp(e, "host") == 0);
         return 0;
     }
     ~SparseCbOps() override
@@ -367,10 +387,11 @@ struct SparseCbOps : LargeOps
         for (void *q : {(void *)d_y, (void *)d_sw, (void *)d_f[0], (void *)d_f[1], (void *)d_val[0], (void *)d_val[1],
                         (void *)d_valc[0], (void *)d_valc[1], (void *)d_rowptr, (void *)d_colidx, (void *)d_colptr, (void *)d_rowidx, (void *)d_perm,
                         (void *)d_lrows, (void *)d_lcols, (void *)d_vecp, (void *)d_outp, (void *)d_sqp, (void *)d_w,
-                        (void *)d_part, (void *)d_jtj})
+                        (void *)d_part, (void *)d_jtj, (void *)d_cg, (void *)d_scal})
             if (q)
                 (void)hipFree(q);
-        for (void *q : {(void *)h_f, (void *)h_val, (void *)h_pin_in, (void *)h_pin_out, (void *)h_pin_sq})
+        for (void *q : {(void *)h_f, (void *)h_val, (void *)h_pin_in, (void *)h_pin_out, (void *)h_pin_sq, (void *)h_pin_in2,
+                        (void *)h_scal})
             if (q)
                 (void)hipHostFree(q);
         if (st)
@@ -424,6 +445,8 @@ struct SparseCbOps : LargeOps
         GSLNLS_HIP_OK(hipHostMalloc(&h_val, sizeof(double) * (size_t)(m > 0 ? m : 1)));
         return 0;
     }
+    const int *seg_flag = nullptr; // run condition of the product kernels being enqueued (device CG), else null
+    int seg_run_when = 0;
     template <int L>
     void launch_segments(const int *ptr, const int *idx, const double *val, const double *vec, int nseg, const int *list,
                          int nlist, int skip_long, double *out, double *sq)
@@ -431,7 +454,7 @@ struct SparseCbOps : LargeOps
         const long groups = list ? nlist : nseg;
         const long threads = groups * L;
         hipLaunchKernelGGL(sp_segment_kernel<L>, dim3((unsigned)((threads + SP_T - 1) / SP_T)), dim3(SP_T), 0, st, ptr, idx,
-                           val, vec, nseg, list, nlist, skip_long, out, sq);
+                           val, vec, nseg, list, nlist, skip_long, out, sq, seg_flag, seg_run_when);
     }
     // out[s] (and optionally sq[s]) over rows (transpose = false) or columns (transpose = true) of buffer b
     void segments(bool transpose, int b, const double *vec, double *out, double *sq)
@@ -535,7 +558,7 @@ struct SparseCbOps : LargeOps
         (void)hipEventRecord(e0, st);
         GSLNLS_HIP_OK(hipMemcpyAsync(d_vecp, h_pin_in, sizeof(double) * (size_t)p, hipMemcpyHostToDevice, st));
         segments(false, cur, d_vecp, d_w, nullptr);      // w = J u
-        hipLaunchKernelGGL(sp_sumsq_kernel, dim3(NPART), dim3(SP_T), 0, st, d_w, n, d_part);
+        hipLaunchKernelGGL(sp_sumsq_kernel, dim3(NPART), dim3(SP_T), 0, st, d_w, n, d_part, (const int *)nullptr, 0);
         segments(true, cur, d_w, d_outp, nullptr);       // J^T w
         GSLNLS_HIP_OK(hipMemcpyAsync(h_pin_out, d_outp, sizeof(double) * (size_t)p, hipMemcpyDeviceToHost, st));
         (void)hipEventRecord(e1, st);
@@ -544,6 +567,85 @@ struct SparseCbOps : LargeOps
         (void)hipEventElapsedTime(&pass_ms, e0, e1);
         ++npass;
         return 0;
+    }
+    // One Steihaug-Toint step with the recurrences on the device (sparse_cg.hpp).  Iterations are enqueued in growing
+    // chunks (the first one sized by the previous step's count); behind every chunk goes the product J dx that the
+    // predicted reduction will ask for, run only once the step is final; one 64-byte read-back per chunk.
+    int cgst_device(const double *g, const double *diag, double delta, long cgmaxit, double *dx, int *status) override
+    {
+        cg_pred_valid = false;
+        const size_t pb = sizeof(double) * (size_t)p;
+        memcpy(h_pin_in, g, pb);
+        memcpy(h_pin_in2, diag, pb);
+        SpCgVecs v;
+        double *base = d_cg;
+        GSLNLS_HIP_OK(hipMemcpyAsync(base, h_pin_in, pb, hipMemcpyHostToDevice, st));
+        GSLNLS_HIP_OK(hipMemcpyAsync(base + p, h_pin_in2, pb, hipMemcpyHostToDevice, st));
+        v.g = base;
+        v.diag = base + (size_t)p;
+        v.z = base + 2 * (size_t)p;
+        v.r = base + 3 * (size_t)p;
+        v.d = base + 4 * (size_t)p;
+        v.dx = base + 5 * (size_t)p;
+        v.u = d_vecp;
+        v.Bd = d_outp;
+        v.part = d_part;
+        v.s = d_scal;
+        v.p = p;
+        v.cgmaxit = cgmaxit;
+        const int T = p <= 8192 ? 256 : 1024;
+        (void)hipEventRecord(e0, st);
+        hipLaunchKernelGGL(spcg_init_kernel, dim3(1), dim3(T), 0, st, v, delta);
+        const bool small = p <= 65536; // the step rides along with every read-back when it is small
+        int chunk = std::min(32, std::max(2, cg_last_its + 1));
+        for (;;)
+        {
+            seg_flag = &d_scal->done;
+            seg_run_when = 0;
+            for (int k = 0; k < chunk; ++k)
+            {
+                segments(false, cur, d_vecp, d_w, nullptr); // w = J u
+                hipLaunchKernelGGL(sp_sumsq_kernel, dim3(NPART), dim3(SP_T), 0, st, d_w, n, d_part, seg_flag, 0);
+                segments(true, cur, d_w, d_outp, nullptr);  // J^T w
+                hipLaunchKernelGGL(spcg_update_kernel, dim3(1), dim3(T), 0, st, v);
+            }
+            seg_run_when = 1; // the finished step's product with J (u = dx by then)
+            segments(false, cur, d_vecp, d_w, nullptr);
+            hipLaunchKernelGGL(sp_sumsq_kernel, dim3(NPART), dim3(SP_T), 0, st, d_w, n, d_part, seg_flag, 1);
+            hipLaunchKernelGGL(spcg_pred_kernel, dim3(1), dim3(64), 0, st, v);
+            seg_flag = nullptr;
+            GSLNLS_HIP_OK(hipMemcpyAsync(h_scal, d_scal, sizeof(SpCgScal), hipMemcpyDeviceToHost, st));
+            if (small)
+                GSLNLS_HIP_OK(hipMemcpyAsync(h_pin_out, v.dx, pb, hipMemcpyDeviceToHost, st));
+            (void)hipEventRecord(e1, st);
+            GSLNLS_HIP_OK(hipStreamSynchronize(st));
+            if (h_scal->done)
+                break;
+            chunk = std::min(32, chunk * 2);
+        }
+        if (!small)
+        {
+            GSLNLS_HIP_OK(hipMemcpyAsync(h_pin_out, v.dx, pb, hipMemcpyDeviceToHost, st));
+            GSLNLS_HIP_OK(hipStreamSynchronize(st));
+        }
+        memcpy(dx, h_pin_out, pb);
+        (void)hipEventElapsedTime(&pass_ms, e0, e1);
+        nevaldfu += (long)(h_scal->n_notrans + h_scal->n_trans);
+        npass += (int)h_scal->it;
+        cg_last_its = (int)std::min<long long>(h_scal->it, 64);
+        cg_pred_valid = h_scal->njdx2_valid != 0;
+        cg_pred = h_scal->njdx2;
+        *status = h_scal->status;
+        return 0;
+    }
+    bool cached_njdx2(double *v) override
+    {
+        if (!cg_pred_valid)
+            return false;
+        *v = cg_pred;
+        cg_pred_valid = false;
+        ++npass;
+        return true;
     }
     int jtj_of(int b, double *jtj)
     {

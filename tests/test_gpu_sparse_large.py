@@ -60,8 +60,23 @@ def test_penalty_p500_cgst_readme_pin(amd, gslref, pins, fmt):
     assert fit["conv"] == 0 and ref["conv"] == 0
     assert abs(fit["ssr"] - 0.004778845) < 5e-10          # README.md:1100-1101
     assert abs(fit["ssr"] - ref["ssr"]) <= 1e-10 * ref["ssr"]
-    assert np.allclose(fit["par"], ref["par"], rtol=1e-6, atol=1e-9)
+    # flat valley (see the lm test below): the CG recurrences run on the device, whose norms are block reductions
+    # where the oracle adds sequentially -- the same 207 iterations end at points whose ssr agree to 1e-10 while a
+    # few coordinates differ in the 4th digit; with the host loop (GSLNLS_LARGE_CG=host, sequential norms like the
+    # oracle's) they agree to 1e-6
+    assert np.allclose(fit["par"], ref["par"], rtol=2e-3)
     assert fit["niter"] == ref["niter"]
+
+
+def test_penalty_p500_cgst_host_loop_matches_oracle_coordinates(amd, gslref, monkeypatch):
+    monkeypatch.setenv("GSLNLS_LARGE_CG", "host")
+    p = 500
+    fn, jac = penalty(p, "csc")
+    fit = amd.gsl_nls_large(fn, y=np.zeros(p + 1), start=np.arange(1.0, p + 1), algorithm="cgst", jac=jac,
+                            control=dict(maxiter=500))
+    ref = oracle_penalty(gslref, p, "cgst", gslref.control(maxiter=500))
+    assert fit["niter"] == ref["niter"] and fit["neval"]["dfu"] > 0
+    assert np.allclose(fit["par"], ref["par"], rtol=1e-6, atol=1e-9)
 
 
 def test_penalty_p500_lm_sparse_jtj(amd, gslref):
@@ -118,6 +133,39 @@ def test_weighted_banded_problem_long_rows_and_columns(amd):
     r = np.sqrt(w) * (A @ fit["par"] - y)
     assert np.allclose(np.asarray(fit["resid"]), r, rtol=1e-9, atol=1e-12)
     assert abs(fit["ssr"] - r @ r) <= 1e-10 * (r @ r)
+
+
+def test_device_cg_equals_host_cg(amd, monkeypatch):
+    """The Steihaug-Toint step with its p-sized recurrences on the device (csrc/sparse_cg.hpp, the default) against
+    the host loop it replaces (GSLNLS_LARGE_CG=host: one round trip per CG iteration): same iterations, same
+    evaluation counts (the products the reference would have made), results equal to rounding of the norms."""
+    p = 500
+    fn, jac = penalty(p, "csc")
+    rng = np.random.Generator(np.random.PCG64(11))
+    n2, p2 = 3000, 400
+    A = sp.random(n2, p2, density=0.02, random_state=np.random.RandomState(5), format="csr") + sp.eye(n2, p2, format="csr")
+    y2 = A @ rng.standard_normal(p2) + 0.01 * rng.standard_normal(n2)
+    out = {}
+    for mode in ("device", "host"):
+        if mode == "host":
+            monkeypatch.setenv("GSLNLS_LARGE_CG", "host")
+        else:
+            monkeypatch.delenv("GSLNLS_LARGE_CG", raising=False)
+        a = amd.gsl_nls_large(fn, y=np.zeros(p + 1), start=np.arange(1.0, p + 1), algorithm="cgst", jac=jac,
+                              control=dict(maxiter=500))
+        b = amd.gsl_nls_large(lambda th: A @ th, y=y2, start=np.zeros(p2), algorithm="cgst", jac=lambda th: A,
+                              control=dict(maxiter=100))
+        out[mode] = (a, b)
+    for k in (0, 1):
+        d, h = out["device"][k], out["host"][k]
+        assert d["conv"] == h["conv"] == 0
+        assert d["niter"] == h["niter"]
+        # products with J: the same count, or one CG iteration more or less where ||r|| / ||g|| crosses 1e-6 within
+        # rounding of the norms (seen: 95 against 93 on the linear problem)
+        assert d["neval"]["f"] == h["neval"]["f"] and d["neval"]["df2"] == h["neval"]["df2"]
+        assert abs(d["neval"]["dfu"] - h["neval"]["dfu"]) <= 2
+        assert abs(d["ssr"] - h["ssr"]) <= 1e-10 * h["ssr"]
+        assert np.allclose(d["par"], h["par"], rtol=2e-3 if k == 0 else 1e-8, atol=1e-11)  # k = 0: the flat valley
 
 
 def test_callback_errors_surface(amd):
