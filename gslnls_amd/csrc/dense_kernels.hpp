@@ -371,10 +371,7 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
     {
         // Wave 0 has nothing to do until the totals are there, so its own rows are requested right away (one
         // eighth of the workgroup's prefetch; the other waves hold theirs back until the totals are published,
-        // because 64 KB per CU in front of the partial sums delays them).  The rows go first: the compiler
-        // shuffles a few state registers as soon as they are loaded, and that wait must not sit in front of
-        // anything that still has to be issued.
-        fetch_rows(i0);
+        // because 64 KB per CU in front of the partial sums delays them).
         const double *src = reinterpret_cast<const double *>(prev) + z0;
         double *dst = reinterpret_cast<double *>(&s);
         constexpr int ND = (int)(offsetof(LmState<P>, bad_steps) / 8);
@@ -389,6 +386,12 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             cnt[k] = src[ND + k];
+        // the rows behind the state: vector-memory results return in issue order, and the state is what the critical
+        // path waits for.  The scheduling barriers keep the compiler from moving a use of a state register (and the
+        // wait that goes with it) in front of the row requests.  (6.24 against 6.32 us per launch, same box.)
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_rows(i0);
+        __builtin_amdgcn_sched_barrier(0);
     }
     else
         load_partials(0);
