@@ -165,6 +165,12 @@ struct DenseFit : DenseBase
     // wide workgroups while the accumulators fit in 128 VGPRs, narrow ones beyond that
     static constexpr int T = (NV <= 24) ? 512 : (NV <= 70 ? 256 : 128); // lds_red[NV * T] must fit 160 KB
 
+    // interpreted expression models: slots the program needs when they fit the workgroup's LDS (set by VmDenseFit
+    // before every fit), 0 = slot file in scratch memory
+    int vm_lds_slots = 0;
+    static constexpr int VM_LDS_CAP = (160 * 1024 - 1024) / (T * 8); // slots of T doubles beside ~0.5 KB of static LDS
+    bool vm_lds_ready[3] = {false, false, false};
+
     DenseCtx<P> ctx;
     bool owns_data = false;
     double *d_x = nullptr, *d_y = nullptr, *d_sw = nullptr;
@@ -431,6 +437,47 @@ struct DenseFit : DenseBase
         if (fresh)
             parity |= FRESH_LAUNCH;
         parity |= (int)((index & 0x0fffffff) << 2);
+        if constexpr (M::ID == 100)
+        {
+            if (vm_lds_slots > 0 && vm_lds_slots <= VM_LDS_CAP)
+            {
+                using ML = typename M::LdsTwin;
+                const int rows_lds = vm_lds_slots > NV ? vm_lds_slots : NV;
+                const size_t dyn = sizeof(double) * (size_t)rows_lds * T;
+                const int jm = jacmode == JAC_ANALYTIC ? 0 : (jacmode == JAC_FORWARD ? 1 : 2);
+                if (!vm_lds_ready[jm])
+                {
+                    // more than 64 KB of dynamic LDS has to be asked for once per kernel
+                    const int cap = 160 * 1024 - 1024;
+                    hipError_t e = hipSuccess;
+                    if (jm == 0)
+                        e = hipFuncSetAttribute((const void *)lm_step_kernel<ML, JAC_ANALYTIC, T>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+                    else if (jm == 1)
+                        e = hipFuncSetAttribute((const void *)lm_step_kernel<ML, JAC_FORWARD, T>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+                    else
+                        e = hipFuncSetAttribute((const void *)lm_step_kernel<ML, JAC_CENTER, T>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+                    if (e != hipSuccess)
+                        vm_lds_slots = 0; // (the scratch form below)
+                    vm_lds_ready[jm] = (e == hipSuccess);
+                }
+                if (vm_lds_slots > 0)
+                {
+                    if (jm == 0)
+                        hipLaunchKernelGGL((lm_step_kernel<ML, JAC_ANALYTIC, T>), grid, block, dyn, stream, prev, pp, ctx.x[0],
+                                           ctx.y, ctx.sw, ctx.n, ctx.G, parity, ctx);
+                    else if (jm == 1)
+                        hipLaunchKernelGGL((lm_step_kernel<ML, JAC_FORWARD, T>), grid, block, dyn, stream, prev, pp, ctx.x[0],
+                                           ctx.y, ctx.sw, ctx.n, ctx.G, parity, ctx);
+                    else
+                        hipLaunchKernelGGL((lm_step_kernel<ML, JAC_CENTER, T>), grid, block, dyn, stream, prev, pp, ctx.x[0],
+                                           ctx.y, ctx.sw, ctx.n, ctx.G, parity, ctx);
+                    return;
+                }
+            }
+        }
         switch (jacmode)
         {
         case JAC_ANALYTIC:

@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstddef>
+#include <type_traits>
 #include "lm_core.hpp"
 #include "models.hpp"
 #include "rowops.hpp"
@@ -277,8 +278,32 @@ struct StepBcast
     double vel[P]; // velocity (PH_FVV only)
 };
 
+// models that keep per-thread data in the workgroup's dynamic LDS (ModelVM<P, true>)
+template <class M, class = void>
+struct vm_lds_twin
+{
+    static constexpr bool value = false;
+};
+template <class M>
+struct vm_lds_twin<M, std::enable_if_t<(M::ID == 100)>>
+{
+    static constexpr bool value = M::LDS_SLOTS;
+};
+extern __shared__ double gslnls_dyn_lds[];
+template <bool VML>
+__device__ __forceinline__ double *vm_lds_region(double *static_area)
+{
+    if constexpr (VML)
+        return gslnls_dyn_lds;
+    else
+        return static_area;
+}
+
 // rows prefetched into registers before the prologue so their latency hides behind it
 constexpr int ROWS_AHEAD = 8;
+#ifndef GSLNLS_VM_ROWS_AHEAD
+#define GSLNLS_VM_ROWS_AHEAD 2
+#endif
 
 // The first arguments are the pointers every wave needs before it can issue a single load; they are
 // plain scalars so that the backend can preload them into SGPRs at wave launch
@@ -297,9 +322,16 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
     const bool fresh_launch = (parity_and_flags & FRESH_LAUNCH) != 0; // first launch of a fit: no previous state
     constexpr int NV = Sums::NV;
     constexpr int NW = T / 64;
-    constexpr int R = ROWS_AHEAD;
+    // interpreted expression models: every unrolled row is one more inlined copy of the interpreter (8 copies are
+    // ~300 KB of code per kernel)
+    constexpr int R = (M::ID == 100) ? GSLNLS_VM_ROWS_AHEAD : ROWS_AHEAD;
 
-    __shared__ double lds_red[NV * T];
+    // interpreted model with its slot file in LDS (vm_model.hpp): the block reduction's staging area shares the
+    // dynamic region with the slot files -- they are never live together (a barrier separates the row loop from the
+    // reduction) -- so that the whole 160 KB minus a few hundred bytes is available: max(NV, slots) * T doubles
+    constexpr bool VML = vm_lds_twin<M>::value;
+    __shared__ double lds_red_static[VML ? 1 : NV * T];
+    double *const lds_red = vm_lds_region<VML>(lds_red_static);
     __shared__ double lds_tot[NV];
     __shared__ StepBcast<P> lds_bc;
 

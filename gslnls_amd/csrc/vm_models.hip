@@ -29,6 +29,11 @@ struct VmDenseFit : DenseFit<ModelVM<P>>
     int upload()
     {
         GSLNLS_HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(c_vm_prog), &prog, sizeof(VmProgram)));
+        // slot file of the step kernel in LDS when it fits (vm_model.hpp); GSLNLS_VM_LDS=0 keeps it in scratch memory
+        const int ops = prog.nfvv > prog.nops ? prog.nfvv : prog.nops;
+        const int slots = 2 * prog.p + prog.nx + prog.nconst + ops;
+        const char *e = getenv("GSLNLS_VM_LDS");
+        this->vm_lds_slots = (e && e[0] == '0') ? 0 : (slots <= Base::VM_LDS_CAP ? slots : 0);
         return 0;
     }
     int solve(int jac, int fvv, const double *start, const double *lupars, const int *ci, const double *cd, int chunk,

@@ -83,7 +83,10 @@ GSLNLS_HD double vm_apply(unsigned char op, double x, double y)
 }
 
 // run instructions [0, upto) of the program on one row
-GSLNLS_HD void vm_run(const VmProgram &prog, const double *th, const double *xr, const double *v, int upto, double *slot)
+// `slot`: anything indexable that yields double lvalues -- a local array (scratch memory on the device), or the
+// strided view of the workgroup's LDS that vm_model.hpp uses in the step kernel
+template <class Slots>
+GSLNLS_HD void vm_run(const VmProgram &prog, const double *th, const double *xr, const double *v, int upto, Slots &&slot)
 {
     const int p = prog.p, nx = prog.nx, nc = prog.nconst;
     for (int k = 0; k < p; ++k)
