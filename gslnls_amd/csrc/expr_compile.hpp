@@ -371,6 +371,7 @@ struct ExprCompiler
             out.op[i] = nd.op;
             out.a[i] = (unsigned short)slot(nd.a);
             out.b[i] = (unsigned short)slot(nd.b);
+            out.word[i] = (unsigned int)out.op[i] | ((unsigned int)out.a[i] << 8) | ((unsigned int)out.b[i] << 20);
             slot_of[order[i]] = base + (int)i;
         }
         out.nops = ngrad;

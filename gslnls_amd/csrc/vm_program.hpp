@@ -55,8 +55,37 @@ struct VmProgram
     int grad_slot[VM_MAX_P];
     unsigned char op[VM_MAX_OPS];
     unsigned short a[VM_MAX_OPS], b[VM_MAX_OPS];
+    // the same instruction as one word for the interpreter: op | a << 8 | b << 20 (one scalar load instead of three
+    // sub-word ones); op / a / b above stay the form the native lowering and the tests read
+    unsigned int word[VM_MAX_OPS];
     double consts[VM_MAX_CONST];
 };
+static_assert(VM_MAX_SLOTS < 4096, "slot numbers are packed in 12 bits");
+
+GSLNLS_HD bool vm_is_binary(unsigned op) { return op <= VM_DIV || op == VM_POW; }
+
+// The library functions with long bodies (pow and the trigonometric ones carry their argument reduction: hundreds to
+// thousands of instructions each) stay out of line: inlined into the interpreter's switch, in every unrolled copy of the
+// row loop, they made the loop tens of KB of code that no instruction cache holds, and every interpreted instruction
+// paid for fetching its case.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __attribute__((noinline)) inline double vm_apply_long(unsigned int op, double x, double y)
+#else
+inline double vm_apply_long(unsigned int op, double x, double y)
+#endif
+{
+    switch (op)
+    {
+    case VM_POW: return pow(x, y);
+    case VM_LOG: return log(x);
+    case VM_SIN: return sin(x);
+    case VM_COS: return cos(x);
+    case VM_TAN: return tan(x);
+    case VM_ATAN: return atan(x);
+    case VM_TANH: return tanh(x);
+    default: return NAN;
+    }
+}
 
 GSLNLS_HD double vm_apply(unsigned char op, double x, double y)
 {
@@ -67,18 +96,11 @@ GSLNLS_HD double vm_apply(unsigned char op, double x, double y)
     case VM_MUL: return x * y;
     case VM_DIV: return x / y;
     case VM_NEG: return -x;
-    case VM_POW: return pow(x, y);
     case VM_EXP: return gexp(x);
-    case VM_LOG: return log(x);
-    case VM_SIN: return sin(x);
-    case VM_COS: return cos(x);
-    case VM_TAN: return tan(x);
-    case VM_ATAN: return atan(x);
     case VM_SQRT: return sqrt(x);
     case VM_ABS: return fabs(x);
-    case VM_TANH: return tanh(x);
     case VM_SIGN: return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : 0.0);
-    default: return NAN;
+    default: return vm_apply_long(op, x, y);
     }
 }
 
@@ -98,8 +120,36 @@ GSLNLS_HD void vm_run(const VmProgram &prog, const double *th, const double *xr,
     for (int c = 0; c < nc; ++c)
         slot[2 * p + nx + c] = prog.consts[c];
     const int base = 2 * p + nx + nc;
+    // The result of an instruction is very often an operand of the next one: it is kept in a register and forwarded, so
+    // that the chain does not go store -> load through the slot file at every step; the second operand is only read for
+    // the binary operations.  (Program, operands and operations are the same for every lane: the branches are scalar.)
+    int last = -1;
+    double lastv = 0.0;
+    // (Tried and measured on the C2 formula, 8 instructions per row: requesting the next word one instruction ahead,
+    // and holding the program in registers read with v_readlane so that no scalar load sits in the loop -- both within
+    // 1 % of this form.  What an interpreted instruction costs now is its ~60-100 machine instructions of decoding,
+    // address arithmetic and scalar branches.)
     for (int i = 0; i < upto; ++i)
-        slot[base + i] = vm_apply(prog.op[i], slot[prog.a[i]], slot[prog.b[i]]);
+    {
+        const unsigned int w = prog.word[i];
+        const unsigned int op = w & 0xffu;
+        const int a = (int)((w >> 8) & 0xfffu), b = (int)(w >> 20);
+        double x, y = 0.0;
+        if (a == last)
+            x = lastv;
+        else
+            x = slot[a];
+        if (vm_is_binary(op))
+        {
+            if (b == last)
+                y = lastv;
+            else
+                y = slot[b];
+        }
+        lastv = vm_apply((unsigned char)op, x, y);
+        last = base + i;
+        slot[last] = lastv;
+    }
 }
 
 } // namespace gslnls
