@@ -312,3 +312,38 @@ def test_hard_nist_problems_behave_like_the_oracle(amd, gslref, nist, name):
     # a request for the QR solver on an ill-conditioned problem is flagged for the GSL path, never silently served
     if dflt["conv"] in (0, 11) and dflt["jtj_cond"] > 1e10:
         assert not dflt["solver_served"]
+
+
+def test_interpreter_slot_file_in_lds_equals_scratch_form(amd, nist, monkeypatch):
+    """csrc/vm_model.hpp: the step kernel of an interpreted model keeps the per-thread slot file in the workgroup's LDS
+    when the program fits (`ModelVM<P, true>`), else in a local array (GSLNLS_VM_LDS=0 forces that form; read at every
+    fit).  Same program, same operations in the same order: every number of the fit identical to the last bit, on a
+    grid of 256 workgroups (n = 1e6, launch-per-step) and on NIST-sized problems, analytic and finite-difference
+    Jacobians, lmaccel with the symbolic second derivative."""
+    from conftest import c2_data
+    from gslnls_amd import _lib
+    cases = []
+    for n in (50000, 1000000):
+        x, y = c2_data(n)
+        for kw in (dict(jac=True, trace=True), dict(jac=False), dict(jac=True, fvv=True, algorithm="lmaccel")):
+            cases.append(("c2 n=%d %s" % (n, sorted(kw)), "A*exp(-lam*x)+b", ["A", "lam", "b"], x, y, [1.0, 1.0, 0.0], kw))
+    q = nist["Misra1b"]
+    cases.append(("Misra1b", q["formula"].split("~", 1)[1].strip(), list(q["start"].keys()),
+                  np.asarray(q["data"]["x"], dtype=np.float64), np.asarray(q["data"]["y"], dtype=np.float64),
+                  list(q["start"].values()), dict(jac=True)))
+    for name, expr, parnames, x, y, start, kw in cases:
+        prob = amd.DenseProblem(_lib.MODEL_EXPR, len(parnames), x.reshape(-1, 1), y, expr=expr, parnames=parnames,
+                                xnames=["x"], lowering="vm")
+        res = {}
+        for mode in ("lds", "scratch"):
+            if mode == "scratch":
+                monkeypatch.setenv("GSLNLS_VM_LDS", "0")
+            else:
+                monkeypatch.delenv("GSLNLS_VM_LDS", raising=False)
+            res[mode] = prob.solve(start, want_vectors=False, chunk=-1, control=amd.gsl_nls_control(solver="cholesky"), **kw)
+        prob.close()
+        a, b = res["lds"], res["scratch"]
+        for k in ("par", "ssr", "covar", "ssrtrace", "partrace"):
+            if k in a and a[k] is not None:
+                assert np.array_equal(np.asarray(a[k]), np.asarray(b[k]), equal_nan=True), (name, k)
+        assert a["niter"] == b["niter"] and a["neval"] == b["neval"] and a["conv"] == b["conv"] == 0, name
