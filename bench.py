@@ -310,6 +310,23 @@ def batch_irls_bench(_lib, torch, dist, rank, world, B=4096, n=10000):
     alg_bytes = lm_passes * n * 24.0 + rws * n * 24.0
     rw = float(out["irls_niter"].sum())
     kms = out["kernel_ms"]
+    # counters of the same kernel on the same workload from the committed profile (separate rocprofv3 --pmc passes,
+    # scripts/profile_c4c5_pmc.sh): L2-miss traffic (gfx950 correction applied) and fp64-VALU issue share
+    pmc = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_c4c5_pmc.json")) as f:
+            k5 = next(v for k, v in json.load(f).items() if k.startswith("irls_batch_kernel"))
+        valu, gui = k5["SQ_INSTS_VALU"]["median_per_dispatch"], k5["GRBM_GUI_ACTIVE"]["median_per_dispatch"]
+        pmc = {"traffic": k5["hbm_bytes_per_dispatch_corrected"],
+               "traffic_source": "committed profile profiles/r02_c4c5_pmc.json (4096 data sets per dispatch; bytes that "
+                                 "missed L2 -- served by Infinity Cache or HBM), NOT measured in this run",
+               "valu_wave_instructions_per_dispatch": valu,
+               "valu_issue_share": valu * 4.0 / (1024.0 * gui / 8.0),
+               "valu_issue_share_note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE per XCD): the share "
+                                        "of SIMD issue slots the kernel's vector instructions take if each took the 4 "
+                                        "cycles of a wave64 fp64 FMA (divisions, exp and sqrt sequences take longer)"}
+    except Exception:
+        pmc = {"traffic": None}
     return {"workload": "C5: %d data sets x n=%d, Gauss1 family p=8, bisquare IRLS, %d rank(s)" % (B, n, world),
             "datasets_per_s": B / el, "irls_iterations_per_s": rw / el, "wall_ms": el * 1e3,
             "kernel_ms_rank0": kms, "converged": int((out["conv"] == 0).sum()),
@@ -322,7 +339,7 @@ def batch_irls_bench(_lib, torch, dist, rank, world, B=4096, n=10000):
                                        "counted by the kernel, this rank's data sets / its kernel time.  The 240 KB of a data "
                                        "set stay in L2 / Infinity Cache for its whole fit and every row costs three fp64 exp "
                                        "and 46 accumulator FMAs: the kernel is bound by fp64 VALU issue (two workgroups per "
-                                       "CU, 256 VGPRs each), not by HBM"}}
+                                       "CU, 256 VGPRs each), not by HBM", **pmc}}
 
 
 def spawn_ranks(n_ranks):

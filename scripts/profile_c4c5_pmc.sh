@@ -1,0 +1,36 @@
+#!/bin/bash
+# PMC passes for the C5 (irls_batch_kernel) and C4 (ms_fit_kernel) kernels: instruction counts, busy cycles and HBM
+# traffic, each counter group in its own run (rocprofv3 --kernel-trace --pmc only, program directly after `--`).
+#   bash scripts/profile_c4c5_pmc.sh r02      -> gpurun_out/<tag>_c4c5/ ; summary json printed and written there
+set -u
+TAG=${1:-rXX}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/${TAG}_c4c5
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+i=0
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  for wl in c5 mstart; do
+    timeout -k 10 170 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/p${i}_$wl" -o run -- python3 "$ROOT/scripts/dev_time_$wl.py" > "$OUT/p${i}_$wl.log" 2>&1
+    echo "group $i ($grp) $wl rc=$?"
+  done
+done
+python3 - "$OUT" "$TAG" <<'PY'
+import csv, glob, json, os, statistics, sys
+out, tag = sys.argv[1], sys.argv[2]
+res = {}
+for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"].split("(")[0].replace("void gslnls::", "")
+        if not (k.startswith("irls_batch_kernel") or k.startswith("ms_fit_kernel")):
+            continue
+        res.setdefault(k, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+summ = {k: {c: {"median_per_dispatch": statistics.median(v), "dispatches": len(v)} for c, v in d.items()} for k, d in res.items()}
+for k, d in summ.items():
+    if "FETCH_SIZE" in d:
+        # gfx950: FETCH_SIZE tallies 128-B requests at 64 B -> x2 (MI355X_MICROARCH.md, HBM section); KB units
+        d["hbm_bytes_per_dispatch_corrected"] = 2 * 1024 * d["FETCH_SIZE"]["median_per_dispatch"] + 1024 * d.get("WRITE_SIZE", {"median_per_dispatch": 0})["median_per_dispatch"]
+json.dump(summ, open(os.path.join(out, "%s_c4c5_pmc.json" % tag), "w"), indent=1, sort_keys=True)
+print(json.dumps(summ, indent=1, sort_keys=True))
+PY
