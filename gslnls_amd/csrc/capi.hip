@@ -367,10 +367,23 @@ gslnls_large *gslnls_large_create(const gslnls_model *fn, const double *y, int n
     return h;
 }
 
+// one destroyed sparse-callback problem is parked for the next create (sparse_large.hpp: allocation vs binding)
+static SparseCbOps *g_parked_sparse = nullptr;
+
 void gslnls_large_destroy(gslnls_large *h)
 {
     if (h)
     {
+        if (auto *sp = dynamic_cast<SparseCbOps *>(h->ops))
+        {
+            // (large ones give their memory back at once: 64 MB of n- and p-sized buffers is the limit)
+            if ((size_t)sp->cap_n * 40 + (size_t)sp->cap_p * 100 + (size_t)sp->cap_nnz * 40 <= (size_t)64 << 20)
+            {
+                delete g_parked_sparse;
+                g_parked_sparse = sp;
+                h->ops = nullptr;
+            }
+        }
         delete h->ops;
         release_dense(h->dense);
         delete h;
@@ -465,8 +478,18 @@ gslnls_large *gslnls_large_create_sparse(int n, int p, const double *y, const do
             for (int i = 0; i < n; ++i)
                 sw[i] = sqrt(weights[i]);
         }
-        auto *ops = new SparseCbOps();
-        e = ops->init(n, p, y, weights ? sw.data() : nullptr, f, jac, user);
+        SparseCbOps *ops = nullptr;
+        if (g_parked_sparse && g_parked_sparse->fits(n, p))
+        {
+            ops = g_parked_sparse;
+            g_parked_sparse = nullptr;
+            e = ops->bind(n, p, y, weights ? sw.data() : nullptr, f, jac, user);
+        }
+        else
+        {
+            ops = new SparseCbOps();
+            e = ops->init(n, p, y, weights ? sw.data() : nullptr, f, jac, user);
+        }
         if (e == GSLNLS_SUCCESS)
         {
             h = new gslnls_large;
@@ -970,6 +993,8 @@ int gslnls_device_count(void)
 
 void gslnls_trim_cache(void)
 {
+    delete g_parked_sparse;
+    g_parked_sparse = nullptr;
     DenseFit<ModelExpDecay>::trim_pool();
     DenseFit<ModelMisra1a>::trim_pool();
     DenseFit<ModelGaussPeak>::trim_pool();

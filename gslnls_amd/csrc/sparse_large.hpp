@@ -324,7 +324,7 @@ struct SparseCbOps : LargeOps
     int *d_rowptr = nullptr, *d_colidx = nullptr, *d_colptr = nullptr, *d_rowidx = nullptr, *d_perm = nullptr,
         *d_lrows = nullptr, *d_lcols = nullptr;
     double *d_vecp = nullptr, *d_outp = nullptr, *d_sqp = nullptr, *d_w = nullptr, *d_part = nullptr, *d_jtj = nullptr;
-    long cap_nnz = 0;
+    long cap_nnz = 0, cap_hval = 0;
     int cur = 0; // index of the accepted point's buffers; 1 - cur receives the trial
     // host staging in pinned memory: uploads of f (n) and the Jacobian values (nnz), p-sized vectors both ways
     double *h_f = nullptr, *h_val = nullptr, *h_pin_in = nullptr, *h_pin_out = nullptr, *h_pin_sq = nullptr;
@@ -338,28 +338,23 @@ struct SparseCbOps : LargeOps
     bool cg_pred_valid = false;
     double cg_pred = 0.0;
 
-    int init(int n_, int p_, const double *y, const double *sw, gslnls_large_f_cb f, gslnls_large_jac_cb j, void *u)
+    // Allocation (streams, ~20 device and pinned buffers: ~25 ms) is separated from binding a problem: a destroyed
+    // problem is parked by capi.hip and re-bound by the next gslnls_large_create_sparse of at most its size, like the
+    // dense problems are (one-shot gsl_nls_large() calls on small problems were mostly allocation).
+    int cap_n = 0, cap_p = 0;
+    bool sw_allocated = false;
+    int allocate(int n_, int p_)
     {
-        n = n_;
-        p = p_;
-        cb_f = f;
-        cb_jac = j;
-        user = u;
-        lazy_jac = true;
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
             return GSLNLS_E_NODEVICE;
+        cap_n = n_;
+        cap_p = p_;
         GSLNLS_HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         GSLNLS_HIP_OK(hipEventCreate(&e0));
         GSLNLS_HIP_OK(hipEventCreate(&e1));
-        const size_t nb = sizeof(double) * (size_t)n, pb = sizeof(double) * (size_t)p;
+        const size_t nb = sizeof(double) * (size_t)cap_n, pb = sizeof(double) * (size_t)cap_p;
         GSLNLS_HIP_OK(hipMalloc(&d_y, nb));
-        GSLNLS_HIP_OK(hipMemcpy(d_y, y, nb, hipMemcpyHostToDevice));
-        if (sw)
-        {
-            GSLNLS_HIP_OK(hipMalloc(&d_sw, nb));
-            GSLNLS_HIP_OK(hipMemcpy(d_sw, sw, nb, hipMemcpyHostToDevice));
-        }
         for (int k = 0; k < 2; ++k)
             GSLNLS_HIP_OK(hipMalloc(&d_f[k], nb));
         GSLNLS_HIP_OK(hipMalloc(&d_w, nb));
@@ -367,8 +362,8 @@ struct SparseCbOps : LargeOps
         GSLNLS_HIP_OK(hipMalloc(&d_outp, pb));
         GSLNLS_HIP_OK(hipMalloc(&d_sqp, pb));
         GSLNLS_HIP_OK(hipMalloc(&d_part, sizeof(double) * NPART));
-        GSLNLS_HIP_OK(hipMalloc(&d_rowptr, sizeof(int) * ((size_t)n + 1)));
-        GSLNLS_HIP_OK(hipMalloc(&d_colptr, sizeof(int) * ((size_t)p + 1)));
+        GSLNLS_HIP_OK(hipMalloc(&d_rowptr, sizeof(int) * ((size_t)cap_n + 1)));
+        GSLNLS_HIP_OK(hipMalloc(&d_colptr, sizeof(int) * ((size_t)cap_p + 1)));
         GSLNLS_HIP_OK(hipHostMalloc(&h_f, nb));
         GSLNLS_HIP_OK(hipHostMalloc(&h_pin_in, pb));
         GSLNLS_HIP_OK(hipHostMalloc(&h_pin_out, pb));
@@ -378,13 +373,61 @@ struct SparseCbOps : LargeOps
         GSLNLS_HIP_OK(hipMalloc(&d_scal, sizeof(SpCgScal)));
         GSLNLS_HIP_OK(hipHostMalloc(&h_scal, sizeof(SpCgScal)));
         h_part.resize(NPART);
+        return 0;
+    }
+    bool fits(int n_, int p_) const { return st != nullptr && n_ <= cap_n && p_ <= cap_p; }
+    // a (new) problem on the allocated buffers: data up, pattern and counters reset
+    int bind(int n_, int p_, const double *y, const double *sw, gslnls_large_f_cb f, gslnls_large_jac_cb j, void *u)
+    {
+        n = n_;
+        p = p_;
+        cb_f = f;
+        cb_jac = j;
+        user = u;
+        lazy_jac = true;
+        nevalf = nevaldfu = nevaldf2 = 0;
+        npass = 0;
+        pass_ms = 0.f;
+        cur = 0;
+        cg_last_its = 1;
+        cg_pred_valid = false;
+        {
+            // (keeps what upload_pattern allocated: cap_nnz, the value and index buffers)
+            SparsePattern fresh;
+            pat = fresh;
+        }
+        if (d_jtj)
+        {
+            (void)hipFree(d_jtj); // p x p of the previous problem
+            d_jtj = nullptr;
+        }
+        const size_t nb = sizeof(double) * (size_t)n;
+        GSLNLS_HIP_OK(hipMemcpy(d_y, y, nb, hipMemcpyHostToDevice));
+        if (sw)
+        {
+            if (!sw_allocated)
+            {
+                GSLNLS_HIP_OK(hipMalloc(&d_sw_buf, sizeof(double) * (size_t)cap_n));
+                sw_allocated = true;
+            }
+            d_sw = d_sw_buf;
+            GSLNLS_HIP_OK(hipMemcpy(d_sw, sw, nb, hipMemcpyHostToDevice));
+        }
+        else
+            d_sw = nullptr;
         const char *e = getenv("GSLNLS_LARGE_CG");
         device_cg = !(e && strcmp(e, "host") == 0);
         return 0;
     }
+    double *d_sw_buf = nullptr;
+    int init(int n_, int p_, const double *y, const double *sw, gslnls_large_f_cb f, gslnls_large_jac_cb j, void *u)
+    {
+        const int rc = allocate(n_, p_);
+        return rc ? rc : bind(n_, p_, y, sw, f, j, u);
+    }
     ~SparseCbOps() override
     {
-        for (void *q : {(void *)d_y, (void *)d_sw, (void *)d_f[0], (void *)d_f[1], (void *)d_val[0], (void *)d_val[1],
+        for (void *q : {(void *)d_y, (void *)d_sw_buf, (void *)d_f[0], (void *)d_f[1], (void *)d_val[0], (void *)d_val[1],
                         (void *)d_valc[0], (void *)d_valc[1], (void *)d_rowptr, (void *)d_colidx, (void *)d_colptr, (void *)d_rowidx, (void *)d_perm,
                         (void *)d_lrows, (void *)d_lcols, (void *)d_vecp, (void *)d_outp, (void *)d_sqp, (void *)d_w,
                         (void *)d_part, (void *)d_jtj, (void *)d_cg, (void *)d_scal})
@@ -439,10 +482,14 @@ struct SparseCbOps : LargeOps
             GSLNLS_HIP_OK(hipMalloc(&d_lcols, sizeof(int) * pat.long_cols.size()));
             GSLNLS_HIP_OK(hipMemcpy(d_lcols, pat.long_cols.data(), sizeof(int) * pat.long_cols.size(), hipMemcpyHostToDevice));
         }
-        if (h_val)
-            (void)hipHostFree(h_val);
-        h_val = nullptr;
-        GSLNLS_HIP_OK(hipHostMalloc(&h_val, sizeof(double) * (size_t)(m > 0 ? m : 1)));
+        if (!h_val || m > cap_hval)
+        {
+            if (h_val)
+                (void)hipHostFree(h_val);
+            h_val = nullptr;
+            cap_hval = m > 0 ? m : 1;
+            GSLNLS_HIP_OK(hipHostMalloc(&h_val, sizeof(double) * (size_t)cap_hval));
+        }
         return 0;
     }
     const int *seg_flag = nullptr; // run condition of the product kernels being enqueued (device CG), else null
