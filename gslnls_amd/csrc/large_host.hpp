@@ -123,20 +123,20 @@ inline void lg_chol_invert(int p, std::vector<double> &A)
 // lm_solve<P> in lm_core.hpp with run-time p
 inline void lg_mchol_solve(int p, const std::vector<double> &Ain, const std::vector<double> &rhs, std::vector<double> &sol)
 {
-    std::vector<double> M(Ain), b(rhs);
+    // Only the lower triangle is kept (row-major): the symmetric interchange touches each stored element once, and
+    // the rank-one update of step j reads column j from a contiguous copy and walks rows -- no mirrored stores down
+    // columns, so the inner loop is contiguous and vectorises (p = 500: ~10 ms per solve before).  Same operations on
+    // the same values in the same order as the full-matrix form this replaces.
+    std::vector<double> M(Ain), b(rhs), cj(p);
     std::vector<int> perm(p);
     for (int i = 0; i < p; ++i)
-    {
         perm[i] = i;
-        for (int j = 0; j < i; ++j)
-            M[j * p + i] = M[i * p + j];
-    }
     double gamma = 0.0, xi = 0.0;
     for (int i = 0; i < p; ++i)
     {
-        gamma = fmax(gamma, fabs(M[i * p + i]));
+        gamma = fmax(gamma, fabs(M[(size_t)i * p + i]));
         for (int j = 0; j < i; ++j)
-            xi = fmax(xi, fabs(M[i * p + j]));
+            xi = fmax(xi, fabs(M[(size_t)i * p + j]));
     }
     double beta = (p == 1) ? fmax(fmax(gamma, xi), DBL_EPSILON)
                            : fmax(fmax(gamma, xi / sqrt((double)p * p - 1.0)), DBL_EPSILON);
@@ -144,49 +144,58 @@ inline void lg_mchol_solve(int p, const std::vector<double> &Ain, const std::vec
     for (int j = 0; j < p; ++j)
     {
         int q = j;
-        double maxd = fabs(M[j * p + j]);
+        double maxd = fabs(M[(size_t)j * p + j]);
         for (int i = j + 1; i < p; ++i)
-            if (fabs(M[i * p + i]) > maxd)
+            if (fabs(M[(size_t)i * p + i]) > maxd)
             {
-                maxd = fabs(M[i * p + i]);
+                maxd = fabs(M[(size_t)i * p + i]);
                 q = i;
             }
         if (q != j)
         {
-            for (int c = 0; c < p; ++c)
-                std::swap(M[j * p + c], M[q * p + c]);
-            for (int c = 0; c < p; ++c)
-                std::swap(M[c * p + j], M[c * p + q]);
+            // rows / columns j and q (q > j) of the symmetric matrix, in the lower triangle:
+            // (j,j) <-> (q,q);  (j,k) <-> (q,k) for k < j;  (k,j) <-> (q,k) for j < k < q;  (k,j) <-> (k,q) for k > q
+            std::swap(M[(size_t)j * p + j], M[(size_t)q * p + q]);
+            for (int k = 0; k < j; ++k)
+                std::swap(M[(size_t)j * p + k], M[(size_t)q * p + k]);
+            for (int k = j + 1; k < q; ++k)
+                std::swap(M[(size_t)k * p + j], M[(size_t)q * p + k]);
+            for (int k = q + 1; k < p; ++k)
+                std::swap(M[(size_t)k * p + j], M[(size_t)k * p + q]);
             std::swap(b[j], b[q]);
             std::swap(perm[j], perm[q]);
         }
         double theta = 0.0;
         for (int i = j + 1; i < p; ++i)
-            theta = fmax(theta, fabs(M[i * p + j]));
+        {
+            cj[i] = M[(size_t)i * p + j];
+            theta = fmax(theta, fabs(cj[i]));
+        }
         const double u = theta / beta;
-        const double alpha = fmax(fmax(DBL_EPSILON, fabs(M[j * p + j])), u * u);
+        const double alpha = fmax(fmax(DBL_EPSILON, fabs(M[(size_t)j * p + j])), u * u);
         const double ainv = 1.0 / alpha;
         for (int i = j + 1; i < p; ++i)
         {
-            const double vi = M[i * p + j];
+            const double vi = cj[i];
+            double *row = &M[(size_t)i * p];
             for (int k = j + 1; k <= i; ++k)
-            {
-                M[i * p + k] -= ainv * vi * M[k * p + j];
-                M[k * p + i] = M[i * p + k];
-            }
+                row[k] -= ainv * vi * cj[k];
         }
         for (int i = j + 1; i < p; ++i)
-            M[i * p + j] *= ainv;
-        M[j * p + j] = alpha;
+            M[(size_t)i * p + j] = cj[i] * ainv;
+        M[(size_t)j * p + j] = alpha;
     }
     for (int i = 0; i < p; ++i)
+    {
+        const double *row = &M[(size_t)i * p];
         for (int j = 0; j < i; ++j)
-            b[i] -= M[i * p + j] * b[j];
+            b[i] -= row[j] * b[j];
+    }
     for (int i = 0; i < p; ++i)
-        b[i] /= M[i * p + i];
+        b[i] /= M[(size_t)i * p + i];
     for (int i = p - 1; i >= 0; --i)
         for (int j = i + 1; j < p; ++j)
-            b[i] -= M[j * p + i] * b[j];
+            b[i] -= M[(size_t)j * p + i] * b[j];
     sol.assign(p, 0.0);
     for (int i = 0; i < p; ++i)
         sol[perm[i]] = b[i];
