@@ -89,14 +89,21 @@ inline double vm_apply_long(unsigned int op, double x, double y)
 
 GSLNLS_HD double vm_apply(unsigned char op, double x, double y)
 {
+    // the one-instruction operations (most of any program) are computed side by side and selected: one test instead
+    // of the compare-and-branch tree of a switch, which cost more than the operation itself
+    if (op <= VM_MUL)
+    {
+        const double s = (op == VM_SUB) ? -y : y;
+        return (op == VM_MUL) ? x * y : x + s;
+    }
+    if (op == VM_NEG)
+        return -x;
+    if (op == VM_EXP)
+        return gexp(x);
+    if (op == VM_DIV)
+        return x / y;
     switch (op)
     {
-    case VM_ADD: return x + y;
-    case VM_SUB: return x - y;
-    case VM_MUL: return x * y;
-    case VM_DIV: return x / y;
-    case VM_NEG: return -x;
-    case VM_EXP: return gexp(x);
     case VM_SQRT: return sqrt(x);
     case VM_ABS: return fabs(x);
     case VM_SIGN: return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : 0.0);
