@@ -371,7 +371,9 @@ struct ExprCompiler
             out.op[i] = nd.op;
             out.a[i] = (unsigned short)slot(nd.a);
             out.b[i] = (unsigned short)slot(nd.b);
-            out.word[i] = (unsigned int)out.op[i] | ((unsigned int)out.a[i] << 8) | ((unsigned int)out.b[i] << 20);
+            // (the interpreter always reads both operands: a unary instruction names its operand twice)
+            const unsigned int wb = vm_is_binary(out.op[i]) ? out.b[i] : out.a[i];
+            out.word[i] = (unsigned int)out.op[i] | ((unsigned int)out.a[i] << 8) | (wb << 20);
             slot_of[order[i]] = base + (int)i;
         }
         out.nops = ngrad;

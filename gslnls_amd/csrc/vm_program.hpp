@@ -111,7 +111,22 @@ GSLNLS_HD double vm_apply(unsigned char op, double x, double y)
     }
 }
 
-// run instructions [0, upto) of the program on one row
+// everything that is not add / subtract / multiply / negate
+GSLNLS_HD double vm_apply_rest(unsigned int op, double x, double y)
+{
+    if (op == VM_EXP)
+        return gexp(x);
+    if (op == VM_DIV)
+        return x / y;
+    switch (op)
+    {
+    case VM_SQRT: return sqrt(x);
+    case VM_ABS: return fabs(x);
+    case VM_SIGN: return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : 0.0);
+    default: return vm_apply_long(op, x, y);
+    }
+}
+
 // `slot`: anything indexable that yields double lvalues -- a local array (scratch memory on the device), or the
 // strided view of the workgroup's LDS that vm_model.hpp uses in the step kernel
 template <class Slots>
@@ -134,26 +149,32 @@ GSLNLS_HD void vm_run(const VmProgram &prog, const double *th, const double *xr,
     double lastv = 0.0;
     // (Tried and measured on the C2 formula, 8 instructions per row: requesting the next word one instruction ahead,
     // and holding the program in registers read with v_readlane so that no scalar load sits in the loop -- both within
-    // 1 % of this form.  What an interpreted instruction costs now is its ~60-100 machine instructions of decoding,
-    // address arithmetic and scalar branches.)
+    // 1 % of this form.)
+    // Counters of the interpreted step kernel (scripts/dev_vm_pmc.sh) said what an instruction cost: 14 scalar
+    // branches and 40 scalar instructions, at ~18 cycles per instruction issued -- the loop was control flow.  So
+    // the four one-instruction operations are computed side by side and selected, the second operand is always read
+    // (unary instructions carry b = a), and one test sends everything else to vm_apply_rest: four branches per
+    // instruction (loop, two forwards, the class).
     for (int i = 0; i < upto; ++i)
     {
         const unsigned int w = prog.word[i];
         const unsigned int op = w & 0xffu;
         const int a = (int)((w >> 8) & 0xfffu), b = (int)(w >> 20);
-        double x, y = 0.0;
+        double x, y;
         if (a == last)
             x = lastv;
         else
             x = slot[a];
-        if (vm_is_binary(op))
-        {
-            if (b == last)
-                y = lastv;
-            else
-                y = slot[b];
-        }
-        lastv = vm_apply((unsigned char)op, x, y);
+        if (b == last)
+            y = lastv;
+        else
+            y = slot[b];
+        const double ys = (op == VM_SUB) ? -y : y;
+        double r = (op == VM_MUL) ? x * y : x + ys;
+        r = (op == VM_NEG) ? -x : r;
+        if (op == VM_DIV || op > VM_NEG)
+            r = vm_apply_rest(op, x, y);
+        lastv = r;
         last = base + i;
         slot[last] = lastv;
     }
