@@ -380,8 +380,8 @@ __global__ __launch_bounds__(T, 2) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
                     may_collect = false;
                     // every listed key carries the prefix: the rank within the list is sel_k, the passes go on below
                 }
-                if (tid < 256)
-                    hist[tid] = 0;
+                for (int bq = tid; bq < 256; bq += T)
+                    hist[bq] = 0;
                 __syncthreads();
                 const unsigned long long prefix = sel_prefix, mask = sel_mask;
                 // the first two bytes examined are shared by most keys of a wavefront: aggregate; later bytes are
