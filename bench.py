@@ -19,7 +19,8 @@ issued by libgslnls_hip.so itself) and batched robust fits (C5: one final all-ga
 the ranks, in the "multistart" and "batched_irls" objects of the same JSON line.
 
 Extra objects: "roofline" (dominant kernel lm_step_kernel: algorithmic bytes 16 n per launch,
-duration from HIP events on the library's stream), "cpu_baseline" (the oracle, single core).
+duration from HIP events on the library's stream), "cpu_baseline" (the oracle, single core); at N = 1 also
+"large_cgst" (C3) and "large_sparse_readme" (the reference's own sparse example, README Example 4).
 """
 import argparse
 import ctypes as C
@@ -263,6 +264,37 @@ def large_bench(L, _lib, n=10_000_000, p=64):
             "fit": {"niter": int(fit["niter"]), "conv": int(fit["conv"]), "passes": int(fit["n_passes"]),
                     "wall_s": el, "outer_iterations_per_s": fit["niter"] / el, "ssr": float(fit["ssr"]),
                     "max_abs_err_vs_truth": float(np.max(np.abs(fit["par"] - th)))}}
+
+
+def sparse_readme_bench():
+    """The reference's own sparse example (README.md:1040-1146: penalty function I, p = 500, Jacobian a dgCMatrix)
+    through gsl_nls_large(fn, jac) -- host closures, every product with J on the device.  One call each for cgst and lm
+    (the second of two: the first pays for the allocations that are parked afterwards)."""
+    import scipy.sparse as sp
+    import gslnls_amd as A
+    p = 500
+    a = np.sqrt(1e-5)
+    J0 = sp.vstack([sp.identity(p, format="csr") * a, sp.csr_matrix(np.ones((1, p)))]).tocsc()
+    J0.sort_indices()
+    last_row = np.flatnonzero(J0.indices == p)
+
+    def fn(th):
+        return np.concatenate([a * (th - 1.0), [np.sum(th ** 2) - 0.25]])
+
+    def jac(th):
+        J0.data[last_row] = 2.0 * th  # values of a prebuilt pattern (what Matrix does for a dgCMatrix of fixed structure)
+        return J0
+    out = {"workload": "README Example 4: penalty function I, p = 500, n = 501, sparse Jacobian (dgCMatrix), Python closures",
+           "reference_readme_quotes_ms": {"cgst": 158.0, "lm": 5670.0, "note": "README.md:1146, unstated hardware; not a baseline"}}
+    for alg in ("cgst", "lm"):
+        for _ in range(2):
+            t0 = time.perf_counter()
+            fit = A.gsl_nls_large(fn, y=np.zeros(p + 1), start=np.arange(1.0, p + 1), algorithm=alg, jac=jac,
+                                  control=dict(maxiter=500))
+            el = time.perf_counter() - t0
+        out[alg] = {"wall_ms": el * 1e3, "niter": int(fit["niter"]), "conv": int(fit["conv"]), "ssr": float(fit["ssr"]),
+                    "device_passes": int(fit["n_passes"]), "ssr_target": 0.004778845}
+    return out
 
 
 def batch_irls_bench(_lib, torch, dist, rank, world, B=4096, n=10000):
@@ -603,6 +635,10 @@ def main():
         line["batched_irls"] = batch_irls_bench(_lib, torch, dist, rank, world)
         if world == 1:
             line["large_cgst"] = large_bench(L, _lib)
+            try:
+                line["large_sparse_readme"] = sparse_readme_bench()
+            except Exception as e:  # noqa: a side measurement must not cost the line
+                line["large_sparse_readme"] = {"error": repr(e)}
     if world > 1:
         L.gslnls_comm_destroy()
     if rank == 0 and not args.no_cpu_baseline:
