@@ -168,7 +168,10 @@ struct DenseFit : DenseBase
     // interpreted expression models: slots the program needs when they fit the workgroup's LDS (set by VmDenseFit
     // before every fit), 0 = slot file in scratch memory
     int vm_lds_slots = 0;
-    static constexpr int VM_LDS_CAP = (160 * 1024 - 1024) / (T * 8); // slots of T doubles beside ~0.5 KB of static LDS
+    // slots of T doubles beside the kernel's static LDS (sums, broadcast block, the state copy of the interpreted
+    // models: 0.5 KB at p = 2, 2.5 KB at p = 12)
+    static constexpr int VM_LDS_STATIC_MAX = 4 * 1024;
+    static constexpr int VM_LDS_CAP = (160 * 1024 - VM_LDS_STATIC_MAX) / (T * 8);
     bool vm_lds_ready[3] = {false, false, false};
 
     DenseCtx<P> ctx;
@@ -448,7 +451,7 @@ struct DenseFit : DenseBase
                 if (!vm_lds_ready[jm])
                 {
                     // more than 64 KB of dynamic LDS has to be asked for once per kernel
-                    const int cap = 160 * 1024 - 1024;
+                    const int cap = 160 * 1024 - VM_LDS_STATIC_MAX;
                     hipError_t e = hipSuccess;
                     if (jm == 0)
                         e = hipFuncSetAttribute((const void *)lm_step_kernel<ML, JAC_ANALYTIC, T>,
@@ -460,7 +463,10 @@ struct DenseFit : DenseBase
                         e = hipFuncSetAttribute((const void *)lm_step_kernel<ML, JAC_CENTER, T>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, cap);
                     if (e != hipSuccess)
-                        vm_lds_slots = 0; // (the scratch form below)
+                    {
+                        vm_lds_slots = 0;         // (the scratch form below)
+                        (void)hipGetLastError(); // not an error of the fit: do not leave it for the loop's check
+                    }
                     vm_lds_ready[jm] = (e == hipSuccess);
                 }
                 if (vm_lds_slots > 0)

@@ -334,6 +334,7 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
     double *const lds_red = vm_lds_region<VML>(lds_red_static);
     __shared__ double lds_tot[NV];
     __shared__ StepBcast<P> lds_bc;
+    __shared__ LmState<P> lds_vm_state[1]; // used by the interpreted models only (their state machine runs on it)
 
     const int tid = threadIdx.x;
 
@@ -551,7 +552,12 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
                 // lm_advance inlined into it the forward-difference instance for p = 4 took its first step with the
                 // damping parameter of the reset state (mu = 0) instead of the one just computed -- seen on Roszman1,
                 // gone with the state machine compiled on its own.
-                lm_advance_lds<P>(&s, &r, &prm);
+                // ... and on a copy of the state in LDS, addressed by LDS offsets: through pointers into this
+                // wavefront's private memory every access of the state machine was a scratch round trip
+                if (lane == 0)
+                    lds_vm_state[0] = s;
+                lm_advance_lds3<P>(lds_offset_of(&lds_vm_state[0]), lds_offset_of(lds_tot), &prm);
+                s = lds_vm_state[0];
             }
             else
                 lm_advance<P>(s, r, prm);
