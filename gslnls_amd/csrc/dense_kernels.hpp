@@ -245,17 +245,12 @@ __device__ __forceinline__ void pin_params(LmParams &q)
 
 // lm_advance out of line: its own register allocation, nothing of the caller's row loop live across it.
 // Used where the caller is already short of registers -- the workgroup-per-dataset kernel (irls_batch.hpp) and the
-// step kernel of the interpreted expression models.
-template <int P>
-__device__ __attribute__((noinline)) void lm_advance_lds(LmState<P> *s, const PassSums<P> *r, const LmParams *prm)
-{
-    lm_advance<P>(*s, *r, *prm);
-}
-
-// The same for a state that LIVES IN LDS (irls_batch.hpp), passed as 32-bit LDS byte offsets.  Through generic pointers
-// the out-of-line function cannot know which memory they name: the compiler proved "LDS or null" and guarded each of
-// the ~700 accesses of the p = 8 instance with a 64-bit null test and two selects (718 v_cmp_ne_u64 + 828 v_cndmask
-// in 12 k instructions).  Rebuilt from an LDS offset inside the function, every access is a plain ds_read / ds_write.
+// step kernel of the interpreted expression models.  The state LIVES IN LDS and is passed as 32-bit LDS byte offsets.
+// Through generic pointers the out-of-line function cannot know which memory they name: for an LDS state the compiler
+// proved "LDS or null" and guarded each of the ~700 accesses of the p = 8 instance with a 64-bit null test and two
+// selects (718 v_cmp_ne_u64 + 828 v_cndmask in 12 k instructions); for a state in the caller's private memory every
+// access was a scratch round trip (6 us per launch of the interpreted kernel).  Rebuilt from an LDS offset inside the
+// function, every access is a plain ds_read / ds_write.
 __device__ __forceinline__ unsigned lds_offset_of(const void *p)
 {
     return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
