@@ -255,13 +255,16 @@ __device__ __forceinline__ unsigned lds_offset_of(const void *p)
 {
     return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
 }
+// (the control values too: a pointer to the caller's copy of them is a pointer into its private memory)
 template <int P>
-__device__ __attribute__((noinline)) void lm_advance_lds3(unsigned s_off, unsigned r_off, const LmParams *prm)
+__device__ __attribute__((noinline)) void lm_advance_lds3(unsigned s_off, unsigned r_off, unsigned prm_off)
 {
     typedef __attribute__((address_space(3))) LmState<P> *S3;
     typedef __attribute__((address_space(3))) const PassSums<P> *R3;
+    typedef __attribute__((address_space(3))) const LmParams *Q3;
     LmState<P> *s = (LmState<P> *)(S3)(uintptr_t)s_off;
     const PassSums<P> *r = (const PassSums<P> *)(R3)(uintptr_t)r_off;
+    const LmParams *prm = (const LmParams *)(Q3)(uintptr_t)prm_off;
     lm_advance<P>(*s, *r, *prm);
 }
 
@@ -330,6 +333,7 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
     __shared__ double lds_tot[NV];
     __shared__ StepBcast<P> lds_bc;
     __shared__ LmState<P> lds_vm_state[1]; // used by the interpreted models only (their state machine runs on it)
+    __shared__ LmParams lds_vm_prm[1];
 
     const int tid = threadIdx.x;
 
@@ -550,8 +554,11 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
                 // ... and on a copy of the state in LDS, addressed by LDS offsets: through pointers into this
                 // wavefront's private memory every access of the state machine was a scratch round trip
                 if (lane == 0)
+                {
                     lds_vm_state[0] = s;
-                lm_advance_lds3<P>(lds_offset_of(&lds_vm_state[0]), lds_offset_of(lds_tot), &prm);
+                    lds_vm_prm[0] = prm;
+                }
+                lm_advance_lds3<P>(lds_offset_of(&lds_vm_state[0]), lds_offset_of(lds_tot), lds_offset_of(&lds_vm_prm[0]));
                 s = lds_vm_state[0];
             }
             else

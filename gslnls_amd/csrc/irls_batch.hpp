@@ -58,6 +58,7 @@ __global__ __launch_bounds__(T, 2) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
     __shared__ double lds_grp[GV * T];
     __shared__ double lds_tot[NV];
     __shared__ LmState<P> lds_state;
+    __shared__ LmParams lds_prm;
     __shared__ unsigned int hist[256];
     __shared__ unsigned long long sel_prefix, sel_mask, sel_k, sel_lo, sel_hi;
     __shared__ unsigned int sel_cnt_le, sel_cand;
@@ -99,9 +100,12 @@ __global__ __launch_bounds__(T, 2) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
     {
         irls_iter += 1;
         // ---------------- cold LM solve from the original start with the current weights ----------------
-        if (tid == 0)
-            lm_state_reset<P>(lds_state, a.start, a.has_lu ? a.lu : nullptr);
         prm.chisq_in = (irls_iter > 1) ? chisq_carry : NAN;
+        if (tid == 0)
+        {
+            lm_state_reset<P>(lds_state, a.start, a.has_lu ? a.lu : nullptr);
+            lds_prm = prm; // what the out-of-line state machine reads (LDS, like the state)
+        }
         __syncthreads();
         for (int guard = 0; guard < 1000000; ++guard)
         {
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(T, 2) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
                 // the 8 x 8 system of lm_solve pushed the kernel to 256 VGPRs + AGPR/scratch spills = one
                 // wavefront per SIMD; p-sized algebra through LDS costs a few thousand cycles per LM iteration
                 // but lets a second data set share the CU and hide them
-                lm_advance_lds3<P>(lds_offset_of(&lds_state), lds_offset_of(lds_tot), &prm);
+                lm_advance_lds3<P>(lds_offset_of(&lds_state), lds_offset_of(lds_tot), lds_offset_of(&lds_prm));
             }
             __syncthreads();
             const unsigned long long t3 = now();
