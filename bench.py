@@ -102,15 +102,16 @@ def bind_library_comm(L, torch, dist, rank, world, backend):
     libgslnls_hip.so itself on its own stream).  Returns a label of what the data path uses."""
     idbuf = C.create_string_buffer(128)
     ok = torch.zeros(1, dtype=torch.int32)
-    if rank == 0:
-        ok[0] = 1 if L.gslnls_comm_get_unique_id(idbuf) == 0 else 0
+    # EVERY rank makes an id (only rank 0's is used): that binds RCCL (dlopen) on each of them, so that a rank without
+    # a usable RCCL is known before any rank enters ncclCommInitRank, which is itself a collective
+    ok[0] = 1 if L.gslnls_comm_get_unique_id(idbuf) == 0 else 0
     t = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).clone()
     dev = "cuda" if backend == "nccl" else "cpu"
     t, okd = t.to(dev), ok.to(dev)
     dist.broadcast(t, 0)
-    dist.broadcast(okd, 0)
+    dist.all_reduce(okd, op=dist.ReduceOp.MIN)
     if int(okd.item()) != 1:
-        return None, "RCCL unavailable on rank 0: %s" % L.gslnls_comm_last_error().decode()
+        return None, "RCCL unavailable on some rank: %s" % L.gslnls_comm_last_error().decode()
     rc = L.gslnls_comm_init_rank(bytes(t.cpu().numpy().tobytes()), rank, world)
     flag = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -120,16 +121,18 @@ def bind_library_comm(L, torch, dist, rank, world, backend):
     return True, "ncclAllGather issued by libgslnls_hip.so on its own stream (RCCL bound with dlopen)"
 
 
-def multistart_bench(L, _lib, torch, dist, rank, world, steps, warmup, lib_comm):
+def multistart_bench(L, _lib, job, steps, warmup, lib_comm):
     """C4: concentration fits/sec of multi-start (src/nls_mstart.c:42-128) on NIST BoxBOD, Sobol starts in
     b1 in [1,500], b2 in [0.01,5], mstart_p = 5 LM iterations each, analytic Jacobian; the points of a batch are
     sharded over the ranks in contiguous blocks and completed with ONE all-gather of the records (RCCL)."""
     from gslnls_amd.control import gsl_nls_control, pack_control
+    torch, dist, rank, world = job.torch, job.dist, job.rank, job.world
     x = np.asfortranarray(np.array(BOXBOD_X).reshape(6, 1))
     y = np.array(BOXBOD_Y)
     model = _lib.Model(2, 2, 1, x.ctypes.data_as(C.c_void_p), 0)
     err = C.c_int(0)
     h = L.gslnls_dense_create(C.byref(model), y.ctypes.data_as(C.c_void_p), 6, None, C.byref(err))
+    job.barrier(bool(h), "multistart: gslnls_dense_create")
     ci, cd = pack_control(gsl_nls_control(solver="cholesky"), "lm")
     ranges = np.array([1.0, 500.0, 0.01, 5.0])
     kd = np.array([0.75, 0.75])
@@ -154,7 +157,13 @@ def multistart_bench(L, _lib, torch, dist, rank, world, steps, warmup, lib_comm)
         out_p = C.c_void_p(shard.data_ptr()) if shard is not None else None
         host_p, ms_p = rec_host.ctypes.data_as(C.c_void_p), C.byref(ms)
 
+        state = {"rc": 0}
+
         def step(to_host=False):
+            # a failed batch is carried to the next sync point, never raised between two collectives.  (The library
+            # fails together: a rank whose shard failed still enters the all-gather, every rank gets the error.)
+            if state["rc"]:
+                return
             if use_lib:
                 # lo = -1: this rank's block + the library's own all-gather; records stay in HBM unless asked for
                 rc = L.gslnls_mstart_batch(h, 1, rg_p, kd_p, 0, total, -1, 0, 5, 1e-6, ci_p, cd_p, None,
@@ -162,7 +171,8 @@ def multistart_bench(L, _lib, torch, dist, rank, world, steps, warmup, lib_comm)
             else:
                 rc = L.gslnls_mstart_batch(h, 1, rg_p, kd_p, 0, total, lo, hi, 5, 1e-6, ci_p, cd_p, None, out_p, 1, ms_p)
             if rc != 0:
-                raise SystemExit("mstart batch failed: %d" % rc)
+                state["rc"] = rc
+                return
             kms.append(ms.value)
             if not use_lib:
                 dist.all_gather_into_tensor(allb, shard)
@@ -170,27 +180,32 @@ def multistart_bench(L, _lib, torch, dist, rank, world, steps, warmup, lib_comm)
         def timed(to_host):
             for _ in range(warmup):
                 step(to_host)
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
+            job.barrier(state["rc"] == 0, "multistart %s warmup (rc %d)" % (label, state["rc"]))
             kms.clear()
             t0 = time.perf_counter()
             for _ in range(steps):
                 step(to_host)
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
+            ok = job.sync(state["rc"] == 0)
             el = time.perf_counter() - t0
-            if dist is not None:
-                t = torch.tensor([el], dtype=torch.float64, device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                el = float(t.item())
-            return el
+            if not ok:
+                raise LegFailed("multistart %s timed batches (rc %d on this rank)" % (label, state["rc"]))
+            return job.max_over_ranks(el)
         n0 = L.gslnls_comm_allgather_count()
         el = timed(False)
         n_coll = L.gslnls_comm_allgather_count() - n0
         kernel_ms = float(np.mean(kms))
         el_host = timed(True) if use_lib else None
+        coll_us = None
+        if use_lib and world > 1:
+            # device time of the exchange alone: HIP-event pair around the library's ncclAllGather, a few extra batches
+            L.gslnls_comm_set_timing(1)
+            for _ in range(max(5, steps)):
+                step(False)
+            job.barrier(state["rc"] == 0, "multistart %s all-gather timing" % label)
+            nt = C.c_longlong(0)
+            tot_ms = L.gslnls_comm_allgather_ms(C.byref(nt))
+            L.gslnls_comm_set_timing(0)
+            coll_us = 1e3 * tot_ms / nt.value if nt.value else None
         if use_lib:
             rec = rec_host
         else:
@@ -201,7 +216,9 @@ def multistart_bench(L, _lib, torch, dist, rank, world, steps, warmup, lib_comm)
         # is ~25 flop in this library (devmath.hpp): 4 x 6 x 37 = 888 flop per iteration, 5 iterations per fit
         flop_fit = (2 + 2) * 6 * (25 + 12) * 5
         out[label] = {"fits_per_s": total * steps / el, "points_per_batch": total, "ms_per_batch": el / steps * 1e3,
-                      "kernel_ms_per_batch_rank0": kernel_ms, "points_passing_det_filter": int(fitted.sum()),
+                      "kernel_ms_per_batch_rank0": kernel_ms, "kernel_us_per_batch_rank0": 1e3 * kernel_ms,
+                      "allgather_us_per_batch_rank0": coll_us, "points_per_rank": hi - lo,
+                      "points_passing_det_filter": int(fitted.sum()),
                       "points_in_global_basin_after_5_iters": good,
                       "allgathers_by_library_in_timed_region": int(n_coll),
                       "fits_per_s_records_on_host": (total * steps / el_host) if el_host else None,
@@ -223,6 +240,13 @@ def multistart_bench(L, _lib, torch, dist, rank, world, steps, warmup, lib_comm)
     out["metric"] = "multi-start concentration fits/s (BoxBOD n=6 p=2, 5 LM iterations each, all-gather of records)"
     out["collective"] = ("none (one rank)" if world == 1 else
                          (lib_comm if isinstance(lib_comm, str) else "torch.distributed all_gather_into_tensor (fallback)"))
+    if world > 1:
+        out["scaling_note"] = ("strong_8192_total is LATENCY-bound by construction: 8192 points are one 35-40 us kernel on one "
+                               "GPU (its duration is the slowest lane's walk through its trials, not the number of points), so "
+                               "%d ranks x %d points each take about as long per batch, plus the all-gather "
+                               "(allgather_us_per_batch_rank0) and one host wait: expect flat or negative strong scaling. "
+                               "weak_65536_per_gpu (65536 points per rank, one all-gather of the %d x 14 doubles) is the "
+                               "throughput figure." % (world, (8192 + world - 1) // world, 65536 * world))
     out["note"] = ("working set is 96 B per fit: bound by fp64 VALU + exp latency and by launch/collective latency, "
                    "an HBM fraction is not meaningful (SURVEY.md 8(d)); fits_per_s leaves the gathered records in HBM, "
                    "fits_per_s_records_on_host adds the D2H the host-side commit of the real procedure needs")
@@ -297,11 +321,12 @@ def sparse_readme_bench():
     return out
 
 
-def batch_irls_bench(_lib, torch, dist, rank, world, B=4096, n=10000):
+def batch_irls_bench(_lib, job, B=4096, n=10000):
     """C5: B data sets x n rows, NIST Gauss1 family p = 8, 2 % outliers, loss = bisquare; data sets are
     independent, so rank r fits the contiguous block [r B/W, (r+1) B/W) with no traffic, and ONE all-gather of
     theta-hat, sigma-hat and the status words completes the result on every rank (gslnls_batch_irls_gather)"""
     from gslnls_amd.batch import BatchProblem
+    rank, world = job.rank, job.world
     truth = np.array([98.778210871, 0.010497276517, 100.48990633, 67.481111276, 23.129773360, 71.994503004,
                       178.99805021, 18.389389025])
     start = np.array([97.0, 0.009, 100.0, 65.0, 20.0, 70.0, 178.0, 16.5])
@@ -317,22 +342,29 @@ def batch_irls_bench(_lib, torch, dist, rank, world, B=4096, n=10000):
               + th[5] * np.exp(-(x - th[6]) ** 2 / th[7] ** 2)) + 2.5 * rng.standard_normal(n)
         yy[rng.choice(n, n // 50, replace=False)] += 50.0
         Y[d - lo] = yy
-    prob = BatchProblem(4, 8, X, Y)
+    prob, out, state = None, None, {"err": None}
+
+    def guarded(fn):
+        # library failures are carried to the next sync point (gslnls_batch_irls_gather itself fails on every rank
+        # together: a rank-local failure is taken through the collective)
+        if state["err"] is None:
+            try:
+                return fn()
+            except Exception as e:  # noqa
+                state["err"] = repr(e)
+        return None
+    prob = guarded(lambda: BatchProblem(4, 8, X, Y))
+    job.barrier(state["err"] is None, "batched IRLS: problem creation (%s)" % state["err"])
     kw = dict(loss="bisquare", jac=True, control=dict(solver="cholesky"))
-    prob.irls_gathered(B, start, **kw)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    guarded(lambda: prob.irls_gathered(B, start, **kw))
+    job.barrier(state["err"] is None, "batched IRLS warm-up (%s)" % state["err"])
     t0 = time.perf_counter()
-    out = prob.irls_gathered(B, start, **kw)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    out = guarded(lambda: prob.irls_gathered(B, start, **kw))
+    ok = job.sync(state["err"] is None)
     el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    if not ok:
+        raise LegFailed("batched IRLS timed call (%s)" % state["err"])
+    el = job.max_over_ranks(el)
     prob_passes = dict(prob.last_passes)
     prob.close()
     # Algorithmic bytes by SURVEY.md 8(d): the unit is one pass over a data set's rows (x, y, w = 24 B per row; an LM
@@ -374,12 +406,122 @@ def batch_irls_bench(_lib, torch, dist, rank, world, B=4096, n=10000):
                                        "CU, 256 VGPRs each), not by HBM", **pmc}}
 
 
+DEADLINE_S = float(os.environ.get("GSLNLS_BENCH_DEADLINE_S", "480"))
+
+
+class LegFailed(RuntimeError):
+    """A leg failed and every rank already knows (the failure was agreed at a sync point)."""
+
+
+class Job:
+    """The ranks of one bench run.  Every synchronisation point of a leg is `sync(ok)`: ONE all-reduce(MIN) of an ok
+    flag (itself a barrier: no rank gets the result before every rank has contributed) + torch.cuda.synchronize(),
+    followed by dist.barrier() when everybody is fine.  A rank that failed locally never raises between two
+    collectives: it carries `ok = False` to the next sync point, where all ranks learn it and raise LegFailed
+    together.  A rank that threw something unforeseen lands in run_leg's closing `sync(False)`, which pairs with
+    whatever sync point the other ranks are waiting in (same collective, same shape) -- so no rank is left alone
+    in a collective because a peer raised."""
+
+    def __init__(self, rank, world, dist=None, torch=None, device="cpu"):
+        self.rank, self.world, self.dist, self.torch, self.device = rank, world, dist, torch, device
+
+    def cuda_sync(self):
+        if self.torch is not None and self.device != "cpu":
+            self.torch.cuda.synchronize()
+
+    def sync(self, ok=True):
+        """agreeing barrier; returns True iff every rank said ok"""
+        if self.dist is None:
+            self.cuda_sync()
+            return bool(ok)
+        self.cuda_sync()
+        flag = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device=self.device)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        agreed = int(flag.item()) == 1
+        if agreed:
+            self.dist.barrier()
+        self.cuda_sync()
+        return agreed
+
+    def barrier(self, ok=True, what="leg"):
+        if not self.sync(ok):
+            raise LegFailed("%s: failed on %s" % (what, "this rank" if not ok else "another rank"))
+
+    def max_over_ranks(self, v):
+        if self.dist is None:
+            return float(v)
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, v):
+        if self.dist is None:
+            return float(v)
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+
+def run_leg(job, name, fn, *a, **kw):
+    """Run one leg on every rank; returns (result, None) on all ranks or (None, error string) on all ranks."""
+    try:
+        out = fn(*a, **kw)
+        err = None
+    except LegFailed as e:          # agreed at a sync point inside the leg: every rank is here, nothing to exchange
+        return None, "%s: %s" % (name, e)
+    except Exception as e:          # noqa: unforeseen, this rank only -- tell the others at their next sync point
+        out, err = None, "%s: %r" % (name, e)
+    if job.sync(err is None):
+        return out, None
+    return None, err or ("%s: failed on another rank" % name)
+
+
+def install_watchdog(rank):
+    """No code path may block longer than the deadline: a daemon timer ends this rank (exit code 124) when the run
+    has not finished by then -- whatever it is blocked in (a collective whose peer died, a hung kernel)."""
+    import threading
+
+    def _fire():
+        sys.stderr.write("bench.py: rank %d still running after %.0f s (GSLNLS_BENCH_DEADLINE_S): giving up\n" % (rank, DEADLINE_S))
+        sys.stderr.flush()
+        os._exit(124)
+    t = threading.Timer(DEADLINE_S, _fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
+def fault(where, rank):
+    """Test hook (GPU-free tests of the N > 1 failure paths): GSLNLS_BENCH_FAULT = "<kind>:<where>:<rank>" with kind in
+    raise | fail | kill | hang, where in headline | side.  `fail` is returned to the caller (a library call that
+    reported an error), the others happen here."""
+    spec = os.environ.get("GSLNLS_BENCH_FAULT", "")
+    if not spec:
+        return False
+    kind, w, r = spec.split(":")
+    if w != where or int(r) != rank:
+        return False
+    if kind == "raise":
+        raise RuntimeError("injected fault in %s on rank %d" % (where, rank))
+    if kind == "kill":
+        import signal
+        os.kill(os.getpid(), signal.SIGKILL)
+    if kind == "hang":
+        time.sleep(1e6)
+    return kind == "fail"
+
+
 def spawn_ranks(n_ranks):
     """`python bench.py --gpus N` without a launcher: start N rank processes of this script (RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would set), relay rank 0's one
-    JSON line, return the worst exit code."""
+    JSON line, return the worst exit code.  The launcher owns an overall deadline (GSLNLS_BENCH_DEADLINE_S, default
+    480 s): when it passes, or when one rank has died and the others have not followed within the grace period, it
+    kills ITS OWN children (each in its own session, by process group id -- never by pattern), still relays what rank 0
+    wrote, and exits non-zero."""
+    import signal
     import socket
     import subprocess
+    import threading
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -390,32 +532,98 @@ def spawn_ranks(n_ranks):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, start_new_session=True))
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.extend(iter(lambda: procs[0].stdout.read(65536), b"")), daemon=True)
+    reader.start()
+    grace = float(os.environ.get("GSLNLS_BENCH_GRACE_S", "20"))
+    t0 = time.monotonic()
+    first_death = None
+    verdict = 0
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(rc is not None for rc in rcs):
+            break
+        now = time.monotonic()
+        if first_death is None and any(rc not in (None, 0) for rc in rcs):
+            first_death = now
+        timed_out = now - t0 > DEADLINE_S
+        orphaned = first_death is not None and now - first_death > grace
+        if timed_out or orphaned:
+            verdict = 124 if timed_out else 1
+            sys.stderr.write("bench.py launcher: %s; stopping the remaining ranks\n" %
+                             ("deadline of %.0f s passed" % DEADLINE_S if timed_out else
+                              "a rank died (exit codes so far %s) and the others did not finish within %.0f s" % (rcs, grace)))
+            for sig in (signal.SIGTERM, signal.SIGKILL):
+                for p in procs:
+                    if p.poll() is None:
+                        try:
+                            os.killpg(p.pid, sig)
+                        except ProcessLookupError:
+                            pass
+                t1 = time.monotonic()
+                while time.monotonic() - t1 < 5.0 and any(p.poll() is None for p in procs):
+                    time.sleep(0.05)
+            break
+        time.sleep(0.05)
+    for p in procs:
+        try:
+            p.wait(timeout=10)
+        except Exception:  # noqa
+            pass
+    reader.join(timeout=5)
+    sys.stdout.write(b"".join(chunks).decode(errors="replace"))
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    worst = max([abs(p.returncode) if p.returncode is not None else 125 for p in procs] + [verdict])
+    return min(worst, 125)
 
 
 def plumbing_only(args):
-    """The launch path without a GPU: rendezvous, one all-gather of (rank, pid), barrier, one line from rank 0."""
+    """The launch path and the failure handling without a GPU: rendezvous (gloo), a 'headline' leg and a 'side' leg with
+    the same structure as the real ones (agreeing sync points, run_leg), one line from rank 0.  A failed headline leg
+    ends every rank non-zero; a failed side leg becomes {"error": ...} in the line."""
+    import datetime
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    ranks, pids = [rank], [os.getpid()]
+    install_watchdog(rank)
+    job = Job(rank, world)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("GSLNLS_BENCH_BACKEND", "gloo"), rank=rank, world_size=world)
-        mine = torch.tensor([rank, os.getpid()], dtype=torch.int64)
-        allv = torch.zeros(2 * world, dtype=torch.int64)
-        dist.all_gather_into_tensor(allv, mine)
-        dist.barrier()
-        ranks, pids = [int(v) for v in allv[0::2]], [int(v) for v in allv[1::2]]
+        dist.init_process_group(os.environ.get("GSLNLS_BENCH_BACKEND", "gloo"), rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=min(DEADLINE_S, 300.0)))
+        job = Job(rank, world, dist, torch, "cpu")
+
+    def headline():
+        ok = not fault("headline", rank)            # a library call that reported failure: carried, not raised
+        job.barrier(ok, "headline warmup")
+        ranks, pids = [rank], [os.getpid()]
+        if world > 1:
+            mine = torch.tensor([rank, os.getpid()], dtype=torch.int64)
+            allv = torch.zeros(2 * world, dtype=torch.int64)
+            dist.all_gather_into_tensor(allv, mine)
+            ranks, pids = [int(v) for v in allv[0::2]], [int(v) for v in allv[1::2]]
+        job.barrier(True, "headline timed region")
+        return {"ranks": ranks, "pids": pids}
+
+    def side():
+        ok = not fault("side", rank)
+        job.barrier(ok, "side leg")
+        return {"ok": True}
+    head, err = run_leg(job, "headline", headline)
+    if err:
+        sys.stderr.write("bench.py: %s\n" % err)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return 1
+    side_out, side_err = run_leg(job, "side", side)
+    if world > 1:
+        job.sync(True)
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"plumbing_only": True, "n_gpus": world, "gpus_flag": args.gpus, "ranks": ranks, "pids": pids,
-                          "steps": args.steps, "warmup": args.warmup}))
+        print(json.dumps({"plumbing_only": True, "n_gpus": world, "gpus_flag": args.gpus, "ranks": head["ranks"],
+                          "pids": head["pids"], "steps": args.steps, "warmup": args.warmup,
+                          "side": side_out if side_err is None else {"error": side_err}}))
     return 0
 
 
@@ -446,6 +654,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    install_watchdog(rank)
     import torch
     dist = None
     # developer dry-run of the N > 1 code path on a 1-GPU box: GSLNLS_BENCH_BACKEND=gloo GSLNLS_BENCH_ONE_DEVICE=1
@@ -453,17 +662,20 @@ def main():
     if os.environ.get("GSLNLS_BENCH_ONE_DEVICE"):
         local_rank = 0
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=min(DEADLINE_S, 300.0)))
+    job = Job(rank, world, dist, torch, "cuda" if (world > 1 and backend == "nccl") else ("cpu" if world > 1 else "cuda"))
 
     from gslnls_amd import _lib
     from gslnls_amd.control import gsl_nls_control, pack_control
     L = _lib.lib()
-    if L.gslnls_device_count() < 1:
-        raise SystemExit("bench.py: no MI355X visible; the HIP path has no CPU fallback")
-    _lib.check(L.gslnls_set_device(local_rank))
+    have_dev = L.gslnls_device_count() >= 1 and L.gslnls_set_device(local_rank) == 0
+    if not job.sync(have_dev):
+        raise SystemExit("bench.py: no MI355X visible on some rank; the HIP path has no CPU fallback")
 
     # the interpreter's cyclic collector can pause for tens of ms once torch's object graph is loaded (seen: one
     # 38 ms step among 0.1 ms ones); the timed regions allocate nothing that needs it
@@ -474,9 +686,6 @@ def main():
     X = np.asfortranarray(x.reshape(n, 1))
     model = _lib.Model(1, 3, 1, X.ctypes.data_as(C.c_void_p), 0)
     err = C.c_int(0)
-    h = L.gslnls_dense_create(C.byref(model), y.ctypes.data_as(C.c_void_p), n, None, C.byref(err))
-    if not h:
-        raise SystemExit("gslnls_dense_create failed: %s" % _lib.strerror(err.value))
     ctrl = gsl_nls_control(solver="cholesky", xtol=1.49e-8, gtol=1.49e-8)
     ci, cd = pack_control(ctrl, "lm")
     par = np.zeros(3)
@@ -484,49 +693,59 @@ def main():
     res.par = par.ctypes.data_as(_lib.DP)
     jac = 0 if args.fd else 1
     st = START.copy()
-
     # argument pointers built once: numpy's .ctypes.data_as costs ~1 us per call, which is harness, not the path
     st_p, ci_p, cd_p, res_p = st.ctypes.data_as(_lib.DP), ci.ctypes.data_as(_lib.IP), cd.ctypes.data_as(_lib.DP), C.byref(res)
     solve = L.gslnls_dense_solve
+    H = {}
 
-    def one_fit():
-        rc = solve(h, jac, 0, st_p, None, ci_p, cd_p, args.chunk, res_p)
-        if rc != 0:
-            raise SystemExit("fit failed: %s" % _lib.strerror(rc))
-        return res.niter, res.n_launches, res.loop_ms, res.neval[0] + res.neval[1]
+    def headline():
+        """The timed region of the contract: W untimed fits, barrier + synchronize, EXACTLY K fits, barrier + synchronize,
+        max over ranks.  A failed library call is carried to the next sync point, where every rank stops together."""
+        h = L.gslnls_dense_create(C.byref(model), y.ctypes.data_as(C.c_void_p), n, None, C.byref(err))
+        H["h"] = h
+        job.barrier(bool(h), "gslnls_dense_create (%s)" % _lib.strerror(err.value))
+        bad = {"rc": 0}
 
-    def barrier():
+        def one_fit():
+            if bad["rc"]:
+                return 0, 0, 0.0, 0
+            rc = solve(h, jac, 0, st_p, None, ci_p, cd_p, args.chunk, res_p)
+            if rc != 0:
+                bad["rc"] = rc
+                return 0, 0, 0.0, 0
+            return res.niter, res.n_launches, res.loop_ms, res.neval[0] + res.neval[1]
+
+        for _ in range(args.warmup):
+            one_fit()
+        job.barrier(bad["rc"] == 0, "warm-up fits (%s)" % _lib.strerror(bad["rc"]))
+        L.gslnls_dense_loop_event_stats(h, None, None, 1)  # HIP-event totals of the launch loops: start from zero
+        t0 = time.perf_counter()
+        iters = launches = ref_passes = 0
+        loop_ms = 0.0
+        for _ in range(args.steps):
+            a, b, c, d = one_fit()
+            iters += a
+            launches += b
+            loop_ms += c
+            ref_passes += d
+        ok = job.sync(bad["rc"] == 0)
+        elapsed = time.perf_counter() - t0
+        if not ok:
+            raise LegFailed("timed fits (%s on this rank)" % _lib.strerror(bad["rc"]))
+        return dict(iters=iters, launches=launches, ref_passes=ref_passes, loop_ms=loop_ms, elapsed=elapsed,
+                    tmax=job.max_over_ranks(elapsed), tot_iters=job.sum_over_ranks(float(iters)))
+    hd, herr = run_leg(job, "headline", headline)
+    if herr:
+        # no valid headline: every rank leaves non-zero (they all know), nothing is printed on stdout
+        sys.stderr.write("bench.py: %s\n" % herr)
         if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        one_fit()
-    barrier()
-    L.gslnls_dense_loop_event_stats(h, None, None, 1)  # HIP-event totals of the launch loops: start from zero
-    t0 = time.perf_counter()
-    iters = launches = ref_passes = 0
-    loop_ms = 0.0
-    for _ in range(args.steps):
-        a, b, c, d = one_fit()
-        iters += a
-        launches += b
-        loop_ms += c
-        ref_passes += d
-    barrier()
-    elapsed = time.perf_counter() - t0
+            dist.destroy_process_group()
+        raise SystemExit(1)
+    h = H["h"]
+    iters, launches, ref_passes, loop_ms = hd["iters"], hd["launches"], hd["ref_passes"], hd["loop_ms"]
+    tmax, tot_iters = hd["tmax"], hd["tot_iters"]
     ev_ms, ev_launches = C.c_double(0.0), C.c_longlong(0)
     L.gslnls_dense_loop_event_stats(h, C.byref(ev_ms), C.byref(ev_launches), 0)
-
-    tot_iters = float(iters)
-    tmax = elapsed
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        tmax = float(t.item())
-        it = torch.tensor([tot_iters], dtype=torch.float64, device="cuda")
-        dist.all_reduce(it, op=dist.ReduceOp.SUM)
-        tot_iters = float(it.item())
 
     # Dominant kernel lm_step_kernel, HIP events on the library's own stream.
     # (1) over the timed region: every fit brackets its launch loop with an event pair on that stream (first step
@@ -545,10 +764,10 @@ def main():
     achieved = alg_bytes_fit / (ms_loop_fit * 1e-3) / 1e9
     th = np.array([4.0, 1.2, 0.8])
     ms_launch = float(L.gslnls_dense_time_pass(h, jac, th.ctypes.data_as(_lib.DP), 2000))
-    streamed = 16.0 * n / (ms_launch * 1e-3) / 1e9
+    streamed = 16.0 * n / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else None
     traffic = None
     traffic_source = None
-    tpath = next((os.path.join(ROOT, "profiles", f) for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+    tpath = next((os.path.join(ROOT, "profiles", f) for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
                   if os.path.exists(os.path.join(ROOT, "profiles", f))), "")
     if os.path.exists(tpath):
         traffic_source = "committed profile %s (separate rocprofv3 --pmc passes), NOT measured in this run" % os.path.relpath(tpath, ROOT)
@@ -586,43 +805,60 @@ def main():
                                    "done in %.0f launches; device time = HIP event pair around every fit's launch loop on the "
                                    "library's stream, summed over the timed region" % (ref_passes / args.steps, launches_fit),
                      "streamed": {"bytes_per_launch": 16.0 * n, "ms_per_full_launch": ms_launch, "GBs": streamed,
-                                  "frac": streamed / HBM_PEAK_GBS,
+                                  "frac": streamed / HBM_PEAK_GBS if streamed else None,
                                   "note": "bytes actually read by one fused launch (x and y once); compare traffic"}},
     }
+
+    def side(name, fn, *a, **kw):
+        """A side measurement must not cost the line: a failure becomes {"error": ...} -- on every rank, agreed."""
+        out, e = run_leg(job, name, fn, *a, **kw)
+        line[name] = out if e is None else {"error": e}
+        if e is not None:
+            sys.stderr.write("bench.py: side leg failed -- %s\n" % e)
+
     if rank == 0 and world == 1:
-        # (a) SURVEY.md 8(d) asks for the forward-difference run beside the analytic one; (b) a fit on a fresh handle
-        # (the launch count of the previous fit is not known yet: 16 launches + top-ups of 16, trailing ones run as no-ops)
-        # beside the repeated-fit loop timed above, whose first chunk is sized by the previous fit
-        other = 1 - jac
-        for _ in range(3):
-            solve(h, other, 0, st_p, None, ci_p, cd_p, args.chunk, res_p)
-        torch.cuda.synchronize()
-        kfd = max(5, min(50, args.steps))
-        t1 = time.perf_counter()
-        it_o = 0
-        for _ in range(kfd):
-            solve(h, other, 0, st_p, None, ci_p, cd_p, args.chunk, res_p)
-            it_o += res.niter
-        torch.cuda.synchronize()
-        el_o = time.perf_counter() - t1
-        line["other_jacobian"] = {"jacobian": "analytic" if other else "forward-FD", "value": it_o / el_o,
-                                  "unit": "LM iterations/s", "fits": kfd, "niter_per_fit": it_o / kfd,
-                                  "launches_per_fit": res.n_launches, "neval_f": res.neval[0], "neval_J": res.neval[1]}
-        h2 = L.gslnls_dense_create(C.byref(model), y.ctypes.data_as(C.c_void_p), n, None, C.byref(err))
-        solve(h2, jac, 0, st_p, None, ci_p, cd_p, args.chunk, res_p)
-        first = {"loop_ms": res.loop_ms, "launches": res.n_launches, "niter": res.niter}
-        solve(h2, jac, 0, st_p, None, ci_p, cd_p, args.chunk, res_p)
-        line["one_shot_vs_repeated"] = {"first_fit_on_a_fresh_handle": first,
-                                        "second_fit_on_it": {"loop_ms": res.loop_ms, "launches": res.n_launches},
-                                        "timed_loop_ms_per_fit": loop_ms / args.steps,
-                                        "note": "value/ms_per_step above are the repeated-fit loop (the best case)"}
-        L.gslnls_dense_destroy(h2)
+        def other_jacobian():
+            # SURVEY.md 8(d) asks for the forward-difference run beside the analytic one
+            other = 1 - jac
+            for _ in range(3):
+                solve(h, other, 0, st_p, None, ci_p, cd_p, args.chunk, res_p)
+            torch.cuda.synchronize()
+            kfd = max(5, min(50, args.steps))
+            t1 = time.perf_counter()
+            it_o = 0
+            for _ in range(kfd):
+                solve(h, other, 0, st_p, None, ci_p, cd_p, args.chunk, res_p)
+                it_o += res.niter
+            torch.cuda.synchronize()
+            el_o = time.perf_counter() - t1
+            return {"jacobian": "analytic" if other else "forward-FD", "value": it_o / el_o,
+                    "unit": "LM iterations/s", "fits": kfd, "niter_per_fit": it_o / kfd,
+                    "launches_per_fit": res.n_launches, "neval_f": res.neval[0], "neval_J": res.neval[1]}
+
+        def one_shot_vs_repeated():
+            # a fit on a fresh handle (the launch count of the previous fit is not known yet: 16 launches + top-ups,
+            # trailing ones run as no-ops) beside the repeated-fit loop timed above, whose first chunk is sized by the
+            # previous fit
+            h2 = L.gslnls_dense_create(C.byref(model), y.ctypes.data_as(C.c_void_p), n, None, C.byref(err))
+            solve(h2, jac, 0, st_p, None, ci_p, cd_p, args.chunk, res_p)
+            first = {"loop_ms": res.loop_ms, "launches": res.n_launches, "niter": res.niter}
+            solve(h2, jac, 0, st_p, None, ci_p, cd_p, args.chunk, res_p)
+            out = {"first_fit_on_a_fresh_handle": first,
+                   "second_fit_on_it": {"loop_ms": res.loop_ms, "launches": res.n_launches},
+                   "timed_loop_ms_per_fit": loop_ms / args.steps,
+                   "note": "value/ms_per_step above are the repeated-fit loop (the best case)"}
+            L.gslnls_dense_destroy(h2)
+            return out
+        side("other_jacobian", other_jacobian)
+        side("one_shot_vs_repeated", one_shot_vs_repeated)
     lib_comm = None
     if world > 1:
-        if os.environ.get("GSLNLS_BENCH_ONE_DEVICE"):
-            lib_comm, why = None, "developer dry run: the ranks share one device, RCCL refuses that"
-        else:
-            lib_comm, why = bind_library_comm(L, torch, dist, rank, world, backend)
+        def bind():
+            if os.environ.get("GSLNLS_BENCH_ONE_DEVICE"):
+                return None, "developer dry run: the ranks share one device, RCCL refuses that"
+            return bind_library_comm(L, torch, dist, rank, world, backend)
+        got, e = run_leg(job, "communicator", bind)
+        lib_comm, why = got if e is None else (None, e)
         if lib_comm:
             lib_comm = why
         else:
@@ -630,28 +866,27 @@ def main():
             print("bench.py: in-library RCCL communicator not available (%s); torch.distributed gathers" % why, file=sys.stderr)
             from gslnls_amd import dist as gdist
             gdist.init_multistart_comm(65536 * world, 8)
-    line["multistart"] = multistart_bench(L, _lib, torch, dist, rank, world, max(5, args.steps // 4), 3, lib_comm)
+    side("multistart", multistart_bench, L, _lib, job, max(5, args.steps // 4), 3, lib_comm)
     if not args.headline_only:
-        line["batched_irls"] = batch_irls_bench(_lib, torch, dist, rank, world)
+        side("batched_irls", batch_irls_bench, _lib, job)
         if world == 1:
-            line["large_cgst"] = large_bench(L, _lib)
-            try:
-                line["large_sparse_readme"] = sparse_readme_bench()
-            except Exception as e:  # noqa: a side measurement must not cost the line
-                line["large_sparse_readme"] = {"error": repr(e)}
+            side("large_cgst", large_bench, L, _lib)
+            side("large_sparse_readme", sparse_readme_bench)
     if world > 1:
         L.gslnls_comm_destroy()
-    if rank == 0 and not args.no_cpu_baseline:
-        # N = 1: the full sample (about 20 s of one core) plus the all-core figure; N > 1: a short sample only, the
-        # other ranks wait at the final barrier meanwhile
-        line["cpu_baseline"] = cpu_baseline(x, y) if world == 1 else cpu_baseline(x, y, budget_s=4.0, max_fits=12)
-        if world == 1 and not args.headline_only:
-            line["cpu_baseline"]["all_cores"] = cpu_baseline_allcores(n, 20250927 + rank)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # rank 0 at N = 1 only (the contract): about 20 s of one core plus the all-core figure
+        line["cpu_baseline"] = cpu_baseline(x, y)
+        if not args.headline_only:
+            try:
+                line["cpu_baseline"]["all_cores"] = cpu_baseline_allcores(n, 20250927 + rank)
+            except Exception as e:  # noqa
+                line["cpu_baseline"]["all_cores"] = {"error": repr(e)}
     elif rank == 0:
         line["cpu_baseline"] = None
     L.gslnls_dense_destroy(h)
     if dist is not None:
-        dist.barrier()
+        job.sync(True)
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(line))

@@ -89,6 +89,8 @@ _SIGNATURES = {
     "gslnls_comm_init_file": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int]),
     "gslnls_comm_destroy": (None, []),
     "gslnls_comm_allgather_count": (C.c_longlong, []),
+    "gslnls_comm_set_timing": (None, [C.c_int]),
+    "gslnls_comm_allgather_ms": (C.c_double, [C.POINTER(C.c_longlong)]),
     "gslnls_comm_last_error": (C.c_char_p, []),
     "gslnls_dense_mstart": (C.c_int, [C.c_void_p, C.c_int, C.c_int, DP, DP, IP, DP, IP, C.POINTER(Result)]),
     "gslnls_mstart_batch": (C.c_int, [C.c_void_p, C.c_int, DP, DP, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -15,7 +15,11 @@ class BatchProblem:
         """x: (B, n) or (B, nx, n); y: (B, n); weights: (B, n) or None"""
         y = np.ascontiguousarray(y, dtype=np.float64)
         self.B, self.n = y.shape
-        x = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(self.B, -1, self.n))
+        x = np.asarray(x, dtype=np.float64)
+        if self.B == 0:
+            # an empty block of a sharded job (more ranks than data sets): the handle only joins the final all-gather
+            x = x.reshape(0, x.shape[1] if x.ndim == 3 else 1, self.n)
+        x = np.ascontiguousarray(x.reshape(self.B, -1, self.n)) if self.B else x
         self.p, self.model_id, self.nx = int(p), int(model_id), x.shape[1]
         sw = None if weights is None else np.ascontiguousarray(np.sqrt(np.asarray(weights, dtype=np.float64)))
         err = C.c_int(0)

@@ -32,12 +32,16 @@ static RcclComm g_rccl;
 namespace gslnls
 {
 // the multi-rank form of one batch with the in-library collective: kernel -> ncclAllGather -> D2H, all on the
-// evaluator's stream; the host only enqueues and then waits once
+// evaluator's stream; the host only enqueues and then waits once.  Collective safety: between the point where the
+// ranks are known to agree (after ensure_together) and ncclAllGather there is no return -- a rank whose shard fails
+// says so in the status slot of its first record, enters the collective like the others, and all ranks fail
+// together after it.
 int ms_rccl_run_batch(MsEvaluator &ev, const MsComm &comm, MsBatch &b, int per, int lo, int hi)
 {
     RcclComm &rc = *comm.rccl;
     const size_t shard_doubles = (size_t)per * b.K;
-    int e = rc.ensure(shard_doubles);
+    hipStream_t st = (hipStream_t)ev.stream();
+    int e = rc.ensure_together(shard_doubles, st); // all ranks or none: the outcome is itself all-gathered
     if (e)
         return e;
     const int status_slot = 3 * b.p + 6;
@@ -46,18 +50,34 @@ int ms_rccl_run_batch(MsEvaluator &ev, const MsComm &comm, MsBatch &b, int per, 
         run_rc = ev.run_async(b, lo, hi, rc.shard);
     if (run_rc && hi > lo)
         (void)ev.poke(rc.shard + status_slot, MS_SHARD_FAILED); // fail together, after the collective
-    e = rc.allgather(shard_doubles, (hipStream_t)ev.stream());
+    e = rc.allgather(shard_doubles, st);
     if (e)
-        return e;
+        return e; // the collective itself could not be enqueued: RCCL is unusable for every rank of the communicator
+    const double *status = nullptr;
+    size_t status_stride = 0;
     if (!b.host_records)
-        return ev.fetch_stream(rc.all, nullptr, 0); // records stay in HBM: only wait for the collective
-    e = ev.fetch_stream_view(rc.all, (size_t)b.count * b.K, b, &b.rec); // pinned destination, consumed in place
-    if (e)
-        return e;
+    {
+        // records stay in HBM: only the status word of every rank's first record crosses (one strided copy)
+        const bool ok = hipMemcpy2DAsync(rc.h_flags, sizeof(double), rc.all + status_slot, sizeof(double) * shard_doubles,
+                                         sizeof(double), (size_t)rc.world, hipMemcpyDeviceToHost, st) == hipSuccess;
+        e = ev.fetch_stream(rc.all, nullptr, 0); // waits for the stream
+        if (e || !ok)
+            return e ? e : GSLNLS_E_NODEVICE;
+        status = rc.h_flags;
+        status_stride = 1;
+    }
+    else
+    {
+        e = ev.fetch_stream_view(rc.all, (size_t)b.count * b.K, b, &b.rec); // pinned destination, consumed in place
+        if (e)
+            return e;
+        status = b.rec + status_slot;
+        status_stride = shard_doubles;
+    }
     for (int r = 0; r < rc.world; ++r)
-        if ((long long)r * per < b.count && b.rec[((size_t)r * per) * b.K + status_slot] == MS_SHARD_FAILED)
-            return run_rc ? run_rc : -1;
-    return 0;
+        if ((long long)r * per < b.count && status[(size_t)r * status_stride] == MS_SHARD_FAILED)
+            return run_rc ? run_rc : GSLNLS_FAILURE;
+    return run_rc; // (0 unless this rank's failure could not even be written into its shard)
 }
 } // namespace gslnls
 
@@ -560,7 +580,22 @@ gslnls_batch *gslnls_batch_create(int model_id, int p, int nx, const double *x, 
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         e = GSLNLS_E_NODEVICE;
     gslnls_batch *h = nullptr;
-    if (e == GSLNLS_SUCCESS)
+    if (e == GSLNLS_SUCCESS && (B < 0 || n < 1 || p < 1 || (B > 0 && (!x || !y))))
+        e = GSLNLS_EINVAL;
+    if (e == GSLNLS_SUCCESS && B == 0)
+    {
+        // an empty block (B_total = 9 over 8 ranks leaves ranks 5..7 without data sets): the handle only takes part
+        // in the final all-gather of gslnls_batch_irls_gather
+        h = new gslnls_batch;
+        h->model_id = model_id;
+        h->p = p;
+        h->nx = nx;
+        h->n = n;
+        h->B = 0;
+        if (hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess)
+            e = GSLNLS_E_NODEVICE;
+    }
+    else if (e == GSLNLS_SUCCESS)
     {
         h = new gslnls_batch;
         h->model_id = model_id;
@@ -686,72 +721,108 @@ int gslnls_batch_irls_gather(gslnls_batch *h, int B_total, int jac, int fvv, con
     const int world = g_comm.world, rank = g_comm.rank;
     const int per = (B_total + world - 1) / world;
     const int lo = std::min(B_total, rank * per), hi = std::min(B_total, lo + per);
-    if (h->B != hi - lo)
-        return GSLNLS_EINVAL; // the handle must hold exactly this rank's block
     const int p = h->p, K = p + 8;
-    int rc = 0;
-    if (hi > lo)
-        rc = gslnls_batch_irls(h, 0, h->B, jac, fvv, start, lupars, control_int, control_dbl, loss_rho, loss_cc, nullptr,
-                               nullptr, nullptr, kernel_ms);
-    std::vector<double> rec((size_t)world * per * K, 0.0);
     if (world == 1)
     {
-        if (rc)
-            return rc;
+        if (h->B != B_total)
+            return GSLNLS_EINVAL;
+        int rc1 = gslnls_batch_irls(h, 0, h->B, jac, fvv, start, lupars, control_int, control_dbl, loss_rho, loss_cc, nullptr,
+                                    nullptr, nullptr, kernel_ms);
+        if (rc1)
+            return rc1;
         GSLNLS_HIP_OK(hipMemcpy(par, h->d_par, sizeof(double) * (size_t)h->B * p, hipMemcpyDeviceToHost));
         GSLNLS_HIP_OK(hipMemcpy(scal, h->d_scal, sizeof(double) * (size_t)h->B * 4, hipMemcpyDeviceToHost));
         GSLNLS_HIP_OK(hipMemcpy(ints, h->d_ints, sizeof(int) * (size_t)h->B * 4, hipMemcpyDeviceToHost));
         return GSLNLS_SUCCESS;
     }
     // one all-gather of per x (p + 8) doubles per rank: the final exchange of SURVEY.md 8(e), row "batched IRLS".
-    // A rank that failed still enters it (status slot of its first record = MS_SHARD_FAILED).
+    // What the ranks can only disagree on (this rank's handle, its fit, its HIP calls) is folded into `rc` and carried
+    // through the collective in the status slot of the shard's first record (MS_SHARD_FAILED): from here to the
+    // all-gather there is no return that the other ranks would not take as well.
     const size_t shard_doubles = (size_t)per * K;
-    double *d_shard = nullptr, *d_all = nullptr;
     const bool lib = g_comm.rccl != nullptr;
     if (lib)
     {
-        int e = g_rccl.ensure(shard_doubles);
+        const int e = g_rccl.ensure_together(shard_doubles, h->st); // all ranks or none
         if (e)
             return e;
-        d_shard = g_rccl.shard;
-        d_all = g_rccl.all;
+    }
+    else if (!g_comm.allgather || !g_comm.shard_buf || !g_comm.all_buf ||
+             (long long)per * K * world > g_comm.cap_points * (long long)gslnls_mstart_record_size(p))
+        return GSLNLS_EINVAL; // the registration (gslnls_set_comm) is the same on every rank
+    int rc = 0;
+    if (h->B != hi - lo)
+        rc = GSLNLS_EINVAL; // the handle must hold exactly this rank's block (an empty one: a handle created with B = 0)
+    else if (hi > lo)
+        rc = gslnls_batch_irls(h, 0, h->B, jac, fvv, start, lupars, control_int, control_dbl, loss_rho, loss_cc, nullptr,
+                               nullptr, nullptr, kernel_ms);
+    else if (kernel_ms)
+        *kernel_ms = 0.f;
+    auto soft = [&rc](hipError_t e) {
+        if (e != hipSuccess && rc == 0)
+        {
+            fprintf(stderr, "gslnls: HIP error %s in gslnls_batch_irls_gather (carried into the collective)\n", hipGetErrorString(e));
+            (void)hipGetLastError();
+            rc = GSLNLS_E_NODEVICE;
+        }
+    };
+    std::vector<double> rec((size_t)world * per * K, 0.0);
+    const bool dev_shard = lib || g_comm.buffers_on_device;
+    double *d_shard = lib ? g_rccl.shard : (g_comm.buffers_on_device ? g_comm.shard_buf : nullptr);
+    if (dev_shard)
+    {
+        soft(hipMemsetAsync(d_shard, 0, sizeof(double) * shard_doubles, h->st));
+        if (hi > lo && rc == 0)
+        {
+            hipLaunchKernelGGL(batch_pack_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->st, h->d_par, h->d_scal, h->d_ints, p,
+                               h->B, d_shard);
+            soft(hipGetLastError());
+        }
+        if (rc)
+        {
+            static const double bad = MS_SHARD_FAILED;
+            (void)hipMemcpyAsync(d_shard + p + 4, &bad, sizeof(double), hipMemcpyHostToDevice, h->st);
+        }
     }
     else
     {
-        if (!g_comm.allgather || !g_comm.shard_buf || !g_comm.all_buf ||
-            (long long)per * K * world > g_comm.cap_points * (long long)gslnls_mstart_record_size(p))
-            return GSLNLS_EINVAL;
-        if (g_comm.buffers_on_device)
-            d_shard = g_comm.shard_buf;
-        else
-            GSLNLS_HIP_OK(hipMalloc(&d_shard, sizeof(double) * shard_doubles));
-    }
-    GSLNLS_HIP_OK(hipMemsetAsync(d_shard, 0, sizeof(double) * shard_doubles, h->st));
-    if (hi > lo && rc == 0)
-        hipLaunchKernelGGL(batch_pack_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->st, h->d_par, h->d_scal, h->d_ints, p,
-                           h->B, d_shard);
-    if (rc)
-    {
-        const double bad = MS_SHARD_FAILED;
-        GSLNLS_HIP_OK(hipMemcpyAsync(d_shard + p + 4, &bad, sizeof(double), hipMemcpyHostToDevice, h->st));
+        // host buffers (gloo in the CPU-side tests): pack the shard on the host, nothing to allocate
+        double *sh = g_comm.shard_buf;
+        std::fill(sh, sh + shard_doubles, 0.0);
+        if (hi > lo && rc == 0)
+        {
+            std::vector<double> hp((size_t)h->B * p), hs((size_t)h->B * 4);
+            std::vector<int> hi4((size_t)h->B * 4);
+            soft(hipMemcpy(hp.data(), h->d_par, sizeof(double) * hp.size(), hipMemcpyDeviceToHost));
+            soft(hipMemcpy(hs.data(), h->d_scal, sizeof(double) * hs.size(), hipMemcpyDeviceToHost));
+            soft(hipMemcpy(hi4.data(), h->d_ints, sizeof(int) * hi4.size(), hipMemcpyDeviceToHost));
+            for (int d = 0; d < h->B && rc == 0; ++d)
+            {
+                double *o = sh + (size_t)d * K;
+                for (int k = 0; k < p; ++k)
+                    o[k] = hp[(size_t)d * p + k];
+                for (int k = 0; k < 4; ++k)
+                {
+                    o[p + k] = hs[(size_t)d * 4 + k];
+                    o[p + 4 + k] = (double)hi4[(size_t)d * 4 + k];
+                }
+            }
+        }
+        if (rc)
+            sh[p + 4] = MS_SHARD_FAILED;
     }
     if (lib)
     {
         int e = g_rccl.allgather(shard_doubles, h->st);
         if (e)
             return e;
-        GSLNLS_HIP_OK(hipMemcpyAsync(rec.data(), d_all, sizeof(double) * rec.size(), hipMemcpyDeviceToHost, h->st));
+        GSLNLS_HIP_OK(hipMemcpyAsync(rec.data(), g_rccl.all, sizeof(double) * rec.size(), hipMemcpyDeviceToHost, h->st));
         GSLNLS_HIP_OK(hipStreamSynchronize(h->st));
     }
     else
     {
-        if (!g_comm.buffers_on_device)
-        {
-            GSLNLS_HIP_OK(hipMemcpyAsync(g_comm.shard_buf, d_shard, sizeof(double) * shard_doubles, hipMemcpyDeviceToHost, h->st));
-        }
-        GSLNLS_HIP_OK(hipStreamSynchronize(h->st));
-        if (!g_comm.buffers_on_device)
-            hipFree(d_shard);
+        if (dev_shard)
+            soft(hipStreamSynchronize(h->st));
         // the callback form counts in records of the multi-start size; hand it the doubles as (per * K) x 1
         const int e = g_comm.allgather(g_comm.ctx, (int)shard_doubles, 1);
         if (e)
@@ -764,6 +835,8 @@ int gslnls_batch_irls_gather(gslnls_batch *h, int B_total, int jac, int fvv, con
     for (int r = 0; r < world; ++r)
         if ((long long)r * per < B_total && rec[(size_t)r * per * K + p + 4] == MS_SHARD_FAILED)
             return rc ? rc : GSLNLS_FAILURE;
+    if (rc)
+        return rc;
     for (int d = 0; d < B_total; ++d)
     {
         const double *o = rec.data() + (size_t)d * K; // block r starts at r * per: contiguous in d
@@ -857,6 +930,16 @@ void gslnls_comm_destroy(void)
 }
 
 long long gslnls_comm_allgather_count(void) { return g_rccl.n_allgathers; }
+
+void gslnls_comm_set_timing(int on) { g_rccl.set_timing(on); }
+
+double gslnls_comm_allgather_ms(long long *timed)
+{
+    g_rccl.collect_timing();
+    if (timed)
+        *timed = g_rccl.allgather_timed;
+    return g_rccl.allgather_ms_total;
+}
 
 const char *gslnls_comm_last_error(void) { return g_rccl.api.err; }
 

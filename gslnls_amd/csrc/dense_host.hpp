@@ -540,12 +540,16 @@ struct DenseFit : DenseBase
         return (int)(need < fit ? need : fit);
     }
     bool lds_attr_set[3] = {false, false, false};
-    void launch_fit(int jacmode, PersistArgs pa)
+    // false: the kernel could not be given its LDS budget -- the caller takes the launch-per-step kernel instead
+    bool launch_fit(int jacmode, PersistArgs pa)
     {
         const dim3 grid(PGrid()), block(PT);
         pa.rows_resident = PRows();
         {
-            static const int fast_env = getenv("GSLNLS_PERSIST_FAST") ? atoi(getenv("GSLNLS_PERSIST_FAST")) : 1;
+            // Hops 1 and 3 as plain (workgroup-scope) stores that stop in the XCD's L2 rely on such stores being visible
+            // to agent-scope loads of other CUs of the same XCD -- true of gfx950's shared L2, measured 3x faster, but
+            // not something the HIP memory model promises: opt-in (GSLNLS_PERSIST_FAST=1), write-through by default
+            static const int fast_env = getenv("GSLNLS_PERSIST_FAST") ? atoi(getenv("GSLNLS_PERSIST_FAST")) : 0;
             pa.fast = fast_env;
         }
         const size_t dyn = (size_t)pa.rows_resident * PT * (M::NX + 1 + (ctx.sw ? 1 : 0)) * 8;
@@ -557,7 +561,12 @@ struct DenseFit : DenseBase
                 const void *fn = jacmode == JAC_ANALYTIC ? (const void *)lm_fit_kernel<M, JAC_ANALYTIC, PT>
                                : jacmode == JAC_FORWARD ? (const void *)lm_fit_kernel<M, JAC_FORWARD, PT>
                                                         : (const void *)lm_fit_kernel<M, JAC_CENTER, PT>;
-                (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, persist_lds_budget());
+                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, persist_lds_budget()) != hipSuccess)
+                {
+                    (void)hipGetLastError(); // not an error of the fit: the other kernel serves it
+                    persist_state = 0;
+                    return false;
+                }
             }
             lds_attr_set[jacmode] = true;
         }
@@ -577,6 +586,7 @@ struct DenseFit : DenseBase
                                (int)grid.x, pa, ctx);
             break;
         }
+        return true;
     }
 
     // May this handle run whole fits in one launch?  All G workgroups have to be resident together (one per CU):
@@ -664,7 +674,11 @@ struct DenseFit : DenseBase
         long long launches = 0;
         for (;;)
         {
-            launch_fit(jacmode, pa);
+            if (!launch_fit(jacmode, pa))
+            {
+                ev_pending[ev_head] = false;
+                return 1; // no LDS budget for the resident kernel: same fit through the launch-per-step kernel
+            }
             if (hipGetLastError() != hipSuccess)
                 return GSLNLS_E_NODEVICE;
             launches += 1;
@@ -1039,11 +1053,12 @@ struct DenseFit : DenseBase
             // resident kernel: -reps steps in one launch (bench_hold keeps the fit alive), average per step
             const double st[P > 0 ? P : 1] = {};
             (void)st;
-            if (run_loop_persist(jacmode, theta, nullptr, 8) < 0) // warm-up launch
+            // (1 = a bounded spin gave up or the kernel could not be set up: no timing of the resident kernel exists)
+            if (run_loop_persist(jacmode, theta, nullptr, 8) != 0) // warm-up launch
                 return -1.f;
             (void)hipStreamSynchronize(stream);
             hipEventRecord(ev0, stream);
-            if (run_loop_persist(jacmode, theta, nullptr, -reps) < 0)
+            if (run_loop_persist(jacmode, theta, nullptr, -reps) != 0)
                 return -1.f;
             hipEventRecord(ev1, stream);
             if (hipStreamSynchronize(stream) != hipSuccess)

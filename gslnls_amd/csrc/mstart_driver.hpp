@@ -147,15 +147,16 @@ inline int ms_run_batch(MsEvaluator &ev, const MsComm &comm, MsBatch &b)
     b.rec = nullptr;
     if (comm.world <= 1 && !(comm.rccl && comm.force_collective))
         return b.host_records ? ev.run_view(b, &b.rec) : ev.run(b, 0, b.count, nullptr, true);
-    if (b.host_records)
-        b.records.assign((size_t)b.count * b.K, 0.0);
     // contiguous blocks of ceil(count / world) points per rank; the last block may be short
     const int per = (b.count + comm.world - 1) / comm.world;
     const int lo = std::min(b.count, comm.rank * per), hi = std::min(b.count, lo + per);
     if (comm.rccl && comm.rccl_run)
         return comm.rccl_run(ev, comm, b, per, lo, hi);
     if (!comm.allgather || !comm.shard_buf || !comm.all_buf || (long long)per * comm.world > comm.cap_points)
-        return -1;
+        return -1; // (the registration is the same on every rank: all of them return here, none enters the collective)
+    // the callback form always completes the batch in host memory -- also when the caller asked for no records
+    // (host_records == false): the status words of the shards are read from there
+    b.records.assign((size_t)b.count * b.K, 0.0);
     int rc = 0;
     if (hi > lo)
         rc = ev.run(b, lo, hi, comm.shard_buf, comm.buffers_on_device != 0);

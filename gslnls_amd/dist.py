@@ -65,7 +65,9 @@ def init_library_comm():
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     buf = C.create_string_buffer(128)
-    ok = torch.tensor([1 if (rank != 0 or L.gslnls_comm_get_unique_id(buf) == 0) else 0], dtype=torch.int32, device=dev)
+    # every rank makes an id (only rank 0's is used): RCCL is thereby bound on each of them before any rank enters
+    # ncclCommInitRank, which is itself a collective
+    ok = torch.tensor([1 if L.gslnls_comm_get_unique_id(buf) == 0 else 0], dtype=torch.int32, device=dev)
     t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone().to(dev)
     dist.broadcast(t, 0)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)

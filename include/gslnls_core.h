@@ -206,7 +206,8 @@ int gslnls_set_comm(int rank, int world, gslnls_allgather_fn fn, void *ctx, doub
  * Bootstrap, once per job: rank 0 calls gslnls_comm_get_unique_id (128 bytes, ncclGetUniqueId), the host application
  * hands the id to the other ranks over whatever channel it has (MPI, a socket, a file), every rank calls
  * gslnls_comm_init_rank after gslnls_set_device.  gslnls_comm_init_file does both over a file all ranks can see
- * (rank 0 writes it atomically, the others wait up to timeout_s seconds).  Every gslnls_nls() / gslnls_dense_mstart()
+ * (rank 0 removes a stale file, writes the new one atomically and removes it again once every rank has joined; the
+ * others wait up to timeout_s seconds; GSLNLS_COMM_NONCE in the environment, when set, must match across the job).  Every gslnls_nls() / gslnls_dense_mstart()
  * with start ranges is then sharded; all ranks must make the same calls with the same arguments and get identical
  * results.  Replaces nothing in the reference (its loop over the sample points, src/nls_mstart.c:42-128, is sequential
  * in one process, src/nls.c:372-399). */
@@ -216,6 +217,11 @@ int gslnls_comm_init_rank(const char *id128, int rank, int world);
 int gslnls_comm_init_file(const char *path, int rank, int world, int timeout_s);
 void gslnls_comm_destroy(void);
 long long gslnls_comm_allgather_count(void); /* collectives issued so far (tests, benchmark) */
+/* Optional HIP-event pair around every ncclAllGather the library issues (off by default: two event records per batch):
+ * gslnls_comm_allgather_ms returns the milliseconds summed since set_timing(1) and, in *timed, how many collectives
+ * they cover -- the device time of the exchange alone, next to kernel_ms of gslnls_mstart_batch. */
+void gslnls_comm_set_timing(int on);
+double gslnls_comm_allgather_ms(long long *timed);
 const char *gslnls_comm_last_error(void);
 /* multi-start + final solve on resident data; start2p = 2 x p column-major ranges */
 int gslnls_dense_mstart(gslnls_dense *h, int jac, int fvv, const double *start2p, const double *lupars,
@@ -255,7 +261,10 @@ int gslnls_batch_last_passes(gslnls_batch *h, long long *lm_passes, long long *r
  * ceil(B_total / world) per rank, `h` holds exactly this rank's block (created from its slice of x / y); every rank
  * fits its block with no traffic, then ONE all-gather of (p + 8) doubles per data set completes par / scal / ints
  * (B_total entries each, same layout as above) on every rank -- through the in-library RCCL communicator when one is
- * bound (gslnls_comm_init_*), else through the gslnls_set_comm callback.  With one rank it is gslnls_batch_irls. */
+ * bound (gslnls_comm_init_*), else through the gslnls_set_comm callback.  With one rank it is gslnls_batch_irls.
+ * Every rank must call it, with a handle: a rank whose block is empty (B_total = 9 over 8 ranks: ranks 5..7) passes one
+ * created with B = 0 (x = y = NULL).  A rank-local failure (wrong block size, a failed fit, a HIP error) does not return
+ * before the collective: it is carried through it and every rank returns a failure afterwards. */
 int gslnls_batch_irls_gather(gslnls_batch *h, int B_total, int jac, int fvv, const double *start, const double *lupars,
                              const int *control_int, const double *control_dbl, int loss_rho, const double *loss_cc,
                              double *par, double *scal, int *ints, float *kernel_ms);

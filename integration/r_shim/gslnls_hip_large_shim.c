@@ -189,10 +189,20 @@ SEXP C_nls_large_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, 
         /* grad: the reference returns the dense n x p copy of the Jacobian it evaluated last (src/nls_large.c:353-384).
          * The device never densifies J; the last Jacobian object the closure returned (evaluated at the last accepted
          * point = the returned par) is still held, so R's own as.matrix() produces the same matrix. */
+        /* every intermediate stays protected across the next allocating call: the call object during Rf_eval, the
+         * as.matrix() result during Rf_coerceVector (an ngCMatrix / lgCMatrix Jacobian coerces from logical) */
         SEXP g = R_NilValue;
+        PROTECT_INDEX gi;
+        PROTECT_WITH_INDEX(g, &gi);
         if (ok && s.keep != R_NilValue)
-            g = Rf_eval(Rf_lang2(Rf_install("as.matrix"), s.keep), R_BaseEnv);
-        g = PROTECT(g == R_NilValue ? Rf_allocMatrix(REALSXP, n, p) : Rf_coerceVector(g, REALSXP));
+        {
+            SEXP call = PROTECT(Rf_lang2(Rf_install("as.matrix"), s.keep));
+            REPROTECT(g = Rf_eval(call, R_BaseEnv), gi);
+            UNPROTECT(1); /* call */
+            REPROTECT(g = Rf_coerceVector(g, REALSXP), gi);
+        }
+        else
+            REPROTECT(g = Rf_allocMatrix(REALSXP, n, p), gi);
         if (!ok || s.keep == R_NilValue)
             for (size_t i = 0; i < (size_t)n * p; i++)
                 REAL(g)[i] = NA_REAL;

@@ -47,9 +47,10 @@ static SEXP closure_formula(SEXP fn)
 
 static SEXP deparse_rhs(SEXP formula)
 {
-    SEXP call = PROTECT(Rf_lang2(Rf_install("deparse1"), Rf_lang2(Rf_install("quote"), CADDR(formula))));
+    SEXP quoted = PROTECT(Rf_lang2(Rf_install("quote"), CADDR(formula))); /* held while the outer call is allocated */
+    SEXP call = PROTECT(Rf_lang2(Rf_install("deparse1"), quoted));
     SEXP txt = PROTECT(Rf_eval(call, R_BaseEnv));
-    UNPROTECT(2);
+    UNPROTECT(3);
     return txt;
 }
 
@@ -119,8 +120,11 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
         /* not a hand-written device model: hand the expression itself to the core (GSLNLS_MODEL_EXPR), which
          * compiles it with its symbolic gradient -- the analogue of R/nls.R:565,588-599.  Data columns are the
          * variables of the RHS that are not parameters: all.vars(formula[[3]]) minus names(start). */
-        SEXP vars = PROTECT(Rf_eval(Rf_lang2(Rf_install("all.vars"), Rf_lang2(Rf_install("quote"), CADDR(formula))),
-                                    R_BaseEnv));
+        SEXP quoted = PROTECT(Rf_lang2(Rf_install("quote"), CADDR(formula)));
+        SEXP avcall = PROTECT(Rf_lang2(Rf_install("all.vars"), quoted));
+        SEXP vars = Rf_eval(avcall, R_BaseEnv);
+        UNPROTECT(2);
+        PROTECT(vars);
         int nxe = 0, ok = 1;
         cols[0] = 0;
         for (int v = 0; v < Rf_length(vars) && ok; v++)

@@ -360,6 +360,66 @@ extern "C" int hostsim_mstart_batch(int n, const double *x, const double *y, con
     return ev.run(b, 0, count, records, false);
 }
 
+// one concentration batch through ms_run_batch with a callback communicator, records wanted or not (host_records):
+// the multi-rank branch of gslnls_mstart_batch(lo < 0, records = NULL) without a device
+extern "C" int hostsim_run_batch_comm(int n, const double *x, const double *y, int count, int rank, int world,
+                                      allgather_fn fn, double *shard_buf, double *all_buf, long long cap_points,
+                                      int want_records, const int *ci, const double *cd, double *records_out)
+{
+    using M = ModelMisra1a;
+    constexpr int P = M::P;
+    CpuEvaluator<M> ev;
+    ev.rows = RowsHost<M::NX>{x, y, nullptr, n};
+    ev.prm.maxiter = ci[0];
+    ev.prm.trs = 0;
+    ev.prm.scale = ci[3];
+    ev.prm.fdtype = 0;
+    ev.prm.jac_analytic = 1;
+    ev.prm.fvv_analytic = 0;
+    ev.prm.has_bounds = 0;
+    ev.prm.has_weights = 0;
+    ev.prm.bench_hold = 0;
+    ev.prm.chisq_in = NAN;
+    ev.prm.factor_up = cd[0];
+    ev.prm.factor_down = cd[1];
+    ev.prm.avmax = cd[2];
+    ev.prm.h_df = cd[3];
+    ev.prm.h_fvv = cd[4];
+    ev.prm.xtol = cd[5];
+    ev.prm.ftol = cd[6];
+    ev.prm.gtol = cd[7];
+    ev.jacmode = JAC_ANALYTIC;
+    ev.lupars = nullptr;
+    sobol_build(ev.tab, P);
+    MsComm comm;
+    comm.rank = rank;
+    comm.world = world;
+    comm.allgather = fn;
+    comm.shard_buf = shard_buf;
+    comm.all_buf = all_buf;
+    comm.cap_points = cap_points;
+    comm.buffers_on_device = 0;
+    MsBatch b;
+    b.count = count;
+    b.p = P;
+    b.K = MsRecord<P>::K;
+    b.draw.resize(count);
+    for (int i = 0; i < count; ++i)
+        b.draw[i] = i;
+    b.start.assign((size_t)count * P, 0.0);
+    const double rg[4] = {1.0, 500.0, 0.01, 5.0};
+    b.range.assign(rg, rg + 4);
+    b.kd.assign(P, 0.75);
+    b.maxiter = 5;
+    b.dtol = 1e-6;
+    b.always_fit = 0;
+    b.host_records = want_records != 0;
+    const int rc = ms_run_batch(ev, comm, b);
+    if (rc == 0 && want_records && records_out)
+        memcpy(records_out, b.rec, sizeof(double) * (size_t)count * b.K);
+    return rc;
+}
+
 extern "C" void hostsim_psi(int rho, const double *cc, int n, const double *x, double *psi, double *psip)
 {
     LossCfg L;

@@ -107,6 +107,35 @@ def mstart_batch_misra(x, y, ranges, kd, first_draw, count, maxiter, dtol, ci, c
     return rec
 
 
+def run_batch_comm(x, y, count, rank, world, ci, cd, want_records=True, failing_peer=False):
+    """one concentration batch through ms_run_batch's callback branch (world ranks simulated in this process: the
+    all-gather callback leaves the other ranks' blocks zero, or marks the peer's shard failed).  Returns (rc, records)"""
+    n = len(y)
+    x = np.asfortranarray(np.asarray(x, dtype=np.float64).reshape(n, -1))
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    K = 3 * 2 + 8
+    per = (count + world - 1) // world
+    shard = np.zeros(per * K)
+    allb = np.zeros(world * per * K)
+    calls = []
+    CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
+
+    def _ag(_ctx, per_points, k):
+        calls.append((per_points, k))
+        allb[:] = 0.0
+        allb[rank * per_points * k:(rank + 1) * per_points * k] = shard[:per_points * k]
+        if failing_peer:
+            peer = (rank + 1) % world
+            allb[peer * per_points * k + 3 * 2 + 6] = -424242.0   # MS_SHARD_FAILED in the peer's first record
+        return 0
+    cb = CB(_ag)
+    rec = np.zeros((count, K))
+    rc = lib().hostsim_run_batch_comm(n, _dp(x), _dp(y), count, rank, world, cb, _dp(shard), _dp(allb),
+                                      C.c_longlong(world * per), int(want_records), ci.ctypes.data_as(IP), _dp(cd),
+                                      _dp(rec) if want_records else None)
+    return rc, rec, calls
+
+
 def psi(rho, cc, x):
     x = np.ascontiguousarray(x, dtype=np.float64)
     c3 = np.zeros(3)

@@ -42,6 +42,11 @@ SEXP Rf_protect(SEXP);
 void Rf_unprotect(int);
 #define PROTECT(s) Rf_protect(s)
 #define UNPROTECT(n) Rf_unprotect(n)
+typedef int PROTECT_INDEX;
+void R_ProtectWithIndex(SEXP, PROTECT_INDEX *);
+void R_Reprotect(SEXP, PROTECT_INDEX);
+#define PROTECT_WITH_INDEX(x, i) R_ProtectWithIndex(x, i)
+#define REPROTECT(x, i) R_Reprotect(x, i)
 void R_PreserveObject(SEXP);
 void R_ReleaseObject(SEXP);
 

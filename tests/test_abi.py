@@ -78,3 +78,45 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--plumbing-only"],
                          capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="2", RANK="0"))
     assert bad.returncode != 0 and "refusing" in bad.stderr
+
+
+def _bench(env_extra, timeout=120):
+    import subprocess
+    import sys
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GSLNLS_BENCH_FAULT")}
+    env.update(env_extra)
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only"],
+                         capture_output=True, text=True, timeout=timeout, env=env)
+    return out, time.monotonic() - t0
+
+
+def test_bench_failed_headline_leg_ends_every_rank_nonzero():
+    """N > 1 failure handling, GPU-free (gloo): a library failure on ONE rank inside the headline leg is carried to the
+    next sync point; every rank stops there together, the launcher exits non-zero, nobody hangs"""
+    out, el = _bench({"GSLNLS_BENCH_FAULT": "fail:headline:1"})
+    assert out.returncode != 0 and el < 60
+    assert "failed on another rank" in out.stderr and "failed on this rank" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]      # no line without a valid headline
+
+
+def test_bench_raising_rank_in_a_side_leg_costs_only_that_leg():
+    import json
+    out, el = _bench({"GSLNLS_BENCH_FAULT": "raise:side:1"})
+    assert out.returncode == 0 and el < 60, out.stderr[-1500:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and "error" in d["side"] and d["ranks"] == [0, 1]
+
+
+def test_bench_killed_rank_cannot_hang_the_job():
+    """rank 1 dies (SIGKILL) inside the headline leg: the launcher notices, gives the survivor the grace period, kills
+    its own children and exits non-zero -- long before the overall deadline"""
+    out, el = _bench({"GSLNLS_BENCH_FAULT": "kill:headline:1", "GSLNLS_BENCH_GRACE_S": "3"})
+    assert out.returncode != 0 and el < 60
+
+
+def test_bench_hung_rank_is_ended_by_the_deadline():
+    out, el = _bench({"GSLNLS_BENCH_FAULT": "hang:side:1", "GSLNLS_BENCH_DEADLINE_S": "12"})
+    assert out.returncode != 0 and 10 < el < 60
+    assert "deadline" in out.stderr or "giving up" in out.stderr

@@ -141,3 +141,61 @@ def test_batched_irls_world2_gathers_every_data_set(amd):
     assert r0[1:5] == r1[1:5] and r0[5] == r1[5] == 1         # same on both ranks, exactly one collective
     assert np.array_equal(np.array(r0[1]), solo["par"]) and np.array_equal(np.array(r0[2]), solo["sigma"])
     assert r0[3] == solo["irls_niter"].tolist() and r0[4] == solo["conv"].tolist()
+
+
+def _irls_empty_block_worker(rank, world, port, n, q):
+    import os
+    import sys
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import gslnls_amd
+    from gslnls_amd import dist as gdist
+    from test_gpu_batch import c5_data, GAUSS1_START
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = 1                                                            # one data set over two ranks: rank 1's block is empty
+    X, Y, _ = c5_data(B, n)
+    per = (B + world - 1) // world
+    lo, hi = min(B, rank * per), min(B, rank * per + per)
+    gdist.init_multistart_comm(max_points=64, p=8)
+    prob = gslnls_amd.BatchProblem(4, 8, X[lo:hi].reshape(hi - lo, 1, n), Y[lo:hi])     # B = 0 on rank 1
+    out = prob.irls_gathered(B, GAUSS1_START, loss="bisquare", jac=True, control=dict(solver="cholesky"))
+    # a handle of the wrong size on ONE rank: carried through the collective, both ranks get an error, none hangs
+    bad = gslnls_amd.BatchProblem(4, 8, X[0:1].reshape(1, 1, n), Y[0:1]) if rank == 1 else prob
+    try:
+        bad.irls_gathered(B, GAUSS1_START, loss="bisquare", jac=True, control=dict(solver="cholesky"))
+        failed = False
+    except Exception:  # noqa
+        failed = True
+    q.put((rank, out["par"].tolist(), out["conv"].tolist(), failed))
+    dist.barrier()
+    prob.close()
+    gdist.reset_comm()
+    dist.destroy_process_group()
+
+
+def test_batched_irls_gather_with_an_empty_block_and_a_failing_rank(amd):
+    """B_total smaller than the number of ranks (B_total = 9 on 8 ranks leaves ranks without data sets): the
+    rank with the empty block joins the collective through a B = 0 handle; a rank-local argument error is carried
+    through the all-gather and fails every rank instead of leaving the others blocked"""
+    import torch.multiprocessing as mp
+    n = 500
+    X, Y, _ = c5_data(1, n)
+    prob = amd.BatchProblem(4, 8, X, Y)
+    solo = prob.irls(GAUSS1_START, loss="bisquare", jac=True, control=dict(solver="cholesky"))
+    prob.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + int(np.random.default_rng().integers(0, 2000))
+    procs = [ctx.Process(target=_irls_empty_block_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+    for r in res:
+        assert np.array_equal(np.array(r[1]), solo["par"]) and r[2] == solo["conv"].tolist() and r[3] is True

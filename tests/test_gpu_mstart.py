@@ -249,3 +249,133 @@ print(json.dumps(dict(rc=rc, err=L.gslnls_comm_last_error().decode(), collective
     assert r["coll"] == r["plain"] == r["after"]        # and nothing changed, bit for bit
     tgt = np.array(list(nist["BoxBOD"]["target"].values()))
     assert np.all(np.abs(np.array(r["coll"][0]) - tgt) < 1.3e-4)
+
+
+def test_rccl_path_fails_together_and_recovers(amd, nist):
+    """Collective safety of the in-library all-gather (one rank, forced collective path): (a) a rank whose buffer growth
+    fails (test hook GSLNLS_COMM_FAIL_ENSURE_RANK) makes the agreed growth fail -- an error, not a hang, and the next
+    batch (which grows again) succeeds; (b) gslnls_mstart_batch(lo < 0, records = NULL) leaves the records in HBM and
+    still reads the status words; (c) the bootstrap file is gone once every rank has joined; (d) the optional event
+    pair reports the collective's own device time"""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = r"""
+import ctypes as C, json, os, sys, numpy as np
+sys.path.insert(0, %r)
+from gslnls_amd import _lib
+from gslnls_amd.control import gsl_nls_control, pack_control
+L = _lib.lib()
+x = np.asfortranarray(np.array([1.0, 2.0, 3.0, 5.0, 7.0, 10.0]).reshape(6, 1)); y = np.array([109.0, 149.0, 149.0, 191.0, 213.0, 224.0])
+model = _lib.Model(2, 2, 1, x.ctypes.data_as(C.c_void_p), 0); err = C.c_int(0)
+h = L.gslnls_dense_create(C.byref(model), y.ctypes.data_as(C.c_void_p), 6, None, C.byref(err))
+ci, cd = pack_control(gsl_nls_control(solver="cholesky"), "lm")
+rg = np.array([1.0, 500.0, 0.01, 5.0]); kd = np.array([0.75, 0.75]); ms = C.c_float(0)
+DP, IP = _lib.DP, _lib.IP
+def batch(count, rec):
+    return L.gslnls_mstart_batch(h, 1, rg.ctypes.data_as(DP), kd.ctypes.data_as(DP), 0, count, -1, 0, 5, 1e-6, ci.ctypes.data_as(IP),
+                                 cd.ctypes.data_as(DP), None, None if rec is None else rec.ctypes.data_as(C.c_void_p), 0, C.byref(ms))
+K = L.gslnls_mstart_record_size(2)
+plain = np.zeros((512, K)); rc_plain = batch(512, plain)              # no communicator yet: the plain path
+rc_init = L.gslnls_comm_init_file(sys.argv[1].encode(), 0, 1, 30)
+file_left = os.path.exists(sys.argv[1])
+rc_fail = batch(512, None)                                             # growth reported as failed -> agreed failure
+msg = L.gslnls_comm_last_error().decode()
+L.gslnls_comm_set_timing(1)
+rc_none = batch(512, None)                                             # records stay in HBM
+rec = np.zeros((512, K)); rc_rec = batch(512, rec)
+nt = C.c_longlong(0); tot = L.gslnls_comm_allgather_ms(C.byref(nt))
+n_coll = L.gslnls_comm_allgather_count()
+L.gslnls_comm_destroy(); L.gslnls_dense_destroy(h)
+print(json.dumps(dict(rc_plain=rc_plain, rc_init=rc_init, file_left=file_left, rc_fail=rc_fail, msg=msg, rc_none=rc_none, rc_rec=rc_rec,
+                      same=bool(np.array_equal(rec, plain)), timed=nt.value, ms=tot, n_coll=n_coll)))
+""" % (ROOT,)
+    with tempfile.TemporaryDirectory() as td:
+        env = dict(os.environ, GSLNLS_COMM_FORCE_COLLECTIVE="1", GSLNLS_COMM_FAIL_ENSURE_RANK="0", GSLNLS_COMM_NONCE="job-42")
+        out = subprocess.run([sys.executable, "-c", code, os.path.join(td, "nccl_id")], capture_output=True, text=True,
+                             timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    import json
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["rc_plain"] == 0 and r["rc_init"] == 0 and not r["file_left"]
+    assert r["rc_fail"] != 0 and "every rank" in r["msg"]
+    assert r["rc_none"] == 0 and r["rc_rec"] == 0 and r["same"]
+    assert r["timed"] == 2 and r["ms"] > 0.0 and r["n_coll"] >= 2
+
+
+def _ms_rank_worker(rank, world, port, q):
+    import ctypes as C
+    import os
+    import sys
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from gslnls_amd import _lib, dist as gdist
+    from gslnls_amd.control import gsl_nls_control, pack_control
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L = _lib.lib()
+    x = np.asfortranarray(np.array([1.0, 2.0, 3.0, 5.0, 7.0, 10.0]).reshape(6, 1))
+    y = np.array([109.0, 149.0, 149.0, 191.0, 213.0, 224.0])
+    model = _lib.Model(2, 2, 1, x.ctypes.data_as(C.c_void_p), 0)
+    err = C.c_int(0)
+    h = L.gslnls_dense_create(C.byref(model), y.ctypes.data_as(C.c_void_p), 6, None, C.byref(err))
+    calls = gdist.init_multistart_comm(max_points=256, p=2)        # callback communicator over gloo (host buffers)
+    ci, cd = pack_control(gsl_nls_control(solver="cholesky"), "lm")
+    rg, kd, ms = np.array([1.0, 500.0, 0.01, 5.0]), np.array([0.75, 0.75]), C.c_float(0)
+    K = L.gslnls_mstart_record_size(2)
+    DP, IP = _lib.DP, _lib.IP
+
+    def batch(count, rec):
+        return L.gslnls_mstart_batch(h, 1, rg.ctypes.data_as(DP), kd.ctypes.data_as(DP), 0, count, -1, 0, 5, 1e-6,
+                                     ci.ctypes.data_as(IP), cd.ctypes.data_as(DP), None,
+                                     None if rec is None else rec.ctypes.data_as(C.c_void_p), 0, C.byref(ms))
+    rc_none = batch(101, None)                                     # records = NULL: was a write through a null vector
+    rec = np.zeros((101, K))
+    rc_rec = batch(101, rec)
+    rc_tiny = batch(1, None)                                       # one point over two ranks: rank 1 owns an empty block
+    q.put((rank, rc_none, rc_rec, rc_tiny, rec.tolist(), calls["n"]))
+    dist.barrier()
+    L.gslnls_dense_destroy(h)
+    gdist.reset_comm()
+    dist.destroy_process_group()
+
+
+def test_sharded_batch_world2_without_host_records(amd):
+    """two rank processes (gloo, sharing the test box's GPU): gslnls_mstart_batch(lo < 0, records = NULL) on the
+    callback communicator completes on both ranks, and the same batch with records gives the single-process records"""
+    import ctypes as C
+    import torch.multiprocessing as mp
+    from gslnls_amd import _lib
+    from gslnls_amd.control import gsl_nls_control, pack_control
+    L = _lib.lib()
+    x = np.asfortranarray(np.array([1.0, 2.0, 3.0, 5.0, 7.0, 10.0]).reshape(6, 1))
+    y = np.array([109.0, 149.0, 149.0, 191.0, 213.0, 224.0])
+    model = _lib.Model(2, 2, 1, x.ctypes.data_as(C.c_void_p), 0)
+    err = C.c_int(0)
+    h = L.gslnls_dense_create(C.byref(model), y.ctypes.data_as(C.c_void_p), 6, None, C.byref(err))
+    ci, cd = pack_control(gsl_nls_control(solver="cholesky"), "lm")
+    rg, kd, ms = np.array([1.0, 500.0, 0.01, 5.0]), np.array([0.75, 0.75]), C.c_float(0)
+    K = L.gslnls_mstart_record_size(2)
+    solo = np.zeros((101, K))
+    rc = L.gslnls_mstart_batch(h, 1, rg.ctypes.data_as(_lib.DP), kd.ctypes.data_as(_lib.DP), 0, 101, 0, 101, 5, 1e-6,
+                               ci.ctypes.data_as(_lib.IP), cd.ctypes.data_as(_lib.DP), None, solo.ctypes.data_as(C.c_void_p),
+                               0, C.byref(ms))
+    L.gslnls_dense_destroy(h)
+    assert rc == 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + int(np.random.default_rng().integers(0, 2000))
+    procs = [ctx.Process(target=_ms_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+    for r in res:
+        assert r[1] == 0 and r[2] == 0 and r[3] == 0 and r[5] == 3          # three collectives, no failure
+        assert np.array_equal(np.array(r[4]), solo)                          # bitwise the unsharded records

@@ -134,3 +134,20 @@ def test_sharded_multistart_world2_gloo(gslref, hostsim, nist):
     assert (r0[3], r0[4], r0[5]) == (solo["nsp"], solo["nwsp"], solo["iters"]) and r0[6] == solo["ssropt"]
     f = hostsim.fit(2, 2, x, y, np.array(r0[2]), ci, cd, jac=1)
     assert np.all(np.abs(f["par"] - tgt) <= TOL)
+
+
+def test_sharded_batch_without_host_records_reads_the_status_words(gslref, hostsim, nist):
+    """gslnls_mstart_batch(lo < 0, records = NULL) on a callback communicator: the records of the batch are
+    not wanted on the host, but the status words of the shards are still read from the gathered array -- no write
+    through the unsized record vector, and a peer's failed shard still fails this rank"""
+    x, y, _ = _boxbod(nist)
+    ci, cd = gslref.pack_control(gslref.control(solver="cholesky"), "lm")
+    rc, _, calls = hostsim.run_batch_comm(x, y, 101, 0, 2, ci, cd, want_records=False)
+    assert rc == 0 and calls == [(51, 14)]
+    rc1, rec1, _ = hostsim.run_batch_comm(x, y, 101, 1, 2, ci, cd, want_records=True)
+    assert rc1 == 0 and np.all(rec1[:51] == 0.0) and np.any(rec1[51:] != 0.0)   # rank 1 computed the second block only
+    rc2, _, calls2 = hostsim.run_batch_comm(x, y, 101, 0, 2, ci, cd, want_records=False, failing_peer=True)
+    assert rc2 != 0 and len(calls2) == 1                                      # entered the collective, then failed
+    # more ranks than points: the last ranks own an empty block and still take part
+    rc3, _, calls3 = hostsim.run_batch_comm(x, y, 3, 3, 4, ci, cd, want_records=False)
+    assert rc3 == 0 and calls3 == [(1, 14)]
