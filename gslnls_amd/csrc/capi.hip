@@ -832,8 +832,10 @@ int gslnls_batch_irls_gather(gslnls_batch *h, int B_total, int jac, int fvv, con
         else
             memcpy(rec.data(), g_comm.all_buf, sizeof(double) * rec.size());
     }
+    // (every shard was zero-filled before it was packed, so the status slot of a rank with an empty block is valid too:
+    // such a rank can still fail -- a handle of the wrong size, a HIP error)
     for (int r = 0; r < world; ++r)
-        if ((long long)r * per < B_total && rec[(size_t)r * per * K + p + 4] == MS_SHARD_FAILED)
+        if (rec[(size_t)r * per * K + p + 4] == MS_SHARD_FAILED)
             return rc ? rc : GSLNLS_FAILURE;
     if (rc)
         return rc;

@@ -21,9 +21,10 @@
 // in the same launch.  All reductions have a fixed shape => results are run-to-run
 // bit-identical.
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <hip/hip_runtime.h>
 #include <cstddef>
-#include <type_traits>
+#endif
 #include "lm_core.hpp"
 #include "models.hpp"
 #include "rowops.hpp"
@@ -277,15 +278,17 @@ struct StepBcast
 };
 
 // models that keep per-thread data in the workgroup's dynamic LDS (ModelVM<P, true>)
-template <class M, class = void>
+template <class M>
 struct vm_lds_twin
 {
-    static constexpr bool value = false;
-};
-template <class M>
-struct vm_lds_twin<M, std::enable_if_t<(M::ID == 100)>>
-{
-    static constexpr bool value = M::LDS_SLOTS;
+    static constexpr bool get()
+    {
+        if constexpr (M::ID == 100)
+            return M::LDS_SLOTS;
+        else
+            return false;
+    }
+    static constexpr bool value = get();
 };
 extern __shared__ double gslnls_dyn_lds[];
 template <bool VML>

@@ -8,7 +8,9 @@
 // v_fma_f64 per step.  fp64 VALU issue is what bounds the row loops, so this is a direct
 // cut of the pass time.  Host compilation (tests/hostsim) uses the C library.
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <cmath>
+#endif
 #include "lm_core.hpp"
 
 namespace gslnls

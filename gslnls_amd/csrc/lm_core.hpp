@@ -22,9 +22,13 @@
 //   (batch_kernels.hip).  It is host-compilable only so that tests/ can drive the
 //   state machine on a CPU-only box; the shipped library never runs it on the host.
 #pragma once
+#if defined(__HIPCC_RTC__)
+#include "rtc_prelude.hpp"
+#else
 #include <math.h>
 #include <float.h>
 #include <stdint.h>
+#endif
 
 #if defined(__HIPCC__)
 #define GSLNLS_HD __host__ __device__ __forceinline__

@@ -1,0 +1,604 @@
+// rtc_host.hpp -- expression models at native speed, compiled IN PROCESS.
+//
+// The reference needs nothing at run time to evaluate a new formula: R builds the closure and its derivative
+// (stats::deriv) on the spot (R/nls.R:565,588-599).  Here the compiled program (vm_program.hpp) is printed as a
+// straight-line C++ row model and handed, together with the SAME kernel templates the library itself is built from
+// (dense_kernels.hpp ... embedded in the shared object as text, rtc_embed.cpp), to hiprtc -- the compiler that ships
+// with the HIP runtime (libhiprtc / comgr).  No hipcc, no source tree, no child process on the deployment box.  The
+// resulting code object is cached on disk by content hash, loaded with hipModuleLoadData, and its kernels are
+// launched with hipModuleLaunchKernel by the host classes that otherwise launch the interpreter's kernels: same
+// signatures, same state layout, same arithmetic in the same order -- the interpreted and the native fit of one
+// formula agree bit for bit (tests/test_gpu_expr.py).
+//
+// GSLNLS_LOWER_AUTO: the first fit of a formula starts the build on a background thread and runs on the
+// interpreter; calls that come after the build has finished bind the native kernels.  GSLNLS_LOWER_JIT builds
+// synchronously (about 1-3 s once per formula and Jacobian kind).  hiprtc is bound with dlopen at first use, so a
+// host without it still loads the library (and is served by the interpreter; the wide path, p > 9, needs it).
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../../include/gslnls_core.h"
+#include "vm_program.hpp"
+
+namespace gslnls
+{
+
+// ---------------------------------------------------------------------------------------------------------
+// text of the device headers, linked into the library by rtc_embed.cpp (.incbin)
+struct RtcHeader
+{
+    const char *name;
+    const char *begin, *end;
+};
+const RtcHeader *rtc_embedded_headers(int *count); // rtc_embed.cpp
+
+inline std::string rtc_fmt_double(double v)
+{
+    char buf[64];
+    if (v != v)
+        return "NAN";
+    if (v == INFINITY)
+        return "INFINITY";
+    if (v == -INFINITY)
+        return "(-INFINITY)";
+    snprintf(buf, sizeof buf, "%.17g", v);
+    std::string s(buf);
+    if (s.find_first_of(".eEn") == std::string::npos)
+        s += ".0";
+    return v < 0 ? "(" + s + ")" : s;
+}
+
+// C++ text of instructions [0, upto) of the program; `sink` (value + gradient form of the wide path): gradient k is
+// handed to out.set(k, value) as soon as it exists instead of living in an array of P registers
+inline std::string rtc_emit_ops(const VmProgram &pr, int upto)
+{
+    const int base = 2 * pr.p + pr.nx + pr.nconst;
+    auto ref = [&](int slot) -> std::string {
+        if (slot < pr.p)
+            return "th[" + std::to_string(slot) + "]";
+        if (slot < pr.p + pr.nx)
+            return "xr[" + std::to_string(slot - pr.p) + "]";
+        if (slot < 2 * pr.p + pr.nx)
+            return "dir[" + std::to_string(slot - pr.p - pr.nx) + "]";
+        if (slot < base)
+            return rtc_fmt_double(pr.consts[slot - 2 * pr.p - pr.nx]);
+        return "v" + std::to_string(slot - base);
+    };
+    static const char *fn1[] = {"", "", "", "", "", "", "", "gexp", "log", "sin", "cos", "tan", "atan", "sqrt", "fabs", "tanh", ""};
+    std::string s;
+    for (int i = 0; i < upto; ++i)
+    {
+        const std::string a = ref(pr.a[i]), b = ref(pr.b[i]);
+        std::string e;
+        switch (pr.op[i])
+        {
+        case VM_ADD: e = a + " + " + b; break;
+        case VM_SUB: e = a + " - " + b; break;
+        case VM_MUL: e = a + " * " + b; break;
+        case VM_DIV: e = a + " / " + b; break;
+        case VM_NEG: e = "-" + a; break;
+        case VM_POW: e = "pow(" + a + ", " + b + ")"; break;
+        case VM_SIGN: e = "(" + a + " > 0.0 ? 1.0 : (" + a + " < 0.0 ? -1.0 : 0.0))"; break;
+        default: e = std::string(fn1[pr.op[i]]) + "(" + a + ")"; break;
+        }
+        s += "        const double v" + std::to_string(i) + " = " + e + ";\n";
+    }
+    return s;
+}
+
+// struct ModelJit: the row-model interface of models.hpp for this program.  One interpreted instruction = one
+// statement, contraction off inside the bodies: a product and the sum that follows it stay two roundings, as in the
+// interpreter -- that is what makes the native and the interpreted fit agree bit for bit.
+inline std::string rtc_emit_model(const VmProgram &pr, int nx_model)
+{
+    const int base = 2 * pr.p + pr.nx + pr.nconst;
+    auto ref = [&](int slot) -> std::string {
+        if (slot < pr.p)
+            return "th[" + std::to_string(slot) + "]";
+        if (slot < pr.p + pr.nx)
+            return "xr[" + std::to_string(slot - pr.p) + "]";
+        if (slot < 2 * pr.p + pr.nx)
+            return "dir[" + std::to_string(slot - pr.p - pr.nx) + "]";
+        if (slot < base)
+            return rtc_fmt_double(pr.consts[slot - 2 * pr.p - pr.nx]);
+        return "v" + std::to_string(slot - base);
+    };
+    const std::string off = "        _Pragma(\"clang fp contract(off)\")\n";
+    std::string s;
+    s += "namespace gslnls {\nstruct ModelJit {\n";
+    s += "    static constexpr int ID = 101, P = " + std::to_string(pr.p) + ", NX = " + std::to_string(nx_model) + ";\n";
+    s += std::string("    static constexpr bool HAS_FVV = ") + (pr.nfvv > 0 ? "true" : "false") + ";\n";
+    s += "    template <class TH, class XR> __device__ __forceinline__ static double value(const TH &th, const XR &xr) {\n" + off;
+    s += rtc_emit_ops(pr, pr.nvalue);
+    s += "        return " + ref(pr.value_slot) + ";\n    }\n";
+    s += "    template <class TH, class XR> __device__ __forceinline__ static double value_grad(const TH &th, const XR &xr, double *g) {\n" + off;
+    s += rtc_emit_ops(pr, pr.nops);
+    for (int k = 0; k < pr.p; ++k)
+        s += "        g[" + std::to_string(k) + "] = " + ref(pr.grad_slot[k]) + ";\n";
+    s += "        return " + ref(pr.value_slot) + ";\n    }\n";
+    // gradient entries handed out one by one (wide path: straight into the LDS tile, no P-register array)
+    s += "    template <class TH, class XR, class SINK> __device__ __forceinline__ static double value_grad_sink(const TH &th, const XR &xr, SINK &out) {\n" + off;
+    s += rtc_emit_ops(pr, pr.nops);
+    for (int k = 0; k < pr.p; ++k)
+        s += "        out.set(" + std::to_string(k) + ", " + ref(pr.grad_slot[k]) + ");\n";
+    s += "        return " + ref(pr.value_slot) + ";\n    }\n";
+    if (pr.nfvv > 0)
+    {
+        s += "    template <class TH, class DIR, class XR> __device__ __forceinline__ static double fvv(const TH &th, const DIR &dir, const XR &xr) {\n" + off;
+        s += rtc_emit_ops(pr, pr.nfvv);
+        s += "        return " + ref(pr.fvv_slot) + ";\n    }\n";
+    }
+    else
+        s += "    template <class TH, class DIR, class XR> __device__ static double fvv(const TH &, const DIR &, const XR &) { return NAN; }\n";
+    s += "};\n}\n";
+    return s;
+}
+
+inline unsigned long long rtc_hash(const std::string &s)
+{
+    unsigned long long h = 1469598103934665603ull;
+    for (unsigned char c : s)
+    {
+        h ^= c;
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+// A cache directory is only used when it belongs to this user and nobody else can write to it: code objects found
+// there are loaded onto the device of the calling process, so a directory another local user could have prepared (or
+// can write to) must never be trusted.
+inline bool rtc_dir_is_private(const std::string &d)
+{
+    struct stat st;
+    if (lstat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) // lstat: a symlink planted under /tmp is not a directory
+        return false;
+    if (st.st_uid != getuid() || (st.st_mode & (S_IWGRP | S_IWOTH)) != 0)
+        return false;
+    return access(d.c_str(), W_OK) == 0;
+}
+
+// "" = no usable private cache directory: every process then compiles for itself (nothing is written)
+inline std::string rtc_cache_dir()
+{
+    std::vector<std::string> cand;
+    if (const char *e = getenv("GSLNLS_JIT_CACHE"))
+        cand.push_back(e);
+    else if (const char *h = getenv("HOME"))
+        cand.push_back(std::string(h) + "/.cache/gslnls_amd");
+    cand.push_back("/tmp/gslnls_amd_jit_" + std::to_string((long)getuid()));
+    for (const std::string &d : cand)
+    {
+        const size_t k = d.rfind('/');
+        if (k != std::string::npos && k > 0)
+            mkdir(d.substr(0, k).c_str(), 0700);
+        mkdir(d.c_str(), 0700);
+        if (rtc_dir_is_private(d))
+            return d;
+    }
+    return "";
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct RtcApi
+{
+    void *handle = nullptr;
+    decltype(&hiprtcCreateProgram) CreateProgram = nullptr;
+    decltype(&hiprtcCompileProgram) CompileProgram = nullptr;
+    decltype(&hiprtcDestroyProgram) DestroyProgram = nullptr;
+    decltype(&hiprtcGetCodeSize) GetCodeSize = nullptr;
+    decltype(&hiprtcGetCode) GetCode = nullptr;
+    decltype(&hiprtcGetProgramLogSize) GetProgramLogSize = nullptr;
+    decltype(&hiprtcGetProgramLog) GetProgramLog = nullptr;
+    decltype(&hiprtcAddNameExpression) AddNameExpression = nullptr;
+    decltype(&hiprtcGetLoweredName) GetLoweredName = nullptr;
+    std::string err;
+
+    bool load()
+    {
+        if (handle)
+            return true;
+        if (const char *e = getenv("GSLNLS_HIPRTC")) // test hook: "none" simulates a host without the compiler
+            if (!strcmp(e, "none"))
+            {
+                err = "hiprtc disabled (GSLNLS_HIPRTC=none)";
+                return false;
+            }
+        for (const char *nm : {"libhiprtc.so", "libhiprtc.so.7"})
+            if ((handle = dlopen(nm, RTLD_NOW | RTLD_NOLOAD)))
+                break;
+        if (!handle)
+            for (const char *nm : {"libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"})
+                if ((handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL)))
+                    break;
+        if (!handle)
+        {
+            err = std::string("hiprtc not found: ") + dlerror();
+            return false;
+        }
+#define GSLNLS_RTC_SYM(f) f = (decltype(f))dlsym(handle, "hiprtc" #f)
+        GSLNLS_RTC_SYM(CreateProgram);
+        GSLNLS_RTC_SYM(CompileProgram);
+        GSLNLS_RTC_SYM(DestroyProgram);
+        GSLNLS_RTC_SYM(GetCodeSize);
+        GSLNLS_RTC_SYM(GetCode);
+        GSLNLS_RTC_SYM(GetProgramLogSize);
+        GSLNLS_RTC_SYM(GetProgramLog);
+        GSLNLS_RTC_SYM(AddNameExpression);
+        GSLNLS_RTC_SYM(GetLoweredName);
+#undef GSLNLS_RTC_SYM
+        if (!CreateProgram || !CompileProgram || !DestroyProgram || !GetCodeSize || !GetCode || !AddNameExpression ||
+            !GetLoweredName)
+        {
+            err = "hiprtc lacks a symbol";
+            handle = nullptr;
+            return false;
+        }
+        return true;
+    }
+};
+
+inline RtcApi &rtc_api()
+{
+    static RtcApi api;
+    return api;
+}
+
+// one compiled translation unit: code object + the mangled names of the kernels that were asked for
+struct RtcUnit
+{
+    std::vector<char> code;
+    std::map<std::string, std::string> lowered;
+};
+
+inline const char *rtc_flags_text() { return "--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=on -mllvm -amdgpu-kernarg-preload-count=16"; }
+
+// source -> code object (no device needed; thread-safe with respect to the HIP runtime: hiprtc / comgr only)
+inline bool rtc_compile(const std::string &source, const std::vector<std::string> &exprs, RtcUnit &out, std::string &log)
+{
+    static std::mutex mu; // one compilation at a time per process
+    std::lock_guard<std::mutex> lock(mu);
+    RtcApi &api = rtc_api();
+    if (!api.load())
+    {
+        log = api.err;
+        return false;
+    }
+    int nh = 0;
+    const RtcHeader *hd = rtc_embedded_headers(&nh);
+    std::vector<std::string> texts(nh);
+    std::vector<const char *> hsrc(nh), hname(nh);
+    for (int k = 0; k < nh; ++k)
+    {
+        texts[k].assign(hd[k].begin, hd[k].end);
+        hsrc[k] = texts[k].c_str();
+        hname[k] = hd[k].name;
+    }
+    hiprtcProgram prog = nullptr;
+    if (api.CreateProgram(&prog, source.c_str(), "gslnls_model.hip", nh, hsrc.data(), hname.data()) != HIPRTC_SUCCESS)
+    {
+        log = "hiprtcCreateProgram failed";
+        return false;
+    }
+    for (const std::string &e : exprs)
+        (void)api.AddNameExpression(prog, e.c_str());
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-mllvm",
+                          "-amdgpu-kernarg-preload-count=16"};
+    const hiprtcResult r = api.CompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+    size_t ls = 0;
+    if (api.GetProgramLogSize && api.GetProgramLog && api.GetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1)
+    {
+        log.assign(ls, '\0');
+        (void)api.GetProgramLog(prog, &log[0]);
+    }
+    bool ok = (r == HIPRTC_SUCCESS);
+    if (ok)
+    {
+        size_t cs = 0;
+        ok = api.GetCodeSize(prog, &cs) == HIPRTC_SUCCESS && cs > 0;
+        if (ok)
+        {
+            out.code.resize(cs);
+            ok = api.GetCode(prog, out.code.data()) == HIPRTC_SUCCESS;
+        }
+        for (const std::string &e : exprs)
+        {
+            const char *low = nullptr;
+            if (ok && api.GetLoweredName(prog, e.c_str(), &low) == HIPRTC_SUCCESS && low)
+                out.lowered[e] = low;
+            else
+                ok = false;
+        }
+    }
+    else if (log.empty())
+        log = "hiprtcCompileProgram failed";
+    (void)api.DestroyProgram(&prog);
+    return ok;
+}
+
+// cache file: "GSLRTC1\n" | n | n x (len expr, expr, len name, name) | len code | code
+inline bool rtc_cache_read(const std::string &path, RtcUnit &u)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f)
+        return false;
+    bool ok = false;
+    char magic[8];
+    unsigned long long n = 0;
+    auto rd_str = [&](std::string &s) {
+        unsigned long long len = 0;
+        if (fread(&len, sizeof len, 1, f) != 1 || len > (1u << 20))
+            return false;
+        s.resize(len);
+        return len == 0 || fread(&s[0], 1, len, f) == len;
+    };
+    if (fread(magic, 1, 8, f) == 8 && !memcmp(magic, "GSLRTC1\n", 8) && fread(&n, sizeof n, 1, f) == 1 && n < 64)
+    {
+        ok = true;
+        for (unsigned long long k = 0; ok && k < n; ++k)
+        {
+            std::string e, l;
+            ok = rd_str(e) && rd_str(l);
+            if (ok)
+                u.lowered[e] = l;
+        }
+        unsigned long long cs = 0;
+        ok = ok && fread(&cs, sizeof cs, 1, f) == 1 && cs > 0 && cs < (1ull << 30);
+        if (ok)
+        {
+            u.code.resize(cs);
+            ok = fread(u.code.data(), 1, cs, f) == cs;
+        }
+    }
+    fclose(f);
+    return ok;
+}
+
+inline void rtc_cache_write(const std::string &path, const RtcUnit &u)
+{
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f)
+        return;
+    auto wr_str = [&](const std::string &s) {
+        const unsigned long long len = s.size();
+        fwrite(&len, sizeof len, 1, f);
+        fwrite(s.data(), 1, s.size(), f);
+    };
+    fwrite("GSLRTC1\n", 1, 8, f);
+    const unsigned long long n = u.lowered.size(), cs = u.code.size();
+    fwrite(&n, sizeof n, 1, f);
+    for (const auto &kv : u.lowered)
+    {
+        wr_str(kv.first);
+        wr_str(kv.second);
+    }
+    fwrite(&cs, sizeof cs, 1, f);
+    fwrite(u.code.data(), 1, u.code.size(), f);
+    const bool ok = !ferror(f);
+    fclose(f);
+    if (ok)
+        rename(tmp.c_str(), path.c_str()); // atomic: concurrent processes see nothing or the whole file
+    else
+        unlink(tmp.c_str());
+}
+
+// ---------------------------------------------------------------------------------------------------------
+enum
+{
+    RTC_NONE = 0,
+    RTC_BUILDING = 1,
+    RTC_READY = 2,
+    RTC_FAILED = -1
+};
+
+struct RtcEntry
+{
+    std::atomic<int> state{RTC_NONE};
+    RtcUnit unit;
+    std::string log, cache_path;
+    double build_s = 0.0;
+    bool from_cache = false;
+    std::thread worker;
+    // modules per device ordinal (loaded by the thread that launches)
+    std::map<int, hipModule_t> modules;
+    std::map<std::pair<int, std::string>, hipFunction_t> functions;
+    ~RtcEntry()
+    {
+        if (worker.joinable())
+            worker.join();
+    }
+};
+
+struct RtcRegistry
+{
+    std::mutex mu;
+    std::map<unsigned long long, std::shared_ptr<RtcEntry>> entries;
+    ~RtcRegistry()
+    {
+        // a build still running at process exit is waited for (a compiler thread torn down in the middle of comgr
+        // takes the process with it)
+        for (auto &kv : entries)
+            if (kv.second->worker.joinable())
+                kv.second->worker.join();
+    }
+};
+
+inline RtcRegistry &rtc_registry()
+{
+    static RtcRegistry r;
+    return r;
+}
+
+inline double rtc_now()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+inline void rtc_build(RtcEntry *e, std::string source, std::vector<std::string> exprs)
+{
+    const double t0 = rtc_now();
+    RtcUnit u;
+    std::string log;
+    const bool ok = rtc_compile(source, exprs, u, log);
+    e->log = log;
+    e->build_s = rtc_now() - t0;
+    if (ok)
+    {
+        e->unit = std::move(u);
+        if (!e->cache_path.empty())
+            rtc_cache_write(e->cache_path, e->unit);
+        e->state.store(RTC_READY, std::memory_order_release);
+    }
+    else
+        e->state.store(RTC_FAILED, std::memory_order_release);
+}
+
+// The code object of `source` (which must name every kernel in `exprs`).  wait: build now if it is neither in memory
+// nor in the disk cache; otherwise a missing one is built on a background thread and nullptr-like (state BUILDING)
+// comes back at once.  Never blocks on a build another call started unless `wait`.
+inline std::shared_ptr<RtcEntry> rtc_request(const std::string &source, const std::vector<std::string> &exprs, bool wait)
+{
+    std::string keytext = source + "\n//" + rtc_flags_text() + "\n//" + gslnls_version();
+    int nh = 0;
+    const RtcHeader *hd = rtc_embedded_headers(&nh);
+    unsigned long long h = rtc_hash(keytext);
+    for (int k = 0; k < nh; ++k) // the kernels' own text is part of the key: a rebuilt library never picks up stale code
+        h = h * 1099511628211ull ^ rtc_hash(std::string(hd[k].begin, hd[k].end));
+    for (const std::string &e : exprs)
+        h = h * 1099511628211ull ^ rtc_hash(e);
+    RtcRegistry &reg = rtc_registry();
+    std::shared_ptr<RtcEntry> ent;
+    {
+        std::lock_guard<std::mutex> lock(reg.mu);
+        auto it = reg.entries.find(h);
+        if (it != reg.entries.end())
+            ent = it->second;
+        else
+        {
+            ent = std::make_shared<RtcEntry>();
+            reg.entries[h] = ent;
+            const std::string dir = rtc_cache_dir();
+            if (!dir.empty())
+            {
+                char name[64];
+                snprintf(name, sizeof name, "/gslnls_rtc_%016llx.bin", h);
+                ent->cache_path = dir + name;
+                RtcUnit u;
+                if (rtc_cache_read(ent->cache_path, u))
+                {
+                    bool all = true;
+                    for (const std::string &e : exprs)
+                        all = all && u.lowered.count(e);
+                    if (all)
+                    {
+                        ent->unit = std::move(u);
+                        ent->from_cache = true;
+                        ent->state.store(RTC_READY, std::memory_order_release);
+                    }
+                }
+            }
+        }
+    }
+    int st = ent->state.load(std::memory_order_acquire);
+    if (st == RTC_NONE)
+    {
+        int expect = RTC_NONE;
+        if (ent->state.compare_exchange_strong(expect, RTC_BUILDING))
+        {
+            if (wait)
+                rtc_build(ent.get(), source, exprs);
+            else
+                ent->worker = std::thread(rtc_build, ent.get(), source, exprs);
+        }
+        st = ent->state.load(std::memory_order_acquire);
+    }
+    if (st == RTC_BUILDING && wait)
+    {
+        if (ent->worker.joinable())
+            ent->worker.join();
+        while (ent->state.load(std::memory_order_acquire) == RTC_BUILDING)
+            usleep(1000);
+    }
+    return ent;
+}
+
+// kernel `expr` of a READY entry on the current device (module loaded on first use)
+inline hipFunction_t rtc_function(RtcEntry &e, const std::string &expr, std::string &msg)
+{
+    if (e.state.load(std::memory_order_acquire) != RTC_READY)
+        return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+    {
+        msg = "no current device";
+        return nullptr;
+    }
+    auto fk = std::make_pair(dev, expr);
+    auto fit = e.functions.find(fk);
+    if (fit != e.functions.end())
+        return fit->second;
+    auto mit = e.modules.find(dev);
+    if (mit == e.modules.end())
+    {
+        hipModule_t mod = nullptr;
+        const hipError_t r = hipModuleLoadData(&mod, e.unit.code.data());
+        if (r != hipSuccess)
+        {
+            msg = std::string("hipModuleLoadData: ") + hipGetErrorString(r);
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        mit = e.modules.insert({dev, mod}).first;
+    }
+    auto lit = e.unit.lowered.find(expr);
+    if (lit == e.unit.lowered.end())
+    {
+        msg = "kernel not in this code object: " + expr;
+        return nullptr;
+    }
+    hipFunction_t fn = nullptr;
+    const hipError_t r = hipModuleGetFunction(&fn, mit->second, lit->second.c_str());
+    if (r != hipSuccess)
+    {
+        msg = std::string("hipModuleGetFunction: ") + hipGetErrorString(r);
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    e.functions[fk] = fn;
+    return fn;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// the translation unit of the dense (p <= 9) kernels of one program and one Jacobian kind
+inline std::string rtc_dense_source(const VmProgram &pr, int nx_model)
+{
+    std::string s = "// generated by gslnls rtc_host.hpp\n#include \"dense_kernels.hpp\"\n";
+    s += rtc_emit_model(pr, nx_model);
+    return s;
+}
+inline std::string rtc_step_expr(int jacmode, int T)
+{
+    return "&gslnls::lm_step_kernel<gslnls::ModelJit, " + std::to_string(jacmode) + ", " + std::to_string(T) + ">";
+}
+inline std::string rtc_finalize_expr(int jacmode, int T)
+{
+    return "&gslnls::lm_finalize_kernel<gslnls::ModelJit, " + std::to_string(jacmode) + ", " + std::to_string(T) + ">";
+}
+
+} // namespace gslnls
