@@ -59,7 +59,7 @@ class Result(C.Structure):
                 ("irls_niter", C.c_int), ("partrace", DP), ("ssrtrace", DP), ("mstart_nsp", C.c_int),
                 ("mstart_nwsp", C.c_int), ("mstart_iters", C.c_int), ("mstart_stop", C.c_int),
                 ("mstart_ssropt", C.c_double), ("loop_ms", C.c_float), ("n_launches", C.c_int),
-                ("jtj_cond", C.c_double), ("n_steps", C.c_int)]
+                ("jtj_cond", C.c_double), ("n_steps", C.c_int), ("code_path", C.c_int)]
 
 
 class LargeResult(C.Structure):
@@ -119,6 +119,7 @@ _SIGNATURES = {
     "gslnls_version": (C.c_char_p, []),
     "gslnls_set_interrupt_hook": (None, [C.c_void_p]),
     "gslnls_expr_build": (C.c_int, [C.POINTER(Model), C.c_char_p, C.c_int]),
+    "gslnls_expr_native_state": (C.c_int, [C.POINTER(Model), C.c_int]),
 }
 
 _lib = None

@@ -168,6 +168,9 @@ struct DenseFit : DenseBase
     // interpreted expression models: slots the program needs when they fit the workgroup's LDS (set by VmDenseFit
     // before every fit), 0 = slot file in scratch memory
     int vm_lds_slots = 0;
+    // kernels of this model compiled in process for one formula (rtc_host.hpp): when set (by VmDenseFit, per Jacobian
+    // kind, before a fit) they are launched instead of the interpreter's -- same signature, same state, same sums
+    hipFunction_t native_step[3] = {nullptr, nullptr, nullptr}, native_finalize[3] = {nullptr, nullptr, nullptr};
     // slots of T doubles beside the kernel's static LDS (sums, broadcast block, the state copy of the interpreted
     // models: 0.5 KB at p = 2, 2.5 KB at p = 12)
     static constexpr int VM_LDS_STATIC_MAX = 4 * 1024;
@@ -442,6 +445,17 @@ struct DenseFit : DenseBase
         parity |= (int)((index & 0x0fffffff) << 2);
         if constexpr (M::ID == 100)
         {
+            const int jn = jacmode == JAC_ANALYTIC ? 0 : (jacmode == JAC_FORWARD ? 1 : 2);
+            if (native_step[jn])
+            {
+                const double *x0 = ctx.x[0], *yy = ctx.y, *ss = ctx.sw;
+                long long nn = ctx.n;
+                int gg = ctx.G;
+                void *args[] = {(void *)&prev, (void *)&pp, (void *)&x0, (void *)&yy, (void *)&ss, (void *)&nn, (void *)&gg,
+                                (void *)&parity, (void *)&ctx};
+                (void)hipModuleLaunchKernel(native_step[jn], grid.x, 1, 1, block.x, 1, 1, 0, stream, args, nullptr);
+                return;
+            }
             if (vm_lds_slots > 0 && vm_lds_slots <= VM_LDS_CAP)
             {
                 using ML = typename M::LdsTwin;
@@ -509,6 +523,16 @@ struct DenseFit : DenseBase
         if (Gf < 1)
             Gf = 1;
         const dim3 grid(Gf), block(T);
+        if constexpr (M::ID == 100)
+        {
+            const int jn = jacmode == JAC_ANALYTIC ? 0 : (jacmode == JAC_FORWARD ? 1 : 2);
+            if (native_finalize[jn])
+            {
+                void *args[] = {(void *)&ctx, (void *)&parity, (void *)&resid, (void *)&grad, (void *)&covar};
+                (void)hipModuleLaunchKernel(native_finalize[jn], grid.x, 1, 1, block.x, 1, 1, 0, stream, args, nullptr);
+                return;
+            }
+        }
         switch (jacmode)
         {
         case JAC_ANALYTIC:
@@ -965,6 +989,10 @@ struct DenseFit : DenseBase
         out->n_launches = (int)last_launches;
         out->n_steps = (int)last_steps;
         out->jtj_cond = ok ? scaled_jtj_cond(s.A, P) : NAN;
+        {
+            const int jn = jacmode == JAC_ANALYTIC ? 0 : (jacmode == JAC_FORWARD ? 1 : 2);
+            out->code_path = M::ID < 100 ? 0 : ((M::ID == 100 && !native_step[jn]) ? 1 : 2);
+        }
         return s.status;
     }
 

@@ -472,16 +472,45 @@ inline void rtc_build(RtcEntry *e, std::string source, std::vector<std::string> 
 // The code object of `source` (which must name every kernel in `exprs`).  wait: build now if it is neither in memory
 // nor in the disk cache; otherwise a missing one is built on a background thread and nullptr-like (state BUILDING)
 // comes back at once.  Never blocks on a build another call started unless `wait`.
-inline std::shared_ptr<RtcEntry> rtc_request(const std::string &source, const std::vector<std::string> &exprs, bool wait)
+inline unsigned long long rtc_key(const std::string &source, const std::vector<std::string> &exprs)
 {
     std::string keytext = source + "\n//" + rtc_flags_text() + "\n//" + gslnls_version();
     int nh = 0;
     const RtcHeader *hd = rtc_embedded_headers(&nh);
-    unsigned long long h = rtc_hash(keytext);
-    for (int k = 0; k < nh; ++k) // the kernels' own text is part of the key: a rebuilt library never picks up stale code
-        h = h * 1099511628211ull ^ rtc_hash(std::string(hd[k].begin, hd[k].end));
+    static const unsigned long long hh = [&]() {
+        unsigned long long a = 7;
+        for (int k = 0; k < nh; ++k) // the kernels' own text is part of the key: a rebuilt library never picks up stale code
+            a = a * 1099511628211ull ^ rtc_hash(std::string(hd[k].begin, hd[k].end));
+        return a;
+    }();
+    unsigned long long h = rtc_hash(keytext) * 1099511628211ull ^ hh;
     for (const std::string &e : exprs)
         h = h * 1099511628211ull ^ rtc_hash(e);
+    return h;
+}
+
+// state of a unit without starting anything (RTC_NONE when nobody asked for it yet and the cache does not hold it)
+inline int rtc_request_peek(const std::string &source, const std::vector<std::string> &exprs)
+{
+    const unsigned long long h = rtc_key(source, exprs);
+    RtcRegistry &reg = rtc_registry();
+    {
+        std::lock_guard<std::mutex> lock(reg.mu);
+        auto it = reg.entries.find(h);
+        if (it != reg.entries.end())
+            return it->second->state.load(std::memory_order_acquire);
+    }
+    const std::string dir = rtc_cache_dir();
+    if (dir.empty())
+        return RTC_NONE;
+    char name[64];
+    snprintf(name, sizeof name, "/gslnls_rtc_%016llx.bin", h);
+    return access((dir + name).c_str(), R_OK) == 0 ? RTC_READY : RTC_NONE;
+}
+
+inline std::shared_ptr<RtcEntry> rtc_request(const std::string &source, const std::vector<std::string> &exprs, bool wait)
+{
+    const unsigned long long h = rtc_key(source, exprs);
     RtcRegistry &reg = rtc_registry();
     std::shared_ptr<RtcEntry> ent;
     {

@@ -12,7 +12,7 @@
 #include "large_host.hpp"
 #include "expr_compile.hpp"
 #include "vm_model.hpp"
-#include "jit_host.hpp"
+#include "rtc_host.hpp"
 
 namespace gslnls
 {
@@ -26,6 +26,56 @@ struct VmDenseFit : DenseFit<ModelVM<P>>
 {
     using Base = DenseFit<ModelVM<P>>;
     VmProgram prog;
+    // native code of this program (rtc_host.hpp): one compiled unit per Jacobian kind, requested when a fit of that
+    // kind comes along -- in the background under GSLNLS_LOWER_AUTO (this fit runs on the interpreter, a later one
+    // finds the kernels), at once under GSLNLS_LOWER_JIT
+    int lowering = GSLNLS_LOWER_AUTO, nx_model = 1;
+    std::string rtc_src;
+    std::shared_ptr<RtcEntry> rtc[3];
+    void set_program(const VmProgram &pr, int lower, int nxm)
+    {
+        prog = pr;
+        lowering = lower;
+        nx_model = nxm;
+        rtc_src.clear();
+        for (int k = 0; k < 3; ++k)
+        {
+            rtc[k].reset();
+            this->native_step[k] = this->native_finalize[k] = nullptr;
+        }
+    }
+    // 0 or GSLNLS_E_UNSUPPORTED (native code was demanded and cannot be had)
+    int bind_native(int jac, const int *ci)
+    {
+        const int jm = jac ? 0 : (ci[5] ? 2 : 1);
+        this->native_step[jm] = this->native_finalize[jm] = nullptr;
+        if (lowering == GSLNLS_LOWER_VM)
+            return 0;
+        if (rtc_src.empty())
+            rtc_src = rtc_dense_source(prog, nx_model);
+        const std::string es = rtc_step_expr(jm, Base::T), ef = rtc_finalize_expr(jm, Base::T);
+        const bool wait = lowering == GSLNLS_LOWER_JIT;
+        if (!rtc[jm] || (wait && rtc[jm]->state.load() == RTC_BUILDING))
+            rtc[jm] = rtc_request(rtc_src, {es, ef}, wait);
+        RtcEntry &e = *rtc[jm];
+        const int st = e.state.load(std::memory_order_acquire);
+        std::string msg;
+        if (st == RTC_READY)
+        {
+            this->native_step[jm] = rtc_function(e, es, msg);
+            this->native_finalize[jm] = this->native_step[jm] ? rtc_function(e, ef, msg) : nullptr;
+            if (!this->native_finalize[jm])
+                this->native_step[jm] = nullptr;
+        }
+        else if (st == RTC_FAILED)
+            msg = e.log;
+        if (wait && !this->native_step[jm])
+        {
+            fprintf(stderr, "gslnls: native lowering failed: %s\n", msg.c_str());
+            return GSLNLS_E_UNSUPPORTED;
+        }
+        return 0;
+    }
     int upload()
     {
         GSLNLS_HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(c_vm_prog), &prog, sizeof(VmProgram)));
@@ -43,6 +93,8 @@ struct VmDenseFit : DenseFit<ModelVM<P>>
             return GSLNLS_E_UNSUPPORTED; // second derivatives too large for the program: use fvv = FALSE (finite differences)
         if (upload())
             return GSLNLS_E_NODEVICE;
+        if (const int rc = bind_native(jac, ci))
+            return rc;
         return Base::solve(jac, fvv, start, lupars, ci, cd, chunk, out);
     }
     int irls(int jac, int fvv, const double *start, const double *lupars, const int *ci, const double *cd, int loss_rho,
@@ -52,6 +104,8 @@ struct VmDenseFit : DenseFit<ModelVM<P>>
             return GSLNLS_E_UNSUPPORTED;
         if (upload())
             return GSLNLS_E_NODEVICE;
+        if (const int rc = bind_native(jac, ci))
+            return rc;
         return Base::irls(jac, fvv, start, lupars, ci, cd, loss_rho, loss_cc, out);
     }
     int mstart(int jac, int fvv, const double *start2p, const double *lupars, const int *ci, const double *cd,
@@ -67,6 +121,9 @@ struct VmDenseFit : DenseFit<ModelVM<P>>
     float time_pass(int jac, const double *theta, int reps) override
     {
         upload();
+        const int ci[15] = {0};
+        if (bind_native(jac, ci))
+            return -1.f;
         return Base::time_pass(jac, theta, reps);
     }
     int diagnostics(int jac, const double *theta, const int *ci, const double *cd, double *hat, double *cooks) override
@@ -78,15 +135,15 @@ struct VmDenseFit : DenseFit<ModelVM<P>>
 };
 
 template <int P>
-static DenseBase *make_vm_impl(const VmProgram &prog, const gslnls_model *fn, const double *y, int n, const double *swts,
-                          int *err)
+static DenseBase *make_vm_impl(const VmProgram &prog, int lowering, const gslnls_model *fn, const double *y, int n,
+                               const double *swts, int *err)
 {
     // interpreted expression problems are containers for any program with P parameters: parked ones are re-bound
     // (every DenseFit<ModelVM<P>> that exists is a VmDenseFit<P>: they are only created here)
     auto *d = fn->x_on_device ? nullptr : static_cast<VmDenseFit<P> *>(DenseFit<ModelVM<P>>::acquire());
     if (!d)
         d = new VmDenseFit<P>();
-    d->prog = prog;
+    d->set_program(prog, lowering, fn->nx > 0 ? fn->nx : 1);
     // the expression always sees VM_NX regressor columns; pad the missing ones with zeros
     gslnls_model padded = *fn;
     std::vector<double> xpad;
@@ -116,10 +173,10 @@ static DenseBase *make_vm_impl(const VmProgram &prog, const gslnls_model *fn, co
 
 #define GSLNLS_CAT2(a, b) a##b
 #define GSLNLS_CAT(a, b) GSLNLS_CAT2(a, b)
-DenseBase *GSLNLS_CAT(make_vm_p, GSLNLS_VM_P)(const VmProgram &prog, const gslnls_model *fn, const double *y, int n,
-                                              const double *swts, int *err)
+DenseBase *GSLNLS_CAT(make_vm_p, GSLNLS_VM_P)(const VmProgram &prog, int lowering, const gslnls_model *fn, const double *y,
+                                              int n, const double *swts, int *err)
 {
-    return make_vm_impl<GSLNLS_VM_P>(prog, fn, y, n, swts, err);
+    return make_vm_impl<GSLNLS_VM_P>(prog, lowering, fn, y, n, swts, err);
 }
 
 void GSLNLS_CAT(trim_vm_p, GSLNLS_VM_P)() { DenseFit<ModelVM<GSLNLS_VM_P>>::trim_pool(); }
@@ -127,7 +184,7 @@ void GSLNLS_CAT(trim_vm_p, GSLNLS_VM_P)() { DenseFit<ModelVM<GSLNLS_VM_P>>::trim
 #else // dispatcher
 
 #define GSLNLS_VM_DECL(k)                                                                                              \
-    DenseBase *make_vm_p##k(const VmProgram &, const gslnls_model *, const double *, int, const double *, int *);
+    DenseBase *make_vm_p##k(const VmProgram &, int, const gslnls_model *, const double *, int, const double *, int *);
 GSLNLS_VM_DECL(1) GSLNLS_VM_DECL(2) GSLNLS_VM_DECL(3) GSLNLS_VM_DECL(4) GSLNLS_VM_DECL(5) GSLNLS_VM_DECL(6)
 GSLNLS_VM_DECL(7) GSLNLS_VM_DECL(8) GSLNLS_VM_DECL(9)
 
@@ -155,47 +212,24 @@ DenseBase *make_dense_expr(const gslnls_model *fn, const double *y, int n, const
         *err = GSLNLS_E_UNSUPPORTED;
         return nullptr;
     }
-    // lowering: 0 auto (native code if this expression was built before, else the interpreter), 1 interpreter,
-    // 2 build native code now (hipcc child process, cached).  GSLNLS_LOWERING=vm|jit overrides.
+    // lowering: 0 auto (the interpreter now, native code -- compiled in process on a background thread -- for the fits
+    // that come after the build), 1 interpreter only, 2 native code now.  GSLNLS_LOWERING=vm|jit overrides.
     int mode = fn->lowering;
     if (const char *e = getenv("GSLNLS_LOWERING"))
         mode = !strcmp(e, "jit") ? GSLNLS_LOWER_JIT : (!strcmp(e, "vm") ? GSLNLS_LOWER_VM : mode);
-    if (mode != GSLNLS_LOWER_VM && !fn->x_on_device)
-    {
-        const int nxm = fn->nx > 0 ? fn->nx : 1;
-        std::string msg;
-        const std::string so = jit_artifact(prog, nxm, mode == GSLNLS_LOWER_JIT, msg);
-        jit_make_fn mk = so.empty() ? nullptr : jit_load(so, msg);
-        if (mk)
-        {
-            gslnls_model m = *fn;
-            std::vector<double> zeros;
-            if (fn->nx == 0)
-            {
-                zeros.assign((size_t)n, 0.0);
-                m.x = zeros.data();
-                m.nx = 1;
-            }
-            return mk(&m, y, n, swts, err);
-        }
-        if (mode == GSLNLS_LOWER_JIT)
-        {
-            fprintf(stderr, "gslnls: native lowering failed: %s\n", msg.c_str());
-            *err = GSLNLS_E_UNSUPPORTED;
-            return nullptr;
-        }
-    }
+    if (fn->x_on_device && mode == GSLNLS_LOWER_AUTO)
+        mode = GSLNLS_LOWER_VM;
     switch (fn->p)
     {
-    case 1: return make_vm_p1(prog, fn, y, n, swts, err);
-    case 2: return make_vm_p2(prog, fn, y, n, swts, err);
-    case 3: return make_vm_p3(prog, fn, y, n, swts, err);
-    case 4: return make_vm_p4(prog, fn, y, n, swts, err);
-    case 5: return make_vm_p5(prog, fn, y, n, swts, err);
-    case 6: return make_vm_p6(prog, fn, y, n, swts, err);
-    case 7: return make_vm_p7(prog, fn, y, n, swts, err);
-    case 8: return make_vm_p8(prog, fn, y, n, swts, err);
-    case 9: return make_vm_p9(prog, fn, y, n, swts, err);
+    case 1: return make_vm_p1(prog, mode, fn, y, n, swts, err);
+    case 2: return make_vm_p2(prog, mode, fn, y, n, swts, err);
+    case 3: return make_vm_p3(prog, mode, fn, y, n, swts, err);
+    case 4: return make_vm_p4(prog, mode, fn, y, n, swts, err);
+    case 5: return make_vm_p5(prog, mode, fn, y, n, swts, err);
+    case 6: return make_vm_p6(prog, mode, fn, y, n, swts, err);
+    case 7: return make_vm_p7(prog, mode, fn, y, n, swts, err);
+    case 8: return make_vm_p8(prog, mode, fn, y, n, swts, err);
+    case 9: return make_vm_p9(prog, mode, fn, y, n, swts, err);
     default:
         *err = GSLNLS_E_UNSUPPORTED;
         return nullptr;
@@ -207,7 +241,9 @@ DenseBase *make_dense_expr(const gslnls_model *fn, const double *y, int n, const
 } // namespace gslnls
 
 #ifndef GSLNLS_VM_P
-// ahead-of-time build of the native code for an expression (no device needed: hipcc cross-compiles)
+// ahead-of-time build of the native code of an expression (no device needed: the in-process compiler targets
+// gfx950 whatever the host): the step and finalize kernels for the analytic and the forward-difference Jacobian go
+// into the cache, where the first fit of any later process finds them
 extern "C" int gslnls_expr_build(const gslnls_model *fn, char *path_out, int path_cap)
 {
     using namespace gslnls;
@@ -221,15 +257,44 @@ extern "C" int gslnls_expr_build(const gslnls_model *fn, char *path_out, int pat
         fprintf(stderr, "gslnls: cannot lower model expression: %s\n", e.c_str());
         return GSLNLS_E_UNSUPPORTED;
     }
-    std::string msg;
-    const std::string so = jit_artifact(prog, fn->nx > 0 ? fn->nx : 1, true, msg);
-    if (so.empty() || !jit_load(so, msg))
-    {
-        fprintf(stderr, "gslnls: native lowering failed: %s\n", msg.c_str());
+    if (fn->p > 9)
         return GSLNLS_E_UNSUPPORTED;
+    const std::string src = rtc_dense_source(prog, fn->nx > 0 ? fn->nx : 1);
+    const int NV = 2 + fn->p * (fn->p + 1) / 2 + fn->p;
+    const int T = (NV <= 24) ? 512 : (NV <= 70 ? 256 : 128); // DenseFit<M>::T
+    std::string first;
+    for (int jm = 0; jm < 2; ++jm)
+    {
+        auto ent = rtc_request(src, {rtc_step_expr(jm, T), rtc_finalize_expr(jm, T)}, true);
+        if (ent->state.load() != RTC_READY)
+        {
+            fprintf(stderr, "gslnls: native lowering failed: %s\n", ent->log.c_str());
+            return GSLNLS_E_UNSUPPORTED;
+        }
+        if (jm == 0)
+            first = ent->cache_path;
     }
     if (path_out && path_cap > 0)
-        snprintf(path_out, (size_t)path_cap, "%s", so.c_str());
+        snprintf(path_out, (size_t)path_cap, "%s", first.c_str());
     return GSLNLS_SUCCESS;
+}
+
+// state of the native code of an expression model for one Jacobian kind (jac: 1 analytic, 0 forward differences):
+// 0 not requested yet, 1 being built, 2 ready (in memory or in the cache), -1 the build failed
+extern "C" int gslnls_expr_native_state(const gslnls_model *fn, int jac)
+{
+    using namespace gslnls;
+    if (!fn || fn->id != GSLNLS_MODEL_EXPR || !fn->expr || !fn->parnames || (fn->nx > 0 && !fn->xnames) || fn->nx > VM_NX ||
+        fn->p > 9)
+        return RTC_FAILED;
+    std::vector<std::string> pn(fn->parnames, fn->parnames + fn->p), vn(fn->xnames, fn->xnames + fn->nx);
+    VmProgram prog;
+    if (!compile_expression(fn->expr, pn, vn, prog).empty())
+        return RTC_FAILED;
+    const std::string src = rtc_dense_source(prog, fn->nx > 0 ? fn->nx : 1);
+    const int NV = 2 + fn->p * (fn->p + 1) / 2 + fn->p;
+    const int T = (NV <= 24) ? 512 : (NV <= 70 ? 256 : 128);
+    const int jm = jac ? 0 : 1;
+    return rtc_request_peek(src, {rtc_step_expr(jm, T), rtc_finalize_expr(jm, T)});
 }
 #endif

@@ -191,7 +191,7 @@ def _finish(out, res, trace, algorithm, n):
     out.update(niter=res.niter, conv=res.conv, status=_lib.strerror(res.conv), ssr=res.ssr, ssrtol=res.ssrtol,
                algorithm=_lib.lib().gslnls_algorithm_name(ALGORITHMS.index(algorithm)).decode(),
                neval=dict(f=res.neval[0], J=res.neval[1], fvv=res.neval[2]), info=res.info,
-               chisq_init=res.chisq_init, loop_ms=res.loop_ms, n_launches=res.n_launches, n_steps=res.n_steps, n=n,
+               chisq_init=res.chisq_init, loop_ms=res.loop_ms, n_launches=res.n_launches, n_steps=res.n_steps, code_path=res.code_path, n=n,
                jtj_cond=res.jtj_cond,
                irls=dict(irls_sigma=res.irls_sigma, irls_tol=res.irls_tol, irls_status=res.irls_status,
                          irls_niter=res.irls_niter, irls_conv=res.irls_status),
@@ -211,8 +211,10 @@ def gsl_nls(fn, data=None, start=None, algorithm="lm", control=None, jac=None, f
               (gslnls_amd/formula.py) uses it, any other expression is compiled (value + symbolic gradient);
               or an int registry id together with data = {'x': ..., 'y': ...}
     jac/fvv : True -> analytic derivatives on device (R: symbolic stats::deriv), None/False -> FD
-    lowering: compiled expressions only: "vm" interpreter, "jit" native code built by hipcc (cached),
-              "auto" = native code if already cached, else interpreter
+    lowering: compiled expressions only: "vm" interpreter; "jit" native code, compiled in process by the HIP runtime's
+              own compiler (hiprtc) before the fit, cached on disk; "auto" = interpreter for the first fit of a formula
+              while the native code is built on a background thread, native code for the fits after that.
+              fit["code_path"] says which one ran (0 hand-written model, 1 interpreter, 2 native, 3 native wide path)
     """
     if start is None:
         raise ValueError("starting values 'start' are required")

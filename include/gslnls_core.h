@@ -66,17 +66,23 @@ typedef struct gslnls_model
     int lowering;                /* GSLNLS_LOWER_AUTO / _VM / _JIT */
 } gslnls_model;
 
-/* how a GSLNLS_MODEL_EXPR reaches the device: interpreted per row (no latency), or printed as C++ and built by
-   hipcc into a cached shared object that instantiates the same kernels (runs like a hand-written model;
-   p <= 12).  AUTO uses the native build when the cache already holds it, the interpreter otherwise. */
+/* how a GSLNLS_MODEL_EXPR reaches the device: interpreted per row (no latency), or printed as a C++ row model and
+   compiled IN PROCESS (hiprtc: the compiler that ships with the HIP runtime -- no hipcc, no headers, no child process on
+   the host) into a code object that instantiates the same kernels, cached on disk by content hash; it then runs like a
+   hand-written model, with results identical bit for bit to the interpreter's.  AUTO: the first fit of a formula runs
+   interpreted and starts the build on a background thread, fits that come after the build use the native kernels.
+   VM: interpreter only.  JIT: build now (1-3 s once per formula and Jacobian kind), fail if that is impossible.
+   p > 9 (the wide path, MFMA J^T J tiles) always runs native code. */
 #define GSLNLS_LOWER_AUTO 0
 #define GSLNLS_LOWER_VM 1
 #define GSLNLS_LOWER_JIT 2
 
-/* Build (or find in the cache) the native code of an expression model ahead of time; needs hipcc but no
-   device.  The path of the shared object is copied to path_out.  Replaces nothing in the reference: the
-   analogue is the closure construction of R/nls.R:565,588-599, done once per formula. */
+/* Build (or find in the cache) the native code of an expression model ahead of time; needs no device and no compiler
+   beyond the HIP runtime's own.  The path of the cached code object (analytic-Jacobian unit) is copied to path_out.
+   Replaces nothing in the reference: the analogue is the closure construction of R/nls.R:565,588-599, done once per
+   formula.  gslnls_expr_native_state: 0 not requested, 1 being built, 2 ready, -1 failed (jac: 1 analytic, 0 forward). */
 int gslnls_expr_build(const gslnls_model *fn, char *path_out, int path_cap);
+int gslnls_expr_native_state(const gslnls_model *fn, int jac);
 
 /* mirrors the VECSXP C_nls returns (src/nls.c:632-812).  Pointers may be NULL to skip. */
 typedef struct gslnls_result
@@ -112,6 +118,9 @@ typedef struct gslnls_result
     double jtj_cond;
     int n_steps;      /* passes over the rows (trial steps incl. the initial point) the device ran for this call; equals
                          n_launches on the launch-per-step kernel, while the one-launch-per-fit kernel has n_launches = 1 */
+    int code_path;    /* which device code evaluated the model rows of the (last) solve: 0 hand-written row model,
+                         1 interpreted expression, 2 expression compiled in process (hiprtc), 3 the same on the wide path
+                         (p > 9: MFMA J^T J tiles) */
 } gslnls_result;
 
 /* Solver routing rule of the boundary.  control_int[4]: 0 qr (the R default), 1 cholesky, 2 svd (R/nls.R:702).
