@@ -120,6 +120,10 @@ _SIGNATURES = {
     "gslnls_set_interrupt_hook": (None, [C.c_void_p]),
     "gslnls_expr_build": (C.c_int, [C.POINTER(Model), C.c_char_p, C.c_int]),
     "gslnls_expr_native_state": (C.c_int, [C.POINTER(Model), C.c_int]),
+    "gslnls_expr_prefetch": (C.c_int, [C.POINTER(Model), C.c_int]),
+    "gslnls_shutdown": (None, []),
+    "gslnls_debug_wide_solve": (C.c_int, [C.c_int, DP, DP, C.c_double, DP, DP]),
+    "gslnls_debug_wide_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int, DP, DP]),
 }
 
 _lib = None
@@ -138,6 +142,10 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = L
+        # the background compiler of GSLNLS_LOWER_AUTO must be stopped before the C runtime tears the compiler's own
+        # static objects down (include/gslnls_core.h, gslnls_shutdown): Python's atexit runs long before that
+        import atexit
+        atexit.register(L.gslnls_shutdown)
     return _lib
 
 

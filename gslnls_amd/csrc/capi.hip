@@ -1102,4 +1102,6 @@ const char *gslnls_version(void) { return "gslnls-mi355x 0.1 (gfx950)"; }
 // diagnostic single-TU builds (make stamps) carry no expression lowering
 extern "C" int gslnls_expr_build(const gslnls_model *, char *, int) { return GSLNLS_E_UNSUPPORTED; }
 extern "C" int gslnls_expr_native_state(const gslnls_model *, int) { return -1; }
+extern "C" int gslnls_expr_prefetch(const gslnls_model *, int) { return -1; }
+extern "C" void gslnls_shutdown(void) {}
 #endif

@@ -288,7 +288,8 @@ struct ExprCompiler
 
     // emit: topological order, the value's closure first
     // fvv < 0: no third closure
-    bool emit(int value, const std::vector<int> &grads, int fvv, int p, int nx, VmProgram &out)
+    template <class Prog>
+    bool emit(int value, const std::vector<int> &grads, int fvv, int p, int nx, Prog &out)
     {
         memset(&out, 0, sizeof(out));
         out.p = p;
@@ -344,7 +345,8 @@ struct ExprCompiler
         const int ngrad = (int)order.size();
         if (fvv >= 0)
             visit(fvv);
-        if ((int)consts.size() > VM_MAX_CONST || (int)order.size() > VM_MAX_OPS)
+        if ((int)consts.size() > Prog::CAP_CONST || (int)order.size() > Prog::CAP_OPS ||
+            2 * p + nx + (int)consts.size() + (int)order.size() > 65535)
         {
             error = "expression too large for the device program";
             return false;
@@ -372,8 +374,11 @@ struct ExprCompiler
             out.a[i] = (unsigned short)slot(nd.a);
             out.b[i] = (unsigned short)slot(nd.b);
             // (the interpreter always reads both operands: a unary instruction names its operand twice)
-            const unsigned int wb = vm_is_binary(out.op[i]) ? out.b[i] : out.a[i];
-            out.word[i] = (unsigned int)out.op[i] | ((unsigned int)out.a[i] << 8) | (wb << 20);
+            if constexpr (sizeof(out.word) / sizeof(out.word[0]) > 1)
+            {
+                const unsigned int wb = vm_is_binary(out.op[i]) ? out.b[i] : out.a[i];
+                out.word[i] = (unsigned int)out.op[i] | ((unsigned int)out.a[i] << 8) | (wb << 20);
+            }
             slot_of[order[i]] = base + (int)i;
         }
         out.nops = ngrad;
@@ -387,13 +392,15 @@ struct ExprCompiler
     }
 };
 
-// rhs text + names -> program.  Returns "" on success or an error message.
-inline std::string compile_expression(const char *rhs, const std::vector<std::string> &parnames,
-                                      const std::vector<std::string> &varnames, VmProgram &out)
+// rhs text + names -> program.  Returns "" on success or an error message.  nx_slots: regressor slots of the program's
+// slot layout (the interpreter's kernels always carry VM_NX columns; the wide path as many as the formula names)
+template <class Prog>
+inline std::string compile_expression_t(const char *rhs, const std::vector<std::string> &parnames,
+                                        const std::vector<std::string> &varnames, int nx_slots, Prog &out)
 {
-    if ((int)parnames.size() > VM_MAX_P)
+    if ((int)parnames.size() > Prog::CAP_P)
         return "too many parameters for an expression model";
-    if ((int)varnames.size() > VM_NX)
+    if ((int)varnames.size() > nx_slots)
         return "too many regressors for an expression model";
     FParser fp(rhs);
     FNodeP ast = fp.parse();
@@ -422,13 +429,19 @@ inline std::string compile_expression(const char *rhs, const std::vector<std::st
         std::map<int, bool> dep;
         fvv = ec.op2(VM_ADD, fvv, ec.op2(VM_MUL, ec.vdir(j), ec.diff(g, j, dcache, dep)));
     }
-    if (ec.emit(value, grads, fvv, p, VM_NX, out))
+    if (ec.emit(value, grads, fvv, p, nx_slots, out))
         return "";
     // too large with the third closure: keep value + gradient (fvv then falls back to finite differences)
     ec.error.clear();
-    if (!ec.emit(value, grads, -1, p, VM_NX, out))
+    if (!ec.emit(value, grads, -1, p, nx_slots, out))
         return ec.error;
     return "";
+}
+
+inline std::string compile_expression(const char *rhs, const std::vector<std::string> &parnames,
+                                      const std::vector<std::string> &varnames, VmProgram &out)
+{
+    return compile_expression_t(rhs, parnames, varnames, VM_NX, out);
 }
 
 } // namespace gslnls

@@ -23,6 +23,8 @@ GSLNLS_EMBED(devmath, "devmath.hpp")
 GSLNLS_EMBED(models, "models.hpp")
 GSLNLS_EMBED(rowops, "rowops.hpp")
 GSLNLS_EMBED(dense_kernels, "dense_kernels.hpp")
+GSLNLS_EMBED(wide_core, "wide_core.hpp")
+GSLNLS_EMBED(wide_kernels, "wide_kernels.hpp")
 
 namespace gslnls
 {
@@ -35,6 +37,8 @@ const RtcHeader *rtc_embedded_headers(int *count)
         {"models.hpp", gslnls_rtc_models_begin, gslnls_rtc_models_end},
         {"rowops.hpp", gslnls_rtc_rowops_begin, gslnls_rtc_rowops_end},
         {"dense_kernels.hpp", gslnls_rtc_dense_kernels_begin, gslnls_rtc_dense_kernels_end},
+        {"wide_core.hpp", gslnls_rtc_wide_core_begin, gslnls_rtc_wide_core_end},
+        {"wide_kernels.hpp", gslnls_rtc_wide_kernels_begin, gslnls_rtc_wide_kernels_end},
     };
     *count = (int)(sizeof h / sizeof h[0]);
     return h;

@@ -63,7 +63,8 @@ inline std::string rtc_fmt_double(double v)
 
 // C++ text of instructions [0, upto) of the program; `sink` (value + gradient form of the wide path): gradient k is
 // handed to out.set(k, value) as soon as it exists instead of living in an array of P registers
-inline std::string rtc_emit_ops(const VmProgram &pr, int upto)
+template <class Prog>
+inline std::string rtc_emit_ops(const Prog &pr, int upto)
 {
     const int base = 2 * pr.p + pr.nx + pr.nconst;
     auto ref = [&](int slot) -> std::string {
@@ -102,7 +103,8 @@ inline std::string rtc_emit_ops(const VmProgram &pr, int upto)
 // struct ModelJit: the row-model interface of models.hpp for this program.  One interpreted instruction = one
 // statement, contraction off inside the bodies: a product and the sum that follows it stay two roundings, as in the
 // interpreter -- that is what makes the native and the interpreted fit agree bit for bit.
-inline std::string rtc_emit_model(const VmProgram &pr, int nx_model)
+template <class Prog>
+inline std::string rtc_emit_model(const Prog &pr, int nx_model)
 {
     const int base = 2 * pr.p + pr.nx + pr.nconst;
     auto ref = [&](int slot) -> std::string {
@@ -257,6 +259,8 @@ inline RtcApi &rtc_api()
     return api;
 }
 
+inline std::atomic<bool> &rtc_shutting_down();
+
 // one compiled translation unit: code object + the mangled names of the kernels that were asked for
 struct RtcUnit
 {
@@ -271,6 +275,11 @@ inline bool rtc_compile(const std::string &source, const std::vector<std::string
 {
     static std::mutex mu; // one compilation at a time per process
     std::lock_guard<std::mutex> lock(mu);
+    if (rtc_shutting_down().load())
+    {
+        log = "process is exiting";
+        return false;
+    }
     RtcApi &api = rtc_api();
     if (!api.load())
     {
@@ -450,8 +459,41 @@ inline double rtc_now()
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
+// Process exit: a compiler thread must not run into the teardown of comgr / LLVM (their static objects are destroyed
+// while the thread is still compiling: "LLVM ERROR", heap corruption or a hang -- all three seen).  rtc_at_exit turns
+// queued builds into no-ops and waits for the one in flight.  It has to run BEFORE LLVM's exit handlers, and those are
+// registered lazily, whenever a compile first touches a static: so (1) the host application calls gslnls_shutdown()
+// before it exits (the Python mirror registers it with atexit, the R shim calls it from .onUnload / at session end:
+// INTEGRATION.md) -- that is the guarantee; (2) as a net for hosts that do not, the same function is registered with
+// atexit() again after every finished compile, i.e. behind everything LLVM has registered so far.
+inline std::atomic<bool> &rtc_shutting_down()
+{
+    static std::atomic<bool> f{false};
+    return f;
+}
+inline void rtc_at_exit()
+{
+    if (rtc_shutting_down().exchange(true))
+        return;
+    RtcRegistry &reg = rtc_registry();
+    std::vector<std::shared_ptr<RtcEntry>> all;
+    {
+        std::lock_guard<std::mutex> lock(reg.mu);
+        for (auto &kv : reg.entries)
+            all.push_back(kv.second);
+    }
+    for (auto &e : all)
+        if (e->worker.joinable())
+            e->worker.join();
+}
+
 inline void rtc_build(RtcEntry *e, std::string source, std::vector<std::string> exprs)
 {
+    if (rtc_shutting_down().load())
+    {
+        e->state.store(RTC_FAILED, std::memory_order_release);
+        return;
+    }
     const double t0 = rtc_now();
     RtcUnit u;
     std::string log;
@@ -467,6 +509,9 @@ inline void rtc_build(RtcEntry *e, std::string source, std::vector<std::string> 
     }
     else
         e->state.store(RTC_FAILED, std::memory_order_release);
+    static std::atomic<int> nreg{0};
+    if (!rtc_shutting_down().load() && nreg.fetch_add(1) < 24) // (atexit guarantees 32 slots)
+        (void)atexit(rtc_at_exit);
 }
 
 // The code object of `source` (which must name every kernel in `exprs`).  wait: build now if it is neither in memory
@@ -552,8 +597,17 @@ inline std::shared_ptr<RtcEntry> rtc_request(const std::string &source, const st
         {
             if (wait)
                 rtc_build(ent.get(), source, exprs);
+            else if (!rtc_api().load())
+            {
+                ent->log = rtc_api().err;
+                ent->state.store(RTC_FAILED, std::memory_order_release);
+            }
             else
+            {
+                static const bool registered = (atexit(rtc_at_exit), true); // after hiprtc's own: runs before them
+                (void)registered;
                 ent->worker = std::thread(rtc_build, ent.get(), source, exprs);
+            }
         }
         st = ent->state.load(std::memory_order_acquire);
     }

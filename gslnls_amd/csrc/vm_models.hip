@@ -196,12 +196,26 @@ void trim_dense_expr()
     trim_vm_p1(); trim_vm_p2(); trim_vm_p3(); trim_vm_p4(); trim_vm_p5(); trim_vm_p6(); trim_vm_p7(); trim_vm_p8(); trim_vm_p9();
 }
 
+DenseBase *make_dense_wide(const gslnls_model *fn, const double *y, int n, const double *swts, int *err); // wide_models.hip
+
 DenseBase *make_dense_expr(const gslnls_model *fn, const double *y, int n, const double *swts, int *err)
 {
-    if (!fn->expr || !fn->parnames || (fn->nx > 0 && !fn->xnames) || fn->nx > VM_NX)
+    if (!fn->expr || !fn->parnames || (fn->nx > 0 && !fn->xnames) || fn->nx > WIDE_NX || fn->p < 1 || fn->p > WIDE_MAX_P)
     {
-        *err = GSLNLS_EINVAL;
+        *err = (fn->nx > WIDE_NX || fn->p > WIDE_MAX_P) ? GSLNLS_E_UNSUPPORTED : GSLNLS_EINVAL;
         return nullptr;
+    }
+    // more parameters than the register-resident state machine holds, or more data columns than the interpreter's rows
+    // carry: the wide path (J^T J on the matrix cores, kernels compiled in process)
+    if (fn->p > 9 || fn->nx > VM_NX)
+    {
+        const char *ev = getenv("GSLNLS_LOWERING");
+        if (fn->lowering == GSLNLS_LOWER_VM || (ev && !strcmp(ev, "vm")))
+        {
+            *err = GSLNLS_E_UNSUPPORTED; // the wide path has no interpreted form
+            return nullptr;
+        }
+        return make_dense_wide(fn, y, n, swts, err);
     }
     std::vector<std::string> pn(fn->parnames, fn->parnames + fn->p), vn(fn->xnames, fn->xnames + fn->nx);
     VmProgram prog;
@@ -244,11 +258,24 @@ DenseBase *make_dense_expr(const gslnls_model *fn, const double *y, int n, const
 // ahead-of-time build of the native code of an expression (no device needed: the in-process compiler targets
 // gfx950 whatever the host): the step and finalize kernels for the analytic and the forward-difference Jacobian go
 // into the cache, where the first fit of any later process finds them
+namespace gslnls
+{
+int wide_expr_build(const gslnls_model *fn, std::string &first_path); // wide_models.hip
+}
 extern "C" int gslnls_expr_build(const gslnls_model *fn, char *path_out, int path_cap)
 {
     using namespace gslnls;
-    if (!fn || fn->id != GSLNLS_MODEL_EXPR || !fn->expr || !fn->parnames || (fn->nx > 0 && !fn->xnames) || fn->nx > VM_NX)
+    if (!fn || fn->id != GSLNLS_MODEL_EXPR || !fn->expr || !fn->parnames || (fn->nx > 0 && !fn->xnames) || fn->nx > WIDE_NX ||
+        fn->p < 1 || fn->p > WIDE_MAX_P)
         return GSLNLS_EINVAL;
+    if (fn->p > 9 || fn->nx > VM_NX)
+    {
+        std::string path;
+        const int rc = wide_expr_build(fn, path);
+        if (rc == GSLNLS_SUCCESS && path_out && path_cap > 0)
+            snprintf(path_out, (size_t)path_cap, "%s", path.c_str());
+        return rc;
+    }
     std::vector<std::string> pn(fn->parnames, fn->parnames + fn->p), vn(fn->xnames, fn->xnames + fn->nx);
     VmProgram prog;
     const std::string e = compile_expression(fn->expr, pn, vn, prog);
@@ -257,8 +284,6 @@ extern "C" int gslnls_expr_build(const gslnls_model *fn, char *path_out, int pat
         fprintf(stderr, "gslnls: cannot lower model expression: %s\n", e.c_str());
         return GSLNLS_E_UNSUPPORTED;
     }
-    if (fn->p > 9)
-        return GSLNLS_E_UNSUPPORTED;
     const std::string src = rtc_dense_source(prog, fn->nx > 0 ? fn->nx : 1);
     const int NV = 2 + fn->p * (fn->p + 1) / 2 + fn->p;
     const int T = (NV <= 24) ? 512 : (NV <= 70 ? 256 : 128); // DenseFit<M>::T
@@ -296,5 +321,28 @@ extern "C" int gslnls_expr_native_state(const gslnls_model *fn, int jac)
     const int T = (NV <= 24) ? 512 : (NV <= 70 ? 256 : 128);
     const int jm = jac ? 0 : 1;
     return rtc_request_peek(src, {rtc_step_expr(jm, T), rtc_finalize_expr(jm, T)});
+}
+
+// stop the background compiler before the process exits (rtc_host.hpp, rtc_at_exit)
+extern "C" void gslnls_shutdown(void) { gslnls::rtc_at_exit(); }
+
+// start building the native code of an expression model on a background thread and return at once (what the first
+// GSLNLS_LOWER_AUTO fit does on its own; a front end can call this as soon as it has parsed the formula).  Returns the
+// state as gslnls_expr_native_state does.
+extern "C" int gslnls_expr_prefetch(const gslnls_model *fn, int jac)
+{
+    using namespace gslnls;
+    if (!fn || fn->id != GSLNLS_MODEL_EXPR || !fn->expr || !fn->parnames || (fn->nx > 0 && !fn->xnames) || fn->nx > VM_NX ||
+        fn->p > 9)
+        return RTC_FAILED;
+    std::vector<std::string> pn(fn->parnames, fn->parnames + fn->p), vn(fn->xnames, fn->xnames + fn->nx);
+    VmProgram prog;
+    if (!compile_expression(fn->expr, pn, vn, prog).empty())
+        return RTC_FAILED;
+    const std::string src = rtc_dense_source(prog, fn->nx > 0 ? fn->nx : 1);
+    const int NV = 2 + fn->p * (fn->p + 1) / 2 + fn->p;
+    const int T = (NV <= 24) ? 512 : (NV <= 70 ? 256 : 128);
+    const int jm = jac ? 0 : 1;
+    return rtc_request(src, {rtc_step_expr(jm, T), rtc_finalize_expr(jm, T)}, false)->state.load();
 }
 #endif

@@ -47,19 +47,27 @@ enum VmOp : unsigned char
     VM_SIGN
 };
 
-struct VmProgram
+template <int MAX_OPS, int MAX_CONST, int MAX_P, bool PACKED>
+struct VmProgramT
 {
+    static constexpr int CAP_OPS = MAX_OPS, CAP_CONST = MAX_CONST, CAP_P = MAX_P;
     int p, nx, nconst, nops, nvalue; // nvalue: instructions needed for the value alone; nops: value + gradient
     int nfvv;                        // value + gradient + second directional derivative (0: not available)
     int value_slot, fvv_slot;
-    int grad_slot[VM_MAX_P];
-    unsigned char op[VM_MAX_OPS];
-    unsigned short a[VM_MAX_OPS], b[VM_MAX_OPS];
+    int grad_slot[MAX_P];
+    unsigned char op[MAX_OPS];
+    unsigned short a[MAX_OPS], b[MAX_OPS];
     // the same instruction as one word for the interpreter: op | a << 8 | b << 20 (one scalar load instead of three
     // sub-word ones); op / a / b above stay the form the native lowering and the tests read
-    unsigned int word[VM_MAX_OPS];
-    double consts[VM_MAX_CONST];
+    unsigned int word[PACKED ? MAX_OPS : 1];
+    double consts[MAX_CONST];
 };
+// the interpreter's program (constant memory, slot numbers packed in 12 bits)
+using VmProgram = VmProgramT<VM_MAX_OPS, VM_MAX_CONST, VM_MAX_P, true>;
+// the wide path's program (p <= 64, up to WIDE_NX data columns): host side only -- it is never interpreted, only printed
+// as C++ for the in-process compiler (rtc_host.hpp), so its size is bounded by compile time, not by constant memory
+constexpr int WIDE_MAX_P = 64, WIDE_NX = 8, WIDE_MAX_OPS = 8192, WIDE_MAX_CONST = 256;
+using WideProgram = VmProgramT<WIDE_MAX_OPS, WIDE_MAX_CONST, WIDE_MAX_P, false>;
 static_assert(VM_MAX_SLOTS < 4096, "slot numbers are packed in 12 bits");
 
 GSLNLS_HD bool vm_is_binary(unsigned op) { return op <= VM_DIV || op == VM_POW; }

@@ -1,0 +1,94 @@
+// wide_models.hip -- the wide dense path (10 <= p <= 64): the statically compiled kernels of wide_host.hpp (reduce,
+// advance, the solve test hook) and the factory the expression dispatcher (vm_models.hip) calls.
+#include <hip/hip_runtime.h>
+#include <memory>
+#include <string>
+#include <vector>
+#include "../../include/gslnls_core.h"
+#include "expr_compile.hpp"
+#include "wide_host.hpp"
+
+namespace gslnls
+{
+
+DenseBase *make_dense_wide(const gslnls_model *fn, const double *y, int n, const double *swts, int *err)
+{
+    std::vector<std::string> pn(fn->parnames, fn->parnames + fn->p), vn(fn->xnames, fn->xnames + fn->nx);
+    auto *prog = new WideProgram;
+    const std::string e = compile_expression_t(fn->expr, pn, vn, fn->nx > 0 ? fn->nx : 1, *prog);
+    if (!e.empty())
+    {
+        fprintf(stderr, "gslnls: cannot lower model expression: %s\n", e.c_str());
+        delete prog;
+        *err = GSLNLS_E_UNSUPPORTED;
+        return nullptr;
+    }
+    auto *d = new WideFit();
+    *err = d->init(*prog, fn, y, n, swts);
+    delete prog;
+    if (*err != GSLNLS_SUCCESS)
+    {
+        delete d;
+        return nullptr;
+    }
+    return d;
+}
+
+// ahead-of-time build of the wide kernels of an expression (gslnls_expr_build): analytic + forward-difference units
+int wide_expr_build(const gslnls_model *fn, std::string &first_path)
+{
+    std::vector<std::string> pn(fn->parnames, fn->parnames + fn->p), vn(fn->xnames, fn->xnames + fn->nx);
+    auto prog = std::make_unique<WideProgram>();
+    const std::string e = compile_expression_t(fn->expr, pn, vn, fn->nx > 0 ? fn->nx : 1, *prog);
+    if (!e.empty())
+    {
+        fprintf(stderr, "gslnls: cannot lower model expression: %s\n", e.c_str());
+        return GSLNLS_E_UNSUPPORTED;
+    }
+    const std::string src = rtc_wide_source(*prog, fn->nx > 0 ? fn->nx : 1);
+    const int PW = 16 * ((fn->p + 15) / 16);
+    for (int jm = 0; jm < 2; ++jm)
+    {
+        auto ent = rtc_request(src, {rtc_wide_pass_expr(jm, PW), rtc_wide_finalize_expr(jm)}, true);
+        if (ent->state.load() != RTC_READY)
+        {
+            fprintf(stderr, "gslnls: native lowering failed: %s\n", ent->log.c_str());
+            return GSLNLS_E_UNSUPPORTED;
+        }
+        if (jm == 0)
+            first_path = ent->cache_path;
+    }
+    return GSLNLS_SUCCESS;
+}
+
+} // namespace gslnls
+
+extern "C" int gslnls_debug_wide_sums(gslnls_dense *h, int jac, int fdtype, const double *theta, double *totals)
+{
+    // (gslnls_dense is { DenseBase *impl; }: capi.hip)
+    struct Handle
+    {
+        gslnls::DenseBase *impl;
+    };
+    auto *w = h ? dynamic_cast<gslnls::WideFit *>(reinterpret_cast<Handle *>(h)->impl) : nullptr;
+    if (!w || !theta || !totals)
+        return GSLNLS_EINVAL;
+    return w->sums_at(jac, fdtype, theta, totals);
+}
+
+extern "C" int gslnls_debug_wide_solve(int p, const double *Ap, const double *diag, double mu, const double *rhs, double *sol)
+{
+    using namespace gslnls;
+    if (p < 1 || p > WP || !Ap || !diag || !rhs || !sol)
+        return GSLNLS_EINVAL;
+    const int na = p * (p + 1) / 2;
+    double *d = nullptr;
+    GSLNLS_HIP_OK(hipMalloc(&d, sizeof(double) * (size_t)(na + 3 * p)));
+    GSLNLS_HIP_OK(hipMemcpy(d, Ap, sizeof(double) * na, hipMemcpyHostToDevice));
+    GSLNLS_HIP_OK(hipMemcpy(d + na, diag, sizeof(double) * p, hipMemcpyHostToDevice));
+    GSLNLS_HIP_OK(hipMemcpy(d + na + p, rhs, sizeof(double) * p, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(wide_solve_debug_kernel, dim3(1), dim3(64), 0, 0, p, d, d + na, mu, d + na + p, d + na + 2 * p);
+    GSLNLS_HIP_OK(hipMemcpy(sol, d + na + 2 * p, sizeof(double) * p, hipMemcpyDeviceToHost));
+    hipFree(d);
+    return GSLNLS_SUCCESS;
+}

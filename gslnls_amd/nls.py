@@ -238,9 +238,8 @@ def gsl_nls(fn, data=None, start=None, algorithm="lm", control=None, jac=None, f
             missing = [v for v in xnames if v not in data]
             if missing:
                 raise ValueError("formula symbols %s are neither parameters nor data columns" % missing)
-            if p > 12 or len(xnames) > 3 or (p > 9 and lowering != "jit"):
-                raise NotImplementedError("expression models support p <= 9 (p <= 12 with lowering='jit') and <= 3 "
-                                          "data columns: %s" % fn)
+            if p > 64 or len(xnames) > 8:
+                raise NotImplementedError("expression models support p <= 64 and <= 8 data columns: %s" % fn)
             mid, order = _lib.MODEL_EXPR, list(range(p))
             expr_text = fn.split("~", 1)[1].strip()
         else:

@@ -83,6 +83,13 @@ typedef struct gslnls_model
    formula.  gslnls_expr_native_state: 0 not requested, 1 being built, 2 ready, -1 failed (jac: 1 analytic, 0 forward). */
 int gslnls_expr_build(const gslnls_model *fn, char *path_out, int path_cap);
 int gslnls_expr_native_state(const gslnls_model *fn, int jac);
+/* start the build on a background thread and return at once (what the first GSLNLS_LOWER_AUTO fit does by itself) */
+int gslnls_expr_prefetch(const gslnls_model *fn, int jac);
+/* Call before the process exits when GSLNLS_LOWER_AUTO or gslnls_expr_prefetch may have started background builds:
+   queued builds are dropped, the one in flight is waited for (<= a few seconds).  A compiler thread that is still
+   running when the C runtime tears down the compiler's own static objects takes the process with it.  Idempotent;
+   afterwards new formulas are served by the interpreter (or built synchronously under GSLNLS_LOWER_JIT). */
+void gslnls_shutdown(void);
 
 /* mirrors the VECSXP C_nls returns (src/nls.c:632-812).  Pointers may be NULL to skip. */
 typedef struct gslnls_result
@@ -334,6 +341,15 @@ gslnls_large *gslnls_large_create_sparse(int n, int p, const double *y, const do
  * non-zero return abandons the fit with GSLNLS_E_INTERRUPTED.  The R shim installs a wrapper around
  * R_CheckUserInterrupt (the reference relies on R_ExecWithCleanup, src/nls.c:61, NEWS.md 1.1.1). */
 void gslnls_set_interrupt_hook(int (*check)(void));
+
+/* ---- test hooks ------------------------------------------------------------------------- */
+/* the damped solve (J^T J + mu D^2) sol = rhs of the wide path (p <= 64, packed lower triangle) on the device: GSL's
+ * pivoted modified Cholesky (gsl_linalg_mcholesky_*; multifit_nlinear/cholesky.c) spread over one wavefront */
+int gslnls_debug_wide_solve(int p, const double *Ap, const double *diag, double mu, const double *rhs, double *sol);
+/* the sums of one pass over the rows of a wide problem (p > 9) at theta: totals[0] = ssr, [1] = non-finite flag,
+ * then the packed lower triangle of J^T J (p (p + 1) / 2, row by row) and J^T f (p); jac: 1 analytic, 0 finite
+ * differences (fdtype: 0 forward, 1 central) */
+int gslnls_debug_wide_sums(gslnls_dense *h, int jac, int fdtype, const double *theta, double *totals);
 
 /* ---- introspection ---------------------------------------------------------------------- */
 const char *gslnls_strerror(int code);     /* gsl_strerror strings, App. C.4 */

@@ -6,6 +6,8 @@ import json
 import os
 
 import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import pytest
 
 from gslnls_amd import formula as F
@@ -111,6 +113,39 @@ def test_native_lowering_builds_without_a_device(tmp_path, monkeypatch):
     bad = _lib.Model(_lib.MODEL_EXPR, 1, 1, None, 0)
     keep3 = _lib.set_expr(bad, "a*foo(x)", ["a"], ["x"], "jit")  # noqa: F841
     assert _lib.lib().gslnls_expr_build(C.byref(bad), buf, 512) == _lib.E_UNSUPPORTED
+
+
+def test_process_exit_with_queued_background_builds_is_clean(tmp_path):
+    """GSLNLS_LOWER_AUTO starts builds on a background thread; a process that exits while dozens are queued and one is
+    inside the compiler must neither crash nor hang (seen before gslnls_shutdown existed: "LLVM ERROR", heap
+    corruption, or a hang, as LLVM's static objects were destroyed under the compiling thread).  The Python mirror
+    registers gslnls_shutdown with atexit; queued builds become no-ops, the one in flight is waited for."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes as C, sys, os, time
+sys.path.insert(0, %r)
+from gslnls_amd import _lib
+L = _lib.lib()
+keep = []
+for k in range(40):
+    m = _lib.Model(_lib.MODEL_EXPR, 3, 1, None, 0)
+    keep.append((m, _lib.set_expr(m, "a*exp(-b*x) + c*%%d" %% (k + 2), ["a", "b", "c"], ["x"], "auto")))
+    st = L.gslnls_expr_prefetch(C.byref(m), 1)
+assert st == 1, st
+time.sleep(float(sys.argv[1]))
+print("leaving", flush=True)
+""" % (ROOT,)
+    for delay in ("0.05", "0.6"):
+        out = subprocess.run([sys.executable, "-c", code, delay], capture_output=True, text=True, timeout=120,
+                             env=dict(os.environ, GSLNLS_JIT_CACHE=str(tmp_path)))
+        assert out.returncode == 0, (delay, out.returncode, out.stderr[-1500:])
+        assert "leaving" in out.stdout and "LLVM ERROR" not in out.stderr
+    # at most the builds that got through before the exit are in the cache -- and every file there is whole
+    from gslnls_amd import _lib  # noqa: F401
+    for f in os.listdir(tmp_path):
+        if f.endswith(".bin"):
+            assert open(os.path.join(tmp_path, f), "rb").read(8) == b"GSLRTC1\n"
 
 
 @pytest.mark.parametrize("pb", PROBLEMS, ids=[p["name"] for p in PROBLEMS])

@@ -1,0 +1,235 @@
+"""GPU parity tests of the wide dense path: gsl_nls() with 10 <= p <= 64 parameters (the reference takes any p:
+src/nls.c:266, R/nls.R:588-599).  J^T J is accumulated on the matrix cores (v_mfma_f64_16x16x4_f64 tiles,
+csrc/wide_kernels.hpp), the p x p algebra of a step runs on one workgroup (csrc/wide_core.hpp), the row model is the
+formula compiled in process.  Bars: the oracle (same algorithm, model and Jacobian by numpy): identical iteration
+counts with the analytic Jacobian, coefficients to 1e-6 relative."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import gslnls_amd
+    from gslnls_amd import _lib
+    assert _lib.lib().gslnls_device_count() >= 1, "no MI355X visible: the HIP path cannot be tested"
+    return gslnls_amd
+
+
+def _packed(A):
+    p = A.shape[0]
+    return np.ascontiguousarray(np.concatenate([A[i, :i + 1] for i in range(p)]))
+
+
+@pytest.mark.parametrize("p", [1, 2, 10, 16, 17, 33, 48, 64])
+def test_wide_damped_solve_matches_the_oracles_modified_cholesky(amd, gslref, p):
+    """(J^T J + mu D^2) v = -g on one wavefront against gsl_linalg_mcholesky as restated by the oracle: well
+    conditioned, rank deficient (the modification kicks in) and badly scaled (pivoting matters) matrices"""
+    from gslnls_amd import _lib
+    L = _lib.lib()
+    rng = np.random.Generator(np.random.PCG64(100 + p))
+    for case in ("spd", "rank_deficient", "badly_scaled", "zero_column"):
+        n = 4 * p + 3
+        J = rng.standard_normal((n, p))
+        if case == "rank_deficient" and p > 2:
+            J[:, p - 1] = J[:, 0] + J[:, 1]
+        if case == "badly_scaled":
+            J *= 10.0 ** rng.uniform(-6, 6, p)
+        if case == "zero_column":
+            J[:, p // 2] = 0.0
+        A = J.T @ J
+        diag = np.sqrt(np.maximum(np.diag(A), 1e-300))
+        mu = 1e-3 if case != "rank_deficient" else 1e-14
+        rhs = -(J.T @ rng.standard_normal(n))
+        sol = np.zeros(p)
+        rc = L.gslnls_debug_wide_solve(p, _packed(A).ctypes.data_as(_lib.DP), diag.ctypes.data_as(_lib.DP), mu,
+                                       rhs.ctypes.data_as(_lib.DP), sol.ctypes.data_as(_lib.DP))
+        assert rc == 0
+        M = np.ascontiguousarray(A + mu * np.diag(diag * diag))
+        perm = np.zeros(p, dtype=np.int32)
+        G = gslref.lib()
+        assert G.gslref_mcholesky_decomp(p, M.ctypes.data_as(_lib.DP), perm.ctypes.data_as(_lib.IP)) == 0
+        ref = np.zeros(p)
+        assert G.gslref_mcholesky_solve(p, M.ctypes.data_as(_lib.DP), perm.ctypes.data_as(_lib.IP),
+                                        rhs.ctypes.data_as(_lib.DP), ref.ctypes.data_as(_lib.DP)) == 0
+        scale = np.max(np.abs(ref)) + 1e-300
+        if case == "rank_deficient" and p > 2:
+            # the component along the null vector is decided by round-off (mu = 1e-14): compare what the system sees
+            Mfull = A + mu * np.diag(diag * diag)
+            assert np.max(np.abs(Mfull @ (sol - ref))) <= 1e-9 * np.max(np.abs(rhs)), (case, p)
+        else:
+            tol = 1e-9 if case in ("spd", "zero_column") else 1e-6
+            assert np.max(np.abs(sol - ref)) <= tol * scale, (case, p, np.max(np.abs(sol - ref)) / scale)
+
+
+def gaussians_problem(ng, extra, n, seed, noise=0.05, pert=0.02):
+    """sum of ng Gaussian peaks (+ constant, + slope): p = 3 ng + extra"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x = np.linspace(0.0, 10.0 * ng, n)
+    amp = rng.uniform(2.0, 6.0, ng)
+    mid = 10.0 * np.arange(ng) + rng.uniform(3.0, 7.0, ng)
+    wid = rng.uniform(1.2, 2.4, ng)
+    truth = np.stack([amp, mid, wid], axis=1).reshape(-1)
+    names, terms = [], []
+    for k in range(1, ng + 1):
+        names += ["a%d" % k, "m%d" % k, "s%d" % k]
+        terms.append("a%d*exp(-(x-m%d)^2/s%d^2)" % (k, k, k))
+    if extra >= 1:
+        names.append("c0")
+        terms.append("c0")
+        truth = np.append(truth, 0.5)
+    if extra >= 2:
+        names.append("c1")
+        terms.append("c1*x")
+        truth = np.append(truth, 0.01)
+
+    def model(th):
+        m = sum(th[3 * k] * np.exp(-(x - th[3 * k + 1]) ** 2 / th[3 * k + 2] ** 2) for k in range(ng))
+        if extra >= 1:
+            m = m + th[3 * ng]
+        if extra >= 2:
+            m = m + th[3 * ng + 1] * x
+        return m
+
+    def jac(th):
+        J = np.zeros((n, len(truth)))
+        for k in range(ng):
+            a, m, s = th[3 * k:3 * k + 3]
+            u = x - m
+            e = np.exp(-u * u / (s * s))
+            J[:, 3 * k] = e
+            J[:, 3 * k + 1] = a * e * 2 * u / (s * s)
+            J[:, 3 * k + 2] = a * e * 2 * u * u / (s ** 3)
+        if extra >= 1:
+            J[:, 3 * ng] = 1.0
+        if extra >= 2:
+            J[:, 3 * ng + 1] = x
+        return J
+    y = model(truth) + noise * rng.standard_normal(n)
+    sign = np.where(np.arange(len(truth)) % 2 == 0, 1.0, -1.0)
+    start = truth * (1.0 + pert * sign)
+    return dict(x=x, y=y, truth=truth, start=start, names=names, formula="y ~ " + " + ".join(terms), model=model, jac=jac)
+
+
+@pytest.mark.parametrize("ng,extra,n", [(4, 0, 1000), (5, 1, 4097), (10, 2, 70_001), (11, 0, 3000), (16, 0, 5000), (21, 1, 9999)],
+                         ids=["p12", "p16", "p32", "p33", "p48", "p64"])
+def test_wide_pass_sums_match_numpy(amd, ng, extra, n):
+    """one pass over the rows: ssr, J^T J (MFMA tiles, every lower-triangle block) and J^T f against numpy, for the
+    analytic Jacobian and for forward / central differences; ragged n (not a multiple of the 64-row tile)"""
+    from gslnls_amd import _lib
+    q = gaussians_problem(ng, extra, n, seed=40 + ng)
+    p = len(q["truth"])
+    prob = amd.DenseProblem(_lib.MODEL_EXPR, p, q["x"], q["y"], expr=q["formula"].split("~")[1].strip(),
+                            parnames=q["names"], xnames=["x"], lowering="jit")
+    th = q["start"]
+    f = q["model"](th) - q["y"]
+    J = q["jac"](th)
+    A = J.T @ J
+    NV = 2 + p * (p + 1) // 2 + p
+    for jac, fd, rtol in ((1, 0, 1e-11), (0, 0, 1e-5), (0, 1, 1e-7)):
+        tot = np.zeros(NV)
+        assert _lib.lib().gslnls_debug_wide_sums(prob._h, jac, fd, th.ctypes.data_as(_lib.DP), tot.ctypes.data_as(_lib.DP)) == 0
+        assert abs(tot[0] - f @ f) <= 1e-11 * (f @ f) and tot[1] == 0.0
+        Ap = tot[2:2 + p * (p + 1) // 2]
+        scale = np.sqrt(np.outer(np.diag(A), np.diag(A)))
+        got = np.zeros((p, p))
+        got[np.tril_indices(p)] = Ap
+        err = np.abs(got - np.tril(A)) / scale
+        assert err.max() <= rtol, (jac, fd, err.max(), np.unravel_index(err.argmax(), err.shape))
+        g = tot[2 + p * (p + 1) // 2:]
+        assert np.max(np.abs(g - J.T @ f) / (np.sqrt(np.diag(A)) * np.sqrt(f @ f))) <= rtol
+    prob.close()
+
+
+@pytest.mark.parametrize("ng,extra,n", [(5, 1, 100_000), (10, 2, 100_000), (4, 0, 4000), (11, 0, 20_000), (21, 1, 30_000)],
+                         ids=["p16", "p32", "p12", "p33", "p64"])
+def test_wide_fit_matches_oracle_with_the_analytic_jacobian(amd, gslref, ng, extra, n):
+    """gsl_nls() on a sum-of-Gaussians formula: same iteration count as the oracle, coefficients to 1e-6, ssr to 1e-9,
+    covariance to 1e-5; code_path 3 = the wide path ran"""
+    q = gaussians_problem(ng, extra, n, seed=7 + ng, pert=0.01 if ng > 20 else 0.02)
+    p = len(q["truth"])
+    fit = amd.gsl_nls(q["formula"], data=dict(x=q["x"], y=q["y"]), start=dict(zip(q["names"], q["start"])), jac=True,
+                      control=dict(solver="cholesky"), trace=True)
+    ref = gslref.nls(n, p, q["start"], fn=lambda th: q["model"](th) - q["y"], jac=q["jac"],
+                     ctrl=gslref.control(solver="cholesky"))
+    assert fit["code_path"] == 3
+    assert fit["conv"] == 0 and ref["conv"] == 0
+    assert fit["niter"] == ref["niter"], (fit["niter"], ref["niter"])
+    assert np.allclose(fit["par"], ref["par"], rtol=1e-6, atol=1e-9)
+    assert abs(fit["ssr"] - ref["ssr"]) <= 1e-9 * ref["ssr"]
+    # (the last iterations sit at round-off: a trial whose ssr differs in the last bit is accepted here and rejected
+    # there, or the other way round)
+    # (... up to a whole ladder of 16 rejections in the last iteration)
+    assert abs(fit["neval"]["f"] - ref["neval"]["f"]) <= 16 and abs(fit["neval"]["J"] - ref["neval"]["J"]) <= 1
+    assert np.allclose(fit["covar"], ref["covar"], rtol=1e-5, atol=1e-12)
+    # returned vectors: weighted residual and Jacobian at the final point, R layout
+    assert np.allclose(fit["resid"], q["model"](fit["par"]) - q["y"], rtol=0, atol=1e-10)
+    assert np.allclose(fit["grad"], q["jac"](fit["par"]), rtol=1e-9, atol=1e-12)
+    assert np.allclose(fit["par"], q["truth"], rtol=5e-2, atol=5e-2)
+    # trace: row 0 = start, last row = the result
+    assert np.allclose(fit["partrace"][0], q["start"]) and np.allclose(fit["partrace"][fit["niter"]], fit["par"])
+    assert abs(fit["ssrtrace"][fit["niter"]] - fit["ssr"]) <= 1e-12 * fit["ssr"]
+
+
+@pytest.mark.parametrize("fdtype", ["forward", "center"])
+def test_wide_fit_with_finite_difference_jacobian_weights_and_bounds(amd, gslref, fdtype):
+    """p = 16, forward / central differences (src/fdjac.c), observation weights and box constraints through the wide
+    path against the oracle driven by the same numpy model"""
+    q = gaussians_problem(5, 1, 20_000, seed=3)
+    p, n = 16, 20_000
+    rng = np.random.Generator(np.random.PCG64(5))
+    w = rng.uniform(0.5, 2.0, n)
+    lower = np.where(np.arange(p) % 3 == 2, 0.5, -np.inf)       # widths bounded below
+    upper = np.full(p, np.inf)
+    upper[0] = max(q["truth"][0], q["start"][0]) * 0.999         # one bound that ends up active
+    q["start"][0] = min(q["start"][0], upper[0] * 0.99)
+    ctrl = dict(solver="cholesky", fdtype=fdtype)
+    fit = amd.gsl_nls(q["formula"], data=dict(x=q["x"], y=q["y"]), start=dict(zip(q["names"], q["start"])), jac=False,
+                      weights=w, lower=dict(zip(q["names"], lower)), upper=dict(zip(q["names"], upper)), control=ctrl)
+    ref = gslref.nls(n, p, q["start"], fn=lambda th: q["model"](th) - q["y"], ctrl=gslref.control(**ctrl), weights=w,
+                     lower=lower, upper=upper)
+    assert fit["code_path"] == 3 and fit["conv"] == ref["conv"]
+    assert abs(fit["niter"] - ref["niter"]) <= max(1, ref["niter"] // 10)
+    assert np.allclose(fit["par"], ref["par"], rtol=1e-5, atol=1e-8)
+    assert abs(fit["ssr"] - ref["ssr"]) <= 1e-8 * ref["ssr"]
+    assert fit["par"][0] <= upper[0] + 1e-12
+
+
+def test_wide_path_takes_more_than_three_data_columns(amd, gslref):
+    """five regressors, p = 6: beyond the interpreter's three columns, so the wide path serves it"""
+    rng = np.random.Generator(np.random.PCG64(21))
+    n = 5000
+    X = rng.uniform(0.5, 2.0, (n, 5))
+    truth = np.array([1.5, 0.7, -0.4, 0.9, 0.3, 2.0])
+    names = ["b0", "b1", "b2", "b3", "b4", "b5"]
+
+    def model(th):
+        return th[0] * np.exp(th[1] * X[:, 0] + th[2] * X[:, 1]) + th[3] * X[:, 2] * X[:, 3] + th[4] * X[:, 4] ** 2 + th[5]
+    y = model(truth) + 0.01 * rng.standard_normal(n)
+    data = dict(y=y, **{"x%d" % k: X[:, k] for k in range(5)})
+    formula = "y ~ b0*exp(b1*x0 + b2*x1) + b3*x2*x3 + b4*x4^2 + b5"
+    start = truth * 1.1
+    fit = amd.gsl_nls(formula, data=data, start=dict(zip(names, start)), jac=True, control=dict(solver="cholesky"))
+    ref = gslref.nls(n, 6, start, fn=lambda th: model(th) - y, ctrl=gslref.control(solver="cholesky"))
+    assert fit["code_path"] == 3 and fit["conv"] == 0 and ref["conv"] == 0
+    assert np.allclose(fit["par"], ref["par"], rtol=1e-6)
+    assert np.allclose(fit["par"], truth, rtol=2e-2, atol=2e-2)
+
+
+def test_wide_lmaccel_runs_the_acceleration_pass(amd, gslref):
+    """algorithm = lmaccel on p = 16: the PH_FVV pass (J^T fvv only) with finite-difference and with symbolic second
+    directional derivatives against the oracle"""
+    q = gaussians_problem(5, 1, 8000, seed=9)
+    p, n = 16, 8000
+    ref = gslref.nls(n, p, q["start"], fn=lambda th: q["model"](th) - q["y"], jac=q["jac"], algorithm="lmaccel",
+                     ctrl=gslref.control(solver="cholesky"))
+    for fvv in (False, True):
+        fit = amd.gsl_nls(q["formula"], data=dict(x=q["x"], y=q["y"]), start=dict(zip(q["names"], q["start"])), jac=True,
+                          fvv=fvv, algorithm="lmaccel", control=dict(solver="cholesky"))
+        assert fit["code_path"] == 3 and fit["conv"] == 0 and ref["conv"] == 0
+        assert np.allclose(fit["par"], ref["par"], rtol=1e-6, atol=1e-9)
+        if not fvv:
+            assert fit["niter"] == ref["niter"]
