@@ -780,16 +780,12 @@ struct GlmLargeOps : LargeOps
     }
     int full_jtj(const double *, double *jtj) override
     {
-        const int Gj = (P == 64) ? 1024 : 512; // the MFMA kernel: four 256-thread workgroups per CU
+        constexpr int Gj = 1024; // four 256-thread workgroups per CU
         if (!d_jtjpart)
             GSLNLS_HIP_OK(hipMalloc(&d_jtjpart, sizeof(double) * (size_t)P * P * Gj + sizeof(double) * P * P));
         double *d_out = d_jtjpart + (size_t)P * P * Gj;
-        if (P == 64)
-            hipLaunchKernelGGL((glm_jtj_mfma64_kernel<256>), dim3(Gj), dim3(256), 0, st, d_A, d_m[cur], (long long)n,
-                               d_jtjpart); // matrix cores
-        else
-            hipLaunchKernelGGL((glm_jtj_kernel<P, 256>), dim3(Gj), dim3(256), 0, st, d_A, d_m[cur], (long long)n,
-                               d_jtjpart);
+        // matrix cores for every p the family is built for (16, 32, 48, 64)
+        hipLaunchKernelGGL((glm_jtj_mfma_kernel<P, 256>), dim3(Gj), dim3(256), 0, st, d_A, d_m[cur], (long long)n, d_jtjpart);
         hipLaunchKernelGGL(large_reduce_kernel, dim3(P * P), dim3(64), 0, st, d_jtjpart, P * P, Gj, d_out);
         GSLNLS_HIP_OK(hipMemcpyAsync(jtj, d_out, sizeof(double) * P * P, hipMemcpyDeviceToHost, st));
         GSLNLS_HIP_OK(hipStreamSynchronize(st));

@@ -233,121 +233,89 @@ __global__ __launch_bounds__(T) void glm_pass_kernel(GlmArgs a)
     }
 }
 
-// full J^T J = A^T diag(m^2) A for the covariance at the end (gsl_multilarge_nlinear_covar,
-// src/nls_large.c:255): one workgroup per row chunk, each thread owns a (P/16)^2 block.  Plain
-// fp64 FMA; the MFMA tall-skinny form is the next step for p = 64.
-template <int P, int T>
-__global__ __launch_bounds__(T) void glm_jtj_kernel(const double *A, const double *m, long long n, double *partials)
-{
-    constexpr int TR = 32; // rows per LDS tile
-    __shared__ double tileA[TR][P + 1];
-    constexpr int B = P / 16; // each thread: B x B outputs, 16 x 16 thread grid
-    static_assert(T == 256, "16 x 16 threads");
-    const int ti = threadIdx.x / 16, tj = threadIdx.x % 16;
-    double acc[B][B];
-#pragma unroll
-    for (int i = 0; i < B; ++i)
-#pragma unroll
-        for (int j = 0; j < B; ++j)
-            acc[i][j] = 0.0;
-    const long long ntile = (n + TR - 1) / TR;
-    for (long long t = blockIdx.x; t < ntile; t += gridDim.x)
-    {
-        const long long r0 = t * TR;
-        for (int e = threadIdx.x; e < TR * P; e += T)
-        {
-            const int r = e / P, cc = e % P;
-            const long long row = r0 + r;
-            tileA[r][cc] = (row < n) ? A[row * P + cc] * m[row] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int r = 0; r < TR; ++r)
-        {
-            double ai[B], aj[B];
-#pragma unroll
-            for (int i = 0; i < B; ++i)
-            {
-                ai[i] = tileA[r][ti * B + i];
-                aj[i] = tileA[r][tj * B + i];
-            }
-#pragma unroll
-            for (int i = 0; i < B; ++i)
-#pragma unroll
-                for (int j = 0; j < B; ++j)
-                    acc[i][j] += ai[i] * aj[j];
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < B; ++i)
-#pragma unroll
-        for (int j = 0; j < B; ++j)
-            partials[((size_t)(ti * B + i) * P + (tj * B + j)) * gridDim.x + blockIdx.x] = acc[i][j];
-}
-
 // ------------------------------------------------------------------------------------------------
-// K11: J^T J = A^T diag(m^2) A for p = 64 on the matrix cores (north_star: "MFMA tall-skinny GEMM for
-// J^T J only when p fills a 16-wide tile").  v_mfma_f64_16x16x4_f64: D(16x16) += A'(16x4) B(4x16), operand
-// layout probed on gfx950 (scripts/mfma_probe): lane l supplies A'[l%16][l/16] and B[l/16][l%16] and holds
-// D[4r + l/16][l%16] in result register r.
-// One wave instruction covers 4 consecutive rows: lane l (k = l/16, i = l%16) loads J[row k][2i, 2i+1] and
-// J[row k][32 + 2i, 33 + 2i] (two 16-byte loads, each dense over the wave) and scales by m[row].
-// With the logical column order (b, i) -> physical column c(b, i) = 2i + (b & 1) + 32 (b >> 1) the SAME register is
-// the A' operand of block row b and the B operand of block column b, so the 4 loaded values feed all 10
-// lower-triangle blocks: acc[ba][bb][r] at lane l is J^T J[c(ba, 4r + l/16)][c(bb, l%16)].
+// K11: J^T J = A^T diag(m^2) A on the matrix cores for p = 16, 32, 48, 64 (north_star: "MFMA tall-skinny GEMM for
+// J^T J only when p fills a 16-wide tile"; the reference densifies and calls dsyrk / spdgemm,
+// src/nls_large.c:633,644-647).  v_mfma_f64_16x16x4_f64: D(16x16) += A'(16x4) B(4x16), operand layout probed on
+// gfx950 (scripts/mfma_probe): lane l supplies A'[l%16][l/16] and B[l/16][l%16] and holds D[4r + l/16][l%16] in
+// result register r.
+// One wave instruction covers 4 consecutive rows: lane l (k = l/16, i = l%16) needs one entry of row k from each of
+// the NB = P/16 column blocks.  Blocks are taken in pairs: a 16-byte load of J[row k][32 q + 2i, 32 q + 2i + 1]
+// serves the blocks 2q and 2q+1 (every load instruction is dense over the wave: sixteen lanes read 256 contiguous
+// bytes of a row), an odd last block is an 8-byte load of J[row k][16 (NB-1) + i].  So logical column (b, i) lives at
+// physical column c(b, i) = 32 (b >> 1) + 2i + (b & 1) for the paired blocks and 16 b + i for an unpaired last one.
+// The SAME register is the A' operand of block row b and the B operand of block column b, so the NB loaded values feed
+// all NB (NB + 1) / 2 lower-triangle blocks: acc[ba][bb][r] at lane l is J^T J[c(ba, 4r + l/16)][c(bb, l%16)].
 typedef double v4f64_t __attribute__((ext_vector_type(4)));
 
-// Streaming structure: a wave owns the 4-row chunks c, c + S, c + 2S, ...; the 32 B per lane of the NEXT TWO chunks
-// are already in flight (registers) while the ten MFMAs of the current one issue -- one chunk is 640 MFMA cycles
-// against ~900+ cycles of HBM latency, and the matrix pipe of a SIMD runs one chain per wave, so the loads have to be
-// ahead of it; the hot loop has no bounds check (the ragged tail is one extra, masked chunk per wave).  LDS is only
-// the epilogue's scratch (20 KB, the waves add into it one after the other), so that it does not limit residency.
-template <int T>
-__global__ __launch_bounds__(T, 4) void glm_jtj_mfma64_kernel(const double *__restrict__ A, const double *__restrict__ m,
-                                                           long long n, double *partials /* [4096][gridDim.x] */)
+// Streaming structure: a wave owns the 4-row chunks c, c + S, c + 2S, ...; the loads of the NEXT TWO chunks are already
+// in flight (registers) while the MFMAs of the current one issue -- at p = 64 one chunk is 640 MFMA cycles against
+// ~900+ cycles of HBM latency, and the matrix pipe of a SIMD runs one chain per wave, so the loads have to be ahead
+// of it; the hot loop has no bounds check (the ragged tail is one extra, masked chunk per wave).  LDS is only the
+// epilogue's scratch (the waves add into it one after the other), so that it does not limit residency.
+template <int P>
+__device__ __forceinline__ int glm_jtj_phys(int b, int i)
 {
-    constexpr int P = 64, NW = T / 64;
-    __shared__ double lds_acc[10 * 4 * 64];
+    constexpr int NB = P / 16;
+    return ((NB & 1) && b == NB - 1) ? 16 * b + i : 32 * (b >> 1) + 2 * i + (b & 1);
+}
+
+template <int P, int T>
+__global__ __launch_bounds__(T, 4) void glm_jtj_mfma_kernel(const double *__restrict__ A, const double *__restrict__ m,
+                                                            long long n, double *partials /* [P*P][gridDim.x] */)
+{
+    static_assert(P % 16 == 0 && P >= 16 && P <= 64, "16-wide tiles");
+    constexpr int NB = P / 16, NQ = NB * (NB + 1) / 2, NPAIR = NB / 2, NW = T / 64;
+    constexpr bool ODD = (NB & 1) != 0;
+    __shared__ double lds_acc[NQ * 4 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = lane >> 4, i = lane & 15;
-    v4f64_t acc[10];
+    v4f64_t acc[NQ];
 #pragma unroll
-    for (int q = 0; q < 10; ++q)
+    for (int q = 0; q < NQ; ++q)
         acc[q] = (v4f64_t){0.0, 0.0, 0.0, 0.0};
     const long long nfull = n / 4; // chunks whose four rows all exist
     const long long S = (long long)gridDim.x * NW;
     const long long c0 = (long long)blockIdx.x * NW + wave;
+    typedef double v2f64_t __attribute__((ext_vector_type(2)));
     struct Chunk
     {
-        double2 lo, hi;
+        double v[NB];
         double mm;
     };
     auto fetch = [&](long long c) {
         Chunk t;
         const long long row = c * 4 + k;
-        // logical column (b, i) lives at physical column 2i + (b & 1) + 32 (b >> 1): the sixteen lanes of a row read
-        // 256 contiguous bytes per load instruction (with 4i + b every instruction touched all four 128-B lines of
-        // the row for half of their bytes, and the kernel ran at half the load rate: 3.2 TB/s)
-        const double *src = A + row * P + 2 * i;
-        typedef double v2f64_t __attribute__((ext_vector_type(2)));
-        const v2f64_t lo = __builtin_nontemporal_load(reinterpret_cast<const v2f64_t *>(src));
-        const v2f64_t hi = __builtin_nontemporal_load(reinterpret_cast<const v2f64_t *>(src + 32));
-        t.lo = make_double2(lo.x, lo.y);
-        t.hi = make_double2(hi.x, hi.y);
+        const double *src = A + row * P;
+#pragma unroll
+        for (int q = 0; q < NPAIR; ++q)
+        {
+            const v2f64_t d = __builtin_nontemporal_load(reinterpret_cast<const v2f64_t *>(src + 32 * q + 2 * i));
+            t.v[2 * q] = d.x;
+            t.v[2 * q + 1] = d.y;
+        }
+        if constexpr (ODD)
+            t.v[NB - 1] = __builtin_nontemporal_load(src + 16 * (NB - 1) + i);
         t.mm = m[row];
         return t;
     };
     auto consume = [&](const Chunk &t) {
-        const double val[4] = {t.lo.x * t.mm, t.lo.y * t.mm, t.hi.x * t.mm, t.hi.y * t.mm};
+        double val[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            val[b] = t.v[b] * t.mm;
         int q = 0;
 #pragma unroll
-        for (int ba = 0; ba < 4; ++ba)
+        for (int ba = 0; ba < NB; ++ba)
 #pragma unroll
             for (int bb = 0; bb <= ba; ++bb, ++q)
                 acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(val[ba], val[bb], acc[q], 0, 0, 0);
     };
-    const Chunk zero = {{0.0, 0.0}, {0.0, 0.0}, 0.0};
+    Chunk zero;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        zero.v[b] = 0.0;
+    zero.mm = 0.0;
     Chunk b0 = c0 < nfull ? fetch(c0) : zero;
     Chunk b1 = c0 + S < nfull ? fetch(c0 + S) : zero;
     long long c = c0;
@@ -369,9 +337,15 @@ __global__ __launch_bounds__(T, 4) void glm_jtj_mfma64_kernel(const double *__re
         Chunk t = zero;
         if (row < n)
         {
-            const double *src = A + row * P + 2 * i;
-            t.lo = *reinterpret_cast<const double2 *>(src);
-            t.hi = *reinterpret_cast<const double2 *>(src + 32);
+            const double *src = A + row * P;
+#pragma unroll
+            for (int q = 0; q < NPAIR; ++q)
+            {
+                t.v[2 * q] = src[32 * q + 2 * i];
+                t.v[2 * q + 1] = src[32 * q + 2 * i + 1];
+            }
+            if constexpr (ODD)
+                t.v[NB - 1] = src[16 * (NB - 1) + i];
             t.mm = m[row];
         }
         consume(t);
@@ -382,7 +356,7 @@ __global__ __launch_bounds__(T, 4) void glm_jtj_mfma64_kernel(const double *__re
         if (wave == w)
         {
 #pragma unroll
-            for (int q = 0; q < 10; ++q)
+            for (int q = 0; q < NQ; ++q)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                 {
@@ -392,19 +366,19 @@ __global__ __launch_bounds__(T, 4) void glm_jtj_mfma64_kernel(const double *__re
         }
         __syncthreads();
     }
-    for (int e = threadIdx.x; e < 10 * 4 * 64; e += T)
+    for (int e = threadIdx.x; e < NQ * 4 * 64; e += T)
     {
         const double t = lds_acc[e];
         const int q = e / 256, r = (e / 64) & 3, l = e & 63;
         int ba = 0, bb = 0, cnt = 0;
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < NB; ++a)
             for (int b = 0; b <= a; ++b, ++cnt)
                 if (cnt == q)
                 {
                     ba = a;
                     bb = b;
                 }
-        const int gi = 2 * (4 * r + (l >> 4)) + (ba & 1) + 32 * (ba >> 1), gj = 2 * (l & 15) + (bb & 1) + 32 * (bb >> 1);
+        const int gi = glm_jtj_phys<P>(ba, 4 * r + (l >> 4)), gj = glm_jtj_phys<P>(bb, l & 15);
         partials[((size_t)gi * P + gj) * gridDim.x + blockIdx.x] = t;
         if (ba != bb)
             partials[((size_t)gj * P + gi) * gridDim.x + blockIdx.x] = t; // mirror block

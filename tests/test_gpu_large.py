@@ -25,7 +25,7 @@ def glm_data(n, p, seed=20250928):
     return A, y, th
 
 
-@pytest.mark.parametrize("p,n", [(64, 5000), (64, 33), (32, 4097), (16, 1000)])
+@pytest.mark.parametrize("p,n", [(64, 5000), (64, 33), (32, 4097), (16, 1000), (16, 7), (32, 2)])
 def test_glm_passes_match_numpy(amd, p, n):
     """one EVAL pass and one fused J^T J u pass (ragged n, several tile shapes) against dense numpy algebra"""
     import ctypes as C
@@ -59,7 +59,7 @@ def test_glm_passes_match_numpy(amd, p, n):
 
 
 @pytest.mark.parametrize("alg", ["cgst", "lm"])
-@pytest.mark.parametrize("p,n", [(64, 20000), (64, 20003), (64, 131), (16, 3000)])
+@pytest.mark.parametrize("p,n", [(64, 20000), (64, 20003), (64, 131), (16, 3000), (32, 5001)])
 def test_glm_fit_matches_oracle(amd, gslref, alg, p, n):
     A, y, th = glm_data(n, p)
     fit = amd.gsl_nls_large("glmexp", A=A, y=y, start=np.zeros(p), algorithm=alg, trace=True)
