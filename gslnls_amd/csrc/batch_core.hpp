@@ -140,41 +140,63 @@ GSLNLS_HD void ms_pass(const LmState<M::P> &s, const MsParams &mp, const RowSrc 
     }
 }
 
-template <class M, int JAC, class RowSrc>
-GSLNLS_HD void ms_fit_point(const MsParams &mp, const RowSrc &rows, const double *start, const double *lupars,
-                            MsRecord<M::P> &rec)
+// The fit of one point in three pieces, so that a lane can be handed its next point as soon as this one is done
+// (batch_kernels.hpp, ms_fit_refill_kernel); ms_fit_point below strings them together for one point per lane.
+// One call site for the pass and one for the state machine (the first trip doubles as det_eval_jtj at the sampled
+// point): the lanes of a wavefront hold different fits, and every extra inlined copy is both code the instruction
+// cache has to hold and a place where lanes in different states wait for each other.
+template <int P>
+struct MsPointState
 {
-    constexpr int P = M::P;
     LmState<P> s;
-    lm_state_reset<P>(s, start, lupars);
-    PassSums<P> acc;
-    // One call site for the pass and one for the state machine (the first trip doubles as det_eval_jtj at the
-    // sampled point): the lanes of a wavefront hold different fits, and every extra inlined copy is both code
-    // the instruction cache has to hold and a place where lanes in different states wait for each other.
-    bool fitted = false;
-    double det0 = 0.0;
-    for (int guard = 0; guard < 100000; ++guard)
-    {
-        ms_pass<M, JAC>(s, mp, rows, acc);
-        if (guard == 0)
-        {
-            det0 = det_cholesky<P>(acc.A);
-            if (mp.prm.jac_analytic && !(acc.badj == 0.0))
-                det0 = 0.0; // eval_df failed (src/nls_utils.c:47-48)
-            rec.det0 = det0;
-            rec.ssr_start = acc.ssr;
-            if (!(mp.always_fit || det0 > mp.dtol))
-                break;
-            fitted = true;
-        }
-        lm_advance<P>(s, acc, mp.prm);
-        if (s.phase == PH_DONE)
-            break;
-    }
+    double start[P];
+    double det0, ssr_start;
+    bool first, fitted;
+};
+
+template <int P>
+GSLNLS_HD void ms_point_begin(MsPointState<P> &q, const double *start, const double *lupars)
+{
+    lm_state_reset<P>(q.s, start, lupars);
 #pragma unroll
     for (int k = 0; k < P; ++k)
-        rec.x0[k] = start[k];
-    if (fitted)
+        q.start[k] = start[k];
+    q.det0 = 0.0;
+    q.ssr_start = 0.0;
+    q.first = true;
+    q.fitted = false;
+}
+
+// consume the sums of the pass that q.s.phase asked for; returns true when the point is finished
+template <int P>
+GSLNLS_HD bool ms_point_step(MsPointState<P> &q, const MsParams &mp, const PassSums<P> &acc)
+{
+    if (q.first)
+    {
+        q.first = false;
+        double det0 = det_cholesky<P>(acc.A);
+        if (mp.prm.jac_analytic && !(acc.badj == 0.0))
+            det0 = 0.0; // eval_df failed (src/nls_utils.c:47-48)
+        q.det0 = det0;
+        q.ssr_start = acc.ssr;
+        if (!(mp.always_fit || det0 > mp.dtol))
+            return true;
+        q.fitted = true;
+    }
+    lm_advance<P>(q.s, acc, mp.prm);
+    return q.s.phase == PH_DONE;
+}
+
+template <int P>
+GSLNLS_HD void ms_point_record(const MsPointState<P> &q, const PassSums<P> &last, MsRecord<P> &rec)
+{
+    const LmState<P> &s = q.s;
+    rec.det0 = q.det0;
+    rec.ssr_start = q.ssr_start;
+#pragma unroll
+    for (int k = 0; k < P; ++k)
+        rec.x0[k] = q.start[k];
+    if (q.fitted)
     {
         rec.det1 = det_cholesky<P>(s.A);
         rec.chisq0 = s.chisq0;
@@ -193,17 +215,34 @@ GSLNLS_HD void ms_fit_point(const MsParams &mp, const RowSrc &rows, const double
     {
         rec.det1 = 0.0;
         rec.chisq0 = INFINITY;
-        rec.chisq1 = acc.ssr;
+        rec.chisq1 = last.ssr;
         rec.niter = 0.0;
         rec.status = (double)ST_CONTINUE;
         rec.nevalf = 1.0;
 #pragma unroll
         for (int k = 0; k < P; ++k)
         {
-            rec.x[k] = start[k];
+            rec.x[k] = q.start[k];
             rec.diag[k] = 1.0;
         }
     }
+}
+
+template <class M, int JAC, class RowSrc>
+GSLNLS_HD void ms_fit_point(const MsParams &mp, const RowSrc &rows, const double *start, const double *lupars,
+                            MsRecord<M::P> &rec)
+{
+    constexpr int P = M::P;
+    MsPointState<P> q;
+    ms_point_begin<P>(q, start, lupars);
+    PassSums<P> acc;
+    for (int guard = 0; guard < 100000; ++guard)
+    {
+        ms_pass<M, JAC>(q.s, mp, rows, acc);
+        if (ms_point_step<P>(q, mp, acc))
+            break;
+    }
+    ms_point_record<P>(q, acc, rec);
 }
 
 } // namespace gslnls

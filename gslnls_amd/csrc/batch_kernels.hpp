@@ -209,4 +209,159 @@ __global__ __launch_bounds__(MS_T) void ms_fit_kernel(MsKernelArgs<M::P> a)
         out[k] = src[k];
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Lane refill: in the kernel above a lane is idle from the moment its point is finished until the slowest fit of
+// the wavefront ends -- on BoxBOD about 35 % of the lane-cycles do work (every lane walks its own sequence of
+// trials, up to 16 rejected ones per iteration).  Here a wavefront OWNS a contiguous slice of the batch and a lane
+// that finishes takes the next point of the slice: lanes that finish in the same trip are served in lane order
+// (ballot + popcount below the lane), so the assignment is deterministic given the fits, and since every record is
+// written to its point's own place and a fit depends on nothing but its point, the records are bit-identical to the
+// one-point-per-lane kernel's.  The slice length (points per wavefront) is chosen by the host: batch / waves.
+template <class M, int JAC>
+__global__ __launch_bounds__(MS_T, 2) void ms_fit_refill_kernel(MsKernelArgs<M::P> a, int slice, int thresh)
+{
+    constexpr int P = M::P, NX = M::NX;
+    extern __shared__ __attribute__((aligned(16))) double lds_rows[];
+    const int n = a.mp.n;
+    const bool staged = n <= MS_LDS_ROWS;
+    if (staged)
+    {
+        for (int i = threadIdx.x; i < n; i += MS_T)
+        {
+#pragma unroll
+            for (int c = 0; c < NX; ++c)
+                lds_rows[c * n + i] = a.x[c][i];
+            lds_rows[NX * n + i] = a.y[i];
+            lds_rows[(NX + 1) * n + i] = a.sw ? a.sw[i] : 1.0;
+        }
+        __syncthreads();
+    }
+    __shared__ unsigned int lds_sobol[SOBOL_BITS][P];
+    const bool halton = a.sobol->halton != 0;
+    if (!halton)
+    {
+        for (int e = threadIdx.x; e < SOBOL_BITS * P; e += MS_T)
+            lds_sobol[e / P][e % P] = a.sobol->v[e / P][e % P];
+        __syncthreads();
+    }
+    const int lane = threadIdx.x;
+    const long long s0 = (long long)a.lo + (long long)blockIdx.x * slice;
+    const long long s1 = (s0 + slice < a.hi) ? s0 + slice : a.hi;
+    if (s0 >= s1)
+        return;
+    auto start_of = [&](long long idx, double *start) {
+        const long long d = a.draw ? a.draw[idx] : a.first_draw + idx;
+#pragma unroll
+        for (int k = 0; k < P; ++k)
+        {
+            if (d >= 0)
+            {
+                double u;
+                if (halton)
+                    u = sobol_coord(*a.sobol, (unsigned int)d, k);
+                else
+                {
+                    const unsigned int kk = (unsigned int)d + 1u;
+                    const unsigned int g = kk ^ (kk >> 1);
+                    unsigned int num = 0;
+#pragma unroll
+                    for (int b = 0; b < SOBOL_BITS; ++b)
+                        num ^= lds_sobol[b][k] & (0u - ((g >> b) & 1u));
+                    u = (double)num * (1.0 / 1073741824.0); // 2^-30
+                }
+                start[k] = sobol_to_range(u, a.l0[k], a.l1[k], a.kd[k]);
+            }
+            else
+                start[k] = a.start[(size_t)idx * P + k];
+        }
+    };
+    const double *lu = a.has_lu ? a.lu : nullptr;
+    auto run = [&](const auto &rows) {
+        long long idx = s0 + lane, nxt = s0 + MS_T;
+        bool active = idx < s1;
+        MsPointState<P> q;
+        PassSums<P> acc;
+        {
+            double st[P];
+            start_of(active ? idx : s0, st);
+            ms_point_begin<P>(q, st, lu);
+        }
+        // every trip: one pass + one step of the state machine for the lanes that hold a point; bounded like the
+        // one-point kernel (a point ends after at most maxiter * 17 + 2 trips)
+        // (... times the points of the slice: in the worst case one lane ends up with all of them)
+        const long long max_trips = ((long long)a.mp.prm.maxiter * 17 + 3) * (a.mp.prm.trs ? 2 : 1) * (long long)slice + 8;
+        // A finished lane parks (`pending`) until `thresh` lanes have finished or nobody is left working: writing the
+        // record and setting up the next point (Sobol bits, range map, det of the final J^T J, 3p + 8 stores) is a few
+        // hundred instructions that would otherwise run in almost every trip for a handful of lanes.
+        bool pending = false;
+        for (long long trip = 0; trip < max_trips; ++trip)
+        {
+            if (active && !pending)
+            {
+                ms_pass<M, JAC>(q.s, a.mp, rows, acc);
+                pending = ms_point_step<P>(q, a.mp, acc);
+            }
+            const unsigned long long mask = __ballot(pending);
+            const unsigned long long working = __ballot(active && !pending);
+            if (mask && (__popcll(mask) >= thresh || !working))
+            {
+                if (pending)
+                {
+                    MsRecord<P> rec;
+                    ms_point_record<P>(q, acc, rec);
+                    double *out = a.records + (size_t)idx * MsRecord<P>::K;
+                    const double *src = reinterpret_cast<const double *>(&rec);
+#pragma unroll
+                    for (int k = 0; k < MsRecord<P>::K; ++k)
+                        out[k] = src[k];
+                    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+                    idx = nxt + rank;
+                    active = idx < s1;
+                    pending = false;
+                    if (active)
+                    {
+                        double st[P];
+                        start_of(idx, st);
+                        ms_point_begin<P>(q, st, lu);
+                    }
+                }
+                nxt += __popcll(mask);
+            }
+            if (!__ballot(active))
+                break;
+        }
+    };
+    if (staged && n <= MS_REG_ROWS)
+    {
+        RowsReg<NX, 1> rows;
+        rows.sub = 0;
+#pragma unroll
+        for (int i = 0; i < MS_REG_ROWS; ++i)
+        {
+            const int ic = i < n ? i : 0;
+#pragma unroll
+            for (int c = 0; c < NX; ++c)
+                rows.x[i][c] = lds_rows[c * n + ic];
+            rows.y[i] = lds_rows[NX * n + ic];
+            rows.sw[i] = lds_rows[(NX + 1) * n + ic];
+        }
+        run(rows);
+    }
+    else if (staged)
+    {
+        RowsLds<NX> rows{lds_rows, n};
+        run(rows);
+    }
+    else
+    {
+        RowsGlobal<NX> rows;
+#pragma unroll
+        for (int c = 0; c < NX; ++c)
+            rows.x[c] = a.x[c];
+        rows.y = a.y;
+        rows.sw = a.sw;
+        run(rows);
+    }
+}
+
 } // namespace gslnls

@@ -170,6 +170,22 @@ struct HipMsEvaluator : MsEvaluator
             else if (fit.n > 1 && (long long)(hi - lo) * 2 <= 65536)
                 lpf = 2;
         }
+        // Lane refill (ms_fit_refill_kernel: a wavefront owns a slice of the batch, a lane that finishes takes the slice's
+        // next point) is built, bit-identical, and MEASURED SLOWER than letting the hardware refill at wavefront
+        // granularity: 1,048,576 BoxBOD points 0.455 ms against 0.378 ms, 262,144 points 0.142 against 0.113 ms (best
+        // of 1024 / 2048 / 4096 wavefronts x refill thresholds 8 / 16 / 32; gpurun_out r03d).  The refill
+        // path (record, Sobol point, state reset) runs divergent, the kernel needs 256 VGPRs + scratch against 182, and
+        // with two to four wavefronts per SIMD the scheduler already fills the slots a finished wavefront frees.
+        // Opt-in: GSLNLS_MS_REFILL=1 (GSLNLS_MS_WAVES wavefronts, default two per SIMD; GSLNLS_MS_REFILL_AT lanes).
+        int refill_waves = 0;
+        if (MULTI_LANE && lpf == 1)
+        {
+            const char *re = getenv("GSLNLS_MS_REFILL"), *we = getenv("GSLNLS_MS_WAVES");
+            const int refill_env = re ? atoi(re) : 0, waves_env = we ? atoi(we) : 0;
+            const int waves = waves_env > 0 ? waves_env : 2048;
+            if (refill_env && (long long)(hi - lo) >= 2LL * waves * MS_T)
+                refill_waves = waves;
+        }
         const int nblk = (int)(((long long)(hi - lo) * lpf + MS_T - 1) / MS_T);
         const size_t lds = (fit.n <= MS_LDS_ROWS) ? sizeof(double) * (size_t)fit.n * (M::NX + 2) : 0;
         hipEventRecord(e0, st);
@@ -183,6 +199,29 @@ struct HipMsEvaluator : MsEvaluator
     }                                                                                                          \
     if (lpf == 1)                                                                                              \
         hipLaunchKernelGGL((ms_fit_kernel<M, JACMODE, 1>), dim3(nblk), dim3(MS_T), lds, st, a);
+        if constexpr (MULTI_LANE)
+        {
+            if (refill_waves > 0)
+            {
+                const int slice = (int)(((long long)(hi - lo) + refill_waves - 1) / refill_waves);
+                const char *te = getenv("GSLNLS_MS_REFILL_AT");
+                const int thresh = te ? atoi(te) : 16; // finished lanes that make a wavefront stop for the refill
+                const int nw = (int)(((long long)(hi - lo) + slice - 1) / slice);
+                switch (jacmode)
+                {
+                case JAC_ANALYTIC:
+                    hipLaunchKernelGGL((ms_fit_refill_kernel<M, JAC_ANALYTIC>), dim3(nw), dim3(MS_T), lds, st, a, slice, thresh);
+                    break;
+                case JAC_FORWARD:
+                    hipLaunchKernelGGL((ms_fit_refill_kernel<M, JAC_FORWARD>), dim3(nw), dim3(MS_T), lds, st, a, slice, thresh);
+                    break;
+                default:
+                    hipLaunchKernelGGL((ms_fit_refill_kernel<M, JAC_CENTER>), dim3(nw), dim3(MS_T), lds, st, a, slice, thresh);
+                    break;
+                }
+            }
+        }
+        if (refill_waves == 0)
         switch (jacmode)
         {
         case JAC_ANALYTIC:

@@ -206,6 +206,48 @@ def test_lanes_per_fit_do_not_change_the_records(amd, nist):
                 assert np.sum(np.abs(other[sel, 7] / one[sel, 7] - 1.0) > 1e-6) < 200
 
 
+def test_lane_refill_gives_bit_identical_records(amd, nist, monkeypatch):
+    """Large batches: a wavefront owns a slice of the batch and a lane that finishes takes the slice's next point
+    (ms_fit_refill_kernel).  Which lane fits which point depends on how long the fits take -- the records do not: every
+    record goes to its point's own place and a fit depends on nothing but its point.  Bitwise equal to the
+    one-point-per-lane kernel, for the analytic Jacobian and forward differences, ragged slices, explicit starts."""
+    from gslnls_amd import _lib
+    from gslnls_amd.control import gsl_nls_control, pack_control
+    q, x, y, tgt = _boxbod(nist)
+    ci, cd = pack_control(gsl_nls_control(solver="cholesky"), "lm")
+    prob = amd.DenseProblem(2, 2, x, y)
+    ranges = np.array([1.0, 500.0, 0.01, 5.0])
+    kd = np.array([0.75, 0.75])
+    K = _lib.lib().gslnls_mstart_record_size(2)
+    N = 70_001                                            # > 65536: one lane per fit; ragged last slice
+    out = {}
+    for mode, env in (("plain", {"GSLNLS_MS_REFILL": "0"}), ("refill", {"GSLNLS_MS_REFILL": "1", "GSLNLS_MS_WAVES": "97"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for jac in (1, 0):
+            rec = np.full((N, K), np.nan)
+            ms = C.c_float(0)
+            rc = _lib.lib().gslnls_mstart_batch(prob._h, jac, ranges.ctypes.data_as(_lib.DP), kd.ctypes.data_as(_lib.DP), 5,
+                                                N, 0, N, 5, 1e-6, ci.ctypes.data_as(_lib.IP), cd.ctypes.data_as(_lib.DP),
+                                                None, rec.ctypes.data_as(C.c_void_p), 0, C.byref(ms))
+            assert rc == 0
+            out[mode, jac] = rec
+    prob.close()
+    for jac in (1, 0):
+        assert not np.isnan(out["refill", jac][:, 0:6]).any()                    # every point was served
+        assert np.array_equal(out["plain", jac], out["refill", jac], equal_nan=True)
+    # the whole procedure (sampling, concentration, local searches -- explicit starts go through the same kernel)
+    d = dict(x=x, y=y)
+    kw = dict(data=d, start=dict(b1=[1.0, 500.0], b2=[0.01, 5.0]), jac=True,
+              control=dict(mstart_n=20000, mstart_q=500, solver="cholesky"))
+    monkeypatch.setenv("GSLNLS_MS_REFILL", "0")
+    a = amd.gsl_nls("y ~ b1*(1-exp(-b2*x))", **kw)
+    monkeypatch.setenv("GSLNLS_MS_REFILL", "1")
+    monkeypatch.setenv("GSLNLS_MS_WAVES", "40")
+    b = amd.gsl_nls("y ~ b1*(1-exp(-b2*x))", **kw)
+    assert np.array_equal(a["par"], b["par"]) and a["ssr"] == b["ssr"] and a["mstart"] == b["mstart"]
+
+
 def test_in_library_rccl_allgather_one_rank(amd, nist):
     """The collective of the multi-start path is issued by libgslnls_hip.so itself (csrc/rccl_comm.hpp): bind an RCCL
     communicator of ONE rank through the file bootstrap (the box has one GPU, and RCCL refuses two ranks on one device),
