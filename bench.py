@@ -280,14 +280,57 @@ def large_bench(L, _lib, n=10_000_000, p=64):
             "jtju_pass_ms": ms_jtjv, "jtju_pass_GBs": byt / ms_jtjv / 1e6,
             "roofline_frac_jtju": byt / ms_jtjv / 1e6 / HBM_PEAK_GBS,
             "full_jtj": {"ms_host_clock": ms_jtj, "what": "J^T J for the lm variant: v_mfma_f64_16x16x4 SYRK kernel + reduction of "
-                         "the workgroup partials + 32 KB read-back; the kernel alone is in profiles/r02_c3_kernel_stats.csv "
-                         "(1.17 ms = 43.6 TFLOP/s executed on the 10 lower-triangle blocks, 91 % of the 47.7 TFLOP/s this "
-                         "instruction reaches back to back on the same device, scripts/mfma_probe/rate.hip; it streams A at "
-                         "4.4 TB/s, so the matrix pipe, not HBM, bounds it)",
+                         "the workgroup partials + 32 KB read-back; the kernel alone (glm_jtj_mfma_kernel<64,256>) is in the "
+                         "profiles/ kernel tables (r02: 1.06-1.17 ms = 43.6-48 TFLOP/s executed on the 10 lower-triangle "
+                         "blocks, 91-100 % of the 47.7 TFLOP/s this instruction reaches back to back on the same device, "
+                         "scripts/mfma_probe/rate.hip; it streams A at 4.4-4.8 TB/s, so the matrix pipe, not HBM, bounds it)",
                          "effective_TFLOPs_2np2": 2.0 * n * p * p / ms_jtj / 1e9},
             "fit": {"niter": int(fit["niter"]), "conv": int(fit["conv"]), "passes": int(fit["n_passes"]),
                     "wall_s": el, "outer_iterations_per_s": fit["niter"] / el, "ssr": float(fit["ssr"]),
                     "max_abs_err_vs_truth": float(np.max(np.abs(fit["par"] - th)))}}
+
+
+def wide_dense_bench(_lib, n=100_000, ng=10):
+    """The wide dense path (10 <= p <= 64: the reference takes any p, src/nls.c:266): gsl_nls() on a sum of ten Gaussian
+    peaks + a line, p = 32, n = 1e5 (and the step time at n = 1e6); analytic Jacobian from the formula compiled in
+    process, J^T J accumulated in v_mfma_f64_16x16x4 tiles (csrc/wide_kernels.hpp), one trial step = three launches
+    (pass, reduce, advance)."""
+    import gslnls_amd as A
+    rng = np.random.Generator(np.random.PCG64(20250930))
+    names, terms = [], []
+    for k in range(1, ng + 1):
+        names += ["a%d" % k, "m%d" % k, "s%d" % k]
+        terms.append("a%d*exp(-(x-m%d)^2/s%d^2)" % (k, k, k))
+    names += ["c0", "c1"]
+    rhs = " + ".join(terms) + " + c0 + c1*x"
+    amp, mid, wid = rng.uniform(2.0, 6.0, ng), 10.0 * np.arange(ng) + rng.uniform(3.0, 7.0, ng), rng.uniform(1.2, 2.4, ng)
+    truth = np.append(np.stack([amp, mid, wid], axis=1).reshape(-1), [0.5, 0.01])
+    p = len(truth)
+    out = {"workload": "gsl_nls() on a sum of %d Gaussians + line: p = %d, analytic Jacobian, LM normal equations" % (ng, p)}
+    for nn in (n, 10 * n):
+        x = np.linspace(0.0, 10.0 * ng, nn)
+        m = sum(truth[3 * k] * np.exp(-(x - truth[3 * k + 1]) ** 2 / truth[3 * k + 2] ** 2) for k in range(ng))
+        y = m + truth[-2] + truth[-1] * x + 0.05 * rng.standard_normal(nn)
+        start = truth * (1.0 + 0.02 * np.where(np.arange(p) % 2 == 0, 1.0, -1.0))
+        prob = A.DenseProblem(_lib.MODEL_EXPR, p, x, y, expr=rhs, parnames=names, xnames=["x"], lowering="jit")
+        ctrl = A.gsl_nls_control(solver="cholesky")
+        prob.solve(start, jac=True, control=ctrl, want_vectors=False)          # builds / loads the kernels
+        t0 = time.perf_counter()
+        fit = prob.solve(start, jac=True, control=ctrl, want_vectors=False)
+        wall = time.perf_counter() - t0
+        ms_step = prob.time_pass(start, jac=True, reps=200)
+        prob.close()
+        # flops of the J^T J tiles one pass executes: NQ = 3 lower-triangle 16x16 blocks x 2 * 16 * 16 per row
+        nq = (p + 15) // 16 * ((p + 15) // 16 + 1) // 2
+        out["n=%d" % nn] = {"niter": int(fit["niter"]), "conv": int(fit["conv"]), "steps": int(fit["n_steps"]),
+                            "fit_wall_ms": wall * 1e3, "fit_loop_ms": float(fit["loop_ms"]), "ms_per_trial_step": ms_step,
+                            "LM_iterations_per_s": fit["niter"] / wall, "code_path": int(fit["code_path"]),
+                            "rows_per_s_one_step": nn / (ms_step * 1e-3),
+                            "mfma_tile_GFLOPs_per_step": nq * 512.0 * nn / (ms_step * 1e-3) / 1e9,
+                            "max_rel_err_vs_truth": float(np.max(np.abs(fit["par"] - truth) / np.abs(truth)))}
+    out["note"] = ("a row costs ten fp64 exp + the 32 gradient entries (vector pipe) and 3 MFMA tiles per four rows; "
+                   "ms_per_trial_step is pass + reduce + advance (the p x p modified Cholesky runs on one wavefront)")
+    return out
 
 
 def sparse_readme_bench():
@@ -378,11 +421,13 @@ def batch_irls_bench(_lib, job, B=4096, n=10000):
     # scripts/profile_c4c5_pmc.sh): L2-miss traffic (gfx950 correction applied) and fp64-VALU issue share
     pmc = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_c4c5_pmc.json")) as f:
+        pfile = next(os.path.join(ROOT, "profiles", f) for f in ("r03_c4c5_pmc.json", "r02_c4c5_pmc.json")
+                     if os.path.exists(os.path.join(ROOT, "profiles", f)))
+        with open(pfile) as f:
             k5 = next(v for k, v in json.load(f).items() if k.startswith("irls_batch_kernel"))
         valu, gui = k5["SQ_INSTS_VALU"]["median_per_dispatch"], k5["GRBM_GUI_ACTIVE"]["median_per_dispatch"]
         pmc = {"traffic": k5["hbm_bytes_per_dispatch_corrected"],
-               "traffic_source": "committed profile profiles/r02_c4c5_pmc.json (4096 data sets per dispatch; bytes that "
+               "traffic_source": "committed profile profiles/" + os.path.basename(pfile) + " (4096 data sets per dispatch; bytes that "
                                  "missed L2 -- served by Infinity Cache or HBM), NOT measured in this run",
                "valu_wave_instructions_per_dispatch": valu,
                "valu_issue_share": valu * 4.0 / (1024.0 * gui / 8.0),
@@ -872,6 +917,7 @@ def main():
         if world == 1:
             side("large_cgst", large_bench, L, _lib)
             side("large_sparse_readme", sparse_readme_bench)
+            side("wide_dense", wide_dense_bench, _lib)
     if world > 1:
         L.gslnls_comm_destroy()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

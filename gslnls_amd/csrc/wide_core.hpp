@@ -7,11 +7,14 @@
 // the reference allocates its n x p workspace for any p (src/nls.c:266) and so does the formula front end
 // (R/nls.R:588-599), while lm_core.hpp unrolls everything for p <= 9.
 //
-//   * p-sized vectors and the packed lower triangle of J^T J: LDS copies for the duration of the call;
-//   * scalar control flow (rho, accept / reject, mu, delta, stopping rule): thread 0, decisions published through LDS;
-//   * modified Cholesky with diagonal pivoting (gsl_linalg_mcholesky, Gill-Murray-Wright) of J^T J + mu D^2: wave 0,
-//     lane i owns row i of a full symmetric copy in LDS (leading dimension p + 1: conflict-free column walks), pivot
-//     search by a DPP maximum + ballot, the rank-one update of column step j by all rows at once;
+//   * ONE wavefront runs the whole step: lane k owns component k of every p-vector (p <= 64); the vectors and the packed
+//     lower triangle of J^T J sit in LDS for the duration of the call, the scalars (mu, nu, delta, counters, phase) in
+//     registers, identical in every lane; sums that lm_core.hpp takes sequentially (v^T J^T J v, ||D v||^2, ...) are
+//     taken in the same index order, their terms travelling by ds_bpermute;
+//   * modified Cholesky with diagonal pivoting (gsl_linalg_mcholesky, Gill-Murray-Wright) of J^T J + mu D^2: lane i owns
+//     row i of the lower triangle in LDS (leading dimension p + 1: conflict-free column walks) and its diagonal entry
+//     in a register, pivot search by a wavefront maximum + ballot, the rank-one update of column step j by all rows
+//     at once, four elements per LDS round trip;
 //   * triangular solves: lane i owns b_i, the pivot element travels by ds_bpermute.  The back substitution runs over
 //     columns (j descending) where lm_solve<P> runs over rows (j ascending): same sums, different association --
 //     the one place where the two state machines are not operation for operation the same.
@@ -26,7 +29,7 @@ namespace gslnls
 
 constexpr int WP = 64;                 // capacity in parameters
 constexpr int WNA = WP * (WP + 1) / 2; // packed lower triangle
-constexpr int WT_ADV = 256;            // threads of the advancing workgroup
+constexpr int WT_ADV = 64;             // the advancing workgroup is one wavefront
 
 struct WState
 {
@@ -58,24 +61,44 @@ __device__ __forceinline__ void wide_lds_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// value of lane `src_lane` (wave-uniform index) in every lane: two v_readlane_b32 (a few cycles; through
+// ds_bpermute every broadcast was an LDS round trip on the critical path of the factorisation)
 __device__ __forceinline__ double wide_bcast(double v, int src_lane)
+{
+    const long long bits = __double_as_longlong(v);
+    const int sl = __builtin_amdgcn_readfirstlane(src_lane);
+    const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), sl);
+    const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), sl);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// per-lane source index (ds_bpermute)
+__device__ __forceinline__ double wide_shfl(double v, int src_lane)
 {
     const long long bits = __double_as_longlong(v);
     const int lo = __shfl((int)(bits & 0xffffffffll), src_lane, 64), hi = __shfl((int)(bits >> 32), src_lane, 64);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+template <int CTRL>
+__device__ __forceinline__ double wide_dpp(double v)
+{
+    const long long bits = __double_as_longlong(v);
+    int lo = (int)(bits & 0xffffffffll), hi = (int)(bits >> 32);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// maximum over the 64 lanes, in every lane: DPP butterflies inside each row of 16 lanes, then the four row values by
+// v_readlane.  fmax is exact and order independent: any reduction tree gives the same bits.
 __device__ __forceinline__ double wide_wave_max(double v)
 {
-    // fmax is exact and order independent: any reduction tree gives the same bits
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
-    {
-        const long long bits = __double_as_longlong(v);
-        const int lo = __shfl_xor((int)(bits & 0xffffffffll), m, 64), hi = __shfl_xor((int)(bits >> 32), m, 64);
-        v = fmax(v, __longlong_as_double(((long long)hi << 32) | (unsigned int)lo));
-    }
-    return v;
+    v = fmax(v, wide_dpp<0xB1>(v));  // quad_perm [1,0,3,2]
+    v = fmax(v, wide_dpp<0x4E>(v));  // quad_perm [2,3,0,1]
+    v = fmax(v, wide_dpp<0x141>(v)); // row_half_mirror
+    v = fmax(v, wide_dpp<0x140>(v)); // row_mirror
+    return fmax(fmax(wide_bcast(v, 0), wide_bcast(v, 16)), fmax(wide_bcast(v, 32), wide_bcast(v, 48)));
 }
 
 // wavefront sum by xor butterflies: every lane performs the same tree (a + b and b + a are the same bits), so the
@@ -99,22 +122,30 @@ struct WideLds
     double A[WNA];
     double M[WP * (WP + 1)]; // full symmetric p x p, leading dimension p + 1
     double rhs[WP], sol[WP], row[WP];
-    double fnorm2, mu, nu, delta, avratio, chisq0, chisq1, chisq_init;
-    int bad_steps, niter, phase, status, info, nevalf, nevaldf, nevalfvv;
-    int do_step, do_take, do_solve_acc, advanced, niter_before, phase_before;
 };
 
-// (A + mu D^2) sol = rhs by wave 0 (all 64 lanes of it must call; lanes >= p idle along)
+// sum of v_0 + v_1 + ... + v_{p-1} in index order (the order of the sequential loops of lm_core.hpp), every lane gets it;
+// the p values travel by ds_bpermute, all requests in flight together, instead of p dependent LDS round trips
+__device__ __forceinline__ double wide_seq_sum(double v, int p)
+{
+    double s = 0.0;
+    for (int i = 0; i < p; ++i)
+        s += wide_bcast(v, i);
+    return s;
+}
+
+// (A + mu D^2) sol = rhs by wave 0 (all 64 lanes of it must call; lanes >= p idle along).  Only the lower triangle
+// M[i][k], k <= i, is kept (leading dimension p + 1), as in lm_solve<P>.
 __device__ __forceinline__ void wide_solve(WideLds &L, int p, double mu, const double *rhs, double *sol, int lane)
 {
     const int LD = p + 1;
     double *M = L.M;
-    // build the full symmetric matrix: lane i fills row i
+    double *colj = L.row; // column j of the current step, contiguous (L.row is free while a solve runs)
     if (lane < p)
     {
-        for (int j = 0; j < p; ++j)
+        for (int j = 0; j <= lane; ++j)
         {
-            double v = L.A[j <= lane ? tri(lane, j) : tri(j, lane)];
+            double v = L.A[tri(lane, j)];
             if (j == lane)
                 v += mu * L.diag[lane] * L.diag[lane];
             M[lane * LD + j] = v;
@@ -137,72 +168,89 @@ __device__ __forceinline__ void wide_solve(WideLds &L, int p, double mu, const d
     else
         beta = fmax(fmax(gamma, xi / sqrt((double)p * p - 1.0)), DBL_EPSILON);
     const double betainv = 1.0 / sqrt(beta);
-    double dinv = 0.0; // lane j keeps 1 / alpha_j
+    double dinv = 0.0;                                  // lane j keeps 1 / alpha_j
+    double dg = lane < p ? M[lane * LD + lane] : 0.0;   // lane i keeps the current diagonal entry M[i][i]
     for (int j = 0; j < p; ++j)
     {
-        // pivot: first index of the largest |diagonal| among j..p-1
-        const double d = (lane >= j && lane < p) ? fabs(M[lane * LD + lane]) : -1.0;
+        // pivot: first index of the largest |diagonal| among j..p-1 (`if (d > maxd)` of the sequential scan: the first
+        // element wins ties, NaNs never win)
+        const double d = (lane >= j && lane < p) ? fabs(dg) : -1.0;
         const double maxd = wide_wave_max(d);
         const unsigned long long hit = __ballot(lane >= j && lane < p && d == maxd);
         int q = hit ? (int)__builtin_ctzll(hit) : j;
-        if (!(maxd > fabs(M[j * LD + j])))
-            q = j; // `if (d > maxd)` of the sequential scan: the first element wins ties (and NaNs never win)
+        const double djj = wide_bcast(dg, j);
+        if (!(maxd > fabs(djj)))
+            q = j;
         if (q != j)
         {
-            // symmetric interchange of rows / columns j and q on the full matrix
-            if (lane < p)
+            // symmetric interchange of rows / columns j and q in the lower triangle, one element pair per lane:
+            //   k < j: (j,k) <-> (q,k);  j < k < q: (k,j) <-> (q,k);  k > q: (k,j) <-> (k,q);  the diagonal entries swap
+            if (lane < p && lane != j && lane != q)
             {
-                const double t = M[j * LD + lane];
-                M[j * LD + lane] = M[q * LD + lane];
-                M[q * LD + lane] = t;
+                const int a = lane < j ? j * LD + lane : lane * LD + j;
+                const int c = lane < q ? q * LD + lane : lane * LD + q;
+                const double t = M[a];
+                M[a] = M[c];
+                M[c] = t;
             }
-            wide_lds_sync();
-            if (lane < p)
-            {
-                const double t = M[lane * LD + j];
-                M[lane * LD + j] = M[lane * LD + q];
-                M[lane * LD + q] = t;
-            }
-            wide_lds_sync();
+            const double dq = wide_bcast(dg, q);
             const double bj = wide_bcast(b, j), bq = wide_bcast(b, q);
-            const int pj = __shfl(perm, j, 64), pq = __shfl(perm, q, 64);
+            const int pj = __builtin_amdgcn_readlane(perm, __builtin_amdgcn_readfirstlane(j)),
+                      pq = __builtin_amdgcn_readlane(perm, __builtin_amdgcn_readfirstlane(q));
             if (lane == j)
             {
+                dg = dq;
                 b = bq;
                 perm = pq;
             }
             if (lane == q)
             {
+                dg = djj;
                 b = bj;
                 perm = pj;
             }
+            wide_lds_sync();
         }
         const double vi = (lane > j && lane < p) ? M[lane * LD + j] : 0.0;
         const double theta = wide_wave_max(fabs(vi));
         const double u = theta * betainv;
-        const double alpha = fmax(fmax(DBL_EPSILON, fabs(M[j * LD + j])), u * u);
+        const double alpha = fmax(fmax(DBL_EPSILON, fabs(wide_bcast(dg, j))), u * u);
         const double ainv = 1.0 / alpha;
         if (lane == j)
-            dinv = ainv;
-        if (lane > j && lane < p)
         {
-            for (int k = j + 1; k <= lane; ++k)
-            {
-                double m = M[lane * LD + k];
-                m -= ainv * vi * M[k * LD + j];
-                M[lane * LD + k] = m;
-                M[k * LD + lane] = m; // keep the mirror: later interchanges walk rows across the diagonal
-            }
+            dinv = ainv;
+            dg = alpha;
         }
+        colj[lane] = vi;
         wide_lds_sync();
         if (lane > j && lane < p)
         {
-            const double l = vi * ainv;
-            M[lane * LD + j] = l;
-            M[j * LD + lane] = l;
+            // M[i][k] -= ainv * vi * M[k][j], k = j+1..i: four at a time, all loads of a group ahead of its stores
+            // (the compiler cannot tell that rows and the column copy never overlap and would serialise every element)
+            int k = j + 1;
+            for (; k + 3 < lane; k += 4)
+            {
+                const double m0 = M[lane * LD + k], m1 = M[lane * LD + k + 1], m2 = M[lane * LD + k + 2], m3 = M[lane * LD + k + 3];
+                const double c0 = colj[k], c1 = colj[k + 1], c2 = colj[k + 2], c3 = colj[k + 3];
+                double r0 = m0, r1 = m1, r2 = m2, r3 = m3;
+                r0 -= ainv * vi * c0;
+                r1 -= ainv * vi * c1;
+                r2 -= ainv * vi * c2;
+                r3 -= ainv * vi * c3;
+                M[lane * LD + k] = r0;
+                M[lane * LD + k + 1] = r1;
+                M[lane * LD + k + 2] = r2;
+                M[lane * LD + k + 3] = r3;
+            }
+            for (; k < lane; ++k)
+            {
+                double m = M[lane * LD + k];
+                m -= ainv * vi * colj[k];
+                M[lane * LD + k] = m;
+            }
+            dg -= ainv * vi * vi; // k = i: the diagonal entry lives in a register
+            M[lane * LD + j] = vi * ainv;
         }
-        if (lane == j)
-            M[j * LD + j] = alpha;
         wide_lds_sync();
     }
     // L z = P b: column sweep, every b_i collects its terms in ascending j like the row form
@@ -225,10 +273,11 @@ __device__ __forceinline__ void wide_solve(WideLds &L, int p, double mu, const d
     wide_lds_sync();
 }
 
-// one workgroup of WT_ADV threads; all threads call
+// ONE wavefront (64 lanes >= p: lane k owns component k of every p-vector); all 64 lanes call.  Scalars of the state live
+// in registers, identical in every lane; LDS traffic between lanes is ordered by wide_lds_sync().
 __device__ __forceinline__ void wide_advance(const WAdvanceArgs &a, WideLds &L)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x & 63;
     WState *S = a.state;
     const int p = S->p, NA = p * (p + 1) / 2;
     const LmParams prm = a.prm;
@@ -237,418 +286,323 @@ __device__ __forceinline__ void wide_advance(const WAdvanceArgs &a, WideLds &L)
     const double *tot = a.totals;
     const double r_ssr = tot[0], r_badj = tot[1];
     const double *rA = tot + 2, *rg = tot + 2 + NA;
-    // ---- state -> LDS ----
-    for (int k = tid; k < p; k += WT_ADV)
+    const bool mine = lane < p;
+    // ---- state -> LDS (vectors, packed matrix) and registers (scalars) ----
+    if (mine)
     {
-        L.x[k] = S->x[k];
-        L.xt[k] = S->xt[k];
-        L.dx[k] = S->dx[k];
-        L.vel[k] = S->vel[k];
-        L.acc[k] = S->acc[k];
-        L.g[k] = S->g[k];
-        L.diag[k] = S->diag[k];
-        L.lo[k] = S->lo[k];
-        L.up[k] = S->up[k];
+        L.x[lane] = S->x[lane];
+        L.xt[lane] = S->xt[lane];
+        L.dx[lane] = S->dx[lane];
+        L.vel[lane] = S->vel[lane];
+        L.acc[lane] = S->acc[lane];
+        L.g[lane] = S->g[lane];
+        L.diag[lane] = S->diag[lane];
+        L.lo[lane] = S->lo[lane];
+        L.up[lane] = S->up[lane];
     }
-    for (int k = tid; k < NA; k += WT_ADV)
+    for (int k = lane; k < NA; k += 64)
         L.A[k] = S->A[k];
-    if (tid == 0)
-    {
-        L.fnorm2 = S->fnorm2;
-        L.mu = S->mu;
-        L.nu = S->nu;
-        L.delta = S->delta;
-        L.avratio = S->avratio;
-        L.chisq0 = S->chisq0;
-        L.chisq1 = S->chisq1;
-        L.chisq_init = S->chisq_init;
-        L.bad_steps = S->bad_steps;
-        L.niter = S->niter;
-        L.phase = S->phase;
-        L.status = S->status;
-        L.info = S->info;
-        L.nevalf = S->nevalf;
-        L.nevaldf = S->nevaldf;
-        L.nevalfvv = S->nevalfvv;
-        L.do_step = 0;
-        L.do_take = 0;
-        L.do_solve_acc = 0;
-        L.advanced = 1;
-        L.niter_before = S->niter;
-        L.phase_before = S->phase;
-    }
-    __syncthreads();
+    double fnorm2 = S->fnorm2, mu = S->mu, nu = S->nu, delta = S->delta, avratio = S->avratio, chisq0 = S->chisq0,
+           chisq1 = S->chisq1, chisq_init = S->chisq_init;
+    int bad_steps = S->bad_steps, niter = S->niter, phase = S->phase, status = S->status, info = S->info, nevalf = S->nevalf,
+        nevaldf = S->nevaldf, nevalfvv = S->nevalfvv;
+    const int niter_before = niter, phase_before = phase;
+    wide_lds_sync();
 
-    auto take_point = [&]() { // lm_take_point: x <- xt, g, A, fnorm2 from the pass (all threads)
-        for (int k = tid; k < p; k += WT_ADV)
+    auto take_point = [&]() { // lm_take_point: x <- xt, g, A, fnorm2 from the pass
+        if (mine)
         {
-            L.x[k] = L.xt[k];
-            L.g[k] = rg[k];
+            L.x[lane] = L.xt[lane];
+            L.g[lane] = rg[lane];
         }
-        for (int k = tid; k < NA; k += WT_ADV)
+        for (int k = lane; k < NA; k += 64)
             L.A[k] = rA[k];
-        if (tid == 0)
-            L.fnorm2 = r_ssr;
-        __syncthreads();
+        fnorm2 = r_ssr;
+        wide_lds_sync();
     };
-    auto scale = [&](bool init) { // GSL scaling.c on the diagonal of J^T J (all threads)
-        for (int j = tid; j < p; j += WT_ADV)
+    auto scale = [&](bool init) { // GSL scaling.c on the diagonal of J^T J
+        if (mine)
         {
             if (prm.scale == 1)
             {
                 if (init)
-                    L.diag[j] = 1.0;
+                    L.diag[lane] = 1.0;
             }
             else
             {
-                double norm = sqrt(L.A[tri(j, j)]);
+                double norm = sqrt(L.A[tri(lane, lane)]);
                 if (norm == 0.0)
                     norm = 1.0;
                 if (init || prm.scale == 2)
-                    L.diag[j] = norm;
+                    L.diag[lane] = norm;
                 else
-                    L.diag[j] = fmax(L.diag[j], norm);
+                    L.diag[lane] = fmax(L.diag[lane], norm);
             }
         }
-        __syncthreads();
+        wide_lds_sync();
     };
-    auto test = [&](int *info) -> int { // gsl_multifit_nlinear_test (thread 0)
-        bool ok = true;
-        for (int i = 0; i < p; ++i)
+    auto test = [&](int *inf) -> int { // gsl_multifit_nlinear_test
+        const bool fail = mine && !(fabs(L.dx[lane]) < prm.xtol * prm.xtol + prm.xtol * fabs(L.x[lane]));
+        if (__ballot(fail) == 0)
         {
-            const double tol = prm.xtol * prm.xtol + prm.xtol * fabs(L.x[i]);
-            if (ok && !(fabs(L.dx[i]) < tol))
-                ok = false;
-        }
-        if (ok)
-        {
-            *info = 1;
+            *inf = 1;
             return ST_SUCCESS;
         }
-        double gnorm = 0.0;
-        for (int i = 0; i < p; ++i)
-        {
-            const double t = fabs(fmax(L.x[i], 1.0) * L.g[i]);
-            if (t > gnorm)
-                gnorm = t;
-        }
-        const double phi = 0.5 * L.fnorm2;
+        const double gnorm = wide_wave_max(mine ? fabs(fmax(L.x[lane], 1.0) * L.g[lane]) : 0.0);
+        const double phi = 0.5 * fnorm2;
         if (gnorm <= prm.gtol * fmax(phi, 1.0))
         {
-            *info = 2;
+            *inf = 2;
             return ST_SUCCESS;
         }
-        *info = 0;
+        *inf = 0;
         return ST_CONTINUE;
     };
-    auto end_iteration = [&](int itstatus) -> bool { // lm_end_iteration (thread 0)
-        const int iter = L.niter;
-        L.niter += 1;
-        L.chisq1 = L.fnorm2;
+    auto end_iteration = [&](int itstatus) -> bool { // lm_end_iteration
+        const int iter = niter;
+        niter += 1;
+        chisq1 = fnorm2;
         if (itstatus == ST_EBADFUNC || (itstatus == ST_ENOPROG && iter == 0))
         {
-            L.info = itstatus;
-            L.status = itstatus;
-            L.phase = PH_DONE;
+            info = itstatus;
+            status = itstatus;
+            phase = PH_DONE;
             return false;
         }
-        int info = 0;
-        const int t = test(&info);
-        L.info = info;
+        int inf = 0;
+        const int t = test(&inf);
+        info = inf;
         if (t == ST_SUCCESS)
         {
-            L.status = ST_SUCCESS;
-            L.phase = PH_DONE;
+            status = ST_SUCCESS;
+            phase = PH_DONE;
             return false;
         }
-        if (L.niter >= prm.maxiter)
+        if (niter >= prm.maxiter)
         {
-            L.status = ST_EMAXITER;
-            L.phase = PH_DONE;
+            status = ST_EMAXITER;
+            phase = PH_DONE;
             return false;
         }
-        L.chisq0 = L.chisq1;
-        L.bad_steps = 0;
+        chisq0 = chisq1;
+        bad_steps = 0;
         return true;
     };
-    auto set_trial = [&]() { // trust_trial_step_lu (threads < p)
-        for (int i = tid; i < p; i += WT_ADV)
+    auto set_trial = [&]() { // trust_trial_step_lu
+        if (mine)
         {
-            const double dxi = L.dx[i], xi = L.x[i];
+            const double dxi = L.dx[lane], xi = L.x[lane];
             double xt = xi + dxi;
             if (prm.has_bounds)
             {
-                if (xt < L.lo[i])
-                    xt = xi + (dxi / fmax(fabs(dxi), L.delta) * fabs(xi - L.lo[i]));
-                else if (xt > L.up[i])
-                    xt = xi + (dxi / fmax(fabs(dxi), L.delta) * fabs(xi - L.up[i]));
+                if (xt < L.lo[lane])
+                    xt = xi + (dxi / fmax(fabs(dxi), delta) * fabs(xi - L.lo[lane]));
+                else if (xt > L.up[lane])
+                    xt = xi + (dxi / fmax(fabs(dxi), delta) * fabs(xi - L.up[lane]));
             }
-            L.xt[i] = xt;
+            L.xt[lane] = xt;
         }
+        wide_lds_sync();
     };
 
-    const int phase = L.phase;
+    bool step = false;
     if (phase == PH_INIT)
     {
-        if (tid == 0)
+        nevalf += 1;
+        bool ok = true;
+        if (prm.jac_analytic)
         {
-            L.nevalf += 1;
-            bool ok = true;
-            if (prm.jac_analytic)
-            {
-                L.nevaldf += 1;
-                if (!(r_badj == 0.0))
-                    ok = false;
-            }
-            else
-                L.nevalf += lm_fd_cost(prm, p);
-            L.do_take = ok ? 1 : 2;
+            nevaldf += 1;
+            if (!(r_badj == 0.0))
+                ok = false;
         }
-        __syncthreads();
-        const int how = L.do_take;
+        else
+            nevalf += lm_fd_cost(prm, p);
         take_point();
-        if (how == 2)
+        if (!ok)
         {
-            if (tid == 0)
-            {
-                L.chisq_init = L.chisq0 = L.chisq1 = r_ssr;
-                L.status = ST_EBADFUNC;
-                L.info = ST_EBADFUNC;
-                L.phase = PH_DONE;
-            }
+            chisq_init = chisq0 = chisq1 = r_ssr;
+            status = ST_EBADFUNC;
+            info = ST_EBADFUNC;
+            phase = PH_DONE;
         }
         else
         {
             scale(true);
-            if (tid == 0)
-            {
-                double Dx2 = 0.0, mx = -1.0;
-                for (int j = 0; j < p; ++j)
-                {
-                    const double u = L.diag[j] * L.x[j];
-                    Dx2 += u * u;
-                    mx = fmax(mx, sqrt(L.A[tri(j, j)]) / L.diag[j]);
-                }
-                L.delta = 0.3 * fmax(1.0, sqrt(Dx2));
-                L.mu = 1.0e-3 * mx * mx;
-                L.nu = 2.0;
-                L.avratio = 0.0;
-                L.chisq_init = r_ssr;
-                L.chisq0 = L.chisq1 = (prm.chisq_in == prm.chisq_in) ? prm.chisq_in : r_ssr;
-                L.niter = 0;
-                L.bad_steps = 0;
-                L.do_step = 1;
-            }
+            const double u = mine ? L.diag[lane] * L.x[lane] : 0.0;
+            const double Dx2 = wide_seq_sum(u * u, p);
+            const double mx = wide_wave_max(mine ? sqrt(L.A[tri(lane, lane)]) / L.diag[lane] : -1.0);
+            delta = 0.3 * fmax(1.0, sqrt(Dx2));
+            mu = 1.0e-3 * mx * mx;
+            nu = 2.0;
+            avratio = 0.0;
+            chisq_init = r_ssr;
+            chisq0 = chisq1 = (prm.chisq_in == prm.chisq_in) ? prm.chisq_in : r_ssr;
+            niter = 0;
+            bad_steps = 0;
+            step = true;
         }
-        __syncthreads();
     }
     else if (phase == PH_FVV)
     {
-        if (tid == 0)
+        if (prm.fvv_analytic)
+            nevalfvv += 1;
+        else
+            nevalf += 1;
+        if (prm.fvv_analytic && !(r_badj == 0.0))
         {
-            if (prm.fvv_analytic)
-                L.nevalfvv += 1;
-            else
-                L.nevalf += 1;
-            if (prm.fvv_analytic && !(r_badj == 0.0))
-            {
-                // a failed fvv counts as a rejected step (src/trust.c:452-483, :530-545)
-                L.delta /= prm.factor_down;
-                L.mu *= L.nu;
-                L.nu *= 2.0;
-                const int itstatus = (++L.bad_steps > 15) ? ST_ENOPROG : ST_CONTINUE;
-                L.do_step = ((itstatus == ST_CONTINUE) ? true : end_iteration(itstatus)) ? 1 : 0;
-            }
-            else
-                L.do_solve_acc = 1;
+            // a failed fvv counts as a rejected step (src/trust.c:452-483, :530-545)
+            delta /= prm.factor_down;
+            mu *= nu;
+            nu *= 2.0;
+            const int itstatus = (++bad_steps > 15) ? ST_ENOPROG : ST_CONTINUE;
+            step = (itstatus == ST_CONTINUE) ? true : end_iteration(itstatus);
         }
-        __syncthreads();
-        if (L.do_solve_acc)
+        else
         {
-            for (int i = tid; i < p; i += WT_ADV)
-                L.rhs[i] = -rg[i];
-            __syncthreads();
-            if (wave == 0)
-                wide_solve(L, p, L.mu, L.rhs, L.acc, lane);
-            __syncthreads();
-            if (tid == 0)
-            {
-                double an = 0.0, vn = 0.0;
-                for (int i = 0; i < p; ++i)
-                {
-                    an += L.acc[i] * L.acc[i];
-                    vn += L.vel[i] * L.vel[i];
-                }
-                L.avratio = sqrt(an) / sqrt(vn);
-                L.phase = PH_TRIAL;
-            }
-            for (int i = tid; i < p; i += WT_ADV)
-                L.dx[i] = L.vel[i] + 0.5 * L.acc[i];
-            __syncthreads();
+            if (mine)
+                L.rhs[lane] = -rg[lane];
+            wide_lds_sync();
+            wide_solve(L, p, mu, L.rhs, L.acc, lane);
+            const double ai = mine ? L.acc[lane] : 0.0, vi = mine ? L.vel[lane] : 0.0;
+            const double an = wide_seq_sum(ai * ai, p), vn = wide_seq_sum(vi * vi, p);
+            avratio = sqrt(an) / sqrt(vn);
+            if (mine)
+                L.dx[lane] = vi + 0.5 * ai;
+            wide_lds_sync();
             set_trial();
-            __syncthreads();
+            phase = PH_TRIAL;
         }
     }
     else
     {
         // PH_TRIAL: trust_eval_step + radius / mu updates (src/trust.c:474-545)
-        // lm_preduction needs v^T (J^T J) v: row i of the product by thread i, the outer sum in index order by thread 0
-        for (int i = tid; i < p; i += WT_ADV)
+        nevalf += 1;
+        double rho;
+        if (!(r_ssr < fnorm2))
+            rho = -1.0;
+        else
         {
+            const double finv = 1.0 / fnorm2;
+            const double ared = 1.0 - r_ssr * finv;
+            // lm_preduction: v^T (J^T J) v, row i of the product by lane i (j ascending), the outer sums in index order
             double row = 0.0;
-            for (int j = 0; j < p; ++j)
-                row += L.A[j <= i ? tri(i, j) : tri(j, i)] * L.vel[j];
-            L.row[i] = row;
+            if (mine)
+                for (int j = 0; j < p; ++j)
+                    row += L.A[j <= lane ? tri(lane, j) : tri(j, lane)] * L.vel[j];
+            const double vl = mine ? L.vel[lane] : 0.0;
+            const double vAv = wide_seq_sum(row * vl, p);
+            const double ud = mine ? L.diag[lane] * vl : 0.0;
+            const double Dv2 = wide_seq_sum(ud * ud, p);
+            const double pred = vAv * finv + 2.0 * mu * (Dv2 * finv);
+            rho = (pred > 0.0) ? ared / pred : -1.0;
         }
-        __syncthreads();
-        if (tid == 0)
+        bool found = rho > 0.0;
+        if (prm.trs == 1 && avratio > prm.avmax)
+            found = false;
+        if (rho > 0.75)
+            delta *= prm.factor_up;
+        else if (rho < 0.25)
+            delta /= prm.factor_down;
+        int itstatus = ST_CONTINUE;
+        if (found)
         {
-            L.nevalf += 1;
-            double rho;
-            if (!(r_ssr < L.fnorm2))
-                rho = -1.0;
-            else
+            itstatus = ST_SUCCESS;
+            if (prm.jac_analytic)
             {
-                const double finv = 1.0 / L.fnorm2;
-                const double ared = 1.0 - r_ssr * finv;
-                double vAv = 0.0, Dv2 = 0.0;
-                for (int i = 0; i < p; ++i)
-                {
-                    vAv += L.row[i] * L.vel[i];
-                    const double u = L.diag[i] * L.vel[i];
-                    Dv2 += u * u;
-                }
-                const double pred = vAv * finv + 2.0 * L.mu * (Dv2 * finv);
-                rho = (pred > 0.0) ? ared / pred : -1.0;
-            }
-            bool found = rho > 0.0;
-            if (prm.trs == 1 && L.avratio > prm.avmax)
-                found = false;
-            if (rho > 0.75)
-                L.delta *= prm.factor_up;
-            else if (rho < 0.25)
-                L.delta /= prm.factor_down;
-            int itstatus = ST_CONTINUE;
-            L.do_take = 0;
-            if (found)
-            {
-                itstatus = ST_SUCCESS;
-                if (prm.jac_analytic)
-                {
-                    L.nevaldf += 1;
-                    if (!(r_badj == 0.0))
-                        itstatus = ST_EBADFUNC;
-                }
-                else
-                    L.nevalf += lm_fd_cost(prm, p);
-                if (itstatus == ST_SUCCESS)
-                {
-                    L.do_take = 1;
-                    double b = 2.0 * rho - 1.0;
-                    b = 1.0 - b * b * b;
-                    L.nu = 2.0;
-                    L.mu *= fmax(0.333333333333333, b);
-                    L.bad_steps = 0;
-                }
+                nevaldf += 1;
+                if (!(r_badj == 0.0))
+                    itstatus = ST_EBADFUNC;
             }
             else
+                nevalf += lm_fd_cost(prm, p);
+            if (itstatus == ST_SUCCESS)
             {
-                L.mu *= L.nu;
-                L.nu *= 2.0;
-                if (++L.bad_steps > 15)
-                    itstatus = ST_ENOPROG;
+                take_point();
+                scale(false);
+                double b = 2.0 * rho - 1.0;
+                b = 1.0 - b * b * b;
+                nu = 2.0;
+                mu *= fmax(0.333333333333333, b);
+                bad_steps = 0;
             }
-            L.do_solve_acc = itstatus; // parked for the second half below (after the accepted point has been taken)
-        }
-        __syncthreads();
-        if (L.do_take)
-        {
-            take_point();
-            scale(false);
-        }
-        if (tid == 0)
-        {
-            const int itstatus = L.do_solve_acc;
-            L.do_solve_acc = 0;
-            L.do_step = ((itstatus == ST_CONTINUE) ? true : end_iteration(itstatus)) ? 1 : 0;
-        }
-        __syncthreads();
-    }
-    // ---- lm_begin_step ----
-    if (L.do_step)
-    {
-        for (int i = tid; i < p; i += WT_ADV)
-            L.rhs[i] = -L.g[i];
-        __syncthreads();
-        if (wave == 0)
-            wide_solve(L, p, L.mu, L.rhs, L.vel, lane);
-        __syncthreads();
-        if (prm.trs == 1)
-        {
-            if (tid == 0)
-                L.phase = PH_FVV;
         }
         else
         {
-            for (int i = tid; i < p; i += WT_ADV)
-            {
-                L.acc[i] = 0.0;
-                L.dx[i] = L.vel[i];
-            }
-            __syncthreads();
-            set_trial();
-            if (tid == 0)
-                L.phase = PH_TRIAL;
+            mu *= nu;
+            nu *= 2.0;
+            if (++bad_steps > 15)
+                itstatus = ST_ENOPROG;
         }
-        __syncthreads();
+        step = (itstatus == ST_CONTINUE) ? true : end_iteration(itstatus);
     }
-    if (tid == 0 && prm.bench_hold && L.phase == PH_DONE)
+    if (step)
+    {
+        // lm_begin_step
+        if (mine)
+            L.rhs[lane] = -L.g[lane];
+        wide_lds_sync();
+        wide_solve(L, p, mu, L.rhs, L.vel, lane);
+        if (prm.trs == 1)
+            phase = PH_FVV;
+        else
+        {
+            if (mine)
+            {
+                L.acc[lane] = 0.0;
+                L.dx[lane] = L.vel[lane];
+            }
+            wide_lds_sync();
+            set_trial();
+            phase = PH_TRIAL;
+        }
+    }
+    if (prm.bench_hold && phase == PH_DONE)
     {
         // timing mode: never finish, so that every step pays a full pass
-        L.phase = PH_TRIAL;
-        L.status = ST_CONTINUE;
-        L.mu = 1.0;
-        L.nu = 2.0;
-        L.bad_steps = 0;
+        phase = PH_TRIAL;
+        status = ST_CONTINUE;
+        mu = 1.0;
+        nu = 2.0;
+        bad_steps = 0;
     }
-    __syncthreads();
-    // ---- LDS -> state (+ trace rows, + the host's copy when the fit has ended) ----
-    const bool done = L.phase == PH_DONE;
+    // ---- LDS / registers -> state (+ trace rows, + the host's copy when the fit has ended) ----
+    const bool done = phase == PH_DONE;
     for (int rep = 0; rep < (done ? 2 : 1); ++rep)
     {
         WState *D = rep == 0 ? S : a.host_mirror;
-        for (int k = tid; k < p; k += WT_ADV)
+        if (mine)
         {
-            D->x[k] = L.x[k];
-            D->xt[k] = L.xt[k];
-            D->dx[k] = L.dx[k];
-            D->vel[k] = L.vel[k];
-            D->acc[k] = L.acc[k];
-            D->g[k] = L.g[k];
-            D->diag[k] = L.diag[k];
-            D->lo[k] = L.lo[k];
-            D->up[k] = L.up[k];
+            D->x[lane] = L.x[lane];
+            D->xt[lane] = L.xt[lane];
+            D->dx[lane] = L.dx[lane];
+            D->vel[lane] = L.vel[lane];
+            D->acc[lane] = L.acc[lane];
+            D->g[lane] = L.g[lane];
+            D->diag[lane] = L.diag[lane];
+            D->lo[lane] = L.lo[lane];
+            D->up[lane] = L.up[lane];
         }
-        for (int k = tid; k < NA; k += WT_ADV)
+        for (int k = lane; k < NA; k += 64)
             D->A[k] = L.A[k];
-        if (tid == 0)
+        if (lane == 0)
         {
-            D->fnorm2 = L.fnorm2;
-            D->mu = L.mu;
-            D->nu = L.nu;
-            D->delta = L.delta;
-            D->avratio = L.avratio;
-            D->chisq0 = L.chisq0;
-            D->chisq1 = L.chisq1;
-            D->chisq_init = L.chisq_init;
-            D->bad_steps = L.bad_steps;
-            D->niter = L.niter;
-            D->phase = L.phase;
-            D->status = L.status;
-            D->info = L.info;
-            D->nevalf = L.nevalf;
-            D->nevaldf = L.nevaldf;
-            D->nevalfvv = L.nevalfvv;
+            D->fnorm2 = fnorm2;
+            D->mu = mu;
+            D->nu = nu;
+            D->delta = delta;
+            D->avratio = avratio;
+            D->chisq0 = chisq0;
+            D->chisq1 = chisq1;
+            D->chisq_init = chisq_init;
+            D->bad_steps = bad_steps;
+            D->niter = niter;
+            D->phase = phase;
+            D->status = status;
+            D->info = info;
+            D->nevalf = nevalf;
+            D->nevaldf = nevaldf;
+            D->nevalfvv = nevalfvv;
             D->p = p;
             D->end_launch = a.launch_idx;
         }
@@ -656,30 +610,27 @@ __device__ __forceinline__ void wide_advance(const WAdvanceArgs &a, WideLds &L)
     if (a.ssrtrace)
     {
         // callback (src/nls.c:980-995): trace row 0 after init, row niter after each iteration
-        if (L.phase_before == PH_INIT)
+        if (phase_before == PH_INIT)
         {
-            if (tid == 0)
-                a.ssrtrace[0] = L.chisq_init;
-            for (int k = tid; k < p; k += WT_ADV)
-                a.partrace[(size_t)(prm.maxiter + 1) * k] = L.x[k];
+            if (lane == 0)
+                a.ssrtrace[0] = chisq_init;
+            if (mine)
+                a.partrace[(size_t)(prm.maxiter + 1) * lane] = L.x[lane];
         }
-        else if (L.phase_before != PH_INIT && L.niter != L.niter_before && L.status != ST_EBADFUNC &&
-                 !(L.status == ST_ENOPROG && L.niter_before == 0))
+        else if (niter != niter_before && status != ST_EBADFUNC && !(status == ST_ENOPROG && niter_before == 0))
         {
-            if (tid == 0)
-                a.ssrtrace[L.niter] = L.chisq1;
-            for (int k = tid; k < p; k += WT_ADV)
-                a.partrace[L.niter + (size_t)(prm.maxiter + 1) * k] = L.x[k];
+            if (lane == 0)
+                a.ssrtrace[niter] = chisq1;
+            if (mine)
+                a.partrace[niter + (size_t)(prm.maxiter + 1) * lane] = L.x[lane];
         }
     }
     if (done)
     {
-        __syncthreads();
-        if (tid == 0)
-        {
-            __threadfence_system();
+        __threadfence_system(); // every lane: its own stores to the host's copy are out before the completion word
+        wide_lds_sync();
+        if (lane == 0)
             __hip_atomic_store(a.done_seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
     }
 }
 

@@ -266,8 +266,8 @@ __global__ __launch_bounds__(WIDE_T) void wide_pass_kernel(WPassArgs a)
             for (int b = 0; b < NB; ++b)
             {
                 double s = gacc[b];
-                const double s1 = wide_bcast(s, ii + 16), s2 = wide_bcast(s, ii + 32), s3 = wide_bcast(s, ii + 48);
-                s = ((wide_bcast(s, ii) + s1) + s2) + s3;
+                const double s1 = wide_shfl(s, ii + 16), s2 = wide_shfl(s, ii + 32), s3 = wide_shfl(s, ii + 48);
+                s = ((wide_shfl(s, ii) + s1) + s2) + s3;
                 if (kk == 0)
                     gfull[b * 16 + ii] = (w == 0) ? s : gfull[b * 16 + ii] + s;
             }

@@ -80,6 +80,39 @@ def test_glm_fit_matches_oracle(amd, gslref, alg, p, n):
     assert np.allclose(fit["resid"], o["resid"], atol=1e-7)
 
 
+@pytest.mark.parametrize("alg", ["cgst", "lm"])
+def test_one_shot_entry_equals_create_solve_destroy(amd, alg):
+    """gslnls_nls_large is the C_nls_large counterpart (src/nls_large.c:66-75: one call, everything built and torn
+    down inside it); it must give bit for bit what gslnls_large_create / _solve / _destroy give, weights included"""
+    import ctypes as C
+    from gslnls_amd import _lib
+    from gslnls_amd.control import gsl_nls_control
+    from gslnls_amd.nls_large import pack_control_large
+    n, p = 3001, 16
+    A, y, th = glm_data(n, p)
+    w = np.random.default_rng(3).uniform(0.5, 2.0, n)
+    prob = amd.LargeProblem(5, p, A, y, weights=w)
+    ref = prob.solve(np.zeros(p), alg)
+    prob.close()
+    ci, cd = pack_control_large(gsl_nls_control(), alg, False)
+    Ac, yc, wc, st = np.ascontiguousarray(A), np.ascontiguousarray(y), np.ascontiguousarray(w), np.zeros(p)
+    m = _lib.Model(5, p, p, Ac.ctypes.data_as(C.c_void_p), 0)
+    out = dict(par=np.zeros(p), covar=np.zeros((p, p), order="F"), resid=np.zeros(n))
+    res = _lib.LargeResult()
+    res.par, res.covar, res.resid = (out[k].ctypes.data_as(_lib.DP) for k in ("par", "covar", "resid"))
+    rc = _lib.lib().gslnls_nls_large(C.byref(m), yc.ctypes.data_as(C.c_void_p), n, st.ctypes.data_as(_lib.DP),
+                                     wc.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(_lib.IP), cd.ctypes.data_as(_lib.DP),
+                                     C.byref(res))
+    assert rc == 0 and res.conv == 0 and res.niter == ref["niter"]
+    assert np.array_equal(out["par"], ref["par"]) and res.ssr == ref["ssr"]
+    assert np.array_equal(out["covar"], ref["covar"]) and np.array_equal(out["resid"], ref["resid"])
+    assert [res.neval[k] for k in range(4)] == [ref["neval"][k] for k in ("f", "dfu", "df2", "fvv")]
+    # a model the large path does not know is refused by the one-shot entry like by create
+    bad = _lib.Model(77, p, p, Ac.ctypes.data_as(C.c_void_p), 0)
+    assert _lib.lib().gslnls_nls_large(C.byref(bad), yc.ctypes.data_as(C.c_void_p), n, st.ctypes.data_as(_lib.DP), None,
+                                       ci.ctypes.data_as(_lib.IP), cd.ctypes.data_as(_lib.DP), C.byref(res)) == _lib.E_UNSUPPORTED
+
+
 def test_unit_tests_3_x_large(amd, gslref, nist):
     """unit_tests_gslnls.R:108-131: gsl_nls_large on Misra1a (3.1.1 lm, 3.1.4 weights = 1) and Steihaug-Toint"""
     q = nist["Misra1a"]
