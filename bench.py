@@ -224,6 +224,23 @@ def multistart_bench(L, _lib, job, steps, warmup, lib_comm):
                       "fits_per_s_records_on_host": (total * steps / el_host) if el_host else None,
                       "achieved_GFLOPs_kernel": (hi - lo) * flop_fit / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None}
     L.gslnls_dense_destroy(h)
+    # counters of the SAME kernel at the SAME batch size from the committed profile (one rocprofv3 --pmc capture per
+    # batch size, scripts/profile_c4c5_pmc.sh): share of the SIMD issue slots the kernel's vector instructions take
+    try:
+        pfile = next(os.path.join(ROOT, "profiles", f) for f in ("r03_c4c5_pmc.json", "r02_c4c5_pmc.json")
+                     if os.path.exists(os.path.join(ROOT, "profiles", f)))
+        with open(pfile) as f:
+            pm = json.load(f)
+        for label, pts in (("strong_8192_total", 8192), ("weak_65536_per_gpu", 65536)):
+            k = next((v for kk, v in pm.items() if kk.startswith("ms_fit_kernel") and kk.endswith("@ %d points per dispatch" % pts)), None)
+            if k and label in out:
+                valu, gui = k["SQ_INSTS_VALU"]["median_per_dispatch"], k["GRBM_GUI_ACTIVE"]["median_per_dispatch"]
+                out[label]["valu_issue_share"] = valu * 4.0 / (1024.0 * gui / 8.0)
+                out[label]["valu_issue_share_source"] = ("committed profile profiles/%s, %d points per dispatch (SQ_INSTS_VALU x 4 "
+                                                         "cycles / (1024 SIMDs x GRBM_GUI_ACTIVE per XCD)), NOT measured in this "
+                                                         "run" % (os.path.basename(pfile), pts))
+    except Exception:  # noqa
+        pass
     if world == 1:
         # the whole multi-start procedure of C4 (sampling, concentration, reduction, local searches, final solve)
         import gslnls_amd as A

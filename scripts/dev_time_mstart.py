@@ -13,7 +13,8 @@ h = L.gslnls_dense_create(C.byref(model), y.ctypes.data_as(C.c_void_p), 6, None,
 ci, cd = pack_control(gsl_nls_control(solver="cholesky"), "lm")
 ranges = np.array([1.0, 500.0, 0.01, 5.0]); kd = np.array([0.75, 0.75])
 K = L.gslnls_mstart_record_size(2)
-for total in (8192, 65536, 262144, 1048576):
+SIZES = [int(v) for v in sys.argv[1:]] or [8192, 65536, 262144, 1048576]
+for total in SIZES:
     shard = torch.zeros(total * K, dtype=torch.float64, device="cuda")
     ms = C.c_float(0)
     def step():

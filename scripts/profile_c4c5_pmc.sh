@@ -11,20 +11,27 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  for wl in c5 mstart; do
-    timeout -k 10 170 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/p${i}_$wl" -o run -- python3 "$ROOT/scripts/dev_time_$wl.py" > "$OUT/p${i}_$wl.log" 2>&1
-    echo "group $i ($grp) $wl rc=$?"
+  timeout -k 10 170 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/p${i}_c5" -o run -- python3 "$ROOT/scripts/dev_time_c5.py" > "$OUT/p${i}_c5.log" 2>&1
+  echo "group $i ($grp) c5 rc=$?"
+  # one capture per batch size: the kernel name does not say how many points a dispatch fitted
+  for sz in 8192 65536 262144; do
+    timeout -k 10 170 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/p${i}_mstart_$sz" -o run -- python3 "$ROOT/scripts/dev_time_mstart.py" $sz > "$OUT/p${i}_mstart_$sz.log" 2>&1
+    echo "group $i ($grp) mstart $sz rc=$?"
   done
 done
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, json, os, statistics, sys
 out, tag = sys.argv[1], sys.argv[2]
 res = {}
+import re
 for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
+    m = re.search(r"p\d+_mstart_(\d+)", f)
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0].replace("void gslnls::", "")
         if not (k.startswith("irls_batch_kernel") or k.startswith("ms_fit_kernel")):
             continue
+        if m:
+            k += " @ %s points per dispatch" % m.group(1)
         res.setdefault(k, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
 summ = {k: {c: {"median_per_dispatch": statistics.median(v), "dispatches": len(v)} for c, v in d.items()} for k, d in res.items()}
 for k, d in summ.items():

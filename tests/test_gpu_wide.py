@@ -233,3 +233,25 @@ def test_wide_lmaccel_runs_the_acceleration_pass(amd, gslref):
         assert np.allclose(fit["par"], ref["par"], rtol=1e-6, atol=1e-9)
         if not fvv:
             assert fit["niter"] == ref["niter"]
+
+
+@pytest.mark.parametrize("loss", ["huber", "bisquare"])
+def test_wide_robust_irls_matches_oracle(amd, gslref, loss):
+    """gsl_nls(loss = ...) on p = 16 with 2 % gross outliers: the IRLS driver of src/nls_irls.c:412-546 around the wide
+    solve (cold re-solve per IRLS iteration, median by radix select, psi family) against the oracle's"""
+    q = gaussians_problem(5, 1, 6000, seed=31)
+    p, n = 16, 6000
+    rng = np.random.Generator(np.random.PCG64(77))
+    y = q["y"].copy()
+    y[rng.choice(n, n // 50, replace=False)] += 3.0
+    fit = amd.gsl_nls(q["formula"], data=dict(x=q["x"], y=y), start=dict(zip(q["names"], q["start"])), jac=True,
+                      loss=loss, control=dict(solver="cholesky"))
+    ref = gslref.nls(n, p, q["start"], fn=lambda th: q["model"](th) - y, jac=q["jac"], loss=loss,
+                     ctrl=gslref.control(solver="cholesky"))
+    assert fit["code_path"] == 3 and fit["conv"] == ref["conv"] == 0
+    assert fit["irls"]["irls_niter"] == ref["irls"]["irls_niter"] and fit["irls"]["irls_status"] == ref["irls"]["irls_status"]
+    assert np.allclose(fit["par"], ref["par"], rtol=1e-6, atol=1e-9)
+    assert abs(fit["irls"]["irls_sigma"] - ref["irls"]["irls_sigma"]) <= 1e-9 * ref["irls"]["irls_sigma"]
+    assert np.allclose(fit["irls_weights"], ref["irls_weights"], rtol=1e-6, atol=1e-9)
+    # the outliers are what got down-weighted; the peaks are recovered
+    assert np.allclose(fit["par"], q["truth"], rtol=5e-2, atol=5e-2)
