@@ -115,6 +115,33 @@ def test_native_lowering_builds_without_a_device(tmp_path, monkeypatch):
     assert _lib.lib().gslnls_expr_build(C.byref(bad), buf, 512) == _lib.E_UNSUPPORTED
 
 
+def test_without_the_in_process_compiler_native_lowering_is_refused_not_faked(tmp_path):
+    """a host whose HIP runtime lacks hiprtc (simulated: GSLNLS_HIPRTC=none): building native code fails with
+    GSLNLS_E_UNSUPPORTED and a message, nothing is cached; a background request reports failure instead of hanging"""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from gslnls_amd import _lib
+L = _lib.lib()
+m = _lib.Model(_lib.MODEL_EXPR, 3, 1, None, 0)
+keep = _lib.set_expr(m, "a*exp(-b*x) + c", ["a", "b", "c"], ["x"], "jit")
+buf = C.create_string_buffer(256)
+print("build", L.gslnls_expr_build(C.byref(m), buf, 256), "prefetch", L.gslnls_expr_prefetch(C.byref(m), 0))
+names = ["t%%d" %% k for k in range(12)]
+w = _lib.Model(_lib.MODEL_EXPR, 12, 1, None, 0)
+keep2 = _lib.set_expr(w, " + ".join("%%s*x^%%d" %% (nm, k) for k, nm in enumerate(names)), names, ["x"], "jit")
+print("wide", L.gslnls_expr_build(C.byref(w), buf, 256))
+""" % (ROOT,)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, GSLNLS_JIT_CACHE=str(tmp_path), GSLNLS_HIPRTC="none"))
+    assert out.returncode == 0, out.stderr[-1500:]
+    assert "build -101 prefetch -1" in out.stdout and "wide -101" in out.stdout
+    assert "hiprtc disabled" in out.stderr
+    assert not [f for f in os.listdir(tmp_path) if f.endswith(".bin")]
+
+
 def test_process_exit_with_queued_background_builds_is_clean(tmp_path):
     """GSLNLS_LOWER_AUTO starts builds on a background thread; a process that exits while dozens are queued and one is
     inside the compiler must neither crash nor hang (seen before gslnls_shutdown existed: "LLVM ERROR", heap

@@ -3,6 +3,7 @@ model registry are compiled to a device program (value + symbolic gradient) and 
 LM / multi-start / IRLS kernels.  The cases are the reference's own NIST list
 (inst/unit_tests/unit_tests_gslnls.R 2.x, R/nls_test.R:169-979); bars: the certified values at the
 reference's tolerance eps^0.25 and the oracle (same algorithm, model evaluated by numpy) to 1e-6 relative."""
+import json
 import os
 
 import numpy as np
@@ -12,6 +13,7 @@ from gslnls_amd import formula as F
 from test_oracle_golden import NIST_CONVERGE, nist_callbacks
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 TOL = float(np.finfo(float).eps ** 0.25)
 # formulas with a hand-written device model are covered by test_gpu_dense.py; everything else goes through the VM
@@ -174,6 +176,36 @@ def test_auto_lowering_switches_to_native_code_without_a_compiler_driver(amd, tm
     small.close()
     assert again["code_path"] == 2
     assert len([f for f in os.listdir(tmp_path) if f.endswith(".bin")]) == 1
+
+
+def test_formula_fits_without_the_in_process_compiler(nist, tmp_path):
+    """GSLNLS_HIPRTC=none (a HIP runtime without hiprtc): the default lowering still fits every p <= 9 formula -- on the
+    interpreter, code_path 1 -- "jit" and the wide path say so instead of pretending"""
+    import subprocess
+    import sys
+    q = nist["Thurber"]
+    code = r"""
+import json, sys, numpy as np
+sys.path.insert(0, %r)
+import gslnls_amd as A
+q = json.loads(sys.argv[1])
+data = {k: np.asarray(v, dtype=np.float64) for k, v in q["data"].items()}
+a = A.gsl_nls(q["formula"], data=data, start=q["start"], jac=True)
+b = A.gsl_nls(q["formula"], data=data, start=q["start"], jac=True)
+print("auto", a["code_path"], b["code_path"], a["conv"], list(a["par"]) == list(b["par"]))
+for low, formula, start in (("jit", q["formula"], q["start"]),
+                            ("auto", "y ~ " + " + ".join("t%%d*x^%%d" %% (k, k) for k in range(11)), {"t%%d" %% k: 1.0 for k in range(11)})):
+    try:
+        A.gsl_nls(formula, data=data, start=start, jac=True, lowering=low)
+        print("served", low)
+    except NotImplementedError:
+        print("refused", low)
+""" % (ROOT,)
+    out = subprocess.run([sys.executable, "-c", code, json.dumps(dict(formula=q["formula"], data=q["data"], start=q["start"]))],
+                         capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, GSLNLS_JIT_CACHE=str(tmp_path), GSLNLS_HIPRTC="none"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "auto 1 1 0 True" in out.stdout and out.stdout.count("refused") == 2
 
 
 def test_native_lowering_c2_full_size(amd):
