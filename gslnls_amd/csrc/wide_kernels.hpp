@@ -33,7 +33,7 @@ namespace gslnls
 
 constexpr int WIDE_LD = 68;     // leading dimension of the tile (doubles)
 constexpr int WIDE_T = 256;     // threads per workgroup of the pass
-constexpr int WIDE_MAX_G = 256; // workgroups == partial sets
+constexpr int WIDE_MAX_G = 512; // workgroups == partial sets (two per CU where registers and LDS allow)
 
 struct WPassArgs
 {
@@ -98,8 +98,11 @@ __device__ __forceinline__ double wide_resid(const TH &th, const XR &xr, double 
     return f * sw;
 }
 
+#ifndef GSLNLS_WIDE_WAVES
+#define GSLNLS_WIDE_WAVES(PW) ((PW) <= 32 ? 2 : 1) // workgroups per CU the register budget is cut for (LDS allows 2 up to PW = 32)
+#endif
 template <class M, int JAC, int PW>
-__global__ __launch_bounds__(WIDE_T) void wide_pass_kernel(WPassArgs a)
+__global__ __launch_bounds__(WIDE_T, GSLNLS_WIDE_WAVES(PW)) void wide_pass_kernel(WPassArgs a)
 {
     constexpr int P = M::P, NX = M::NX, NB = PW / 16, NW = WIDE_T / 64, NQ = NB * (NB + 1) / 2;
     constexpr int NA = P * (P + 1) / 2, NV = 2 + NA + P;

@@ -31,6 +31,23 @@ static void probe_interrupt(void *dummy)
 }
 static int interrupt_hook(void) { return R_ToplevelExec(probe_interrupt, NULL) == FALSE; }
 
+/* Unload hook of the package's shared object (library.dynam.unload / R session end via the namespace's .onUnload):
+ * formulas seen under the default lowering start a compiler thread inside libgslnls_hip.so; it must be stopped before
+ * the C runtime tears the compiler's own static objects down (include/gslnls_core.h, gslnls_shutdown).  The maintainer
+ * adds this call to the package's existing R_unload_gslnls, or this function if there is none; R/zzz.R gets
+ * .onUnload <- function(libpath) library.dynam.unload("gslnls", libpath) and a
+ * reg.finalizer(asNamespace("gslnls"), function(e) .Call(C_gslnls_shutdown), onexit = TRUE). */
+void R_unload_gslnls(DllInfo *dll)
+{
+    (void)dll;
+    gslnls_shutdown();
+}
+SEXP C_gslnls_shutdown(void)
+{
+    gslnls_shutdown();
+    return R_NilValue;
+}
+
 /* `formula` as the closure .fn sees it: .fn <- function(par, .data = mf) eval(formula[[3]], ...) is created inside
  * gsl_nls.formula (R/nls.R:565), so its enclosure is that call's frame, which binds `formula` and `mf`.  Only that
  * frame is searched (Rf_findVarInFrame): a plain `function` passed as fn must not pick up some unrelated `formula`

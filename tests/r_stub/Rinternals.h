@@ -19,6 +19,7 @@ typedef int R_len_t;
 typedef enum { FALSE = 0, TRUE } Rboolean;
 typedef unsigned int SEXPTYPE;
 typedef void *(*DL_FUNC)(void);
+typedef struct _DllInfo DllInfo; /* R_ext/Rdynload.h */
 
 #define NILSXP 0
 #define SYMSXP 1
