@@ -225,9 +225,25 @@ __device__ __forceinline__ void wide_solve(WideLds &L, int p, double mu, const d
         wide_lds_sync();
         if (lane > j && lane < p)
         {
-            // M[i][k] -= ainv * vi * M[k][j], k = j+1..i: four at a time, all loads of a group ahead of its stores
+            // M[i][k] -= ainv * vi * M[k][j], k = j+1..i: eight at a time, all loads of a group ahead of its stores
             // (the compiler cannot tell that rows and the column copy never overlap and would serialise every element)
             int k = j + 1;
+            for (; k + 7 < lane; k += 8)
+            {
+                double m[8], c[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                {
+                    m[u] = M[lane * LD + k + u];
+                    c[u] = colj[k + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    m[u] -= ainv * vi * c[u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    M[lane * LD + k + u] = m[u];
+            }
             for (; k + 3 < lane; k += 4)
             {
                 const double m0 = M[lane * LD + k], m1 = M[lane * LD + k + 1], m2 = M[lane * LD + k + 2], m3 = M[lane * LD + k + 3];

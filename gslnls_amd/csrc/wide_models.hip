@@ -89,6 +89,24 @@ extern "C" int gslnls_debug_wide_solve(int p, const double *Ap, const double *di
     GSLNLS_HIP_OK(hipMemcpy(d + na + p, rhs, sizeof(double) * p, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(wide_solve_debug_kernel, dim3(1), dim3(64), 0, 0, p, d, d + na, mu, d + na + p, d + na + 2 * p);
     GSLNLS_HIP_OK(hipMemcpy(sol, d + na + 2 * p, sizeof(double) * p, hipMemcpyDeviceToHost));
+    if (const char *e = getenv("GSLNLS_WIDE_SOLVE_REPS"))
+    {
+        // developer timing of the solve alone (HIP events around `reps` back-to-back launches)
+        const int reps = atoi(e) > 0 ? atoi(e) : 1;
+        hipEvent_t e0, e1;
+        GSLNLS_HIP_OK(hipEventCreate(&e0));
+        GSLNLS_HIP_OK(hipEventCreate(&e1));
+        (void)hipEventRecord(e0, 0);
+        for (int r = 0; r < reps; ++r)
+            hipLaunchKernelGGL(wide_solve_debug_kernel, dim3(1), dim3(64), 0, 0, p, d, d + na, mu, d + na + p, d + na + 2 * p);
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        fprintf(stderr, "[wide solve] p = %d: %.2f us per launch (incl. ~2 us launch boundary)\n", p, 1e3 * ms / reps);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
     hipFree(d);
     return GSLNLS_SUCCESS;
 }
