@@ -16,6 +16,7 @@
 #include "dense_host.hpp"
 #include "irls_kernels.hpp"
 #include "large_host.hpp"
+#include "robust_host.hpp"
 #include "rtc_host.hpp"
 #include "wide_core.hpp"
 #include "wide_kernels.hpp"
@@ -74,6 +75,38 @@ __global__ __launch_bounds__(256) void wide_keys_kernel(const double *r, long lo
 {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
         keys[i] = (unsigned long long)__double_as_longlong(fabs(r[i]));
+}
+
+// hat values h_i = J_i (J^T J)^-1 J_i^T and Cook's distances D_i = e_i^2 / (p s^2) h_i / (1 - h_i)^2 (hat_values, cooks_d:
+// src/nls_utils.c:88-150) from the weighted residual and Jacobian the finalize kernel left in HBM (grad: n x p
+// column-major, so the reads of a wavefront are contiguous for every k); (J^T J)^-1 sits in LDS
+__global__ __launch_bounds__(256) void wide_cooks_kernel(const double *resid, const double *grad, long long n, int p,
+                                                         const double *Cinv, double s2, double *d, unsigned long long *keys,
+                                                         double *hat)
+{
+    __shared__ double C_s[WP * WP];
+    for (int e = threadIdx.x; e < p * p; e += 256)
+        C_s[e] = Cinv[e];
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    {
+        double h = 0.0;
+        for (int j = 0; j < p; ++j)
+        {
+            double t = 0.0;
+            for (int k = 0; k < p; ++k)
+                t += grad[i + (size_t)n * k] * C_s[k * p + j];
+            h += t * grad[i + (size_t)n * j];
+        }
+        const double e = resid[i];
+        const double di = (e * e) / (p * s2) * (h / ((1 - h) * (1 - h)));
+        if (d)
+            d[i] = di;
+        if (keys)
+            keys[i] = (unsigned long long)__double_as_longlong(fabs(di));
+        if (hat)
+            hat[i] = h;
+    }
 }
 
 // test hook: the damped solve alone (tests compare it with the oracle's modified Cholesky)
@@ -186,6 +219,7 @@ struct WideFit : DenseBase
     long long ev_launches_total = 0;
     float last_ms = 0.f;
     long long last_launches = 0;
+    double *d_cinv = nullptr;   // (J^T J)^-1 for the hat values
     void *irls_arena = nullptr; // work arrays of the robust re-weighting, kept between calls
     size_t irls_arena_bytes = 0;
 
@@ -193,6 +227,7 @@ struct WideFit : DenseBase
     {
         delete prog;
         hipFree(irls_arena);
+        hipFree(d_cinv);
         if (owns_data)
         {
             hipFree(d_x);
@@ -627,8 +662,8 @@ struct WideFit : DenseBase
         cur_sw = d_sw;
         return GSLNLS_SUCCESS;
     }
-    // not lowered for p > 9 (the callers get GSLNLS_E_UNSUPPORTED and keep the reference's path): hat values / Cook's
-    // distances (and with them the robust second pass of multi-start), the matrix-free operators of gsl_nls_large
+    // not lowered for p > 9 (the callers get GSLNLS_E_UNSUPPORTED and keep the reference's path): the matrix-free operators
+    // of gsl_nls_large
     // gsl_multifit_nlinear_rho_driver (src/nls_irls.c:412-546) around the wide solve: the same driver as irls_host.hpp
     // (cold re-start from the ORIGINAL start with the current weights, radix-select median, psi family, stopping rule);
     // only the residual pass differs -- the formula's finalize kernel run without weights
@@ -823,15 +858,127 @@ struct WideFit : DenseBase
         return rc;
     }
     LargeOps *make_large_ops() override { return nullptr; }
-    int diagnostics(int, const double *, const int *, const double *, double *, double *) override { return GSLNLS_E_UNSUPPORTED; }
+    // weighted residual, Jacobian (n x p, column-major) and (J^T J)^-1 at theta on the device; returns s^2 = ssr / (n - p).
+    // 1: J^T J is singular (hat_values fails in the reference as well)
+    int cooks_inputs(int jm, const double *theta, double **d_cinv_out, double *s2)
+    {
+        std::vector<double> tot((size_t)NV);
+        int rc = sums_at(jm == 0, jm == 2, theta, tot.data());
+        if (rc)
+            return rc;
+        std::vector<double> A((size_t)p * p);
+        for (int i = 0; i < p; ++i)
+            for (int j = 0; j <= i; ++j)
+                A[(size_t)i * p + j] = A[(size_t)j * p + i] = tot[2 + i * (i + 1) / 2 + j];
+        if (!lg_chol(p, A))
+            return 1;
+        lg_chol_invert(p, A);
+        *s2 = tot[0] / (n - p);
+        if (!d_resid)
+            GSLNLS_HIP_OK(hipMalloc(&d_resid, sizeof(double) * (size_t)n));
+        if (!d_grad)
+            GSLNLS_HIP_OK(hipMalloc(&d_grad, sizeof(double) * (size_t)n * p));
+        if (!d_cinv)
+            GSLNLS_HIP_OK(hipMalloc(&d_cinv, sizeof(double) * WP * WP));
+        GSLNLS_HIP_OK(hipMemcpyAsync(d_cinv, A.data(), sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice, stream));
+        GSLNLS_HIP_OK(hipStreamSynchronize(stream)); // (A is a local)
+        int ci0[15] = {100, 0, 0, 0, 1, jm == 2, 0, 0, 0, 0, 0, 0, 0, 1, 0};
+        double cd0[11] = {2, 3, 0.75, 1.4901161193847656e-08, 0.02, 1e-8, 1e-8, 1e-8, 0, 0, 0};
+        LmParams prm = make_params(ci0, cd0, jm == 0, 0, false, cur_sw != nullptr);
+        WPassArgs pa = pass_args(prm); // d_state holds x = theta (sums_at put it there)
+        double *r = d_resid, *g = d_grad;
+        void *args[] = {(void *)&pa, (void *)&r, (void *)&g};
+        int gf = (int)(((long long)n + 255) / 256);
+        gf = gf > 2048 ? 2048 : (gf < 1 ? 1 : gf);
+        (void)hipModuleLaunchKernel(fn_final[jm], gf, 1, 1, 256, 1, 1, 0, stream, args, nullptr);
+        *d_cinv_out = d_cinv;
+        return 0;
+    }
+
+    // hat values and Cook's distances at theta (src/nls_utils.c:88-150; the S3 methods hatvalues() / cooks.distance())
+    int diagnostics(int jac, const double *theta, const int *ci, const double *cd, double *hat, double *cooks) override
+    {
+        (void)cd;
+        const int jm = jac ? 0 : (ci[5] ? 2 : 1);
+        if (const int rc0 = bind(jm))
+            return rc0;
+        double *dc = nullptr, s2 = 0.0;
+        int rc = cooks_inputs(jm, theta, &dc, &s2);
+        if (rc)
+            return rc == 1 ? GSLNLS_EINVAL : rc;
+        double *d_d = nullptr, *d_h = nullptr;
+        GSLNLS_HIP_OK(hipMalloc(&d_d, sizeof(double) * (size_t)n * 2));
+        d_h = d_d + n;
+        int gf = (int)(((long long)n + 255) / 256);
+        gf = gf > 2048 ? 2048 : (gf < 1 ? 1 : gf);
+        hipLaunchKernelGGL(wide_cooks_kernel, dim3(gf), dim3(256), 0, stream, d_resid, d_grad, (long long)n, p, dc, s2, d_d,
+                           (unsigned long long *)nullptr, d_h);
+        hipError_t e = hipSuccess;
+        if (hat)
+            e = hipMemcpyAsync(hat, d_h, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream);
+        if (cooks && e == hipSuccess)
+            e = hipMemcpyAsync(cooks, d_d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(stream);
+        (void)hipFree(d_d);
+        return e == hipSuccess ? GSLNLS_SUCCESS : GSLNLS_E_NODEVICE;
+    }
+
+    // robust second pass of multi-start (src/nls.c:401-509): Cook's-distance outliers get zero weight.
+    // returns 1 when a second pass has to run (d_sw_robust filled), 0 when not, < 0 on error
+    int robust_weights(int jm, const double *mpopt, double *d_sw_robust)
+    {
+        double *dc = nullptr, s2 = 0.0;
+        int rc = cooks_inputs(jm, mpopt, &dc, &s2);
+        if (rc == 1)
+            return 0; // cooks_d -> hat_values fails: no second pass (src/nls.c:419-421)
+        if (rc)
+            return rc < 0 ? rc : -1;
+        double *d_d = nullptr;
+        unsigned long long *d_keys = nullptr;
+        SelectState *d_sel = nullptr;
+        int *d_cnt = nullptr;
+        GSLNLS_HIP_OK(hipMalloc(&d_d, sizeof(double) * (size_t)n));
+        GSLNLS_HIP_OK(hipMalloc(&d_keys, sizeof(unsigned long long) * (size_t)n));
+        GSLNLS_HIP_OK(hipMalloc(&d_sel, sizeof(SelectState) * 2));
+        GSLNLS_HIP_OK(hipMalloc(&d_cnt, sizeof(int)));
+        GSLNLS_HIP_OK(hipMemsetAsync(d_cnt, 0, sizeof(int), stream));
+        int gf = (int)(((long long)n + 255) / 256);
+        gf = gf > 2048 ? 2048 : (gf < 1 ? 1 : gf);
+        hipLaunchKernelGGL(wide_cooks_kernel, dim3(gf), dim3(256), 0, stream, d_resid, d_grad, (long long)n, p, dc, s2, d_d,
+                           d_keys, (double *)nullptr);
+        double med = 0.0, med2 = 0.0;
+        rc = device_median(stream, d_keys, n, d_sel, &med);
+        if (!rc)
+        {
+            hipLaunchKernelGGL(absdev_keys_kernel, dim3(gf), dim3(256), 0, stream, d_d, (long long)n, med, d_keys);
+            rc = device_median(stream, d_keys, n, d_sel, &med2);
+        }
+        int noutlier = 0;
+        if (!rc)
+        {
+            const double mad = 1.482602218505602 * med2;
+            const double thresh = fmin(4.0 / n, 5 * mad);
+            hipLaunchKernelGGL(outlier_weights_kernel, dim3(gf), dim3(256), 0, stream, d_d, (long long)n, thresh, cur_sw,
+                               d_sw_robust, d_cnt);
+            (void)hipMemcpyAsync(&noutlier, d_cnt, sizeof(int), hipMemcpyDeviceToHost, stream);
+            (void)hipStreamSynchronize(stream);
+        }
+        (void)hipFree(d_d);
+        (void)hipFree(d_keys);
+        (void)hipFree(d_sel);
+        (void)hipFree(d_cnt);
+        if (rc)
+            return rc < 0 ? rc : -1;
+        return (noutlier > 0 && noutlier < (n - p)) ? 1 : 0;
+    }
     // multi-start branch of C_nls (src/nls.c:274-532): the host driver of mstart_driver.hpp (the reference's commit
     // order) around WideMsEvaluator, then the final single-start solve.  The robust second pass (Cook's distances) is
     // not lowered for p > 9.
     int mstart(int jac, int fvv, const double *start2p, const double *lupars, const int *ci, const double *cd,
                const int *has_start, const MsComm &comm, int loss_rho, const double *loss_cc, gslnls_result *out) override
     {
-        (void)loss_cc;
-        if (ci[2] > 1 || loss_rho != 0)
+        if (ci[2] > 1)
             return GSLNLS_E_UNSUPPORTED;
         if (fvv && prog->nfvv == 0)
             return GSLNLS_E_UNSUPPORTED;
@@ -848,6 +995,41 @@ struct WideFit : DenseBase
         int rc = ms_major_loop(m, ev, comm, start2p);
         if (rc)
             return rc < 0 && rc > -100 ? GSLNLS_FAILURE : rc;
+        // robust second pass (src/nls.c:401-509): Cook's-distance outliers get zero weight, then the whole multi-start is
+        // repeated (fresh counters and quasi-random sequence, ranges and exponents carried over)
+        if (loss_rho != 0)
+        {
+            if (m.mssropt[1] < m.mssropt[0])
+                m.mpopt = m.mpopt1;
+            double *d_sw_robust = nullptr;
+            GSLNLS_HIP_OK(hipMalloc(&d_sw_robust, sizeof(double) * (size_t)n));
+            const int second = robust_weights(jm, m.mpopt.data(), d_sw_robust);
+            if (second < 0)
+            {
+                (void)hipFree(d_sw_robust);
+                return second;
+            }
+            if (second == 1)
+            {
+                const double *keep_sw = cur_sw;
+                cur_sw = d_sw_robust;
+                ev.prm.has_weights = 1;
+                m.next_draw = 0; // gsl_qrng_init
+                m.mstop = ST_CONTINUE;
+                m.mstarts = m.nsp = m.nwsp = 0;
+                m.dtol = 1.0e-6;
+                m.rejectscl = 1.25;
+                m.mssropt[0] = m.mssropt[1] = INFINITY;
+                m.ssrconv[0] = m.ssrconv[1] = 1.0;
+                std::fill(m.ntix.begin(), m.ntix.end(), 0);
+                std::fill(m.luchange.begin(), m.luchange.end(), 0);
+                rc = ms_major_loop(m, ev, comm, start2p);
+                cur_sw = keep_sw; // "reset original weights" (src/nls.c:490-507)
+            }
+            (void)hipFree(d_sw_robust);
+            if (rc)
+                return rc < 0 && rc > -100 ? GSLNLS_FAILURE : rc;
+        }
         if (m.mssropt[1] < m.mssropt[0])
         {
             m.mssropt[0] = m.mssropt[1];
@@ -862,7 +1044,10 @@ struct WideFit : DenseBase
             else
                 m.mpopt[0] = m.mpopt[0] + 1.0e-4;
         }
-        rc = solve(jac, fvv, m.mpopt.data(), lupars, ci, cd, 0, out);
+        if (loss_rho != 0)
+            rc = irls(jac, fvv, m.mpopt.data(), lupars, ci, cd, loss_rho, loss_cc, out);
+        else
+            rc = solve(jac, fvv, m.mpopt.data(), lupars, ci, cd, 0, out);
         out->mstart_nsp = m.nsp;
         out->mstart_nwsp = m.nwsp;
         out->mstart_iters = m.mstarts;

@@ -318,3 +318,45 @@ def test_wide_concentration_records_match_the_oracle_point_by_point(amd, gslref)
         assert np.allclose(rec[i, :p], o["par"], rtol=1e-9) and abs(sc[1] - o["ssr"]) <= 1e-10 * o["ssr"]
         J0, J1 = q["jac"](x0[i]), q["jac"](o["par"])
         assert abs(sc[2] / np.linalg.det(J0.T @ J0) - 1.0) < 1e-8 and abs(sc[3] / np.linalg.det(J1.T @ J1) - 1.0) < 1e-8
+
+
+def test_wide_hat_values_and_cooks_distances(amd):
+    """hatvalues() / cooks.distance() for p = 16 (src/nls_utils.c:88-150) from the resident data, weighted, against numpy"""
+    from gslnls_amd import _lib
+    q = gaussians_problem(5, 1, 5000, seed=17)
+    p, n = 16, 5000
+    w = np.random.default_rng(4).uniform(0.5, 2.0, n)
+    prob = amd.DenseProblem(_lib.MODEL_EXPR, p, q["x"], q["y"], weights=w, expr=q["formula"].split("~")[1].strip(),
+                            parnames=q["names"], xnames=["x"], lowering="jit")
+    th = q["truth"] * 1.001
+    hat, cooks = prob.diagnostics(th, jac=True)
+    prob.close()
+    sw = np.sqrt(w)
+    J = q["jac"](th) * sw[:, None]
+    e = (q["model"](th) - q["y"]) * sw
+    H = np.einsum("ij,jk,ik->i", J, np.linalg.inv(J.T @ J), J)
+    s2 = (e @ e) / (n - p)
+    D = e * e / (p * s2) * H / (1.0 - H) ** 2
+    assert np.allclose(hat, H, rtol=1e-9, atol=1e-14) and abs(hat.sum() - p) < 1e-8
+    assert np.allclose(cooks, D, rtol=1e-8, atol=1e-16)
+
+
+def test_wide_robust_multistart_second_pass(amd, gslref):
+    """gsl_nls(start = ranges, loss = "huber") for p = 12: multi-start, Cook's-distance outlier screening, second
+    multi-start with the outliers' weights zeroed, final IRLS solve (src/nls.c:401-509) against the oracle"""
+    q = gaussians_problem(4, 0, 1500, seed=13, noise=0.02)
+    p, n = 12, 1500
+    rng = np.random.Generator(np.random.PCG64(5))
+    y = q["y"].copy()
+    y[rng.choice(n, 30, replace=False)] += 2.0
+    lo = q["truth"] * np.where(np.arange(p) % 3 == 1, 0.97, 0.8)
+    hi = q["truth"] * np.where(np.arange(p) % 3 == 1, 1.03, 1.2)
+    start = {nm: [float(a), float(b)] for nm, a, b in zip(q["names"], lo, hi)}
+    ctrl = dict(solver="cholesky", mstart_n=12, mstart_q=3, mstart_maxstart=40)
+    fit = amd.gsl_nls(q["formula"], data=dict(x=q["x"], y=y), start=start, jac=True, loss="huber", control=ctrl)
+    ref = gslref.nls(n, p, np.stack([lo, hi]), fn=lambda th: q["model"](th) - y, jac=q["jac"], loss="huber",
+                     ctrl=gslref.control(**ctrl))
+    assert fit["code_path"] == 3 and fit["conv"] == ref["conv"] == 0
+    assert fit["irls"]["irls_niter"] == ref["irls"]["irls_niter"]
+    assert np.allclose(fit["par"], ref["par"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(fit["par"], q["truth"], rtol=5e-2, atol=5e-2)
