@@ -373,6 +373,8 @@ gslnls_large *gslnls_large_create(const gslnls_model *fn, const double *y, int n
         if (h->dense)
         {
             h->ops = h->dense->make_large_ops();
+            if (!h->ops && e == GSLNLS_SUCCESS)
+                e = GSLNLS_E_UNSUPPORTED; // (formulas with p > 9: the wide path has no matrix-free operators)
         }
     }
     if (err)
