@@ -219,6 +219,7 @@ struct WideFit : DenseBase
     long long ev_launches_total = 0;
     float last_ms = 0.f;
     long long last_launches = 0;
+    int pred_kind = -1, pred_steps = 0; // trial steps the previous fit of this kind needed (adaptive first chunk)
     double *d_cinv = nullptr;   // (J^T J)^-1 for the hat values
     void *irls_arena = nullptr; // work arrays of the robust re-weighting, kept between calls
     size_t irls_arena_bytes = 0;
@@ -405,9 +406,16 @@ struct WideFit : DenseBase
         }
         adv.seq = seq;
         adv.launch_idx = 0;
+        // steps are enqueued in chunks and the completion word is polled between them; what is enqueued beyond the step
+        // that ends the fit still runs (three no-op launches each).  The first chunk is sized by the previous fit of the
+        // same kind on this handle (IRLS re-solves, repeated fits end where the last one did), then small top-ups.
+        const int kind = jm * 4 + prm.trs * 2 + (cur_sw ? 1 : 0);
+        int next_chunk = 4;
         if (chunk <= 0)
-            chunk = 8;
-        const long long max_steps = ((long long)maxiter * 17 + 2) * (prm.trs ? 2 : 1) + 2 * chunk;
+            chunk = (pred_kind == kind && pred_steps > 0) ? pred_steps : 8;
+        else
+            next_chunk = chunk;
+        const long long max_steps = ((long long)maxiter * 17 + 2) * (prm.trs ? 2 : 1) + 2 * (chunk + next_chunk);
         long long steps = 0;
         hipEventRecord(ev0, stream);
         for (;;)
@@ -415,6 +423,7 @@ struct WideFit : DenseBase
             for (int k = 0; k < chunk; ++k)
                 launch_step(jm, prm, adv, (int)(steps + k));
             steps += chunk;
+            chunk = next_chunk;
             if (hipGetLastError() != hipSuccess)
                 return GSLNLS_E_NODEVICE;
             hipEventRecord(ev1, stream);
@@ -448,6 +457,10 @@ struct WideFit : DenseBase
         __sync_synchronize();
         last_ms = (float)(1e3 * (now_s() - t_begin));
         last_launches = 3 * steps;
+        pred_kind = kind;
+        pred_steps = h_state[1].end_launch + 1;
+        if (pred_steps < 1 || pred_steps > 4096)
+            pred_steps = 0;
         GSLNLS_HIP_OK(hipStreamSynchronize(stream)); // trailing steps (no-ops) + the event pair
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess)
