@@ -24,6 +24,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -409,8 +411,9 @@ inline void rtc_cache_write(const std::string &path, const RtcUnit &u)
 enum
 {
     RTC_NONE = 0,
-    RTC_BUILDING = 1,
+    RTC_BUILDING = 1, // inside the compiler
     RTC_READY = 2,
+    RTC_QUEUED = 3,   // waiting for the background compiler (reported as "being built" at the C ABI)
     RTC_FAILED = -1
 };
 
@@ -421,28 +424,48 @@ struct RtcEntry
     std::string log, cache_path;
     double build_s = 0.0;
     bool from_cache = false;
-    std::thread worker;
     // modules per device ordinal (loaded by the thread that launches)
     std::map<int, hipModule_t> modules;
     std::map<std::pair<int, std::string>, hipFunction_t> functions;
-    ~RtcEntry()
-    {
-        if (worker.joinable())
-            worker.join();
-    }
 };
 
+struct RtcJob
+{
+    std::shared_ptr<RtcEntry> entry;
+    std::string source;
+    std::vector<std::string> exprs;
+};
+
+// ONE background compiler thread per process, fed through a queue (a thread per formula would be unbounded: every new
+// formula x Jacobian kind under GSLNLS_LOWER_AUTO asks for a build)
 struct RtcRegistry
 {
     std::mutex mu;
     std::map<unsigned long long, std::shared_ptr<RtcEntry>> entries;
-    ~RtcRegistry()
+    std::mutex qmu;
+    std::condition_variable qcv;
+    std::deque<RtcJob> queue;
+    std::thread worker;
+    bool stop = false;
+    static constexpr size_t QUEUE_CAP = 256; // beyond that a request is dropped (the interpreter keeps serving it)
+    ~RtcRegistry() { shutdown(); }
+    void shutdown()
     {
+        {
+            std::lock_guard<std::mutex> lock(qmu);
+            stop = true;
+            for (RtcJob &j : queue)
+            {
+                int expect = RTC_QUEUED;
+                j.entry->state.compare_exchange_strong(expect, RTC_FAILED);
+            }
+            queue.clear();
+        }
+        qcv.notify_all();
         // a build still running at process exit is waited for (a compiler thread torn down in the middle of comgr
         // takes the process with it)
-        for (auto &kv : entries)
-            if (kv.second->worker.joinable())
-                kv.second->worker.join();
+        if (worker.joinable())
+            worker.join();
     }
 };
 
@@ -475,19 +498,10 @@ inline void rtc_at_exit()
 {
     if (rtc_shutting_down().exchange(true))
         return;
-    RtcRegistry &reg = rtc_registry();
-    std::vector<std::shared_ptr<RtcEntry>> all;
-    {
-        std::lock_guard<std::mutex> lock(reg.mu);
-        for (auto &kv : reg.entries)
-            all.push_back(kv.second);
-    }
-    for (auto &e : all)
-        if (e->worker.joinable())
-            e->worker.join();
+    rtc_registry().shutdown();
 }
 
-inline void rtc_build(RtcEntry *e, std::string source, std::vector<std::string> exprs)
+inline void rtc_build(RtcEntry *e, const std::string &source, const std::vector<std::string> &exprs)
 {
     if (rtc_shutting_down().load())
     {
@@ -512,6 +526,26 @@ inline void rtc_build(RtcEntry *e, std::string source, std::vector<std::string> 
     static std::atomic<int> nreg{0};
     if (!rtc_shutting_down().load() && nreg.fetch_add(1) < 24) // (atexit guarantees 32 slots)
         (void)atexit(rtc_at_exit);
+}
+
+inline void rtc_worker_main()
+{
+    RtcRegistry &reg = rtc_registry();
+    for (;;)
+    {
+        RtcJob job;
+        {
+            std::unique_lock<std::mutex> lock(reg.qmu);
+            reg.qcv.wait(lock, [&] { return reg.stop || !reg.queue.empty(); });
+            if (reg.stop)
+                return;
+            job = std::move(reg.queue.front());
+            reg.queue.pop_front();
+        }
+        int expect = RTC_QUEUED;
+        if (job.entry->state.compare_exchange_strong(expect, RTC_BUILDING)) // (else: a waiting caller took it over)
+            rtc_build(job.entry.get(), job.source, job.exprs);
+    }
 }
 
 // The code object of `source` (which must name every kernel in `exprs`).  wait: build now if it is neither in memory
@@ -593,31 +627,45 @@ inline std::shared_ptr<RtcEntry> rtc_request(const std::string &source, const st
     if (st == RTC_NONE)
     {
         int expect = RTC_NONE;
-        if (ent->state.compare_exchange_strong(expect, RTC_BUILDING))
+        if (wait)
         {
-            if (wait)
+            if (ent->state.compare_exchange_strong(expect, RTC_BUILDING))
                 rtc_build(ent.get(), source, exprs);
-            else if (!rtc_api().load())
-            {
+        }
+        else if (!rtc_api().load())
+        {
+            if (ent->state.compare_exchange_strong(expect, RTC_FAILED))
                 ent->log = rtc_api().err;
-                ent->state.store(RTC_FAILED, std::memory_order_release);
-            }
+        }
+        else if (ent->state.compare_exchange_strong(expect, RTC_QUEUED))
+        {
+            static const bool registered = (atexit(rtc_at_exit), true); // after hiprtc's own: runs before them
+            (void)registered;
+            std::lock_guard<std::mutex> lock(reg.qmu);
+            if (reg.stop || reg.queue.size() >= RtcRegistry::QUEUE_CAP)
+                ent->state.store(RTC_NONE, std::memory_order_release); // dropped: a later request may try again
             else
             {
-                static const bool registered = (atexit(rtc_at_exit), true); // after hiprtc's own: runs before them
-                (void)registered;
-                ent->worker = std::thread(rtc_build, ent.get(), source, exprs);
+                reg.queue.push_back({ent, source, exprs});
+                if (!reg.worker.joinable())
+                    reg.worker = std::thread(rtc_worker_main);
+                reg.qcv.notify_one();
             }
         }
         st = ent->state.load(std::memory_order_acquire);
     }
-    if (st == RTC_BUILDING && wait)
+    if (wait && st == RTC_QUEUED)
     {
-        if (ent->worker.joinable())
-            ent->worker.join();
-        while (ent->state.load(std::memory_order_acquire) == RTC_BUILDING)
-            usleep(1000);
+        // still waiting for the background compiler: build it here and now instead (the worker skips what it no
+        // longer finds QUEUED)
+        int expect = RTC_QUEUED;
+        if (ent->state.compare_exchange_strong(expect, RTC_BUILDING))
+            rtc_build(ent.get(), source, exprs);
+        st = ent->state.load(std::memory_order_acquire);
     }
+    if (wait)
+        while (ent->state.load(std::memory_order_acquire) == RTC_BUILDING) // the background compiler is in it
+            usleep(1000);
     return ent;
 }
 

@@ -55,7 +55,7 @@ struct VmDenseFit : DenseFit<ModelVM<P>>
             rtc_src = rtc_dense_source(prog, nx_model);
         const std::string es = rtc_step_expr(jm, Base::T), ef = rtc_finalize_expr(jm, Base::T);
         const bool wait = lowering == GSLNLS_LOWER_JIT;
-        if (!rtc[jm] || (wait && rtc[jm]->state.load() == RTC_BUILDING))
+        if (!rtc[jm] || rtc[jm]->state.load() == RTC_NONE || (wait && rtc[jm]->state.load() != RTC_READY && rtc[jm]->state.load() != RTC_FAILED))
             rtc[jm] = rtc_request(rtc_src, {es, ef}, wait);
         RtcEntry &e = *rtc[jm];
         const int st = e.state.load(std::memory_order_acquire);
@@ -320,7 +320,8 @@ extern "C" int gslnls_expr_native_state(const gslnls_model *fn, int jac)
     const int NV = 2 + fn->p * (fn->p + 1) / 2 + fn->p;
     const int T = (NV <= 24) ? 512 : (NV <= 70 ? 256 : 128);
     const int jm = jac ? 0 : 1;
-    return rtc_request_peek(src, {rtc_step_expr(jm, T), rtc_finalize_expr(jm, T)});
+    const int st = rtc_request_peek(src, {rtc_step_expr(jm, T), rtc_finalize_expr(jm, T)});
+    return st == RTC_QUEUED ? RTC_BUILDING : st;
 }
 
 // stop the background compiler before the process exits (rtc_host.hpp, rtc_at_exit)
@@ -343,6 +344,7 @@ extern "C" int gslnls_expr_prefetch(const gslnls_model *fn, int jac)
     const int NV = 2 + fn->p * (fn->p + 1) / 2 + fn->p;
     const int T = (NV <= 24) ? 512 : (NV <= 70 ? 256 : 128);
     const int jm = jac ? 0 : 1;
-    return rtc_request(src, {rtc_step_expr(jm, T), rtc_finalize_expr(jm, T)}, false)->state.load();
+    const int st = rtc_request(src, {rtc_step_expr(jm, T), rtc_finalize_expr(jm, T)}, false)->state.load();
+    return st == RTC_QUEUED ? RTC_BUILDING : st;
 }
 #endif

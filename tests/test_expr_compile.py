@@ -175,6 +175,40 @@ print("leaving", flush=True)
             assert open(os.path.join(tmp_path, f), "rb").read(8) == b"GSLRTC1\n"
 
 
+def test_a_waiting_build_takes_a_queued_unit_over_from_the_background_compiler(tmp_path):
+    """ONE background compiler thread serves GSLNLS_LOWER_AUTO through a queue; a caller that needs a unit NOW
+    (gslnls_expr_build, lowering "jit") does not wait behind the queue: it compiles the unit itself and the background
+    thread skips it."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes as C, sys, os, time
+sys.path.insert(0, %r)
+from gslnls_amd import _lib
+L = _lib.lib()
+keep = []
+for k in range(24):
+    m = _lib.Model(_lib.MODEL_EXPR, 3, 1, None, 0)
+    keep.append((m, _lib.set_expr(m, "a*exp(-b*x) + c*%%d" %% (k + 2), ["a", "b", "c"], ["x"], "auto")))
+    assert L.gslnls_expr_prefetch(C.byref(m), 1) == 1
+    assert L.gslnls_expr_prefetch(C.byref(m), 1) == 1       # asking again queues nothing new
+last = keep[-1][0]
+buf = C.create_string_buffer(512)
+t0 = time.time()
+assert L.gslnls_expr_build(C.byref(last), buf, 512) == 0
+dt = time.time() - t0
+assert L.gslnls_expr_native_state(C.byref(last), 1) == 2 and L.gslnls_expr_native_state(C.byref(last), 0) == 2
+nthreads = len(os.listdir("/proc/self/task"))
+print("took %%.2f threads %%d" %% (dt, nthreads), flush=True)
+""" % (ROOT,)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240,
+                         env=dict(os.environ, GSLNLS_JIT_CACHE=str(tmp_path)))
+    assert out.returncode == 0, (out.returncode, out.stderr[-1500:])
+    took, nthreads = out.stdout.split()[1], int(out.stdout.split()[3])
+    assert float(took) < 20.0          # two units (~1-2 s each) plus at most the one the background thread was inside
+    assert nthreads < 12               # not a thread per request (hiprtc/comgr keep a few of their own)
+
+
 @pytest.mark.parametrize("pb", PROBLEMS, ids=[p["name"] for p in PROBLEMS])
 def test_second_directional_derivative(pb):
     """fvv = TRUE on a formula: D^2 f[v, v] of the compiled program (third closure) against a central second
