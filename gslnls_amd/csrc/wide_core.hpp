@@ -134,159 +134,251 @@ __device__ __forceinline__ double wide_seq_sum(double v, int p)
     return s;
 }
 
-// (A + mu D^2) sol = rhs by wave 0 (all 64 lanes of it must call; lanes >= p idle along).  Only the lower triangle
-// M[i][k], k <= i, is kept (leading dimension p + 1), as in lm_solve<P>.
-__device__ __forceinline__ void wide_solve(WideLds &L, int p, double mu, const double *rhs, double *sol, int lane)
+// m += (lane K of this lane's row of 16 lanes of vb) * t: the 64-bit DPP form of v_fmac_f64 (row_newbcast is the one DPP
+// control the double-precision ALU takes), one instruction where v_readlane x 2 + v_fma_f64 were three.  All 64 lanes
+// must be active.
+template <int K>
+__device__ __forceinline__ void wide_fmac_rowbcast(double &m, double vb, double t)
 {
-    const int LD = p + 1;
-    double *M = L.M;
-    double *colj = L.row; // column j of the current step, contiguous (L.row is free while a solve runs)
-    if (lane < p)
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(m) : "v"(vb), "v"(t), "n"(K));
+}
+
+// maximum over the first 16 R lanes (the others hold values that cannot win), in every lane
+template <int R>
+__device__ __forceinline__ double wide_wave_max_rows(double v)
+{
+    v = fmax(v, wide_dpp<0xB1>(v));  // quad_perm [1,0,3,2]
+    v = fmax(v, wide_dpp<0x4E>(v));  // quad_perm [2,3,0,1]
+    v = fmax(v, wide_dpp<0x141>(v)); // row_half_mirror
+    v = fmax(v, wide_dpp<0x140>(v)); // row_mirror
+    double r = wide_bcast(v, 0);
+    if constexpr (R > 1)
+        r = fmax(r, wide_bcast(v, 16));
+    if constexpr (R > 2)
+        r = fmax(r, wide_bcast(v, 32));
+    if constexpr (R > 3)
+        r = fmax(r, wide_bcast(v, 48));
+    return r;
+}
+
+// m[q] for a wave-uniform q: a scalar branch tree over the register file (a run-time register index would send the whole
+// row to scratch memory)
+template <int PW>
+__device__ __forceinline__ double wide_pick(const double (&m)[PW], int q)
+{
+    double v = 0.0;
+#define GSLNLS_WPICK(k)                                                                                                      \
+    case k:                                                                                                                  \
+        if constexpr (k < PW)                                                                                                \
+        {                                                                                                                    \
+            v = m[k < PW ? k : 0];                                                                                           \
+            asm volatile("" : "+v"(v));                                                                                      \
+        }                                                                                                                    \
+        break;
+#define GSLNLS_WPICK8(b)                                                                                                     \
+    GSLNLS_WPICK(b + 0)                                                                                                      \
+    GSLNLS_WPICK(b + 1) GSLNLS_WPICK(b + 2) GSLNLS_WPICK(b + 3) GSLNLS_WPICK(b + 4) GSLNLS_WPICK(b + 5) GSLNLS_WPICK(b + 6)  \
+        GSLNLS_WPICK(b + 7)
+    switch (__builtin_amdgcn_readfirstlane(q))
     {
-        for (int j = 0; j <= lane; ++j)
+        GSLNLS_WPICK8(0)
+        GSLNLS_WPICK8(8)
+        GSLNLS_WPICK8(16)
+        GSLNLS_WPICK8(24)
+        GSLNLS_WPICK8(32)
+        GSLNLS_WPICK8(40)
+        GSLNLS_WPICK8(48)
+        GSLNLS_WPICK8(56)
+    default:
+        break;
+    }
+#undef GSLNLS_WPICK8
+#undef GSLNLS_WPICK
+    return v;
+}
+
+// (A + mu D^2) sol = rhs by ONE wavefront (all 64 lanes of it must call; lanes >= p idle along), p <= PW.
+//
+// gsl_linalg_mcholesky (Gill-Murray-Wright modified Cholesky with diagonal pivoting) with the matrix in REGISTERS: lane i
+// holds row i of the symmetric matrix, m[k] = S[i][k], by ORIGINAL index -- nothing is ever interchanged.  The
+// reference's permutation lives in `pos` (lane i: the position row i has in the permuted order; the tie rule of the pivot
+// search -- the first position wins -- reads it), the pivot sequence in `ord` (lane j: the row eliminated at step j).
+// One step: pivot row q (wavefront maximum of the diagonal, which every lane keeps in `dg`), its column v_i = S[i][q] is
+// each lane's own m[q], theta = max |v_i|, alpha, then the rank-one update S[i][k] -= (v_i / alpha) v_k of ALL columns in
+// PW instructions (v_fmac_f64 with a DPP row broadcast of v_k) -- columns and rows already eliminated see v = 0.  The
+// forward substitution rides along (b_i -= l_i b_q); the multipliers l_i = v_i / alpha also go to LDS, T[q][i], so that
+// the back substitution L^T w = z finds row q_j of L^T as T[i][q_j]: lane i's own row, conflict-free.
+// Against lm_solve<P> / the reference: the same sums in the same order with one exception -- an entry S[i][k] whose rows
+// were interchanged relative to each other is updated as (v_i / alpha) v_k here where the reference's single (lower)
+// copy gets (v_k / alpha) v_i: one rounding apart.
+template <int PW>
+__device__ __forceinline__ void wide_solve_reg(WideLds &L, int p, double mu, const double *rhs, double *sol, int lane)
+{
+    constexpr int R = PW / 16;
+    constexpr int LD = WP + 1;
+    double *T = L.M;
+    const bool mine = lane < p;
+    double m[PW];
+    {
+        const int base = lane * (lane + 1) / 2;
+#pragma unroll
+        for (int k = 0; k < PW; ++k)
         {
-            double v = L.A[tri(lane, j)];
-            if (j == lane)
-                v += mu * L.diag[lane] * L.diag[lane];
-            M[lane * LD + j] = v;
+            const int idx = k < lane ? base + k : k * (k + 1) / 2 + lane;
+            const double a = L.A[(mine && k < p) ? idx : 0];
+            m[k] = (mine && k < p && k != lane) ? a : 0.0; // (the diagonal lives in dg)
         }
     }
-    wide_lds_sync();
-    double b = lane < p ? rhs[lane] : 0.0;
-    int perm = lane;
-    double gm = 0.0, xm = 0.0;
-    if (lane < p)
+    double dg = 0.0, b = 0.0;
+    if (mine)
     {
-        gm = fabs(M[lane * LD + lane]);
-        for (int j = 0; j < lane; ++j)
-            xm = fmax(xm, fabs(M[lane * LD + j]));
+        dg = L.A[tri(lane, lane)] + mu * L.diag[lane] * L.diag[lane];
+        b = rhs[lane];
     }
-    const double gamma = wide_wave_max(gm), xi = wide_wave_max(xm);
+    double xm = 0.0;
+#pragma unroll
+    for (int k = 0; k < PW; ++k)
+        xm = fmax(xm, fabs(m[k]));
+    const double gamma = wide_wave_max_rows<R>(fabs(dg)), xi = wide_wave_max_rows<R>(xm);
     double beta;
     if (p == 1)
         beta = fmax(fmax(gamma, xi), DBL_EPSILON);
     else
         beta = fmax(fmax(gamma, xi / sqrt((double)p * p - 1.0)), DBL_EPSILON);
     const double betainv = 1.0 / sqrt(beta);
-    double dinv = 0.0;                                  // lane j keeps 1 / alpha_j
-    double dg = lane < p ? M[lane * LD + lane] : 0.0;   // lane i keeps the current diagonal entry M[i][i]
+    double dinv = 0.0; // 1 / alpha of the step that eliminated this row
+    int pos = lane, ord = 0;
+    bool act = mine;
+    const int sub = lane & 15;
     for (int j = 0; j < p; ++j)
     {
-        // pivot: first index of the largest |diagonal| among j..p-1 (`if (d > maxd)` of the sequential scan: the first
-        // element wins ties, NaNs never win)
-        const double d = (lane >= j && lane < p) ? fabs(dg) : -1.0;
-        const double maxd = wide_wave_max(d);
-        const unsigned long long hit = __ballot(lane >= j && lane < p && d == maxd);
-        int q = hit ? (int)__builtin_ctzll(hit) : j;
-        const double djj = wide_bcast(dg, j);
-        if (!(maxd > fabs(djj)))
-            q = j;
-        if (q != j)
+        // pivot: the first position holding the largest |diagonal| among positions j..p-1 (`if (d > maxd)` of the
+        // sequential scan from position j: the first element wins ties, NaNs never win)
+        const double d = act ? fabs(dg) : -1.0;
+        const double maxd = wide_wave_max_rows<R>(d);
+        const int r = (int)__builtin_ctzll(__ballot(act && pos == j) | (1ull << 63)); // the row at position j
+        int q = r;
+        if (maxd > fabs(wide_bcast(dg, r)))
         {
-            // symmetric interchange of rows / columns j and q in the lower triangle, one element pair per lane:
-            //   k < j: (j,k) <-> (q,k);  j < k < q: (k,j) <-> (q,k);  k > q: (k,j) <-> (k,q);  the diagonal entries swap
-            if (lane < p && lane != j && lane != q)
+            unsigned long long hit = __ballot(act && d == maxd);
+            q = hit ? (int)__builtin_ctzll(hit) : r;
+            if (hit & (hit - 1))
             {
-                const int a = lane < j ? j * LD + lane : lane * LD + j;
-                const int c = lane < q ? q * LD + lane : lane * LD + q;
-                const double t = M[a];
-                M[a] = M[c];
-                M[c] = t;
+                int best = 1 << 30;
+                while (hit)
+                {
+                    const int c = (int)__builtin_ctzll(hit);
+                    hit &= hit - 1;
+                    const int pc = __builtin_amdgcn_readlane(pos, c);
+                    if (pc < best)
+                    {
+                        best = pc;
+                        q = c;
+                    }
+                }
             }
-            const double dq = wide_bcast(dg, q);
-            const double bj = wide_bcast(b, j), bq = wide_bcast(b, q);
-            const int pj = __builtin_amdgcn_readlane(perm, __builtin_amdgcn_readfirstlane(j)),
-                      pq = __builtin_amdgcn_readlane(perm, __builtin_amdgcn_readfirstlane(q));
-            if (lane == j)
-            {
-                dg = dq;
-                b = bq;
-                perm = pq;
-            }
-            if (lane == q)
-            {
-                dg = djj;
-                b = bj;
-                perm = pj;
-            }
-            wide_lds_sync();
         }
-        const double vi = (lane > j && lane < p) ? M[lane * LD + j] : 0.0;
-        const double theta = wide_wave_max(fabs(vi));
+        q = __builtin_amdgcn_readfirstlane(q);
+        // rows r and q trade positions (nothing moves)
+        const int pq = __builtin_amdgcn_readlane(pos, q);
+        if (lane == r)
+            pos = pq;
+        if (lane == q)
+            pos = j;
+        ord = lane == j ? q : ord;
+        const bool upd = act && lane != q;
+        double v = wide_pick<PW>(m, q);
+        v = upd ? v : 0.0;
+        const double theta = wide_wave_max_rows<R>(fabs(v));
         const double u = theta * betainv;
-        const double alpha = fmax(fmax(DBL_EPSILON, fabs(wide_bcast(dg, j))), u * u);
+        const double alpha = fmax(fmax(DBL_EPSILON, fabs(wide_bcast(dg, q))), u * u);
         const double ainv = 1.0 / alpha;
-        if (lane == j)
+        if (lane == q)
         {
             dinv = ainv;
-            dg = alpha;
+            act = false;
         }
-        colj[lane] = vi;
-        wide_lds_sync();
-        if (lane > j && lane < p)
+        const double t = ainv * v; // the multiplier l_i (0 in rows that take no part)
+        const double bq = wide_bcast(b, q);
+        if (upd)
         {
-            // M[i][k] -= ainv * vi * M[k][j], k = j+1..i: eight at a time, all loads of a group ahead of its stores
-            // (the compiler cannot tell that rows and the column copy never overlap and would serialise every element)
-            int k = j + 1;
-            for (; k + 7 < lane; k += 8)
-            {
-                double m[8], c[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                {
-                    m[u] = M[lane * LD + k + u];
-                    c[u] = colj[k + u];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    m[u] -= ainv * vi * c[u];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    M[lane * LD + k + u] = m[u];
-            }
-            for (; k + 3 < lane; k += 4)
-            {
-                const double m0 = M[lane * LD + k], m1 = M[lane * LD + k + 1], m2 = M[lane * LD + k + 2], m3 = M[lane * LD + k + 3];
-                const double c0 = colj[k], c1 = colj[k + 1], c2 = colj[k + 2], c3 = colj[k + 3];
-                double r0 = m0, r1 = m1, r2 = m2, r3 = m3;
-                r0 -= ainv * vi * c0;
-                r1 -= ainv * vi * c1;
-                r2 -= ainv * vi * c2;
-                r3 -= ainv * vi * c3;
-                M[lane * LD + k] = r0;
-                M[lane * LD + k + 1] = r1;
-                M[lane * LD + k + 2] = r2;
-                M[lane * LD + k + 3] = r3;
-            }
-            for (; k < lane; ++k)
-            {
-                double m = M[lane * LD + k];
-                m -= ainv * vi * colj[k];
-                M[lane * LD + k] = m;
-            }
-            dg -= ainv * vi * vi; // k = i: the diagonal entry lives in a register
-            M[lane * LD + j] = vi * ainv;
+            dg -= t * v;
+            b -= t * bq;
         }
-        wide_lds_sync();
-    }
-    // L z = P b: column sweep, every b_i collects its terms in ascending j like the row form
-    for (int j = 0; j < p; ++j)
-    {
-        const double bj = wide_bcast(b, j);
-        if (lane > j && lane < p)
-            b -= M[lane * LD + j] * bj;
+        T[q * LD + lane] = t;
+        const double tn = -t;
+#pragma unroll
+        for (int g = 0; g < R; ++g)
+        {
+            double vb = wide_shfl(v, 16 * g + sub); // lane l: v of row 16 g + l % 16
+            asm volatile("s_nop 1" : "+v"(vb));     // (a DPP operand written by the instruction before: 2 wait states)
+            wide_fmac_rowbcast<0>(m[16 * g + 0], vb, tn);
+            wide_fmac_rowbcast<1>(m[16 * g + 1], vb, tn);
+            wide_fmac_rowbcast<2>(m[16 * g + 2], vb, tn);
+            wide_fmac_rowbcast<3>(m[16 * g + 3], vb, tn);
+            wide_fmac_rowbcast<4>(m[16 * g + 4], vb, tn);
+            wide_fmac_rowbcast<5>(m[16 * g + 5], vb, tn);
+            wide_fmac_rowbcast<6>(m[16 * g + 6], vb, tn);
+            wide_fmac_rowbcast<7>(m[16 * g + 7], vb, tn);
+            wide_fmac_rowbcast<8>(m[16 * g + 8], vb, tn);
+            wide_fmac_rowbcast<9>(m[16 * g + 9], vb, tn);
+            wide_fmac_rowbcast<10>(m[16 * g + 10], vb, tn);
+            wide_fmac_rowbcast<11>(m[16 * g + 11], vb, tn);
+            wide_fmac_rowbcast<12>(m[16 * g + 12], vb, tn);
+            wide_fmac_rowbcast<13>(m[16 * g + 13], vb, tn);
+            wide_fmac_rowbcast<14>(m[16 * g + 14], vb, tn);
+            wide_fmac_rowbcast<15>(m[16 * g + 15], vb, tn);
+        }
     }
     b *= dinv;
-    // L^T w = z: column sweep from the last column (j descending per element; lm_solve<P> adds them ascending)
-    for (int j = p - 1; j >= 1; --j)
-    {
-        const double bj = wide_bcast(b, j);
-        if (lane < j)
-            b -= M[j * LD + lane] * bj;
-    }
-    if (lane < p)
-        sol[perm] = b;
     wide_lds_sync();
+    // L^T w = z: column sweep from the last pivot (j descending per element; lm_solve<P> adds them ascending).  `pos` is
+    // now the step that eliminated the row; the element of L^T that row i needs from pivot row q_j is T[i][q_j].
+    {
+        const double *Trow = T + lane * LD;
+        int j = p - 1;
+        for (; j >= 4; j -= 4)
+        {
+            const int q0 = __builtin_amdgcn_readlane(ord, j), q1 = __builtin_amdgcn_readlane(ord, j - 1),
+                      q2 = __builtin_amdgcn_readlane(ord, j - 2), q3 = __builtin_amdgcn_readlane(ord, j - 3);
+            const double t0 = Trow[q0], t1 = Trow[q1], t2 = Trow[q2], t3 = Trow[q3];
+            double w = wide_bcast(b, q0);
+            if (mine && pos < j)
+                b -= t0 * w;
+            w = wide_bcast(b, q1);
+            if (mine && pos < j - 1)
+                b -= t1 * w;
+            w = wide_bcast(b, q2);
+            if (mine && pos < j - 2)
+                b -= t2 * w;
+            w = wide_bcast(b, q3);
+            if (mine && pos < j - 3)
+                b -= t3 * w;
+        }
+        for (; j >= 1; --j)
+        {
+            const int qj = __builtin_amdgcn_readlane(ord, j);
+            const double w = wide_bcast(b, qj);
+            if (mine && pos < j)
+                b -= Trow[qj] * w;
+        }
+    }
+    if (mine)
+        sol[lane] = b;
+    wide_lds_sync();
+}
+
+__device__ __forceinline__ void wide_solve(WideLds &L, int p, double mu, const double *rhs, double *sol, int lane)
+{
+    // (noinline-sized bodies, one per register-file width; the caller has ONE call site)
+    if (p <= 16)
+        wide_solve_reg<16>(L, p, mu, rhs, sol, lane);
+    else if (p <= 32)
+        wide_solve_reg<32>(L, p, mu, rhs, sol, lane);
+    else if (p <= 48)
+        wide_solve_reg<48>(L, p, mu, rhs, sol, lane);
+    else
+        wide_solve_reg<64>(L, p, mu, rhs, sol, lane);
 }
 
 // ONE wavefront (64 lanes >= p: lane k owns component k of every p-vector); all 64 lanes call.  Scalars of the state live
@@ -422,6 +514,7 @@ __device__ __forceinline__ void wide_advance(const WAdvanceArgs &a, WideLds &L)
     };
 
     bool step = false;
+    int want = 0; // which damped solve this call ends with: 1 acceleration, 2 velocity
     if (phase == PH_INIT)
     {
         nevalf += 1;
@@ -475,20 +568,7 @@ __device__ __forceinline__ void wide_advance(const WAdvanceArgs &a, WideLds &L)
             step = (itstatus == ST_CONTINUE) ? true : end_iteration(itstatus);
         }
         else
-        {
-            if (mine)
-                L.rhs[lane] = -rg[lane];
-            wide_lds_sync();
-            wide_solve(L, p, mu, L.rhs, L.acc, lane);
-            const double ai = mine ? L.acc[lane] : 0.0, vi = mine ? L.vel[lane] : 0.0;
-            const double an = wide_seq_sum(ai * ai, p), vn = wide_seq_sum(vi * vi, p);
-            avratio = sqrt(an) / sqrt(vn);
-            if (mine)
-                L.dx[lane] = vi + 0.5 * ai;
-            wide_lds_sync();
-            set_trial();
-            phase = PH_TRIAL;
-        }
+            want = 1;
     }
     else
     {
@@ -553,12 +633,28 @@ __device__ __forceinline__ void wide_advance(const WAdvanceArgs &a, WideLds &L)
         step = (itstatus == ST_CONTINUE) ? true : end_iteration(itstatus);
     }
     if (step)
+        want = 2;
+    if (want)
     {
-        // lm_begin_step
+        // the one damped solve of this call: the acceleration (rhs = -J^T fvv) or the velocity of lm_begin_step (rhs = -g)
         if (mine)
-            L.rhs[lane] = -L.g[lane];
+            L.rhs[lane] = want == 1 ? -rg[lane] : -L.g[lane];
         wide_lds_sync();
-        wide_solve(L, p, mu, L.rhs, L.vel, lane);
+        wide_solve(L, p, mu, L.rhs, want == 1 ? L.acc : L.vel, lane);
+    }
+    if (want == 1)
+    {
+        const double ai = mine ? L.acc[lane] : 0.0, vi = mine ? L.vel[lane] : 0.0;
+        const double an = wide_seq_sum(ai * ai, p), vn = wide_seq_sum(vi * vi, p);
+        avratio = sqrt(an) / sqrt(vn);
+        if (mine)
+            L.dx[lane] = vi + 0.5 * ai;
+        wide_lds_sync();
+        set_trial();
+        phase = PH_TRIAL;
+    }
+    else if (want == 2)
+    {
         if (prm.trs == 1)
             phase = PH_FVV;
         else

@@ -272,6 +272,8 @@ struct WideFit : DenseBase
         const size_t nb = sizeof(double) * (size_t)n;
         if (fn->x_on_device)
         {
+            if (fn->nx < 1 || !fn->x || !y)
+                return GSLNLS_EINVAL; // device-resident data: every column the formula reads must exist
             d_x = const_cast<double *>(fn->x);
             d_y = const_cast<double *>(y);
             d_sw = const_cast<double *>(swts);
@@ -675,8 +677,6 @@ struct WideFit : DenseBase
         cur_sw = d_sw;
         return GSLNLS_SUCCESS;
     }
-    // not lowered for p > 9 (the callers get GSLNLS_E_UNSUPPORTED and keep the reference's path): the matrix-free operators
-    // of gsl_nls_large
     // gsl_multifit_nlinear_rho_driver (src/nls_irls.c:412-546) around the wide solve: the same driver as irls_host.hpp
     // (cold re-start from the ORIGINAL start with the current weights, radix-select median, psi family, stopping rule);
     // only the residual pass differs -- the formula's finalize kernel run without weights
@@ -730,7 +730,13 @@ struct WideFit : DenseBase
         double *d_part = reinterpret_cast<double *>(take(sizeof(double) * nblk));
         SelectState *d_sel = reinterpret_cast<SelectState *>(take(sizeof(SelectState) * 2));
         IrlsScalars *d_sc = reinterpret_cast<IrlsScalars *>(take(sizeof(IrlsScalars)));
-        auto cleanup = [&]() { cur_sw = user_sw; };
+        // the handle's weights are put back however this function is left
+        struct RestoreSw
+        {
+            const double *&ref;
+            const double *val;
+            ~RestoreSw() { ref = val; }
+        } restore_sw{cur_sw, user_sw};
         double *sw_now = d_swA, *sw_next = d_swB;
         if (user_sw)
             GSLNLS_HIP_OK(hipMemcpyAsync(sw_now, user_sw, nb, hipMemcpyDeviceToDevice, stream));
@@ -762,10 +768,7 @@ struct WideFit : DenseBase
             prm.chisq_in = (irls_iter > 1) ? chisq_carry : NAN;
             int rc = run_loop(jm, prm, start, lupars, trace, 0);
             if (rc)
-            {
-                cleanup();
                 return rc;
-            }
             total_launches += last_launches;
             total_ms += last_ms;
             const WState &s = h_state[1];
@@ -867,9 +870,10 @@ struct WideFit : DenseBase
                 if (out->irls_dpsi)
                     out->irls_dpsi[i] = NAN;
             }
-        cleanup();
         return rc;
     }
+    // not lowered for p > 9 (gslnls_large_create answers GSLNLS_E_UNSUPPORTED and the caller keeps the reference's path):
+    // the matrix-free operators of gsl_nls_large on a formula
     LargeOps *make_large_ops() override { return nullptr; }
     // weighted residual, Jacobian (n x p, column-major) and (J^T J)^-1 at theta on the device; returns s^2 = ssr / (n - p).
     // 1: J^T J is singular (hat_values fails in the reference as well)
@@ -947,15 +951,20 @@ struct WideFit : DenseBase
             return 0; // cooks_d -> hat_values fails: no second pass (src/nls.c:419-421)
         if (rc)
             return rc < 0 ? rc : -1;
-        double *d_d = nullptr;
-        unsigned long long *d_keys = nullptr;
-        SelectState *d_sel = nullptr;
-        int *d_cnt = nullptr;
-        GSLNLS_HIP_OK(hipMalloc(&d_d, sizeof(double) * (size_t)n));
-        GSLNLS_HIP_OK(hipMalloc(&d_keys, sizeof(unsigned long long) * (size_t)n));
-        GSLNLS_HIP_OK(hipMalloc(&d_sel, sizeof(SelectState) * 2));
-        GSLNLS_HIP_OK(hipMalloc(&d_cnt, sizeof(int)));
-        GSLNLS_HIP_OK(hipMemsetAsync(d_cnt, 0, sizeof(int), stream));
+        // one allocation: distances, their keys, the two select states, the outlier count
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t nb8 = up(sizeof(double) * (size_t)n);
+        char *arena = nullptr;
+        GSLNLS_HIP_OK(hipMalloc(&arena, 2 * nb8 + up(sizeof(SelectState) * 2) + 256));
+        double *d_d = reinterpret_cast<double *>(arena);
+        unsigned long long *d_keys = reinterpret_cast<unsigned long long *>(arena + nb8);
+        SelectState *d_sel = reinterpret_cast<SelectState *>(arena + 2 * nb8);
+        int *d_cnt = reinterpret_cast<int *>(arena + 2 * nb8 + up(sizeof(SelectState) * 2));
+        if (hipMemsetAsync(d_cnt, 0, sizeof(int), stream) != hipSuccess)
+        {
+            (void)hipFree(arena);
+            return GSLNLS_E_NODEVICE;
+        }
         int gf = (int)(((long long)n + 255) / 256);
         gf = gf > 2048 ? 2048 : (gf < 1 ? 1 : gf);
         hipLaunchKernelGGL(wide_cooks_kernel, dim3(gf), dim3(256), 0, stream, d_resid, d_grad, (long long)n, p, dc, s2, d_d,
@@ -977,17 +986,13 @@ struct WideFit : DenseBase
             (void)hipMemcpyAsync(&noutlier, d_cnt, sizeof(int), hipMemcpyDeviceToHost, stream);
             (void)hipStreamSynchronize(stream);
         }
-        (void)hipFree(d_d);
-        (void)hipFree(d_keys);
-        (void)hipFree(d_sel);
-        (void)hipFree(d_cnt);
+        (void)hipFree(arena);
         if (rc)
             return rc < 0 ? rc : -1;
         return (noutlier > 0 && noutlier < (n - p)) ? 1 : 0;
     }
     // multi-start branch of C_nls (src/nls.c:274-532): the host driver of mstart_driver.hpp (the reference's commit
-    // order) around WideMsEvaluator, then the final single-start solve.  The robust second pass (Cook's distances) is
-    // not lowered for p > 9.
+    // order) around WideMsEvaluator, the robust second pass when a loss function is set, then the final solve.
     int mstart(int jac, int fvv, const double *start2p, const double *lupars, const int *ci, const double *cd,
                const int *has_start, const MsComm &comm, int loss_rho, const double *loss_cc, gslnls_result *out) override
     {

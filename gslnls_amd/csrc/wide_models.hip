@@ -84,11 +84,21 @@ extern "C" int gslnls_debug_wide_solve(int p, const double *Ap, const double *di
     const int na = p * (p + 1) / 2;
     double *d = nullptr;
     GSLNLS_HIP_OK(hipMalloc(&d, sizeof(double) * (size_t)(na + 3 * p)));
-    GSLNLS_HIP_OK(hipMemcpy(d, Ap, sizeof(double) * na, hipMemcpyHostToDevice));
-    GSLNLS_HIP_OK(hipMemcpy(d + na, diag, sizeof(double) * p, hipMemcpyHostToDevice));
-    GSLNLS_HIP_OK(hipMemcpy(d + na + p, rhs, sizeof(double) * p, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(wide_solve_debug_kernel, dim3(1), dim3(64), 0, 0, p, d, d + na, mu, d + na + p, d + na + 2 * p);
-    GSLNLS_HIP_OK(hipMemcpy(sol, d + na + 2 * p, sizeof(double) * p, hipMemcpyDeviceToHost));
+    hipError_t he = hipMemcpy(d, Ap, sizeof(double) * na, hipMemcpyHostToDevice);
+    if (he == hipSuccess)
+        he = hipMemcpy(d + na, diag, sizeof(double) * p, hipMemcpyHostToDevice);
+    if (he == hipSuccess)
+        he = hipMemcpy(d + na + p, rhs, sizeof(double) * p, hipMemcpyHostToDevice);
+    if (he == hipSuccess)
+    {
+        hipLaunchKernelGGL(wide_solve_debug_kernel, dim3(1), dim3(64), 0, 0, p, d, d + na, mu, d + na + p, d + na + 2 * p);
+        he = hipMemcpy(sol, d + na + 2 * p, sizeof(double) * p, hipMemcpyDeviceToHost);
+    }
+    if (he != hipSuccess)
+    {
+        (void)hipFree(d);
+        return GSLNLS_E_NODEVICE;
+    }
     if (const char *e = getenv("GSLNLS_WIDE_SOLVE_REPS"))
     {
         // developer timing of the solve alone (HIP events around `reps` back-to-back launches)
