@@ -137,10 +137,15 @@ __device__ __forceinline__ double wide_seq_sum(double v, int p)
 // m += (lane K of this lane's row of 16 lanes of vb) * t: the 64-bit DPP form of v_fmac_f64 (row_newbcast is the one DPP
 // control the double-precision ALU takes), one instruction where v_readlane x 2 + v_fma_f64 were three.  All 64 lanes
 // must be active.
+template <int V>
+struct WideInt
+{
+    static constexpr int value = V;
+};
 template <int K>
 __device__ __forceinline__ void wide_fmac_rowbcast(double &m, double vb, double t)
 {
-    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(m) : "v"(vb), "v"(t), "n"(K));
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(m) : "v"(vb), "v"(t), "n"(K));
 }
 
 // maximum over the first 16 R lanes (the others hold values that cannot win), in every lane
@@ -161,53 +166,81 @@ __device__ __forceinline__ double wide_wave_max_rows(double v)
     return r;
 }
 
-// m[q] for a wave-uniform q: a scalar branch tree over the register file (a run-time register index would send the whole
-// row to scratch memory)
+// m[q] for a wave-uniform q < PW: a computed jump into a table of `v_mov_b64 v, m[k]; s_branch end` pairs, eight bytes
+// each (a run-time register index would send the whole row to scratch memory, and the compiler's branch tree for a
+// switch costs more than the whole rank-one update at PW = 16)
 template <int PW>
 __device__ __forceinline__ double wide_pick(const double (&m)[PW], int q)
 {
-    double v = 0.0;
-#define GSLNLS_WPICK(k)                                                                                                      \
-    case k:                                                                                                                  \
-        if constexpr (k < PW)                                                                                                \
-        {                                                                                                                    \
-            v = m[k < PW ? k : 0];                                                                                           \
-            asm volatile("" : "+v"(v));                                                                                      \
-        }                                                                                                                    \
-        break;
-#define GSLNLS_WPICK8(b)                                                                                                     \
-    GSLNLS_WPICK(b + 0)                                                                                                      \
-    GSLNLS_WPICK(b + 1) GSLNLS_WPICK(b + 2) GSLNLS_WPICK(b + 3) GSLNLS_WPICK(b + 4) GSLNLS_WPICK(b + 5) GSLNLS_WPICK(b + 6)  \
-        GSLNLS_WPICK(b + 7)
-    switch (__builtin_amdgcn_readfirstlane(q))
-    {
-        GSLNLS_WPICK8(0)
-        GSLNLS_WPICK8(8)
-        GSLNLS_WPICK8(16)
-        GSLNLS_WPICK8(24)
-        GSLNLS_WPICK8(32)
-        GSLNLS_WPICK8(40)
-        GSLNLS_WPICK8(48)
-        GSLNLS_WPICK8(56)
-    default:
-        break;
-    }
-#undef GSLNLS_WPICK8
-#undef GSLNLS_WPICK
+    double v;
+#define GSLNLS_WPICK_E(k) "v_mov_b64 %0, %" #k "\n s_branch 1f\n"
+    asm("s_getpc_b64 s[96:97]\n"
+        "s_lshl_b32 s98, %1, 3\n"
+        "s_add_u32 s98, s98, 20\n" // from the instruction after s_getpc to the first table entry
+        "s_add_u32 s96, s96, s98\n"
+        "s_addc_u32 s97, s97, 0\n"
+        "s_setpc_b64 s[96:97]\n"
+        GSLNLS_WPICK_E(2) GSLNLS_WPICK_E(3) GSLNLS_WPICK_E(4) GSLNLS_WPICK_E(5) GSLNLS_WPICK_E(6) GSLNLS_WPICK_E(7) GSLNLS_WPICK_E(8) GSLNLS_WPICK_E(9)
+        GSLNLS_WPICK_E(10) GSLNLS_WPICK_E(11) GSLNLS_WPICK_E(12) GSLNLS_WPICK_E(13) GSLNLS_WPICK_E(14) GSLNLS_WPICK_E(15) GSLNLS_WPICK_E(16) GSLNLS_WPICK_E(17)
+        GSLNLS_WPICK_E(18) GSLNLS_WPICK_E(19) GSLNLS_WPICK_E(20) GSLNLS_WPICK_E(21) GSLNLS_WPICK_E(22) GSLNLS_WPICK_E(23) GSLNLS_WPICK_E(24) GSLNLS_WPICK_E(25)
+        GSLNLS_WPICK_E(26) GSLNLS_WPICK_E(27) GSLNLS_WPICK_E(28) GSLNLS_WPICK_E(29) GSLNLS_WPICK_E(30) GSLNLS_WPICK_E(31) GSLNLS_WPICK_E(32) GSLNLS_WPICK_E(33)
+        GSLNLS_WPICK_E(34) GSLNLS_WPICK_E(35) GSLNLS_WPICK_E(36) GSLNLS_WPICK_E(37) GSLNLS_WPICK_E(38) GSLNLS_WPICK_E(39) GSLNLS_WPICK_E(40) GSLNLS_WPICK_E(41)
+        GSLNLS_WPICK_E(42) GSLNLS_WPICK_E(43) GSLNLS_WPICK_E(44) GSLNLS_WPICK_E(45) GSLNLS_WPICK_E(46) GSLNLS_WPICK_E(47) GSLNLS_WPICK_E(48) GSLNLS_WPICK_E(49)
+        GSLNLS_WPICK_E(50) GSLNLS_WPICK_E(51) GSLNLS_WPICK_E(52) GSLNLS_WPICK_E(53) GSLNLS_WPICK_E(54) GSLNLS_WPICK_E(55) GSLNLS_WPICK_E(56) GSLNLS_WPICK_E(57)
+        GSLNLS_WPICK_E(58) GSLNLS_WPICK_E(59) GSLNLS_WPICK_E(60) GSLNLS_WPICK_E(61) GSLNLS_WPICK_E(62) GSLNLS_WPICK_E(63) GSLNLS_WPICK_E(64) GSLNLS_WPICK_E(65)
+        "1:\n"
+        : "=&v"(v)
+        : "s"(q), "v"(m[0 < PW ? 0 : 0]), "v"(m[1 < PW ? 1 : 0]), "v"(m[2 < PW ? 2 : 0]), "v"(m[3 < PW ? 3 : 0]),
+          "v"(m[4 < PW ? 4 : 0]), "v"(m[5 < PW ? 5 : 0]), "v"(m[6 < PW ? 6 : 0]), "v"(m[7 < PW ? 7 : 0]),
+          "v"(m[8 < PW ? 8 : 0]), "v"(m[9 < PW ? 9 : 0]), "v"(m[10 < PW ? 10 : 0]), "v"(m[11 < PW ? 11 : 0]),
+          "v"(m[12 < PW ? 12 : 0]), "v"(m[13 < PW ? 13 : 0]), "v"(m[14 < PW ? 14 : 0]), "v"(m[15 < PW ? 15 : 0]),
+          "v"(m[16 < PW ? 16 : 0]), "v"(m[17 < PW ? 17 : 0]), "v"(m[18 < PW ? 18 : 0]), "v"(m[19 < PW ? 19 : 0]),
+          "v"(m[20 < PW ? 20 : 0]), "v"(m[21 < PW ? 21 : 0]), "v"(m[22 < PW ? 22 : 0]), "v"(m[23 < PW ? 23 : 0]),
+          "v"(m[24 < PW ? 24 : 0]), "v"(m[25 < PW ? 25 : 0]), "v"(m[26 < PW ? 26 : 0]), "v"(m[27 < PW ? 27 : 0]),
+          "v"(m[28 < PW ? 28 : 0]), "v"(m[29 < PW ? 29 : 0]), "v"(m[30 < PW ? 30 : 0]), "v"(m[31 < PW ? 31 : 0]),
+          "v"(m[32 < PW ? 32 : 0]), "v"(m[33 < PW ? 33 : 0]), "v"(m[34 < PW ? 34 : 0]), "v"(m[35 < PW ? 35 : 0]),
+          "v"(m[36 < PW ? 36 : 0]), "v"(m[37 < PW ? 37 : 0]), "v"(m[38 < PW ? 38 : 0]), "v"(m[39 < PW ? 39 : 0]),
+          "v"(m[40 < PW ? 40 : 0]), "v"(m[41 < PW ? 41 : 0]), "v"(m[42 < PW ? 42 : 0]), "v"(m[43 < PW ? 43 : 0]),
+          "v"(m[44 < PW ? 44 : 0]), "v"(m[45 < PW ? 45 : 0]), "v"(m[46 < PW ? 46 : 0]), "v"(m[47 < PW ? 47 : 0]),
+          "v"(m[48 < PW ? 48 : 0]), "v"(m[49 < PW ? 49 : 0]), "v"(m[50 < PW ? 50 : 0]), "v"(m[51 < PW ? 51 : 0]),
+          "v"(m[52 < PW ? 52 : 0]), "v"(m[53 < PW ? 53 : 0]), "v"(m[54 < PW ? 54 : 0]), "v"(m[55 < PW ? 55 : 0]),
+          "v"(m[56 < PW ? 56 : 0]), "v"(m[57 < PW ? 57 : 0]), "v"(m[58 < PW ? 58 : 0]), "v"(m[59 < PW ? 59 : 0]),
+          "v"(m[60 < PW ? 60 : 0]), "v"(m[61 < PW ? 61 : 0]), "v"(m[62 < PW ? 62 : 0]), "v"(m[63 < PW ? 63 : 0])
+        : "s96", "s97", "s98", "scc");
+#undef GSLNLS_WPICK_E
     return v;
+}
+
+// v_max_u32 with the DPP exchange folded into the instruction
+template <int CTRL>
+__device__ __forceinline__ unsigned int wide_umax_dpp(unsigned int x)
+{
+    const unsigned int y = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true);
+    return x > y ? x : y;
 }
 
 // (A + mu D^2) sol = rhs by ONE wavefront (all 64 lanes of it must call; lanes >= p idle along), p <= PW.
 //
 // gsl_linalg_mcholesky (Gill-Murray-Wright modified Cholesky with diagonal pivoting) with the matrix in REGISTERS: lane i
 // holds row i of the symmetric matrix, m[k] = S[i][k], by ORIGINAL index -- nothing is ever interchanged.  The
-// reference's permutation lives in `pos` (lane i: the position row i has in the permuted order; the tie rule of the pivot
-// search -- the first position wins -- reads it), the pivot sequence in `ord` (lane j: the row eliminated at step j).
-// One step: pivot row q (wavefront maximum of the diagonal, which every lane keeps in `dg`), its column v_i = S[i][q] is
-// each lane's own m[q], theta = max |v_i|, alpha, then the rank-one update S[i][k] -= (v_i / alpha) v_k of ALL columns in
-// PW instructions (v_fmac_f64 with a DPP row broadcast of v_k) -- columns and rows already eliminated see v = 0.  The
-// forward substitution rides along (b_i -= l_i b_q); the multipliers l_i = v_i / alpha also go to LDS, T[q][i], so that
-// the back substitution L^T w = z finds row q_j of L^T as T[i][q_j]: lane i's own row, conflict-free.
+// reference's permutation lives in `pos` (lane i: the position row i has in the permuted order -- rows at positions
+// > j are the ones still to be eliminated; the tie rule of the pivot search, the first position wins, reads it), the
+// pivot sequence in `ord` (lane j: the row eliminated at step j).
+// One step: pivot row q, its column v_i = S[i][q] is each lane's own m[q], alpha = max(eps, |d_qq|, theta^2 / beta) with
+// theta = max |v_i|, then the rank-one update S[i][k] -= (v_i / alpha) v_k of ALL columns in PW instructions (v_fmac_f64
+// with a DPP row broadcast of v_k) -- columns and rows already eliminated see v = 0.  The forward substitution rides
+// along (b_i -= l_i b_q); the multipliers l_i = v_i / alpha also go to LDS, T[q][i], so that the back substitution
+// L^T w = z finds row q_j of L^T as T[i][q_j]: lane i's own row, conflict-free.
+// A lone wavefront issues one instruction every ~5 clocks, ~10 when it depends on the one before (scripts/lane_probe),
+// so the step is built to be SHORT rather than wide:
+//   * the pivot search reduces the HIGH words of |d_ii| (sign, exponent, 20 mantissa bits; v_max_u32 with the DPP
+//     exchange folded in); one lane holding the largest high word is the common case and ends the search, several go
+//     to the full comparison (exact ties: the first position wins);
+//   * theta is only needed when it raises alpha: (|v_i| / sqrt(beta))^2 > max(eps, |d_qq|) in ANY lane is the same
+//     condition as for the maximum (rounding is monotone), one ballot instead of a reduction;
+//   * 1 / alpha is the compiler's own correctly rounded sequence, spelled out so that the permutation bookkeeping issues
+//     into its dependent chain, and the rank-one update of step j issues into the pivot search of step j + 1 (which
+//     only needs the updated diagonal).
 // Against lm_solve<P> / the reference: the same sums in the same order with one exception -- an entry S[i][k] whose rows
 // were interchanged relative to each other is updated as (v_i / alpha) v_k here where the reference's single (lower)
 // copy gets (v_k / alpha) v_i: one rounding apart.
@@ -216,6 +249,9 @@ __device__ __forceinline__ void wide_solve_reg(WideLds &L, int p, double mu, con
 {
     constexpr int R = PW / 16;
     constexpr int LD = WP + 1;
+    constexpr int NCH = PW / 4; // rank-one update: chunks of four columns
+    constexpr int NSLOT = 8;    // gaps of the pivot search they are issued into
+    static_assert(NCH <= 2 * NSLOT, "every chunk of the rank-one update needs a slot");
     double *T = L.M;
     const bool mine = lane < p;
     double m[PW];
@@ -236,9 +272,14 @@ __device__ __forceinline__ void wide_solve_reg(WideLds &L, int p, double mu, con
         b = rhs[lane];
     }
     double xm = 0.0;
+    {
+        // (four interleaved chains: PW dependent maxima in a row are PW x 10 clocks)
+        double x4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int k = 0; k < PW; ++k)
-        xm = fmax(xm, fabs(m[k]));
+        for (int k = 0; k < PW; ++k)
+            x4[k & 3] = fmax(x4[k & 3], fabs(m[k]));
+        xm = fmax(fmax(x4[0], x4[1]), fmax(x4[2], x4[3]));
+    }
     const double gamma = wide_wave_max_rows<R>(fabs(dg)), xi = wide_wave_max_rows<R>(xm);
     double beta;
     if (p == 1)
@@ -247,88 +288,187 @@ __device__ __forceinline__ void wide_solve_reg(WideLds &L, int p, double mu, con
         beta = fmax(fmax(gamma, xi / sqrt((double)p * p - 1.0)), DBL_EPSILON);
     const double betainv = 1.0 / sqrt(beta);
     double dinv = 0.0; // 1 / alpha of the step that eliminated this row
-    int pos = lane, ord = 0;
-    bool act = mine;
-    const int sub = lane & 15;
-    for (int j = 0; j < p; ++j)
-    {
-        // pivot: the first position holding the largest |diagonal| among positions j..p-1 (`if (d > maxd)` of the
-        // sequential scan from position j: the first element wins ties, NaNs never win)
-        const double d = act ? fabs(dg) : -1.0;
-        const double maxd = wide_wave_max_rows<R>(d);
-        const int r = (int)__builtin_ctzll(__ballot(act && pos == j) | (1ull << 63)); // the row at position j
-        int q = r;
-        if (maxd > fabs(wide_bcast(dg, r)))
+    int pos = mine ? lane : -1, ord = 0;
+
+    // pivot of step jn among the rows `live` (positions >= jn): the first position holding the largest |diagonal|
+    // (`if (d > maxd)` of the sequential scan from position jn: the first element wins ties, NaNs never win -- unless
+    // one sits at position jn, where the scan starts: then nothing compares greater and the pivot stays there).
+    // dq = |diagonal| of the pivot.
+    auto pivot = [&](int jn, bool live, int &q, double &dq, auto &&fill) {
+        double d;
+        asm("v_max_f64 %0, |%1|, 0" : "=v"(d) : "v"(dg)); // |d_ii|, NaN -> 0
+        d = live ? d : 0.0;
+        const unsigned int hi = (unsigned int)((unsigned long long)__double_as_longlong(d) >> 32);
+        fill(0);
+        unsigned int x = wide_umax_dpp<0xB1>(hi); // quad_perm [1,0,3,2]
+        fill(1);
+        x = wide_umax_dpp<0x4E>(x); // quad_perm [2,3,0,1]
+        fill(2);
+        x = wide_umax_dpp<0x141>(x); // row_half_mirror
+        fill(3);
+        x = wide_umax_dpp<0x140>(x); // row_mirror
+        fill(4);
+        unsigned int mh = (unsigned int)__builtin_amdgcn_readlane((int)x, 0);
+        if constexpr (R > 1)
         {
-            unsigned long long hit = __ballot(act && d == maxd);
-            q = hit ? (int)__builtin_ctzll(hit) : r;
-            if (hit & (hit - 1))
+            const unsigned int t1 = (unsigned int)__builtin_amdgcn_readlane((int)x, 16);
+            mh = mh > t1 ? mh : t1;
+        }
+        if constexpr (R > 2)
+        {
+            const unsigned int t2 = (unsigned int)__builtin_amdgcn_readlane((int)x, 32);
+            mh = mh > t2 ? mh : t2;
+        }
+        if constexpr (R > 3)
+        {
+            const unsigned int t3 = (unsigned int)__builtin_amdgcn_readlane((int)x, 48);
+            mh = mh > t3 ? mh : t3;
+        }
+        fill(5);
+        unsigned long long hit = __builtin_amdgcn_ballot_w64(live && hi == mh);
+        const unsigned long long nanr = __builtin_amdgcn_ballot_w64(live && pos == jn && dg != dg);
+        fill(6);
+        q = hit ? (int)__builtin_ctzll(hit) : 0;
+        fill(7);
+        if (hit & (hit - 1))
+        {
+            // several rows share the largest high word: the full comparison, then the first position among the equal
+            const double maxd = wide_wave_max_rows<R>((hit >> lane) & 1 ? d : 0.0);
+            hit = __builtin_amdgcn_ballot_w64(live && d == maxd);
+            int best = 1 << 30;
+            while (hit)
             {
-                int best = 1 << 30;
-                while (hit)
+                const int c = (int)__builtin_ctzll(hit);
+                hit &= hit - 1;
+                const int pc = __builtin_amdgcn_readlane(pos, c);
+                if (pc < best)
                 {
-                    const int c = (int)__builtin_ctzll(hit);
-                    hit &= hit - 1;
-                    const int pc = __builtin_amdgcn_readlane(pos, c);
-                    if (pc < best)
-                    {
-                        best = pc;
-                        q = c;
-                    }
+                    best = pc;
+                    q = c;
                 }
             }
         }
         q = __builtin_amdgcn_readfirstlane(q);
-        // rows r and q trade positions (nothing moves)
-        const int pq = __builtin_amdgcn_readlane(pos, q);
-        if (lane == r)
-            pos = pq;
-        if (lane == q)
-            pos = j;
-        ord = lane == j ? q : ord;
-        const bool upd = act && lane != q;
-        double v = wide_pick<PW>(m, q);
-        v = upd ? v : 0.0;
-        const double theta = wide_wave_max_rows<R>(fabs(v));
-        const double u = theta * betainv;
-        const double alpha = fmax(fmax(DBL_EPSILON, fabs(wide_bcast(dg, q))), u * u);
-        const double ainv = 1.0 / alpha;
-        if (lane == q)
+        dq = wide_bcast(d, q);
+        if (nanr)
         {
-            dinv = ainv;
-            act = false;
+            q = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(nanr));
+            dq = __longlong_as_double(0x7ff8000000000000ll);
+        }
+    };
+
+    int q = 0;
+    double dq = 0.0;
+    pivot(0, mine, q, dq, [](int) {});
+    for (int j = 0; j < p; ++j)
+    {
+        // alpha = max(eps, |d_qq|, theta^2 / beta), theta = max |v_i|: 1 / max(eps, |d_qq|) is started at once
+        const double a0 = fmax(DBL_EPSILON, dq);
+        bool dv_f = false, dv_g = false;
+        const double dv_s = __builtin_amdgcn_div_scale(1.0, a0, false, &dv_g);
+        double dv_r = __builtin_amdgcn_rcp(dv_s);
+        double v = wide_pick<PW>(m, q);
+        __builtin_amdgcn_sched_barrier(0);
+        dv_r = __builtin_fma(dv_r, __builtin_fma(-dv_s, dv_r, 1.0), dv_r);
+        // rows at position j and q trade positions (nothing moves); afterwards the rows still to be eliminated are the
+        // ones at positions > j
+        const int pq = __builtin_amdgcn_readlane(pos, q);
+        pos = pos == j ? pq : pos;
+        pos = lane == q ? j : pos;
+        const bool upd = pos > j;
+        v = upd ? v : 0.0;
+        __builtin_amdgcn_sched_barrier(0);
+        dv_r = __builtin_fma(dv_r, __builtin_fma(-dv_s, dv_r, 1.0), dv_r);
+        const double dv_n = __builtin_amdgcn_div_scale(1.0, a0, true, &dv_f);
+        const double w = fabs(v) * betainv;
+        const unsigned long long raise = __builtin_amdgcn_ballot_w64(w * w > a0);
+        ord = lane == j ? q : ord;
+        __builtin_amdgcn_sched_barrier(0);
+        double dv_q = dv_n * dv_r;
+        dv_q = __builtin_amdgcn_div_fmas(__builtin_fma(-dv_s, dv_q, dv_n), dv_r, dv_q, dv_f);
+        const double bq = wide_bcast(b, q);
+        __builtin_amdgcn_sched_barrier(0);
+        double ainv = __builtin_amdgcn_div_fixup(dv_q, a0, 1.0);
+        if (raise)
+        {
+            const double theta = wide_wave_max_rows<R>(fmax(fabs(v), 0.0));
+            const double u = theta * betainv;
+            ainv = 1.0 / (u * u);
+            asm volatile("" : "+v"(ainv)); // (a branch, not a select in front of a second division)
         }
         const double t = ainv * v; // the multiplier l_i (0 in rows that take no part)
-        const double bq = wide_bcast(b, q);
-        if (upd)
-        {
-            dg -= t * v;
-            b -= t * bq;
-        }
+        dg -= t * v;
+        b = upd ? b - t * bq : b;
+        dinv = lane == q ? ainv : dinv;
         T[q * LD + lane] = t;
         const double tn = -t;
-#pragma unroll
-        for (int g = 0; g < R; ++g)
+        // v of row 16 g + l % 16 in lane l, for the DPP row broadcasts
+        double vb[R];
+        vb[0] = v;
+        if constexpr (R > 1)
         {
-            double vb = wide_shfl(v, 16 * g + sub); // lane l: v of row 16 g + l % 16
-            asm volatile("s_nop 1" : "+v"(vb));     // (a DPP operand written by the instruction before: 2 wait states)
-            wide_fmac_rowbcast<0>(m[16 * g + 0], vb, tn);
-            wide_fmac_rowbcast<1>(m[16 * g + 1], vb, tn);
-            wide_fmac_rowbcast<2>(m[16 * g + 2], vb, tn);
-            wide_fmac_rowbcast<3>(m[16 * g + 3], vb, tn);
-            wide_fmac_rowbcast<4>(m[16 * g + 4], vb, tn);
-            wide_fmac_rowbcast<5>(m[16 * g + 5], vb, tn);
-            wide_fmac_rowbcast<6>(m[16 * g + 6], vb, tn);
-            wide_fmac_rowbcast<7>(m[16 * g + 7], vb, tn);
-            wide_fmac_rowbcast<8>(m[16 * g + 8], vb, tn);
-            wide_fmac_rowbcast<9>(m[16 * g + 9], vb, tn);
-            wide_fmac_rowbcast<10>(m[16 * g + 10], vb, tn);
-            wide_fmac_rowbcast<11>(m[16 * g + 11], vb, tn);
-            wide_fmac_rowbcast<12>(m[16 * g + 12], vb, tn);
-            wide_fmac_rowbcast<13>(m[16 * g + 13], vb, tn);
-            wide_fmac_rowbcast<14>(m[16 * g + 14], vb, tn);
-            wide_fmac_rowbcast<15>(m[16 * g + 15], vb, tn);
+            const long long bits = __double_as_longlong(v);
+            const unsigned int lo = (unsigned int)(bits & 0xffffffffll), hi = (unsigned int)(bits >> 32);
+            const auto l16 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+            const auto h16 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+            // l16[0] = rows [0, 0, 2, 2], l16[1] = rows [1, 1, 3, 3]
+            if constexpr (R == 2)
+            {
+                vb[0] = __longlong_as_double(((long long)h16[0] << 32) | l16[0]);
+                vb[1] = __longlong_as_double(((long long)h16[1] << 32) | l16[1]);
+            }
+            else
+            {
+                const auto l0 = __builtin_amdgcn_permlane32_swap(l16[0], l16[0], false, false);
+                const auto h0 = __builtin_amdgcn_permlane32_swap(h16[0], h16[0], false, false);
+                const auto l1 = __builtin_amdgcn_permlane32_swap(l16[1], l16[1], false, false);
+                const auto h1 = __builtin_amdgcn_permlane32_swap(h16[1], h16[1], false, false);
+                vb[0] = __longlong_as_double(((long long)h0[0] << 32) | l0[0]); // rows [0, 0, 0, 0]
+                vb[2] = __longlong_as_double(((long long)h0[1] << 32) | l0[1]); // rows [2, 2, 2, 2]
+                vb[1] = __longlong_as_double(((long long)h1[0] << 32) | l1[0]);
+                if constexpr (R > 3)
+                    vb[3] = __longlong_as_double(((long long)h1[1] << 32) | l1[1]);
+            }
         }
+        // columns 4 c .. 4 c + 3
+        auto chunk = [&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            if constexpr (c < NCH)
+            {
+                constexpr int g = (4 * c) / 16, k0 = (4 * c) % 16;
+                wide_fmac_rowbcast<k0 + 0>(m[4 * c + 0], vb[g], tn);
+                wide_fmac_rowbcast<k0 + 1>(m[4 * c + 1], vb[g], tn);
+                wide_fmac_rowbcast<k0 + 2>(m[4 * c + 2], vb[g], tn);
+                wide_fmac_rowbcast<k0 + 3>(m[4 * c + 3], vb[g], tn);
+            }
+        };
+        auto fill = [&](int slot) {
+            // (slot is a literal at every call site: the switch folds away)
+            switch (slot)
+            {
+            case 0: chunk(WideInt<0>{}); chunk(WideInt<NSLOT>{}); break;
+            case 1: chunk(WideInt<1>{}); chunk(WideInt<NSLOT + 1>{}); break;
+            case 2: chunk(WideInt<2>{}); chunk(WideInt<NSLOT + 2>{}); break;
+            case 3: chunk(WideInt<3>{}); chunk(WideInt<NSLOT + 3>{}); break;
+            case 4: chunk(WideInt<4>{}); chunk(WideInt<NSLOT + 4>{}); break;
+            case 5: chunk(WideInt<5>{}); chunk(WideInt<NSLOT + 5>{}); break;
+            case 6: chunk(WideInt<6>{}); chunk(WideInt<NSLOT + 6>{}); break;
+            case 7: chunk(WideInt<7>{}); chunk(WideInt<NSLOT + 7>{}); break;
+            default: break;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // (a DPP operand written by the instruction before: 2 wait states)
+        if constexpr (R == 1)
+            asm volatile("s_nop 1" : "+v"(vb[0]));
+        else if constexpr (R == 2)
+            asm volatile("s_nop 1" : "+v"(vb[0]), "+v"(vb[1]));
+        else if constexpr (R == 3)
+            asm volatile("s_nop 1" : "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]));
+        else
+            asm volatile("s_nop 1" : "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]));
+        if (j + 1 < p) // (nothing reads the matrix after the last step)
+            pivot(j + 1, upd, q, dq, fill);
     }
     b *= dinv;
     wide_lds_sync();
@@ -392,28 +532,67 @@ __device__ __forceinline__ void wide_advance(const WAdvanceArgs &a, WideLds &L)
     if (S->phase == PH_DONE)
         return;
     const double *tot = a.totals;
-    const double r_ssr = tot[0], r_badj = tot[1];
-    const double *rA = tot + 2, *rg = tot + 2 + NA;
+    const double *rA = tot + 2;
     const bool mine = lane < p;
     // ---- state -> LDS (vectors, packed matrix) and registers (scalars) ----
-    if (mine)
+    // Every global load of the call is issued here, before the first of them is waited for: a load is most of a
+    // microsecond for this lone wavefront (the data was written by other XCDs), and a copy loop of NA / 64 trips that
+    // waits for each trip's load in turn cost 5 us at p = 32.  J^T J of the pass that just ran is parked in L.M (free
+    // until the solve) for lm_take_point.
+    const double r_ssr = tot[0], r_badj = tot[1];
+    const double r_g = mine ? tot[2 + NA + lane] : 0.0;
+    double sv[9];
     {
-        L.x[lane] = S->x[lane];
-        L.xt[lane] = S->xt[lane];
-        L.dx[lane] = S->dx[lane];
-        L.vel[lane] = S->vel[lane];
-        L.acc[lane] = S->acc[lane];
-        L.g[lane] = S->g[lane];
-        L.diag[lane] = S->diag[lane];
-        L.lo[lane] = S->lo[lane];
-        L.up[lane] = S->up[lane];
+        const double *vec[9] = {S->x, S->xt, S->dx, S->vel, S->acc, S->g, S->diag, S->lo, S->up};
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            sv[k] = mine ? vec[k][lane] : 0.0;
     }
-    for (int k = lane; k < NA; k += 64)
-        L.A[k] = S->A[k];
     double fnorm2 = S->fnorm2, mu = S->mu, nu = S->nu, delta = S->delta, avratio = S->avratio, chisq0 = S->chisq0,
            chisq1 = S->chisq1, chisq_init = S->chisq_init;
     int bad_steps = S->bad_steps, niter = S->niter, phase = S->phase, status = S->status, info = S->info, nevalf = S->nevalf,
         nevaldf = S->nevaldf, nevalfvv = S->nevalfvv;
+    auto stage_matrices = [&](auto trips) {
+        constexpr int IT = decltype(trips)::value;
+        double ba[IT], br[IT];
+#pragma unroll
+        for (int i = 0; i < IT; ++i)
+        {
+            const int k = lane + 64 * i;
+            ba[i] = k < NA ? S->A[k] : 0.0;
+            br[i] = k < NA ? rA[k] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < IT; ++i)
+        {
+            const int k = lane + 64 * i;
+            if (k < NA)
+            {
+                L.A[k] = ba[i];
+                L.M[k] = br[i];
+            }
+        }
+    };
+    if (NA <= 64 * 3)
+        stage_matrices(WideInt<3>{});
+    else if (NA <= 64 * 9)
+        stage_matrices(WideInt<9>{});
+    else if (NA <= 64 * 19)
+        stage_matrices(WideInt<19>{});
+    else
+        stage_matrices(WideInt<(WNA + 63) / 64>{});
+    if (mine)
+    {
+        L.x[lane] = sv[0];
+        L.xt[lane] = sv[1];
+        L.dx[lane] = sv[2];
+        L.vel[lane] = sv[3];
+        L.acc[lane] = sv[4];
+        L.g[lane] = sv[5];
+        L.diag[lane] = sv[6];
+        L.lo[lane] = sv[7];
+        L.up[lane] = sv[8];
+    }
     const int niter_before = niter, phase_before = phase;
     wide_lds_sync();
 
@@ -421,10 +600,10 @@ __device__ __forceinline__ void wide_advance(const WAdvanceArgs &a, WideLds &L)
         if (mine)
         {
             L.x[lane] = L.xt[lane];
-            L.g[lane] = rg[lane];
+            L.g[lane] = r_g;
         }
         for (int k = lane; k < NA; k += 64)
-            L.A[k] = rA[k];
+            L.A[k] = L.M[k];
         fnorm2 = r_ssr;
         wide_lds_sync();
     };
@@ -638,7 +817,7 @@ __device__ __forceinline__ void wide_advance(const WAdvanceArgs &a, WideLds &L)
     {
         // the one damped solve of this call: the acceleration (rhs = -J^T fvv) or the velocity of lm_begin_step (rhs = -g)
         if (mine)
-            L.rhs[lane] = want == 1 ? -rg[lane] : -L.g[lane];
+            L.rhs[lane] = want == 1 ? -r_g : -L.g[lane];
         wide_lds_sync();
         wide_solve(L, p, mu, L.rhs, want == 1 ? L.acc : L.vel, lane);
     }

@@ -115,8 +115,18 @@ __global__ __launch_bounds__(64) void wide_solve_debug_kernel(int p, const doubl
 {
     __shared__ WideLds L;
     const int lane = threadIdx.x;
-    for (int k = lane; k < p * (p + 1) / 2; k += 64)
-        L.A[k] = Ap[k];
+    {
+        // (all loads in flight before the first is waited for, as in wide_advance)
+        constexpr int IT = (WNA + 63) / 64;
+        double buf[IT];
+#pragma unroll
+        for (int i = 0; i < IT; ++i)
+            buf[i] = lane + 64 * i < p * (p + 1) / 2 ? Ap[lane + 64 * i] : 0.0;
+#pragma unroll
+        for (int i = 0; i < IT; ++i)
+            if (lane + 64 * i < p * (p + 1) / 2)
+                L.A[lane + 64 * i] = buf[i];
+    }
     if (lane < p)
     {
         L.diag[lane] = diag[lane];
