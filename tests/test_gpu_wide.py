@@ -65,6 +65,62 @@ def test_wide_damped_solve_matches_the_oracles_modified_cholesky(amd, gslref, p)
             assert np.max(np.abs(sol - ref)) <= tol * scale, (case, p, np.max(np.abs(sol - ref)) / scale)
 
 
+@pytest.mark.parametrize("p", [2, 7, 16, 31, 32, 64])
+def test_wide_solve_pivot_rules_ties_near_ties_and_nans(amd, gslref, p):
+    """The pivot search of the register-resident factorisation reduces the HIGH words of the diagonal first and only
+    then compares whole values: exact ties (identical blocks: the reference's scan keeps the FIRST position), diagonals
+    that differ below the 20th mantissa bit (the full comparison has to find the true maximum, which sits last), and a
+    NaN on the diagonal (the call must come back) -- permutation decisions identical to the oracle's give solutions
+    equal to round-off"""
+    from gslnls_amd import _lib
+    L = _lib.lib()
+    G = gslref.lib()
+    rng = np.random.Generator(np.random.PCG64(900 + p))
+
+    def both(A, diag, mu, rhs):
+        sol = np.zeros(p)
+        rc = L.gslnls_debug_wide_solve(p, _packed(A).ctypes.data_as(_lib.DP), diag.ctypes.data_as(_lib.DP), mu,
+                                       rhs.ctypes.data_as(_lib.DP), sol.ctypes.data_as(_lib.DP))
+        assert rc == 0
+        M = np.ascontiguousarray(A + mu * np.diag(diag * diag))
+        perm = np.zeros(p, dtype=np.int32)
+        assert G.gslref_mcholesky_decomp(p, M.ctypes.data_as(_lib.DP), perm.ctypes.data_as(_lib.IP)) == 0
+        ref = np.zeros(p)
+        assert G.gslref_mcholesky_solve(p, M.ctypes.data_as(_lib.DP), perm.ctypes.data_as(_lib.IP),
+                                        rhs.ctypes.data_as(_lib.DP), ref.ctypes.data_as(_lib.DP)) == 0
+        return sol, ref, perm
+
+    # identical 2 x 2 blocks: ties among all untouched blocks at every other step
+    A = np.zeros((p, p))
+    for k in range(0, p - 1, 2):
+        A[k:k + 2, k:k + 2] = [[2.0, 1.0], [1.0, 2.0]]
+    if p % 2:
+        A[p - 1, p - 1] = 2.0
+    rhs = rng.standard_normal(p)
+    sol, ref, perm = both(A, np.ones(p), 0.0, rhs)
+    assert np.max(np.abs(sol - ref)) <= 1e-13 * np.max(np.abs(ref)), ("ties", p)
+    # with weak coupling between the blocks (still exact ties on the diagonal at the first step)
+    E = 1e-3 * rng.standard_normal((p, p))
+    E = E + E.T
+    np.fill_diagonal(E, 0.0)
+    sol, ref, perm = both(A + E, np.ones(p), 0.25, rhs)
+    assert np.max(np.abs(sol - ref)) <= 1e-12 * np.max(np.abs(ref)), ("coupled ties", p)
+    # near ties: the same high word everywhere, the largest diagonal last
+    B = E.copy()
+    np.fill_diagonal(B, 2.0 + np.arange(p) * 2.0 ** -40)
+    sol, ref, perm = both(B, np.ones(p), 0.0, rhs)
+    assert perm[0] == p - 1                                   # (the oracle's first pivot: the true maximum)
+    assert np.max(np.abs(sol - ref)) <= 1e-12 * np.max(np.abs(ref)), ("near ties", p)
+    # a NaN on the diagonal, at the first position and elsewhere: the call comes back (no endless tie loop, no fault);
+    # where the oracle still produces numbers (the NaN row is pivoted last / damped by eps) so does the device
+    for where in (0, p - 1):
+        Cn = A + E
+        Cn[where, where] = np.nan
+        sol, ref, perm = both(Cn, np.ones(p), 0.5, rhs)
+        if np.all(np.isfinite(ref)):
+            assert np.all(np.isfinite(sol)), ("nan", p, where)
+
+
 def gaussians_problem(ng, extra, n, seed, noise=0.05, pert=0.02):
     """sum of ng Gaussian peaks (+ constant, + slope): p = 3 ng + extra"""
     rng = np.random.Generator(np.random.PCG64(seed))
