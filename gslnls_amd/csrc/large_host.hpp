@@ -121,14 +121,24 @@ inline void lg_chol_invert(int p, std::vector<double> &A)
 
 // GSL's modified Cholesky (Gill-Murray-Wright, pivoted) for the multilarge LM step; same algorithm as
 // lm_solve<P> in lm_core.hpp with run-time p
-inline void lg_mchol_solve(int p, const std::vector<double> &Ain, const std::vector<double> &rhs, std::vector<double> &sol)
+// (wider vectors where the host has them -- the inner loops are contiguous; contraction is off so that every clone rounds
+// like the baseline one: avx512f would bring fused multiply-adds with it.  Raw pointers only in here: a clone cannot
+// count on the out-of-line copies of inline library templates)
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+__attribute__((target_clones("default", "avx2", "avx512f")))
+#endif
+inline void lg_mchol_core(int p, double *M, double *b, double *cj, int *perm)
 {
+#pragma clang fp contract(off)
     // Only the lower triangle is kept (row-major): the symmetric interchange touches each stored element once, and
     // the rank-one update of step j reads column j from a contiguous copy and walks rows -- no mirrored stores down
     // columns, so the inner loop is contiguous and vectorises (p = 500: ~10 ms per solve before).  Same operations on
     // the same values in the same order as the full-matrix form this replaces.
-    std::vector<double> M(Ain), b(rhs), cj(p);
-    std::vector<int> perm(p);
+    auto swp = [](double &x, double &y) {
+        const double t = x;
+        x = y;
+        y = t;
+    };
     for (int i = 0; i < p; ++i)
         perm[i] = i;
     double gamma = 0.0, xi = 0.0;
@@ -155,15 +165,17 @@ inline void lg_mchol_solve(int p, const std::vector<double> &Ain, const std::vec
         {
             // rows / columns j and q (q > j) of the symmetric matrix, in the lower triangle:
             // (j,j) <-> (q,q);  (j,k) <-> (q,k) for k < j;  (k,j) <-> (q,k) for j < k < q;  (k,j) <-> (k,q) for k > q
-            std::swap(M[(size_t)j * p + j], M[(size_t)q * p + q]);
+            swp(M[(size_t)j * p + j], M[(size_t)q * p + q]);
             for (int k = 0; k < j; ++k)
-                std::swap(M[(size_t)j * p + k], M[(size_t)q * p + k]);
+                swp(M[(size_t)j * p + k], M[(size_t)q * p + k]);
             for (int k = j + 1; k < q; ++k)
-                std::swap(M[(size_t)k * p + j], M[(size_t)q * p + k]);
+                swp(M[(size_t)k * p + j], M[(size_t)q * p + k]);
             for (int k = q + 1; k < p; ++k)
-                std::swap(M[(size_t)k * p + j], M[(size_t)k * p + q]);
-            std::swap(b[j], b[q]);
-            std::swap(perm[j], perm[q]);
+                swp(M[(size_t)k * p + j], M[(size_t)k * p + q]);
+            swp(b[j], b[q]);
+            const int tp = perm[j];
+            perm[j] = perm[q];
+            perm[q] = tp;
         }
         double theta = 0.0;
         for (int i = j + 1; i < p; ++i)
@@ -196,10 +208,20 @@ inline void lg_mchol_solve(int p, const std::vector<double> &Ain, const std::vec
     for (int i = p - 1; i >= 0; --i)
         for (int j = i + 1; j < p; ++j)
             b[i] -= M[(size_t)j * p + i] * b[j];
+}
+
+inline void lg_mchol_solve(int p, const std::vector<double> &Ain, const std::vector<double> &rhs, std::vector<double> &sol)
+{
+    std::vector<double> M(Ain), b(rhs), cj(p);
+    std::vector<int> perm(p);
+    lg_mchol_core(p, M.data(), b.data(), cj.data(), perm.data());
     sol.assign(p, 0.0);
     for (int i = 0; i < p; ++i)
         sol[perm[i]] = b[i];
 }
+
+// the same solve on the device (mchol_device.hip); GSLNLS_SUCCESS, or an error code when the device cannot take it
+int mchol_device_solve(int p, const double *A_host, const double *rhs_host, double *sol_host);
 
 struct LargeResult
 {
@@ -364,7 +386,15 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
             A[i * p + i] += mu * diag[i] * diag[i];
             rhs[i] = -g[i];
         }
-        lg_mchol_solve(p, A, rhs, vel);
+        // from a few hundred parameters on the factorisation runs on the device (mchol_device.hip: p = 500 1.8 ms against
+        // 3.96 on the host, p = 1000 4.7 against ~ 50); GSLNLS_LARGE_CHOL_DEVICE_MIN moves the threshold, 0 = host always
+        static const int dev_min = [] {
+            const char *e = getenv("GSLNLS_LARGE_CHOL_DEVICE_MIN");
+            return e ? atoi(e) : 400;
+        }();
+        vel.assign(p, 0.0);
+        if (!(dev_min > 0 && p >= dev_min && mchol_device_solve(p, A.data(), rhs.data(), vel.data()) == GSLNLS_SUCCESS))
+            lg_mchol_solve(p, A, rhs, vel);
         dx = vel;
         return ST_SUCCESS;
     };

@@ -167,3 +167,87 @@ def test_c3_full_size_properties(amd):
     assert abs(c["ssr"] - a["ssr"]) <= 1e-9 * a["ssr"]
     # relative residual variance 0.01^2 on responses exp(a.theta) = O(1)
     assert 0.5e-4 < a["ssr"] / n < 2e-4
+
+
+@pytest.mark.parametrize("p", [3, 65, 130, 500, 777, 1100, 2050])
+def test_device_modified_cholesky_matches_the_oracle(amd, gslref, p):
+    """The damped normal equations of the gsl_nls_large lm step on the device (csrc/mchol_device.hip: panels of pivot
+    steps by one workgroup, grid-wide trailing updates, implicit permutation) against gsl_linalg_mcholesky as restated
+    by the oracle: well conditioned, badly scaled (pivoting matters), rank deficient (the modification kicks in; what the
+    system sees is compared), identical diagonal blocks (exact ties: the first position wins) and a zero column"""
+    from gslnls_amd import _lib
+    L = _lib.lib()
+    G = gslref.lib()
+    rng = np.random.Generator(np.random.PCG64(4200 + p))
+    for case in ("spd", "badly_scaled", "rank_deficient", "ties", "zero_column"):
+        n = 2 * p + 3
+        J = rng.standard_normal((n, p))
+        if case == "badly_scaled":
+            J *= 10.0 ** rng.uniform(-5, 5, p)
+        if case == "rank_deficient" and p > 2:
+            J[:, p - 1] = J[:, 0] + J[:, 1]
+        if case == "zero_column":
+            J[:, p // 2] = 0.0
+        A = np.ascontiguousarray(J.T @ J)
+        if case == "ties":
+            A = np.zeros((p, p))
+            for k in range(0, p - 1, 2):
+                A[k:k + 2, k:k + 2] = [[2.0, 1.0], [1.0, 2.0]]
+            if p % 2:
+                A[p - 1, p - 1] = 2.0
+            E = 1e-3 * rng.standard_normal((p, p))
+            E = E + E.T
+            np.fill_diagonal(E, 0.0)
+            A = np.ascontiguousarray(A + E)
+        diag = np.sqrt(np.maximum(np.diag(A), 1e-300))
+        mu = 1e-14 if case == "rank_deficient" else 1e-3
+        rhs = rng.standard_normal(p) * np.max(np.abs(A))
+        sol = np.zeros(p)
+        assert L.gslnls_debug_mchol_solve(p, A.ctypes.data_as(_lib.DP), diag.ctypes.data_as(_lib.DP), mu,
+                                          rhs.ctypes.data_as(_lib.DP), sol.ctypes.data_as(_lib.DP)) == 0
+        M = np.ascontiguousarray(A + mu * np.diag(diag * diag))
+        Mf = M.copy()
+        perm = np.zeros(p, dtype=np.int32)
+        assert G.gslref_mcholesky_decomp(p, M.ctypes.data_as(_lib.DP), perm.ctypes.data_as(_lib.IP)) == 0
+        ref = np.zeros(p)
+        assert G.gslref_mcholesky_solve(p, M.ctypes.data_as(_lib.DP), perm.ctypes.data_as(_lib.IP),
+                                        rhs.ctypes.data_as(_lib.DP), ref.ctypes.data_as(_lib.DP)) == 0
+        scale = np.max(np.abs(ref)) + 1e-300
+        if case == "rank_deficient" and p > 2:
+            # (the solution is ~ 1 / mu along the null vector: what the system sees, relative to |M| |sol|)
+            assert np.max(np.abs(Mf @ (sol - ref))) <= 1e-8 * np.max(np.abs(rhs)) + 1e-12 * np.max(np.abs(Mf)) * scale, (case, p)
+        else:
+            tol = 1e-6 if case == "badly_scaled" else 1e-9
+            assert np.max(np.abs(sol - ref)) <= tol * scale, (case, p, np.max(np.abs(sol - ref)) / scale)
+
+
+def test_large_lm_takes_the_device_factorisation_from_the_threshold_on(amd, gslref):
+    """gsl_nls_large(algorithm = "lm") on the GLM family at p = 64 with the threshold lowered to 1 (every step's solve on
+    the device) gives the fit of the host factorisation: same iterations, coefficients to round-off (the threshold is
+    read once per process: two child processes)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fits = {}
+    for mode, thr in (("host", "0"), ("device", "1")):
+        code = (
+            "import os, sys, json, numpy as np\n"
+            "os.environ['GSLNLS_LARGE_CHOL_DEVICE_MIN'] = %r\n"
+            "sys.path.insert(0, %r)\n"
+            "sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+            "import gslnls_amd as A\n"
+            "from test_gpu_large import glm_data\n"
+            "X, y, th = glm_data(20003, 64)\n"
+            "fit = A.gsl_nls_large('glmexp', A=X, y=y, start=np.zeros(64), algorithm='lm')\n"
+            "print(json.dumps(dict(par=list(map(float, fit['par'])), niter=int(fit['niter']), conv=int(fit['conv']),"
+            " ssr=float(fit['ssr']))))\n"
+        ) % (thr, root, root)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        fits[mode] = json.loads(out.stdout.strip().splitlines()[-1])
+    assert fits["host"]["conv"] == 0 and fits["device"]["conv"] == 0
+    assert fits["host"]["niter"] == fits["device"]["niter"]
+    assert np.allclose(fits["host"]["par"], fits["device"]["par"], rtol=1e-8, atol=1e-10)
+    assert abs(fits["host"]["ssr"] - fits["device"]["ssr"]) <= 1e-10 * fits["host"]["ssr"]
