@@ -180,6 +180,7 @@ __global__ __launch_bounds__(MC_T) void mchol_panel_kernel(MCholArgs a)
                                      : fmax(fmax(gamma, xi / sqrt((double)p * p - 1.0)), DBL_EPSILON);
         betas = sqrt(beta);
     }
+    const double binv = 1.0 / betas;
     __syncthreads();
     for (int t = 0; t < nb; ++t)
     {
@@ -244,11 +245,25 @@ __global__ __launch_bounds__(MC_T) void mchol_panel_kernel(MCholArgs a)
                 {
                     const double arq = a.A[(size_t)q * p + r];
                     double s = 0.0;
-                    for (int k = 0; k < t; ++k)
+                    int k = 0;
+                    for (; k + 3 < t; k += 4)
+                    {
+                        // (all twelve reads of a group ahead of its arithmetic; the sum keeps its order)
+                        const double c0 = Cp[(size_t)k * p + r], c1 = Cp[(size_t)(k + 1) * p + r], c2 = Cp[(size_t)(k + 2) * p + r],
+                                     c3 = Cp[(size_t)(k + 3) * p + r];
+                        const double q0 = Cp[(size_t)k * p + q], q1 = Cp[(size_t)(k + 1) * p + q], q2 = Cp[(size_t)(k + 2) * p + q],
+                                     q3 = Cp[(size_t)(k + 3) * p + q];
+                        const double i0 = ainv_s[k], i1 = ainv_s[k + 1], i2 = ainv_s[k + 2], i3 = ainv_s[k + 3];
+                        s += (c0 * i0) * q0;
+                        s += (c1 * i1) * q1;
+                        s += (c2 * i2) * q2;
+                        s += (c3 * i3) * q3;
+                    }
+                    for (; k < t; ++k)
                         s += (Cp[(size_t)k * p + r] * ainv_s[k]) * Cp[(size_t)k * p + q];
                     cr[u] = arq - s;
-                    const double wv = fabs(cr[u]) / betas;
-                    raise = raise || (wv * wv > a0);
+                    const double wv = fabs(cr[u]) * binv;
+                    raise = raise || (wv * wv > a0 * 0.9999999999999);
                 }
             }
         }
@@ -394,7 +409,12 @@ __global__ __launch_bounds__(MC_T) void mchol_backsub_kernel(MCholArgs a, double
             nxt[u] = (r < p && s >= 1) ? a.Lg[(size_t)(s - 1) * p + r] : 0.0;
         }
         qn = s >= 1 ? a.ord[s - 1] : 0;
-        part = wave_sum_wide(part);
+        // (within rows of 16 lanes by DPP, the four row sums by v_readlane: a ds_bpermute butterfly is 82 clocks a stage)
+        part += wide_dpp<0xB1>(part);
+        part += wide_dpp<0x4E>(part);
+        part += wide_dpp<0x141>(part);
+        part += wide_dpp<0x140>(part);
+        part = (wide_bcast(part, 0) + wide_bcast(part, 16)) + (wide_bcast(part, 32) + wide_bcast(part, 48));
         if (lane == 0)
             red[s & 1][wave] = part;
         __syncthreads();
