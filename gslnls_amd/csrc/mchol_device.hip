@@ -160,7 +160,9 @@ __global__ __launch_bounds__(MC_T) void mchol_panel_kernel(MCholArgs a)
     double *dcur = Cp + (size_t)nb * p;
     double *bv = dcur + p;
     double *ainv_s = bv + p;
-    MCholCand *rec = reinterpret_cast<MCholCand *>(ainv_s + MC_NB_MAX);
+    double *wq = ainv_s + MC_NB_MAX;  // wq[k] = c_qk / alpha_k of the pivot row, for the left-looking sum of this step
+    double *info = wq + MC_NB_MAX;    // the pivot of this step as the first wavefront publishes it (8 doubles)
+    MCholCand *rec = reinterpret_cast<MCholCand *>(info + 8);
     int *pos = reinterpret_cast<int *>(rec + 2 * MC_W);
     // (rec: MC_W wavefront winners + the block's)
     __shared__ int s_nanq[2];
@@ -212,19 +214,52 @@ __global__ __launch_bounds__(MC_T) void mchol_panel_kernel(MCholArgs a)
                 }
             }
         }
-        const MCholCand w = mchol_block_best(c, rec, tid, nwaves);
-        int q = w.row, posq = w.pos;
-        double dq = w.val, bq = w.b;
-        const int nq = s_nanq[t & 1];
-        if (nq >= 0)
+        // wavefront winners -> LDS; the first wavefront picks the block's, applies the NaN rule, starts 1 / max(eps, |d_qq|)
+        // and lays out the pivot row's share of the left-looking sums (wq[k] = c_qk / alpha_k) while the others wait at
+        // the second barrier anyway
         {
-            q = nq;
-            posq = j;
-            dq = __longlong_as_double(0x7ff8000000000000ll);
-            bq = bv[nq];
+            const int lane = tid & 63, wave = tid >> 6;
+            const int win = mchol_wave_winner<4>(c);
+            if (lane == win)
+                rec[wave] = c;
+            __syncthreads();
+            if (wave == 0)
+            {
+                MCholCand o;
+                o.val = -2.0;
+                o.pos = 0x7fffffff;
+                o.row = 0;
+                o.b = 0.0;
+                if (lane < nwaves)
+                    o = rec[lane];
+                const int w2 = mchol_wave_winner<1>(o);
+                int q0 = __builtin_amdgcn_readlane(o.row, w2), posq0 = __builtin_amdgcn_readlane(o.pos, w2);
+                double dq0 = wide_bcast(o.val, w2), bq0 = wide_bcast(o.b, w2);
+                const int nq = s_nanq[t & 1];
+                if (nq >= 0)
+                {
+                    q0 = nq;
+                    posq0 = j;
+                    dq0 = __longlong_as_double(0x7ff8000000000000ll);
+                    bq0 = bv[nq];
+                }
+                const double a00 = fmax(DBL_EPSILON, dq0);
+                if (lane < t)
+                    wq[lane] = Cp[(size_t)lane * p + q0] * ainv_s[lane];
+                if (lane == 0)
+                {
+                    info[0] = (double)q0;
+                    info[1] = (double)posq0;
+                    info[2] = bq0;
+                    info[3] = a00;
+                    info[4] = 1.0 / a00;
+                }
+            }
+            __syncthreads();
         }
+        const int q = (int)info[0], posq = (int)info[1];
+        const double bq = info[2], a0 = info[3], ainv0 = info[4];
         // ---- the pivot's column: A[q][.] as the panel found it, minus the panel's earlier steps
-        const double a0 = fmax(DBL_EPSILON, dq);
         double cr[MC_RPT];
         bool raise = false;
 #pragma unroll
@@ -248,19 +283,17 @@ __global__ __launch_bounds__(MC_T) void mchol_panel_kernel(MCholArgs a)
                     int k = 0;
                     for (; k + 3 < t; k += 4)
                     {
-                        // (all twelve reads of a group ahead of its arithmetic; the sum keeps its order)
+                        // (the reads of a group ahead of its arithmetic; the sum keeps its order)
                         const double c0 = Cp[(size_t)k * p + r], c1 = Cp[(size_t)(k + 1) * p + r], c2 = Cp[(size_t)(k + 2) * p + r],
                                      c3 = Cp[(size_t)(k + 3) * p + r];
-                        const double q0 = Cp[(size_t)k * p + q], q1 = Cp[(size_t)(k + 1) * p + q], q2 = Cp[(size_t)(k + 2) * p + q],
-                                     q3 = Cp[(size_t)(k + 3) * p + q];
-                        const double i0 = ainv_s[k], i1 = ainv_s[k + 1], i2 = ainv_s[k + 2], i3 = ainv_s[k + 3];
-                        s += (c0 * i0) * q0;
-                        s += (c1 * i1) * q1;
-                        s += (c2 * i2) * q2;
-                        s += (c3 * i3) * q3;
+                        const double w0 = wq[k], w1 = wq[k + 1], w2 = wq[k + 2], w3 = wq[k + 3];
+                        s += c0 * w0;
+                        s += c1 * w1;
+                        s += c2 * w2;
+                        s += c3 * w3;
                     }
                     for (; k < t; ++k)
-                        s += (Cp[(size_t)k * p + r] * ainv_s[k]) * Cp[(size_t)k * p + q];
+                        s += Cp[(size_t)k * p + r] * wq[k];
                     cr[u] = arq - s;
                     const double wv = fabs(cr[u]) * binv;
                     raise = raise || (wv * wv > a0 * 0.9999999999999);
@@ -284,7 +317,7 @@ __global__ __launch_bounds__(MC_T) void mchol_panel_kernel(MCholArgs a)
             const double uu = th.val / betas;
             alpha = fmax(a0, uu * uu);
         }
-        const double ainv = 1.0 / alpha;
+        const double ainv = alpha == a0 ? ainv0 : 1.0 / alpha;
 #pragma unroll
         for (int u = 0; u < MC_RPT; ++u)
         {
@@ -500,7 +533,7 @@ int mchol_device_solve(int p, const double *A_host, const double *rhs_host, doub
     a.kb = 0;
     a.nb = 0;
     // panel width: NB columns of the panel + diagonal, right-hand side, positions in LDS
-    const size_t fixed = sizeof(double) * ((size_t)2 * p + MC_NB_MAX) + sizeof(MCholCand) * 2 * MC_W + sizeof(int) * (size_t)p + 64;
+    const size_t fixed = sizeof(double) * ((size_t)2 * p + 2 * MC_NB_MAX + 8) + sizeof(MCholCand) * 2 * MC_W + sizeof(int) * (size_t)p + 64;
     if (fixed + sizeof(double) * (size_t)2 * p > (size_t)MC_LDS_BYTES)
         return GSLNLS_E_UNSUPPORTED;
     int NB = (int)(((size_t)MC_LDS_BYTES - fixed) / (sizeof(double) * (size_t)p));
