@@ -44,6 +44,8 @@ struct LargeOps
     virtual int cgst_device(const double *, const double *, double, long, double *, int *) { return GSLNLS_E_UNSUPPORTED; }
     virtual bool cached_njdx2(double *) { return false; }
     virtual int full_jtj(const double *xcur, double *jtj) = 0;          // p x p row-major (symmetric)
+    // J^T J of the CURRENT point as it sits on the device (complete: no work pending on it), or nullptr
+    virtual const double *jtj_device() { return nullptr; }
     virtual int residual(const double *xcur, double *resid_host) = 0;  // weighted residual at the current point
 };
 
@@ -222,6 +224,9 @@ inline void lg_mchol_solve(int p, const std::vector<double> &Ain, const std::vec
 
 // the same solve on the device (mchol_device.hip); GSLNLS_SUCCESS, or an error code when the device cannot take it
 int mchol_device_solve(int p, const double *A_host, const double *rhs_host, double *sol_host);
+// ... with J^T J where the operators left it on the device (A = J^T J + mu D^2 is formed there)
+int mchol_device_solve_resident(int p, const double *jtj_dev, const double *diag_host, double mu, const double *rhs_host,
+                                double *sol_host);
 
 struct LargeResult
 {
@@ -393,7 +398,15 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
             return e ? atoi(e) : 400;
         }();
         vel.assign(p, 0.0);
-        if (!(dev_min > 0 && p >= dev_min && mchol_device_solve(p, A.data(), rhs.data(), vel.data()) == GSLNLS_SUCCESS))
+        bool done = false;
+        if (dev_min > 0 && p >= dev_min)
+        {
+            if (const double *jd = ops.jtj_device())
+                done = mchol_device_solve_resident(p, jd, diag.data(), mu, rhs.data(), vel.data()) == GSLNLS_SUCCESS;
+            if (!done)
+                done = mchol_device_solve(p, A.data(), rhs.data(), vel.data()) == GSLNLS_SUCCESS;
+        }
+        if (!done)
             lg_mchol_solve(p, A, rhs, vel);
         dx = vel;
         return ST_SUCCESS;

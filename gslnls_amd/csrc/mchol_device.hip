@@ -119,7 +119,9 @@ __device__ __forceinline__ MCholCand mchol_block_best(MCholCand c, MCholCand *re
 
 // gamma = max |a_ii| and xi = max |a_ij| (i != j) as bit patterns in scal[1], scal[2] (non-negative doubles order like
 // unsigned integers: atomicMax; NaNs are skipped as fmax skips them), and the per-row state
-__global__ __launch_bounds__(256) void mchol_init_kernel(MCholArgs a, const double *rhs)
+// (src != nullptr: the matrix is J^T J as it sits on the device, A = src + mu diag(dmp)^2 is formed on the way)
+__global__ __launch_bounds__(256) void mchol_init_kernel(MCholArgs a, const double *rhs, const double *src, const double *dmp,
+                                                         double mu)
 {
     const int p = a.p;
     const size_t pp = (size_t)p * p, stride = (size_t)gridDim.x * 256;
@@ -127,8 +129,15 @@ __global__ __launch_bounds__(256) void mchol_init_kernel(MCholArgs a, const doub
 #pragma unroll 4
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < pp; e += stride)
     {
-        const double v = fabs(a.A[e]);
         const size_t i = e / p, k = e - i * p;
+        if (src)
+        {
+            double x = src[e];
+            if (i == k)
+                x = __dadd_rn(x, __dmul_rn(__dmul_rn(mu, dmp[i]), dmp[i])); // (rounded like the host's A[i][i] += mu d d)
+            a.A[e] = x;
+        }
+        const double v = fabs(a.A[e]);
         if (i == k)
             gm = fmax(gm, v);
         else
@@ -143,7 +152,8 @@ __global__ __launch_bounds__(256) void mchol_init_kernel(MCholArgs a, const doub
     }
     for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < (size_t)p; r += stride)
     {
-        a.dcur[r] = a.A[r * p + r];
+        // (another thread may own a.A[r][r])
+        a.dcur[r] = src ? __dadd_rn(src[r * p + r], __dmul_rn(__dmul_rn(mu, dmp[r]), dmp[r])) : a.A[r * p + r];
         a.b[r] = rhs[r];
         a.dinv[r] = 0.0;
         a.pos[r] = (int)r;
@@ -480,7 +490,10 @@ static MCholBuffers &mchol_buffers()
 }
 
 // 0, or a GSLNLS_E_* code when the device cannot take it (the caller keeps the host routine)
-int mchol_device_solve(int p, const double *A_host, const double *rhs_host, double *sol_host)
+// A_host != nullptr: the matrix itself from the host.  Otherwise jtj_dev (p x p on the device, left untouched) with
+// diag_host and mu: A = J^T J + mu D^2 is formed on the device -- the 8 p^2 bytes do not travel.
+static int mchol_device_solve_impl(int p, const double *A_host, const double *jtj_dev, const double *diag_host, double mu,
+                                   const double *rhs_host, double *sol_host)
 {
     if (p < 1 || p > MC_PMAX)
         return GSLNLS_E_UNSUPPORTED;
@@ -499,7 +512,7 @@ int mchol_device_solve(int p, const double *A_host, const double *rhs_host, doub
         const size_t pp = (size_t)p * p;
         if (hipMalloc(&B.A, sizeof(double) * pp) != hipSuccess || hipMalloc(&B.Lg, sizeof(double) * pp) != hipSuccess ||
             hipMalloc(&B.Cg, sizeof(double) * (size_t)MC_NB_MAX * p) != hipSuccess ||
-            hipMalloc(&B.vec, sizeof(double) * ((size_t)5 * p + MC_NB_MAX + 8)) != hipSuccess ||
+            hipMalloc(&B.vec, sizeof(double) * ((size_t)6 * p + MC_NB_MAX + 8)) != hipSuccess ||
             hipMalloc(&B.ivec, sizeof(int) * (size_t)2 * p) != hipSuccess)
         {
             (void)hipGetLastError();
@@ -526,7 +539,7 @@ int mchol_device_solve(int p, const double *A_host, const double *rhs_host, doub
     a.b = a.dcur + p;
     a.dinv = a.b + p;
     a.scal = a.dinv + p;
-    double *d_rhs = a.scal + 8, *d_sol = d_rhs + p;
+    double *d_rhs = a.scal + 8, *d_sol = d_rhs + p, *d_dmp = d_sol + p;
     a.pos = B.ivec;
     a.ord = B.ivec + p;
     a.p = p;
@@ -538,13 +551,16 @@ int mchol_device_solve(int p, const double *A_host, const double *rhs_host, doub
         return GSLNLS_E_UNSUPPORTED;
     int NB = (int)(((size_t)MC_LDS_BYTES - fixed) / (sizeof(double) * (size_t)p));
     NB = NB > MC_NB_MAX ? MC_NB_MAX : NB;
-    GSLNLS_HIP_OK(hipMemcpy(B.A, A_host, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice));
+    if (A_host)
+        GSLNLS_HIP_OK(hipMemcpy(B.A, A_host, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice));
+    else
+        GSLNLS_HIP_OK(hipMemcpy(d_dmp, diag_host, sizeof(double) * p, hipMemcpyHostToDevice));
     GSLNLS_HIP_OK(hipMemcpy(d_rhs, rhs_host, sizeof(double) * p, hipMemcpyHostToDevice));
     GSLNLS_HIP_OK(hipMemsetAsync(a.scal, 0, sizeof(double) * 8, 0));
     {
         long long g = ((long long)p * p + 256 * 8 - 1) / (256 * 8);
         g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
-        hipLaunchKernelGGL(mchol_init_kernel, dim3((unsigned)g), dim3(256), 0, 0, a, d_rhs);
+        hipLaunchKernelGGL(mchol_init_kernel, dim3((unsigned)g), dim3(256), 0, 0, a, d_rhs, A_host ? nullptr : jtj_dev, d_dmp, mu);
     }
     // the panel workgroup is sized to p (a wavefront without rows still pays for every barrier and reduction)
     int T = 64 * ((p + 63) / 64);
@@ -563,6 +579,18 @@ int mchol_device_solve(int p, const double *A_host, const double *rhs_host, doub
     GSLNLS_HIP_OK(hipMemcpy(sol_host, d_sol, sizeof(double) * p, hipMemcpyDeviceToHost));
     GSLNLS_HIP_OK(hipGetLastError());
     return GSLNLS_SUCCESS;
+}
+
+int mchol_device_solve(int p, const double *A_host, const double *rhs_host, double *sol_host)
+{
+    return mchol_device_solve_impl(p, A_host, nullptr, nullptr, 0.0, rhs_host, sol_host);
+}
+int mchol_device_solve_resident(int p, const double *jtj_dev, const double *diag_host, double mu, const double *rhs_host,
+                                double *sol_host)
+{
+    if (!jtj_dev || !diag_host)
+        return GSLNLS_EINVAL;
+    return mchol_device_solve_impl(p, nullptr, jtj_dev, diag_host, mu, rhs_host, sol_host);
 }
 
 } // namespace gslnls

@@ -324,6 +324,7 @@ struct SparseCbOps : LargeOps
     int *d_rowptr = nullptr, *d_colidx = nullptr, *d_colptr = nullptr, *d_rowidx = nullptr, *d_perm = nullptr,
         *d_lrows = nullptr, *d_lcols = nullptr;
     double *d_vecp = nullptr, *d_outp = nullptr, *d_sqp = nullptr, *d_w = nullptr, *d_part = nullptr, *d_jtj = nullptr;
+    bool jtj_current = false; // d_jtj holds J^T J of the point the driver is at
     long cap_nnz = 0, cap_hval = 0;
     int cur = 0; // index of the accepted point's buffers; 1 - cur receives the trial
     // host staging in pinned memory: uploads of f (n) and the Jacobian values (nnz), p-sized vectors both ways
@@ -400,6 +401,7 @@ struct SparseCbOps : LargeOps
         {
             (void)hipFree(d_jtj); // p x p of the previous problem
             d_jtj = nullptr;
+            jtj_current = false;
         }
         const size_t nb = sizeof(double) * (size_t)n;
         GSLNLS_HIP_OK(hipMemcpy(d_y, y, nb, hipMemcpyHostToDevice));
@@ -703,12 +705,16 @@ struct SparseCbOps : LargeOps
         const long threads = 64L * p;
         hipLaunchKernelGGL(sp_jtj_kernel, dim3((unsigned)((threads + SP_T - 1) / SP_T)), dim3(SP_T), 0, st, d_colptr, d_rowidx,
                            d_perm, d_rowptr, d_colidx, d_val[b], p, d_jtj);
+        jtj_current = false;
         GSLNLS_HIP_OK(hipMemcpyAsync(jtj, d_jtj, bytes, hipMemcpyDeviceToHost, st));
         GSLNLS_HIP_OK(hipStreamSynchronize(st));
+        jtj_current = true;
         ++npass;
         return 0;
     }
     int full_jtj(const double *, double *jtj) override { return jtj_of(cur, jtj); }
+    // (eval_jac runs at accepted points only and ends in a stream synchronisation: what d_jtj holds is the current point's)
+    const double *jtj_device() override { return jtj_current ? d_jtj : nullptr; }
     int residual(const double *, double *resid_host) override
     {
         GSLNLS_HIP_OK(hipMemcpy(resid_host, d_f[cur], sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));

