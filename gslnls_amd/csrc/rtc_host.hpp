@@ -437,7 +437,8 @@ struct RtcJob
 };
 
 // ONE background compiler thread per process, fed through a queue (a thread per formula would be unbounded: every new
-// formula x Jacobian kind under GSLNLS_LOWER_AUTO asks for a build)
+// formula x Jacobian kind under GSLNLS_LOWER_AUTO asks for a build).  The newest request is served first -- a process that
+// walks through many formulas (a test suite, a model search) must not make the current one wait behind all the others
 struct RtcRegistry
 {
     std::mutex mu;
@@ -646,7 +647,7 @@ inline std::shared_ptr<RtcEntry> rtc_request(const std::string &source, const st
                 ent->state.store(RTC_NONE, std::memory_order_release); // dropped: a later request may try again
             else
             {
-                reg.queue.push_back({ent, source, exprs});
+                reg.queue.push_front({ent, source, exprs}); // (newest first: it is the formula being fitted right now)
                 if (!reg.worker.joinable())
                     reg.worker = std::thread(rtc_worker_main);
                 reg.qcv.notify_one();

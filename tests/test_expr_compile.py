@@ -159,7 +159,7 @@ for k in range(40):
     m = _lib.Model(_lib.MODEL_EXPR, 3, 1, None, 0)
     keep.append((m, _lib.set_expr(m, "a*exp(-b*x) + c*%%d" %% (k + 2), ["a", "b", "c"], ["x"], "auto")))
     st = L.gslnls_expr_prefetch(C.byref(m), 1)
-assert st == 1, st
+assert st in (1, 2), st       # queued -- or found in the cache: the newest request is built first, the first run left it there
 time.sleep(float(sys.argv[1]))
 print("leaving", flush=True)
 """ % (ROOT,)
