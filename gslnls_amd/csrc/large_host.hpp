@@ -398,16 +398,18 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
             return e ? atoi(e) : 400;
         }();
         vel.assign(p, 0.0);
-        bool done = false;
+        int drc = GSLNLS_E_UNSUPPORTED; // (below the threshold, or a size the device routine does not take: p > 4096)
         if (dev_min > 0 && p >= dev_min)
         {
             if (const double *jd = ops.jtj_device())
-                done = mchol_device_solve_resident(p, jd, diag.data(), mu, rhs.data(), vel.data()) == GSLNLS_SUCCESS;
-            if (!done)
-                done = mchol_device_solve(p, A.data(), rhs.data(), vel.data()) == GSLNLS_SUCCESS;
+                drc = mchol_device_solve_resident(p, jd, diag.data(), mu, rhs.data(), vel.data());
+            else
+                drc = mchol_device_solve(p, A.data(), rhs.data(), vel.data());
         }
-        if (!done)
+        if (drc == GSLNLS_E_UNSUPPORTED)
             lg_mchol_solve(p, A, rhs, vel);
+        else if (drc != GSLNLS_SUCCESS)
+            return drc; // a device failure is an error of the fit, not a reason to continue on the host
         dx = vel;
         return ST_SUCCESS;
     };
@@ -427,6 +429,8 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
             int st = (trs == 5) ? cgst_step() : lm_step();
             t_phase[2] += since(tp);
             n_phase[2] += 1;
+            if (st <= GSLNLS_E_NODEVICE)
+                return st; // (the library's own error codes: the device failed under the step)
             double rho = -1.0, ssr_t = 0.0;
             if (st == ST_SUCCESS)
             {
