@@ -378,6 +378,30 @@ def sparse_readme_bench():
             el = time.perf_counter() - t0
         out[alg] = {"wall_ms": el * 1e3, "niter": int(fit["niter"]), "conv": int(fit["conv"]), "ssr": float(fit["ssr"]),
                     "device_passes": int(fit["n_passes"]), "ssr_target": 0.004778845}
+    # the damped solve of the lm step alone (pivoted modified Cholesky on the device, csrc/mchol_device.hip): wall time per
+    # solve including the upload of the p x p matrix, and the residual it leaves
+    from gslnls_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(7)
+    fac = {}
+    for pp in (500, 1000, 2000):
+        J = rng.standard_normal((2 * pp, pp))
+        Aj = np.ascontiguousarray(J.T @ J)
+        dg = np.sqrt(np.diag(Aj)).copy()
+        rhs = rng.standard_normal(pp)
+        sol = np.zeros(pp)
+        args = (pp, Aj.ctypes.data_as(_lib.DP), dg.ctypes.data_as(_lib.DP), 1e-3, rhs.ctypes.data_as(_lib.DP),
+                sol.ctypes.data_as(_lib.DP))
+        rc = L.gslnls_debug_mchol_solve(*args)
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            rc = L.gslnls_debug_mchol_solve(*args) or rc
+        el = (time.perf_counter() - t0) / reps
+        M = Aj + 1e-3 * np.diag(dg ** 2)
+        fac["p=%d" % pp] = {"rc": int(rc), "ms_per_solve": el * 1e3,
+                            "rel_residual": float(np.max(np.abs(M @ sol - rhs)) / np.max(np.abs(rhs)))}
+    out["lm_step_factorisation_on_device"] = fac
     return out
 
 

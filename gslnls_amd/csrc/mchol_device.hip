@@ -161,30 +161,34 @@ __global__ __launch_bounds__(256) void mchol_init_kernel(MCholArgs a, const doub
     }
 }
 
-// steps kb .. kb + nb - 1.  Dynamic LDS: Cp[nb][p] | dcur[p] | b[p] | pos[p] | ainv[NB_MAX] | records
+// steps kb .. kb + nb - 1.  Dynamic LDS: Cp[nb][p] | ainv[NB_MAX] | wq[NB_MAX] | info | records.  The diagonal, the
+// right-hand side and the position of a row live in the registers of the thread that owns it (thread tid: rows tid,
+// tid + T, ...) for the whole panel.
 __global__ __launch_bounds__(MC_T) void mchol_panel_kernel(MCholArgs a)
 {
     extern __shared__ double lds[];
     const int tid = threadIdx.x, p = a.p, kb = a.kb, nb = a.nb;
     double *Cp = lds;
-    double *dcur = Cp + (size_t)nb * p;
-    double *bv = dcur + p;
-    double *ainv_s = bv + p;
+    double *ainv_s = Cp + (size_t)nb * p;
     double *wq = ainv_s + MC_NB_MAX;  // wq[k] = c_qk / alpha_k of the pivot row, for the left-looking sum of this step
     double *info = wq + MC_NB_MAX;    // the pivot of this step as the first wavefront publishes it (8 doubles)
     MCholCand *rec = reinterpret_cast<MCholCand *>(info + 8);
-    int *pos = reinterpret_cast<int *>(rec + 2 * MC_W);
-    // (rec: MC_W wavefront winners + the block's)
+    // (rec: MC_W wavefront winners)
     __shared__ int s_nanq[2];
-    for (int r = tid; r < p; r += blockDim.x)
+    __shared__ double s_nanb[2];
+    const int T = blockDim.x, nwaves = T >> 6;
+    double dreg[MC_RPT], breg[MC_RPT];
+    int preg[MC_RPT];
+#pragma unroll
+    for (int u = 0; u < MC_RPT; ++u)
     {
-        dcur[r] = a.dcur[r];
-        bv[r] = a.b[r];
-        pos[r] = a.pos[r];
+        const int r = tid + u * T;
+        dreg[u] = r < p ? a.dcur[r] : 0.0;
+        breg[u] = r < p ? a.b[r] : 0.0;
+        preg[u] = r < p ? a.pos[r] : -1;
     }
     if (tid == 0)
         s_nanq[0] = s_nanq[1] = -1;
-    const int T = blockDim.x, nwaves = T >> 6;
     double betas;
     {
         const double gamma = a.scal[1], xi = a.scal[2];
@@ -206,21 +210,25 @@ __global__ __launch_bounds__(MC_T) void mchol_panel_kernel(MCholArgs a)
         c.pos = 0x7fffffff;
         c.row = 0;
         c.b = 0.0;
-        for (int r = tid; r < p; r += T)
+#pragma unroll
+        for (int u = 0; u < MC_RPT; ++u)
         {
-            const int ps = pos[r];
+            const int ps = preg[u];
             if (ps >= j)
             {
-                const double d = dcur[r];
+                const double d = dreg[u];
                 const double ad = fmax(fabs(d), 0.0); // NaN -> 0
                 if (ps == j && d != d)
-                    s_nanq[t & 1] = r;
+                {
+                    s_nanq[t & 1] = tid + u * T;
+                    s_nanb[t & 1] = breg[u];
+                }
                 if (mchol_better(ad, ps, c.val, c.pos))
                 {
                     c.val = ad;
                     c.pos = ps;
-                    c.row = r;
-                    c.b = bv[r];
+                    c.row = tid + u * T;
+                    c.b = breg[u];
                 }
             }
         }
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(MC_T) void mchol_panel_kernel(MCholArgs a)
                     q0 = nq;
                     posq0 = j;
                     dq0 = __longlong_as_double(0x7ff8000000000000ll);
-                    bq0 = bv[nq];
+                    bq0 = s_nanb[t & 1];
                 }
                 const double a00 = fmax(DBL_EPSILON, dq0);
                 if (lane < t)
@@ -279,13 +287,13 @@ __global__ __launch_bounds__(MC_T) void mchol_panel_kernel(MCholArgs a)
             cr[u] = 0.0;
             if (r < p)
             {
-                int ps = pos[r];
+                int ps = preg[u];
                 // rows at position j and q trade positions (nothing moves)
                 if (ps == j)
                     ps = posq;
                 if (r == q)
                     ps = j;
-                pos[r] = ps;
+                preg[u] = ps;
                 if (ps > j)
                 {
                     const double arq = a.A[(size_t)q * p + r];
@@ -339,10 +347,10 @@ __global__ __launch_bounds__(MC_T) void mchol_panel_kernel(MCholArgs a)
                 Cp[(size_t)t * p + r] = cv;
                 a.Cg[(size_t)t * p + r] = cv;
                 a.Lg[(size_t)j * p + r] = l;
-                if (pos[r] > j)
+                if (preg[u] > j)
                 {
-                    dcur[r] -= l * cv;
-                    bv[r] -= l * bq;
+                    dreg[u] -= l * cv;
+                    breg[u] -= l * bq;
                 }
                 if (r == q)
                 {
@@ -357,14 +365,18 @@ __global__ __launch_bounds__(MC_T) void mchol_panel_kernel(MCholArgs a)
             a.ainvg[t] = ainv;
         }
         // (no barrier here: the first thing another thread reads of this step -- Cp[t][.], ainv_s[t] -- it reads after
-        // the two barriers of the next pivot search; the diagonal, the right-hand side and the positions are only ever
-        // touched by the thread that owns the row)
+        // the two barriers of the next pivot search)
     }
-    for (int r = tid; r < p; r += T)
+#pragma unroll
+    for (int u = 0; u < MC_RPT; ++u)
     {
-        a.dcur[r] = dcur[r];
-        a.b[r] = bv[r];
-        a.pos[r] = pos[r];
+        const int r = tid + u * T;
+        if (r < p)
+        {
+            a.dcur[r] = dreg[u];
+            a.b[r] = breg[u];
+            a.pos[r] = preg[u];
+        }
     }
 }
 
@@ -478,7 +490,7 @@ __global__ __launch_bounds__(MC_T) void mchol_backsub_kernel(MCholArgs a, double
 struct MCholBuffers
 {
     std::mutex mu;
-    int cap = 0;
+    int cap = 0, device = -1;
     double *A = nullptr, *Lg = nullptr, *Cg = nullptr, *vec = nullptr; // vec: ainvg | dcur | b | dinv | scal | rhs | sol
     int *ivec = nullptr;                                              // pos | ord
     bool attr_set = false;
@@ -499,8 +511,12 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
         return GSLNLS_E_UNSUPPORTED;
     MCholBuffers &B = mchol_buffers();
     std::lock_guard<std::mutex> lock(B.mu);
-    if (B.cap < p)
+    int dev = 0;
+    GSLNLS_HIP_OK(hipGetDevice(&dev));
+    if (B.cap < p || B.device != dev)
     {
+        // (the buffers belong to the device they were allocated on: a process that moved on with gslnls_set_device gets
+        // new ones; hipFree takes pointers of any device)
         (void)hipFree(B.A);
         (void)hipFree(B.Lg);
         (void)hipFree(B.Cg);
@@ -519,6 +535,8 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
             return GSLNLS_E_NODEVICE;
         }
         B.cap = p;
+        B.device = dev;
+        B.attr_set = false;
     }
     if (!B.attr_set)
     {
@@ -545,8 +563,8 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
     a.p = p;
     a.kb = 0;
     a.nb = 0;
-    // panel width: NB columns of the panel + diagonal, right-hand side, positions in LDS
-    const size_t fixed = sizeof(double) * ((size_t)2 * p + 2 * MC_NB_MAX + 8) + sizeof(MCholCand) * 2 * MC_W + sizeof(int) * (size_t)p + 64;
+    // panel width: NB columns of the panel in LDS
+    const size_t fixed = sizeof(double) * ((size_t)2 * MC_NB_MAX + 8) + sizeof(MCholCand) * 2 * MC_W + 64;
     if (fixed + sizeof(double) * (size_t)2 * p > (size_t)MC_LDS_BYTES)
         return GSLNLS_E_UNSUPPORTED;
     int NB = (int)(((size_t)MC_LDS_BYTES - fixed) / (sizeof(double) * (size_t)p));
