@@ -882,9 +882,32 @@ struct WideFit : DenseBase
             }
         return rc;
     }
-    // not lowered for p > 9 (gslnls_large_create answers GSLNLS_E_UNSUPPORTED and the caller keeps the reference's path):
-    // the matrix-free operators of gsl_nls_large on a formula
-    LargeOps *make_large_ops() override { return nullptr; }
+    // gsl_nls_large(formula) for 10 <= p <= 64: the operators of the large driver on the wide pass (WideLargeOps below)
+    LargeOps *make_large_ops() override;
+    // weighted residual at theta through the formula's finalize kernel (analytic-Jacobian unit)
+    int residual_at(const double *theta, double *resid_host)
+    {
+        if (const int rc = bind(0))
+            return rc;
+        std::vector<double> tot((size_t)NV);
+        int rc = sums_at(1, 0, theta, tot.data()); // (leaves x = theta in the device state)
+        if (rc)
+            return rc;
+        if (!d_resid)
+            GSLNLS_HIP_OK(hipMalloc(&d_resid, sizeof(double) * (size_t)n));
+        int ci0[15] = {100, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0};
+        double cd0[11] = {2, 3, 0.75, 1.4901161193847656e-08, 0.02, 1e-8, 1e-8, 1e-8, 0, 0, 0};
+        LmParams prm = make_params(ci0, cd0, 1, 0, false, cur_sw != nullptr);
+        WPassArgs pa = pass_args(prm);
+        double *r = d_resid, *g = nullptr;
+        void *args[] = {(void *)&pa, (void *)&r, (void *)&g};
+        int gf = (int)(((long long)n + 255) / 256);
+        gf = gf > 2048 ? 2048 : (gf < 1 ? 1 : gf);
+        (void)hipModuleLaunchKernel(fn_final[0], gf, 1, 1, 256, 1, 1, 0, stream, args, nullptr);
+        GSLNLS_HIP_OK(hipMemcpyAsync(resid_host, d_resid, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream));
+        GSLNLS_HIP_OK(hipStreamSynchronize(stream));
+        return hipGetLastError() == hipSuccess ? GSLNLS_SUCCESS : GSLNLS_E_NODEVICE;
+    }
     // weighted residual, Jacobian (n x p, column-major) and (J^T J)^-1 at theta on the device; returns s^2 = ssr / (n - p).
     // 1: J^T J is singular (hat_values fails in the reference as well)
     int cooks_inputs(int jm, const double *theta, double **d_cinv_out, double *s2)
@@ -1122,6 +1145,77 @@ struct WideFit : DenseBase
     }
     int debug_stamps(int, const double *, int, unsigned long long *, int *) override { return GSLNLS_E_UNSUPPORTED; }
 };
+
+// The operators of gsl_nls_large (large_host.hpp: trust_iterate of gsl_multilarge_nlinear around eval / J^T J u) on a
+// formula with 10 <= p <= 64: one EVAL is one wide pass (J^T J on the matrix cores) + reduce; with J^T J of the current
+// point at hand the products J^T J u and ||J u||^2 = u^T J^T J u of the Steihaug-Toint iterations are p x p work on the
+// host -- no further pass over the rows (the reference's R closures evaluate J u and J^T v on the full Jacobian).
+struct WideLargeOps : LargeOps
+{
+    WideFit &fit;
+    std::vector<double> tot, jcur, jtrial; // sums of the last pass; packed lower J^T J at the current / trial point
+    bool have_cur = false;
+    explicit WideLargeOps(WideFit &f) : fit(f), tot((size_t)f.NV)
+    {
+        n = f.n;
+        p = f.p;
+        const size_t na = (size_t)p * (p + 1) / 2;
+        jcur.assign(na, 0.0);
+        jtrial.assign(na, 0.0);
+    }
+    int eval(const double *x, double *ssr, double *g, double *diag, double *jtj, double *bad) override
+    {
+        const int rc = fit.sums_at(1, 0, x, tot.data());
+        if (rc)
+            return rc;
+        ++npass;
+        const int NA = p * (p + 1) / 2;
+        *ssr = tot[0];
+        *bad = tot[1];
+        const double *A = tot.data() + 2, *gg = A + NA;
+        for (int i = 0; i < p; ++i)
+        {
+            g[i] = gg[i];
+            diag[i] = A[tri(i, i)];
+            if (jtj)
+                for (int j = 0; j <= i; ++j)
+                    jtj[(size_t)i * p + j] = jtj[(size_t)j * p + i] = A[tri(i, j)];
+        }
+        std::copy(A, A + NA, jtrial.begin());
+        if (!have_cur)
+        {
+            jcur = jtrial; // (the starting point is the current point)
+            have_cur = true;
+        }
+        return 0;
+    }
+    void accept() override { jcur = jtrial; }
+    int jtjv(const double *, const double *u, double *normw2, double *out) override
+    {
+        double nw = 0.0;
+        for (int i = 0; i < p; ++i)
+        {
+            double s = 0.0;
+            for (int j = 0; j < p; ++j)
+                s += jcur[j <= i ? tri(i, j) : tri(j, i)] * u[j];
+            out[i] = s;
+            nw += u[i] * s;
+        }
+        *normw2 = nw;
+        return 0;
+    }
+    int full_jtj(const double *xcur, double *jtj) override
+    {
+        std::vector<double> g(p), dg(p);
+        double ssr, bad;
+        const std::vector<double> keep = jtrial;
+        const int rc = eval(xcur, &ssr, g.data(), dg.data(), jtj, &bad);
+        jtrial = keep;
+        return rc;
+    }
+    int residual(const double *xcur, double *resid_host) override { return fit.residual_at(xcur, resid_host); }
+};
+inline LargeOps *WideFit::make_large_ops() { return new WideLargeOps(*this); }
 
 inline int WideMsEvaluator::run(MsBatch &b, int lo, int hi, double *out, bool out_on_device)
 {

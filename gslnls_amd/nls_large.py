@@ -223,7 +223,7 @@ def gsl_nls_large(fn, data=None, start=None, algorithm="lm", control=None, trace
     if low is None:
         # any other expression: compiled like in gsl_nls() (GSLNLS_MODEL_EXPR)
         xnames = [v for v in F.symbols(rhs) if v not in names and v != "pi"]
-        if len(names) > 12 or len(xnames) > 3 or any(v not in data for v in xnames):
+        if len(names) > 64 or len(xnames) > 8 or any(v not in data for v in xnames):
             raise NotImplementedError("formula RHS does not lower to the device: %s" % fn)
         mid, order = _lib.MODEL_EXPR, list(range(len(names)))
         expr_kw = dict(expr=fn.split("~", 1)[1].strip(), parnames=names, xnames=xnames, lowering=lowering)

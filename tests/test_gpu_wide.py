@@ -416,3 +416,37 @@ def test_wide_robust_multistart_second_pass(amd, gslref):
     assert fit["irls"]["irls_niter"] == ref["irls"]["irls_niter"]
     assert np.allclose(fit["par"], ref["par"], rtol=1e-6, atol=1e-9)
     assert np.allclose(fit["par"], q["truth"], rtol=5e-2, atol=5e-2)
+
+
+@pytest.mark.parametrize("alg", ["lm", "cgst"])
+@pytest.mark.parametrize("ng,extra,n", [(4, 0, 6000), (10, 2, 40_000)], ids=["p12", "p32"])
+def test_wide_formula_through_gsl_nls_large(amd, gslref, alg, ng, extra, n):
+    """gsl_nls_large(formula) with 10 <= p <= 64 (R/nls_large.R:124, formula method): the operators of the large driver
+    sit on the wide pass (J^T J on the matrix cores; the products J^T J u of the Steihaug-Toint iterations are p x p work
+    on the host) -- against the oracle's multilarge driver on the same model and against the dense fit"""
+    q = gaussians_problem(ng, extra, n, seed=40 + ng)
+    p = len(q["truth"])
+    data = dict(x=q["x"], y=q["y"])
+    start = dict(zip(q["names"], q["start"]))
+    fit = amd.gsl_nls_large(q["formula"], data=data, start=start, algorithm=alg, control=dict(maxiter=100), trace=True)
+
+    def dfl(trans, th, u, want_v, want_jtj):
+        J = q["jac"](th)
+        v = None
+        if want_v:
+            v = J.T @ u if trans else J @ u
+        return v, (J.T @ J if want_jtj else None)
+    ref = gslref.nls_large(n, p, q["start"], fn=lambda th: q["model"](th) - q["y"], dfl=dfl, algorithm=alg,
+                           ctrl=gslref.control(maxiter=100), trace=True)
+    assert fit["conv"] == 0 and ref["conv"] == 0
+    assert abs(fit["niter"] - ref["niter"]) <= 1, (fit["niter"], ref["niter"])
+    assert np.allclose(fit["par"], ref["par"], rtol=1e-6, atol=1e-9)
+    assert abs(fit["ssr"] - ref["ssr"]) <= 1e-9 * ref["ssr"]
+    k = min(fit["niter"], ref["niter"]) - 1
+    # (the Steihaug-Toint steps are truncated CG runs: J^T J u from the accumulated J^T J here, J^T (J u) in the oracle --
+    # the iterates agree to ~ 1e-7 on the way and to 1e-9 at the end)
+    assert np.allclose(fit["ssrtrace"][:k], ref["ssrtrace"][:k], rtol=1e-8 if alg == "lm" else 1e-6)
+    assert np.allclose(fit["covar"], ref["covar"], rtol=1e-5, atol=1e-12)
+    assert np.allclose(fit["resid"], q["model"](np.asarray(fit["par"])) - q["y"], rtol=0, atol=1e-9)
+    dense = amd.gsl_nls(q["formula"], data=data, start=start, jac=True, control=dict(solver="cholesky"))
+    assert abs(fit["ssr"] - dense["ssr"]) <= 1e-8 * dense["ssr"]
