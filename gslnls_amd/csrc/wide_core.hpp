@@ -50,6 +50,7 @@ struct WAdvanceArgs
     unsigned int *done_seq;      // pinned word: sequence number of the last finished fit
     unsigned int seq;
     int launch_idx;
+    int p; // (the same as state->p: the loads of a call are issued at once instead of after a first round trip for p)
 };
 
 #if defined(__HIPCC__) || defined(__HIPCC_RTC__)
@@ -527,10 +528,9 @@ __device__ __forceinline__ void wide_advance(const WAdvanceArgs &a, WideLds &L)
 {
     const int lane = threadIdx.x & 63;
     WState *S = a.state;
-    const int p = S->p, NA = p * (p + 1) / 2;
+    const int p = a.p, NA = p * (p + 1) / 2;
     const LmParams prm = a.prm;
-    if (S->phase == PH_DONE)
-        return;
+    const int phase_in = S->phase; // (checked below, after every load of the call is in flight)
     const double *tot = a.totals;
     const double *rA = tot + 2;
     const bool mine = lane < p;
@@ -581,6 +581,8 @@ __device__ __forceinline__ void wide_advance(const WAdvanceArgs &a, WideLds &L)
         stage_matrices(WideInt<19>{});
     else
         stage_matrices(WideInt<(WNA + 63) / 64>{});
+    if (phase_in == PH_DONE)
+        return; // (a launch enqueued past the end of the fit: nothing was written)
     if (mine)
     {
         L.x[lane] = sv[0];

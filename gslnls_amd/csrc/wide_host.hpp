@@ -418,6 +418,7 @@ struct WideFit : DenseBase
         }
         adv.seq = seq;
         adv.launch_idx = 0;
+        adv.p = p;
         // steps are enqueued in chunks and the completion word is polled between them; what is enqueued beyond the step
         // that ends the fit still runs (three no-op launches each).  The first chunk is sized by the previous fit of the
         // same kind on this handle (IRLS re-solves, repeated fits end where the last one did), then small top-ups.
@@ -643,6 +644,7 @@ struct WideFit : DenseBase
         adv.host_mirror = reinterpret_cast<WState *>(dptr) + 1;
         adv.done_seq = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(dptr) + sizeof(WState) * 2);
         adv.seq = seq;
+        adv.p = p;
         for (int k = 0; k < 4; ++k)
             launch_step(jm, prm, adv, k);
         hipEventRecord(ev0, stream);
