@@ -270,7 +270,39 @@ struct RtcUnit
     std::map<std::string, std::string> lowered;
 };
 
-inline const char *rtc_flags_text() { return "--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=on -mllvm -amdgpu-kernarg-preload-count=16"; }
+// developer switch: GSLNLS_RTC_EXTRA_FLAGS = more compiler options (space separated; part of the cache key)
+inline const std::vector<std::string> &rtc_extra_flags()
+{
+    static const std::vector<std::string> v = [] {
+        std::vector<std::string> out;
+        if (const char *e = getenv("GSLNLS_RTC_EXTRA_FLAGS"))
+        {
+            std::string cur;
+            for (const char *c = e;; ++c)
+            {
+                if (*c == ' ' || *c == '\0')
+                {
+                    if (!cur.empty())
+                        out.push_back(cur);
+                    cur.clear();
+                    if (!*c)
+                        break;
+                }
+                else
+                    cur.push_back(*c);
+            }
+        }
+        return out;
+    }();
+    return v;
+}
+inline std::string rtc_flags_text()
+{
+    std::string s = "--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=on -mllvm -amdgpu-kernarg-preload-count=16";
+    for (const std::string &f : rtc_extra_flags())
+        s += " " + f;
+    return s;
+}
 
 // source -> code object (no device needed; thread-safe with respect to the HIP runtime: hiprtc / comgr only)
 inline bool rtc_compile(const std::string &source, const std::vector<std::string> &exprs, RtcUnit &out, std::string &log)
@@ -306,9 +338,11 @@ inline bool rtc_compile(const std::string &source, const std::vector<std::string
     }
     for (const std::string &e : exprs)
         (void)api.AddNameExpression(prog, e.c_str());
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-mllvm",
-                          "-amdgpu-kernarg-preload-count=16"};
-    const hiprtcResult r = api.CompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+    std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-mllvm",
+                                      "-amdgpu-kernarg-preload-count=16"};
+    for (const std::string &f : rtc_extra_flags())
+        opts.push_back(f.c_str());
+    const hiprtcResult r = api.CompileProgram(prog, (int)opts.size(), opts.data());
     size_t ls = 0;
     if (api.GetProgramLogSize && api.GetProgramLog && api.GetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1)
     {
