@@ -29,6 +29,7 @@
 #include <mutex>
 #include "../../include/gslnls_core.h"
 #include "dense_host.hpp"
+#include "large_host.hpp"
 #include "wide_core.hpp"
 
 namespace gslnls
@@ -646,4 +647,21 @@ extern "C" int gslnls_debug_mchol_solve(int p, const double *A, const double *di
     const int rc = gslnls::mchol_device_solve(p, M, rhs, sol);
     free(M);
     return rc;
+}
+
+// test hook (no device needed): the same solve by the host routine of the large path (large_host.hpp: lg_mchol_solve,
+// multiversioned for the host's vector width with the baseline's rounding) -- what runs below the device threshold
+extern "C" int gslnls_debug_host_mchol_solve(int p, const double *A, const double *diag, double mu, const double *rhs,
+                                             double *sol)
+{
+    if (p < 1 || !A || !rhs || !sol)
+        return GSLNLS_EINVAL;
+    std::vector<double> M(A, A + (size_t)p * p), r(rhs, rhs + p), x;
+    if (diag)
+        for (int i = 0; i < p; ++i)
+            M[(size_t)i * p + i] += mu * diag[i] * diag[i];
+    gslnls::lg_mchol_solve(p, M, r, x);
+    for (int i = 0; i < p; ++i)
+        sol[i] = x[i];
+    return GSLNLS_SUCCESS;
 }

@@ -350,6 +350,8 @@ int gslnls_debug_wide_solve(int p, const double *Ap, const double *diag, double 
  * row-major, p <= 4096; d may be NULL): the same pivoted modified Cholesky, panels of pivot steps by one workgroup and
  * grid-wide trailing updates (csrc/mchol_device.hip; gsl_multilarge_nlinear's lm step, multilarge_nlinear/cholesky.c) */
 int gslnls_debug_mchol_solve(int p, const double *A, const double *diag, double mu, const double *rhs, double *sol);
+/* the same solve by the host routine that serves the lm step below the device threshold (no device needed) */
+int gslnls_debug_host_mchol_solve(int p, const double *A, const double *diag, double mu, const double *rhs, double *sol);
 /* the sums of one pass over the rows of a wide problem (p > 9) at theta: totals[0] = ssr, [1] = non-finite flag,
  * then the packed lower triangle of J^T J (p (p + 1) / 2, row by row) and J^T f (p); jac: 1 analytic, 0 finite
  * differences (fdtype: 0 forward, 1 central) */

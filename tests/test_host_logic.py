@@ -247,3 +247,43 @@ def test_bounds_validation_errors_like_the_reference():
         amd.gsl_nls(f, data=d, start=dict(b1=500.0, b2=1.0), upper=dict(b1=300.0))
     with pytest.raises(ValueError, match="Starting parameter ranges must be contained"):
         amd.gsl_nls(f, data=d, start=dict(b1=[1.0, 500.0], b2=[0.0, 1.0]), upper=dict(b1=300.0))
+
+
+@pytest.mark.parametrize("p", [1, 2, 9, 40, 129, 260])
+def test_host_modified_cholesky_of_the_large_lm_step_matches_the_oracle(gslref, p):
+    """lg_mchol_solve (csrc/large_host.hpp: the damped normal equations of the multilarge lm step below the device
+    threshold; multiversioned for AVX2 / AVX-512 with contraction off) against gsl_linalg_mcholesky as restated by the
+    oracle -- the same operations in the same order on whatever vector width this host has: equal to the last bits"""
+    import ctypes as C
+    from gslnls_amd import _lib
+    L = _lib.lib()
+    G = gslref.lib()
+    rng = np.random.Generator(np.random.PCG64(5100 + p))
+    for case in ("spd", "badly_scaled", "rank_deficient", "zero_column"):
+        n = 2 * p + 3
+        J = rng.standard_normal((n, p))
+        if case == "badly_scaled":
+            J *= 10.0 ** rng.uniform(-5, 5, p)
+        if case == "rank_deficient" and p > 2:
+            J[:, p - 1] = J[:, 0] + J[:, 1]
+        if case == "zero_column":
+            J[:, p // 2] = 0.0
+        A = np.ascontiguousarray(J.T @ J)
+        diag = np.sqrt(np.maximum(np.diag(A), 1e-300))
+        mu = 1e-14 if case == "rank_deficient" else 1e-3
+        rhs = rng.standard_normal(p) * np.max(np.abs(A))
+        sol = np.zeros(p)
+        assert L.gslnls_debug_host_mchol_solve(p, A.ctypes.data_as(_lib.DP), diag.ctypes.data_as(_lib.DP), mu,
+                                               rhs.ctypes.data_as(_lib.DP), sol.ctypes.data_as(_lib.DP)) == 0
+        M = np.ascontiguousarray(A + mu * np.diag(diag * diag))
+        perm = np.zeros(p, dtype=np.int32)
+        assert G.gslref_mcholesky_decomp(p, M.ctypes.data_as(_lib.DP), perm.ctypes.data_as(_lib.IP)) == 0
+        ref = np.zeros(p)
+        assert G.gslref_mcholesky_solve(p, M.ctypes.data_as(_lib.DP), perm.ctypes.data_as(_lib.IP),
+                                        rhs.ctypes.data_as(_lib.DP), ref.ctypes.data_as(_lib.DP)) == 0
+        scale = np.max(np.abs(ref)) + 1e-300
+        if case == "rank_deficient" and p > 2:
+            Mf = A + mu * np.diag(diag * diag)
+            assert np.max(np.abs(Mf @ (sol - ref))) <= 1e-8 * np.max(np.abs(rhs)) + 1e-12 * np.max(np.abs(Mf)) * scale
+        else:
+            assert np.max(np.abs(sol - ref)) <= 1e-10 * scale, (case, p, np.max(np.abs(sol - ref)) / scale)
