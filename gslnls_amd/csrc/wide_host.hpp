@@ -230,6 +230,7 @@ struct WideFit : DenseBase
     float last_ms = 0.f;
     long long last_launches = 0;
     int pred_kind = -1, pred_steps = 0; // trial steps the previous fit of this kind needed (adaptive first chunk)
+    int wf_only = 0;                    // gsl_nls_large on this handle: weights scale f only (WideLargeOps)
     double *d_cinv = nullptr;   // (J^T J)^-1 for the hat values
     void *irls_arena = nullptr; // work arrays of the robust re-weighting, kept between calls
     size_t irls_arena_bytes = 0;
@@ -353,6 +354,7 @@ struct WideFit : DenseBase
         a.h_df = prm.h_df;
         a.h_fvv = prm.h_fvv;
         a.fvv_analytic = prm.fvv_analytic;
+        a.wf_only = wf_only;
         return a;
     }
 
@@ -1159,6 +1161,9 @@ struct WideLargeOps : LargeOps
     bool have_cur = false;
     explicit WideLargeOps(WideFit &f) : fit(f), tot((size_t)f.NV)
     {
+        // weights scale f only: the reference's gsl_df_large never weights J (src/nls_large.c:629-633), as in
+        // large_row_kernel for the hand-written models (the handle serves the large driver from here on)
+        f.wf_only = 1;
         n = f.n;
         p = f.p;
         const size_t na = (size_t)p * (p + 1) / 2;

@@ -45,6 +45,7 @@ struct WPassArgs
     double *partials; // [G][NV]: ssr, badj, packed lower J^T J, J^T f -- one contiguous set per workgroup
     double h_df, h_fvv;
     int fvv_analytic;
+    int wf_only; // gsl_nls_large: the weights scale f only -- the reference's callback never weights J (src/nls_large.c:629-633)
 };
 
 typedef double wide_v4f64 __attribute__((ext_vector_type(4)));
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(WIDE_T, GSLNLS_WIDE_WAVES(PW)) void wide_pass_kerne
         double f;
         if constexpr (JAC == JAC_ANALYTIC)
         {
-            WideTileSink sink{mytile + lane, sw, bad};
+            WideTileSink sink{mytile + lane, a.wf_only ? (live ? 1.0 : 0.0) : sw, bad};
             const double m = M::value_grad_sink(th, xr, sink);
             bad = sink.bad;
             f = (isfinite(m) ? m - yy : INFINITY) * sw;

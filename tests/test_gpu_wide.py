@@ -450,3 +450,28 @@ def test_wide_formula_through_gsl_nls_large(amd, gslref, alg, ng, extra, n):
     assert np.allclose(fit["resid"], q["model"](np.asarray(fit["par"])) - q["y"], rtol=0, atol=1e-9)
     dense = amd.gsl_nls(q["formula"], data=data, start=start, jac=True, control=dict(solver="cholesky"))
     assert abs(fit["ssr"] - dense["ssr"]) <= 1e-8 * dense["ssr"]
+
+
+def test_wide_formula_through_gsl_nls_large_with_weights(amd, gslref):
+    """the same with observation weights (R/nls_large.R: `weights`; src/nls_large.c:118-124 takes their square roots):
+    the rows are scaled inside the wide pass"""
+    q = gaussians_problem(4, 1, 5000, seed=77)
+    n, p = len(q["y"]), len(q["truth"])
+    rng = np.random.Generator(np.random.PCG64(78))
+    wts = rng.uniform(0.2, 3.0, n)
+    fit = amd.gsl_nls_large(q["formula"], data=dict(x=q["x"], y=q["y"]), start=dict(zip(q["names"], q["start"])),
+                            algorithm="lm", weights=wts, control=dict(maxiter=100))
+
+    def dfl(trans, th, u, want_v, want_jtj):
+        J = q["jac"](th)
+        v = None
+        if want_v:
+            v = J.T @ u if trans else J @ u
+        return v, (J.T @ J if want_jtj else None)
+    ref = gslref.nls_large(n, p, q["start"], fn=lambda th: q["model"](th) - q["y"], dfl=dfl, algorithm="lm",
+                           ctrl=gslref.control(maxiter=100), weights=wts)
+    assert fit["conv"] == 0 and ref["conv"] == 0
+    assert abs(fit["niter"] - ref["niter"]) <= 1
+    assert np.allclose(fit["par"], ref["par"], rtol=1e-6, atol=1e-9)
+    assert abs(fit["ssr"] - ref["ssr"]) <= 1e-9 * ref["ssr"]
+    assert np.allclose(fit["resid"], np.sqrt(wts) * (q["model"](np.asarray(fit["par"])) - q["y"]), rtol=0, atol=1e-9)
