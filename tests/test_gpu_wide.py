@@ -475,3 +475,4 @@ def test_wide_formula_through_gsl_nls_large_with_weights(amd, gslref):
     assert np.allclose(fit["par"], ref["par"], rtol=1e-6, atol=1e-9)
     assert abs(fit["ssr"] - ref["ssr"]) <= 1e-9 * ref["ssr"]
     assert np.allclose(fit["resid"], np.sqrt(wts) * (q["model"](np.asarray(fit["par"])) - q["y"]), rtol=0, atol=1e-9)
+    assert np.allclose(fit["covar"], ref["covar"], rtol=1e-5, atol=1e-12)
