@@ -476,3 +476,20 @@ def test_wide_formula_through_gsl_nls_large_with_weights(amd, gslref):
     assert abs(fit["ssr"] - ref["ssr"]) <= 1e-9 * ref["ssr"]
     assert np.allclose(fit["resid"], np.sqrt(wts) * (q["model"](np.asarray(fit["par"])) - q["y"]), rtol=0, atol=1e-9)
     assert np.allclose(fit["covar"], ref["covar"], rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.parametrize("scale", ["levenberg", "marquardt"])
+def test_wide_fit_with_the_other_scaling_rules(amd, gslref, scale):
+    """control$scale = "levenberg" (D = 1) and "marquardt" (D_j = ||J_j||, renewed at every accepted point) on the wide
+    path (GSL scaling.c, reached at src/trust.c:334, :524) against the oracle: same iterations, same coefficients"""
+    q = gaussians_problem(4, 1, 3000, seed=91, pert=0.01)
+    n, p = len(q["y"]), len(q["truth"])
+    fit = amd.gsl_nls(q["formula"], data=dict(x=q["x"], y=q["y"]), start=dict(zip(q["names"], q["start"])), jac=True,
+                      control=dict(solver="cholesky", scale=scale, maxiter=200))
+    ref = gslref.nls(n, p, q["start"], fn=lambda th: q["model"](th) - q["y"], jac=q["jac"],
+                     ctrl=gslref.control(solver="cholesky", scale=scale, maxiter=200))
+    assert fit["code_path"] == 3
+    assert fit["conv"] == ref["conv"] == 0
+    assert abs(fit["niter"] - ref["niter"]) <= 1, (fit["niter"], ref["niter"])
+    assert np.allclose(fit["par"], ref["par"], rtol=1e-6, atol=1e-9)
+    assert abs(fit["ssr"] - ref["ssr"]) <= 1e-9 * ref["ssr"]
