@@ -520,3 +520,38 @@ def test_wide_failure_modes_match_the_oracle(amd, gslref):
     assert fit["conv"] == 9 and ref["conv"] in (9, 27), (fit["conv"], ref["conv"])
     assert np.allclose(fit["par"], bad)
     assert np.all(np.isnan(fit["resid"]))
+
+
+def test_wide_robust_irls_with_observation_weights(amd, gslref):
+    """loss = "huber" together with `weights` on the wide path: every inner solve runs with sqrt(w_user) * sqrt(w_irls)
+    (src/nls_irls.c:447-456, :517-521), the scale estimate on the raw residuals -- against the oracle"""
+    q = gaussians_problem(4, 1, 4000, seed=61)
+    n, p = len(q["y"]), len(q["truth"])
+    rng = np.random.Generator(np.random.PCG64(62))
+    y = q["y"].copy()
+    y[rng.choice(n, n // 40, replace=False)] += 2.5
+    wts = rng.uniform(0.5, 2.0, n)
+    fit = amd.gsl_nls(q["formula"], data=dict(x=q["x"], y=y), start=dict(zip(q["names"], q["start"])), jac=True,
+                      loss="huber", weights=wts, control=dict(solver="cholesky"))
+    ref = gslref.nls(n, p, q["start"], fn=lambda th: q["model"](th) - y, jac=q["jac"], loss="huber", weights=wts,
+                     ctrl=gslref.control(solver="cholesky"))
+    assert fit["code_path"] == 3 and fit["conv"] == ref["conv"] == 0
+    assert fit["irls"]["irls_niter"] == ref["irls"]["irls_niter"] and fit["irls"]["irls_status"] == ref["irls"]["irls_status"]
+    assert np.allclose(fit["par"], ref["par"], rtol=1e-6, atol=1e-9)
+    assert abs(fit["irls"]["irls_sigma"] - ref["irls"]["irls_sigma"]) <= 1e-9 * ref["irls"]["irls_sigma"]
+    assert np.allclose(fit["irls_weights"], ref["irls_weights"], rtol=1e-6, atol=1e-9)
+
+
+def test_wide_lmaccel_with_central_differences_everywhere(amd, gslref):
+    """algorithm = "lmaccel" with jac = FALSE, fvv = FALSE and fdtype = "center": Jacobian by central differences
+    (src/fdjac.c:81-128) and the second directional derivative by the finite-difference form (src/fdfvv.c:35-77)"""
+    q = gaussians_problem(4, 0, 3000, seed=63, pert=0.01)
+    n, p = len(q["y"]), len(q["truth"])
+    fit = amd.gsl_nls(q["formula"], data=dict(x=q["x"], y=q["y"]), start=dict(zip(q["names"], q["start"])), jac=False,
+                      fvv=False, algorithm="lmaccel", control=dict(solver="cholesky", fdtype="center"))
+    ref = gslref.nls(n, p, q["start"], fn=lambda th: q["model"](th) - q["y"], algorithm="lmaccel",
+                     ctrl=gslref.control(solver="cholesky", fdtype="center"))
+    assert fit["code_path"] == 3 and fit["conv"] == ref["conv"] == 0
+    assert abs(fit["niter"] - ref["niter"]) <= 1, (fit["niter"], ref["niter"])
+    assert np.allclose(fit["par"], ref["par"], rtol=1e-5, atol=1e-8)
+    assert abs(fit["ssr"] - ref["ssr"]) <= 1e-8 * ref["ssr"]
