@@ -251,3 +251,20 @@ def test_large_lm_takes_the_device_factorisation_from_the_threshold_on(amd, gslr
     assert fits["host"]["niter"] == fits["device"]["niter"]
     assert np.allclose(fits["host"]["par"], fits["device"]["par"], rtol=1e-8, atol=1e-10)
     assert abs(fits["host"]["ssr"] - fits["device"]["ssr"]) <= 1e-10 * fits["host"]["ssr"]
+
+
+@pytest.mark.parametrize("alg", ["cgst", "lm"])
+def test_glm_fit_with_weights_matches_oracle(amd, gslref, alg):
+    """observation weights on the large path: they scale f only -- the reference's gsl_df_large never weights J
+    (src/nls_large.c:629-633; GSL multilarge eval_f applies sqrt(w) to f) -- against the oracle, which keeps the quirk"""
+    p, n = 16, 3000
+    A, y, th = glm_data(n, p)
+    rng = np.random.Generator(np.random.PCG64(404))
+    w = rng.uniform(0.5, 2.0, n)
+    fit = amd.gsl_nls_large("glmexp", A=A, y=y, start=np.zeros(p), algorithm=alg, weights=w)
+    o = gslref.nls_large(n, p, np.zeros(p), rowdata=dict(model=gslref.MODEL_GLMEXP, x=A, y=y), algorithm=alg, weights=w)
+    assert fit["conv"] == 0 and o["conv"] == 0
+    assert fit["niter"] == o["niter"]
+    assert np.allclose(fit["par"], o["par"], rtol=1e-6, atol=1e-9)
+    assert abs(fit["ssr"] - o["ssr"]) <= 1e-9 * o["ssr"]
+    assert np.allclose(fit["covar"], o["covar"], rtol=1e-5, atol=1e-12)
