@@ -157,17 +157,6 @@ __global__ __launch_bounds__(SP_T) void sp_sumsq_kernel(const double *w, int n, 
     }
 }
 
-// rows of J scaled by sqrt(w_i) (eval_df weighting, src/fdf.c:135-166 applied to the stored entries)
-__global__ __launch_bounds__(SP_T) void sp_scale_rows_kernel(const int *rowptr, double *val, const double *sw, int n)
-{
-    const int i = blockIdx.x * SP_T + threadIdx.x;
-    if (i >= n)
-        return;
-    const double s = sw[i];
-    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k)
-        val[k] *= s;
-}
-
 // dense J^T J (row j of the output owned by one wavefront): for every entry (i, j) of column j, in order,
 // lanes walk row i and add v_ij * v_ik into out[j][k] -- columns k are distinct inside a row, so the
 // read-modify-writes of one step never collide; steps are sequential.  (reference: gsl_spblas_dgemm + sp2d,
@@ -584,8 +573,10 @@ struct SparseCbOps : LargeOps
             h_val[pat.map[e]] += J.x[e];
         (void)hipEventRecord(e0, st);
         GSLNLS_HIP_OK(hipMemcpyAsync(d_val[t], h_val, sizeof(double) * (size_t)pat.nnz, hipMemcpyHostToDevice, st));
-        if (d_sw)
-            hipLaunchKernelGGL(sp_scale_rows_kernel, dim3((n + SP_T - 1) / SP_T), dim3(SP_T), 0, st, d_rowptr, d_val[t], d_sw, n);
+        // (the weights scale f only: GSL's multilarge eval_f applies sqrt(w), the Jacobian callback's result is used as it
+        // comes -- gsl_df_large never weights J, src/nls_large.c:629-646 -- exactly as on the row-model and wide paths
+        // and in the oracle; rounds 1-2 scaled the rows of J here, which solved a different (properly weighted) problem
+        // than the reference does)
         permute_values(t);
         segments(true, t, d_f[t], d_outp, d_sqp); // g = J^T f, diag(J^T J)
         GSLNLS_HIP_OK(hipMemcpyAsync(h_pin_out, d_outp, sizeof(double) * (size_t)p, hipMemcpyDeviceToHost, st));

@@ -128,10 +128,16 @@ def test_weighted_banded_problem_long_rows_and_columns(amd):
     y = A @ truth + 0.01 * rng.standard_normal(n)
     fit = amd.gsl_nls_large(lambda th: A @ th, y=y, start=np.zeros(p), algorithm="cgst", jac=lambda th: A, weights=w,
                             control=dict(maxiter=200))
-    W = sp.diags(w)
-    sol = np.linalg.solve((A.T @ W @ A).toarray(), A.T @ (w * y))
+    # Weights on the large path scale f only (GSL's multilarge eval_f; gsl_df_large hands J over unweighted,
+    # src/nls_large.c:629-646): the fit stops where A^T (sqrt(w) o (A theta - y)) = 0, i.e. at the least-squares solution
+    # with weights sqrt(w) -- what the oracle's multilarge driver converges to as well (the linear model makes it a closed
+    # form; rounds 1-2 scaled the rows of J too and landed on the properly weighted solution, which the reference does not)
+    S = sp.diags(np.sqrt(w))
+    sol = np.linalg.solve((A.T @ S @ A).toarray(), A.T @ (np.sqrt(w) * y))
     assert fit["conv"] == 0
-    assert np.allclose(fit["par"], sol, rtol=1e-5, atol=1e-7)
+    # (the trust-region ratio compares a decrease of sum w r^2 with a model built from the unweighted J: the iteration
+    # stops by gtol / xtol a little earlier than on a consistent problem)
+    assert np.allclose(fit["par"], sol, rtol=2e-4, atol=2e-5)
     r = np.sqrt(w) * (A @ fit["par"] - y)
     assert np.allclose(np.asarray(fit["resid"]), r, rtol=1e-9, atol=1e-12)
     assert abs(fit["ssr"] - r @ r) <= 1e-10 * (r @ r)
@@ -175,3 +181,33 @@ def test_callback_errors_surface(amd):
         raise RuntimeError("model blew up")
     with pytest.raises(RuntimeError, match="model blew up"):
         amd.gsl_nls_large(bad_fn, y=np.zeros(3), start=np.ones(2), algorithm="cgst", jac=lambda th: np.ones((3, 2)))
+
+
+def test_weighted_sparse_fit_follows_the_oracles_multilarge_driver(amd, gslref):
+    """gsl_nls_large(fn, jac, weights) against the oracle's multilarge driver with the same weights (which scale f only):
+    same iterations, same coefficients -- and NOT the properly weighted least-squares solution"""
+    rng = np.random.Generator(np.random.PCG64(5))
+    n, p = 400, 12
+    A = (sp.random(n, p, density=0.3, random_state=7, format="csr")
+         + sp.vstack([sp.identity(p), sp.csr_matrix((n - p, p))])).tocsr()
+    truth = rng.standard_normal(p)
+    w = 0.5 + rng.random(n)
+    y = A @ truth + 0.05 * rng.standard_normal(n)
+    Ad = A.toarray()
+
+    def dfl(trans, th, u, want_v, want_jtj):
+        v = None
+        if want_v:
+            v = Ad.T @ u if trans else Ad @ u
+        return v, (Ad.T @ Ad if want_jtj else None)
+    for alg in ("cgst", "lm"):
+        fit = amd.gsl_nls_large(lambda th: A @ th, y=y, start=np.zeros(p), algorithm=alg, jac=lambda th: A, weights=w,
+                                control=dict(maxiter=200))
+        ref = gslref.nls_large(n, p, np.zeros(p), fn=lambda th: Ad @ th - y, dfl=dfl, algorithm=alg,
+                               ctrl=gslref.control(maxiter=200), weights=w)
+        assert fit["conv"] == 0 and ref["conv"] == 0
+        assert abs(fit["niter"] - ref["niter"]) <= 1
+        assert np.allclose(fit["par"], ref["par"], rtol=1e-7, atol=1e-9)
+        assert abs(fit["ssr"] - ref["ssr"]) <= 1e-9 * ref["ssr"]
+        wls = np.linalg.solve(Ad.T @ np.diag(w) @ Ad, Ad.T @ (w * y))
+        assert np.max(np.abs(np.asarray(fit["par"]) - wls)) > 1e-5
