@@ -36,6 +36,24 @@ def amd():
     return gslnls_amd
 
 
+@pytest.mark.parametrize("loss", ["huber", "welsh", "hampel", "lqq"])
+def test_batched_other_losses_match_single_fit_oracle(amd, gslref, loss):
+    """the batched kernel with the other psi families (src/nls_irls.c:10-341; hampel and lqq carry three tuning constants,
+    R/nls_rho.R:106-144) against the oracle's single fits"""
+    B, n = 6, 640
+    X, Y, TH = c5_data(B, n)
+    prob = amd.BatchProblem(4, 8, X, Y)
+    out = prob.irls(GAUSS1_START, loss=loss, jac=True, control=dict(solver="cholesky"))
+    prob.close()
+    for d in range(B):
+        o = gslref.nls(n, 8, GAUSS1_START, rowdata=dict(model=gslref.MODEL_GAUSS1, x=X[d], y=Y[d]), use_jac=True,
+                       ctrl=gslref.control(solver="cholesky"), loss=loss)
+        assert out["conv"][d] == o["conv"] and out["irls_status"][d] == o["irls"]["irls_status"]
+        assert out["irls_niter"][d] == o["irls"]["irls_niter"] and out["niter"][d] == o["niter"]
+        assert np.allclose(out["par"][d], o["par"], rtol=1e-6)
+        assert abs(out["sigma"][d] - o["irls"]["irls_sigma"]) <= 1e-6 * o["irls"]["irls_sigma"]
+
+
 @pytest.mark.parametrize("n", [1000, 777])
 def test_batched_bisquare_matches_single_fit_oracle(amd, gslref, n):
     B = 12
