@@ -509,7 +509,7 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
                 g = gt;
                 dJ = dJt;
                 if (need_jtj)
-                    JTJ = JTJt;
+                    JTJ.swap(JTJt); // (the trial buffer is rewritten by the next evaluation: no 8 p^2-byte copy per iteration)
                 fnorm2 = ssr_t;
                 do_scale(false);
                 double b = 2.0 * rho - 1.0;
