@@ -555,3 +555,17 @@ def test_wide_lmaccel_with_central_differences_everywhere(amd, gslref):
     assert abs(fit["niter"] - ref["niter"]) <= 1, (fit["niter"], ref["niter"])
     assert np.allclose(fit["par"], ref["par"], rtol=1e-5, atol=1e-8)
     assert abs(fit["ssr"] - ref["ssr"]) <= 1e-8 * ref["ssr"]
+
+
+@pytest.mark.parametrize("n", [13, 20, 63, 64, 65, 129])
+def test_wide_path_on_very_few_rows(amd, gslref, n):
+    """one partial 64-row tile, a full one, one row more; n = 13 is barely above p = 12 (ill conditioned: both run into
+    maxiter along the same trajectory) -- the oracle's iterations and coefficients"""
+    q = gaussians_problem(4, 0, n, seed=100 + n, noise=0.01, pert=0.005)
+    fit = amd.gsl_nls(q["formula"], data=dict(x=q["x"], y=q["y"]), start=dict(zip(q["names"], q["start"])), jac=True,
+                      control=dict(solver="cholesky"))
+    o = gslref.nls(n, 12, q["start"], fn=lambda th: q["model"](th) - q["y"], jac=q["jac"],
+                   ctrl=gslref.control(solver="cholesky"))
+    assert fit["code_path"] == 3 and fit["conv"] == o["conv"] and fit["niter"] == o["niter"]
+    assert np.allclose(fit["par"], o["par"], rtol=1e-6, atol=1e-8)
+    assert abs(fit["ssr"] - o["ssr"]) <= 1e-8 * o["ssr"]
