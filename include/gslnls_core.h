@@ -34,7 +34,8 @@ extern "C" {
 #define GSLNLS_MODEL_GAUSSPK 3  /* a*exp(-(x-b)^2/(2c^2))    p=3  README.md:545 */
 #define GSLNLS_MODEL_GAUSS1 4   /* NIST Gauss1 family        p=8  R/nls_test.R:301 */
 #define GSLNLS_MODEL_EXPR 100  /* any formula right-hand side: compiled to a device program with symbolic
-                                   gradient (csrc/expr_compile.hpp); p <= 9, at most 3 regressor columns */
+                                   gradient (csrc/expr_compile.hpp); p <= 64, at most 8 regressor columns (beyond 9
+                                   parameters or 3 columns: the wide path) */
 #define GSLNLS_MODEL_GLMEXP 5   /* exp(a_i . theta), dense A n x p ROW-major in `x`, nx = p in {16,32,64};
                                    gsl_nls_large only */
 

@@ -131,8 +131,10 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
             pn[k] = CHAR(STRING_ELT(parnames, k));
         model_id = gslnls_lower_formula(CHAR(STRING_ELT(rhs, 0)), p, pn, order, cols, sizeof(cols));
     }
-    const char *xn[3] = {0, 0, 0};
-    if (model_id <= 0 && rhs != R_NilValue && p <= 9 && !Rf_isNull(parnames))
+    const char *xn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    /* (up to 9 parameters and 3 data columns: interpreted or natively compiled row models; up to 64 parameters and 8
+     * columns: the wide path, J^T J on the matrix cores -- the core decides, include/gslnls_core.h) */
+    if (model_id <= 0 && rhs != R_NilValue && p <= 64 && !Rf_isNull(parnames))
     {
         /* not a hand-written device model: hand the expression itself to the core (GSLNLS_MODEL_EXPR), which
          * compiles it with its symbolic gradient -- the analogue of R/nls.R:565,588-599.  Data columns are the
@@ -152,7 +154,7 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
                 is_par |= !strcmp(nm, pn[k]);
             if (is_par)
                 continue;
-            if (nxe == 3 || strlen(cols) + strlen(nm) + 2 > sizeof(cols))
+            if (nxe == 8 || strlen(cols) + strlen(nm) + 2 > sizeof(cols))
                 ok = 0;
             else
             {
