@@ -212,7 +212,8 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
         model.expr = CHAR(STRING_ELT(rhs, 0));
         model.parnames = pn;
         model.xnames = xn;
-        /* options(gslnls.lowering = "jit") builds native code for the formula once (hipcc, cached on disk) */
+        /* options(gslnls.lowering = "jit") waits for native code of the formula (built in process by hiprtc, cached on disk);
+         * the default lets the first fit run interpreted while it is built in the background */
         SEXP opt = Rf_GetOption1(Rf_install("gslnls.lowering"));
         if (Rf_isString(opt) && !strcmp(CHAR(STRING_ELT(opt, 0)), "jit"))
             model.lowering = GSLNLS_LOWER_JIT;
