@@ -10,12 +10,19 @@
  * (src/nls_large.c:426-472, :474-653) -- but f once per trial point and J once per accepted point instead
  * of once per matrix-vector product; every product with J then runs on the device
  * (gslnls_amd/csrc/sparse_large.hpp).
+ *
+ * gsl_nls_large(formula, ...): the closures come from the formula method (R/nls_large.R:273, :295-309), whose frame binds
+ * `formula` and `mf` exactly as gsl_nls.formula's does.  Then no closure is evaluated during the fit at all: the
+ * right-hand side itself goes to the core as a GSLNLS_MODEL_EXPR descriptor (symbolic gradient, up to 64 parameters and
+ * 8 data columns) and gslnls_nls_large() runs the multilarge driver on the device's row passes; `grad` of the result is
+ * one evaluation of the `jac` closure at the returned coefficients.
  */
 #define R_NO_REMAP
 #include <R.h>
 #include <Rinternals.h>
 #include <string.h>
 #include "gslnls_core.h"
+#include "gslnls_shim_common.h"
 
 SEXP C_nls_large(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP weights, SEXP control_int,
                  SEXP control_dbl); /* original entry, kept for what is not lowered */
@@ -129,13 +136,62 @@ SEXP C_nls_large_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, 
     SEXP startvec = PROTECT(Rf_coerceVector(start, REALSXP));
     const int p = Rf_length(startvec), n = Rf_length(y);
     shim_state s = {fn, jac, env, Rf_getAttrib(start, R_NamesSymbol), R_NilValue, n, p, 0, NULL, NULL, NULL};
-    int err = 0;
-    gslnls_large *h = gslnls_large_create_sparse(n, p, REAL(y), Rf_isNull(weights) ? NULL : REAL(weights), shim_f,
-                                                 shim_jac, &s, &err);
-    if (!h)
+
+    /* ---- the formula method: lower the right-hand side itself ---- */
+    gslnls_model model;
+    memset(&model, 0, sizeof model);
+    const char *pn[64], *xn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    char cols[256];
+    int lowered = 0;
+    SEXP formula = closure_formula(fn);
+    SEXP rhs = PROTECT(formula == R_NilValue ? R_NilValue : deparse_rhs(formula));
+    if (rhs != R_NilValue && p <= 64 && !Rf_isNull(s.parnames))
     {
-        UNPROTECT(1);
-        return C_nls_large(fn, y, jac, fvv, env, start, weights, control_int, control_dbl);
+        int nxe = 0;
+        for (int k = 0; k < p; k++)
+            pn[k] = CHAR(STRING_ELT(s.parnames, k));
+        if (formula_columns(formula, pn, p, cols, sizeof(cols), xn, &nxe))
+        {
+            SEXP mf = Rf_findVarInFrame(CLOENV(fn), Rf_install("mf"));
+            const int nx = nxe > 0 ? nxe : 1;
+            double *X = (double *)R_alloc((size_t)n * nx, sizeof(double));
+            memset(X, 0, sizeof(double) * (size_t)n * nx);
+            lowered = 1;
+            for (int c = 0; c < nxe && lowered; c++)
+            {
+                /* (a symbol that is not a numeric column of length n of the model frame is something the closure would
+                 * find through its enclosure and the device cannot: the callbacks serve that fit) */
+                SEXP raw = (mf == R_UnboundValue) ? R_NilValue : frame_column(mf, xn[c], n);
+                if (raw == R_NilValue)
+                    lowered = 0;
+                else
+                {
+                    SEXP col = PROTECT(Rf_coerceVector(raw, REALSXP));
+                    memcpy(X + (size_t)c * n, REAL(col), sizeof(double) * n);
+                    UNPROTECT(1);
+                }
+            }
+            model.id = GSLNLS_MODEL_EXPR;
+            model.p = p;
+            model.nx = nxe;
+            model.x = X;
+            model.expr = CHAR(STRING_ELT(rhs, 0));
+            model.parnames = pn;
+            model.xnames = xn;
+            model.lowering = GSLNLS_LOWER_AUTO;
+        }
+    }
+
+    int err = 0;
+    gslnls_large *h = NULL;
+    if (!lowered)
+    {
+        h = gslnls_large_create_sparse(n, p, REAL(y), Rf_isNull(weights) ? NULL : REAL(weights), shim_f, shim_jac, &s, &err);
+        if (!h)
+        {
+            UNPROTECT(2);
+            return C_nls_large(fn, y, jac, fvv, env, start, weights, control_int, control_dbl);
+        }
     }
     const int maxiter = INTEGER(control_int)[0], verbose = INTEGER(control_int)[1];
     /* result list of src/nls_large.c:275-416: par, covar, resid, grad, niter, status, conv, ssr, ssrtol, algorithm,
@@ -152,7 +208,7 @@ SEXP C_nls_large_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, 
     out.par = REAL(par);
     out.covar = REAL(covar);
     out.resid = REAL(resid);
-    int nprot = 5;
+    int nprot = 6;
     SEXP pt = R_NilValue;
     if (verbose)
     {
@@ -164,15 +220,30 @@ SEXP C_nls_large_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, 
         SET_VECTOR_ELT(ans, 11, pt);
         SET_VECTOR_ELT(ans, 12, st);
     }
-    const int rc = gslnls_large_solve(h, REAL(startvec), INTEGER(control_int), REAL(control_dbl), &out);
-    gslnls_large_destroy(h);
+    int rc;
+    if (lowered)
+        rc = gslnls_nls_large(&model, REAL(y), n, REAL(startvec), Rf_isNull(weights) ? NULL : REAL(weights),
+                              INTEGER(control_int), REAL(control_dbl), &out);
+    else
+    {
+        rc = gslnls_large_solve(h, REAL(startvec), INTEGER(control_int), REAL(control_dbl), &out);
+        gslnls_large_destroy(h);
+    }
     if (rc == GSLNLS_E_UNSUPPORTED || rc == GSLNLS_E_NODEVICE)
     {
-        R_ReleaseObject(s.keep);
+        if (s.keep != R_NilValue)
+            R_ReleaseObject(s.keep);
         UNPROTECT(nprot);
         return C_nls_large(fn, y, jac, fvv, env, start, weights, control_int, control_dbl);
     }
     const int ok = (out.conv == GSLNLS_SUCCESS || out.conv == GSLNLS_EMAXITER);
+    if (lowered && ok)
+    {
+        /* `grad`: the Jacobian at the returned coefficients, from the closure the reference would have called last */
+        gslnls_sparse unused;
+        memset(&unused, 0, sizeof unused);
+        (void)shim_jac(out.par, p, &unused, &s); /* (leaves the evaluated object in s.keep) */
+    }
     Rf_setAttrib(par, R_NamesSymbol, s.parnames);
     SET_VECTOR_ELT(ans, 0, par);
     if (!Rf_isNull(s.parnames))
@@ -216,7 +287,8 @@ SEXP C_nls_large_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, 
         SET_VECTOR_ELT(ans, 3, g);
         UNPROTECT(1);
     }
-    R_ReleaseObject(s.keep);
+    if (s.keep != R_NilValue)
+        R_ReleaseObject(s.keep);
     if (!ok)
     {
         for (int k = 0; k < p * p; k++)
