@@ -198,13 +198,17 @@ struct WideMsEvaluator : MsEvaluator
     LmParams prm;
     int jm = 0;
     const double *lupars = nullptr;
+    std::vector<double> staged; // records of a shard on their way to a device buffer (the in-library collective)
     explicit WideMsEvaluator(WideFit &f) : fit(f) {}
     int run(MsBatch &b, int lo, int hi, double *out, bool out_on_device) override;
-    int fetch(const double *src, bool, double *dst, size_t nd) override
-    {
-        memcpy(dst, src, sizeof(double) * nd);
-        return 0;
-    }
+    int run_host(MsBatch &b, int lo, int hi, double *out);
+    int fetch(const double *src, bool src_on_device, double *dst, size_t nd) override;
+    // the stream-ordered forms the RCCL all-gather of capi.hip uses (one process per GPU: a rank fits its block of the
+    // points one after the other, the records reach the shard buffer in one copy)
+    void *stream() override;
+    int run_async(MsBatch &b, int lo, int hi, double *dev_out) override;
+    int fetch_stream(const double *dev_src, double *dst, size_t nd) override;
+    int poke(double *dev_dst, double value) override;
 };
 
 struct WideFit : DenseBase
@@ -1224,10 +1228,60 @@ struct WideLargeOps : LargeOps
 };
 inline LargeOps *WideFit::make_large_ops() { return new WideLargeOps(*this); }
 
+inline void *WideMsEvaluator::stream() { return fit.stream; }
+inline int WideMsEvaluator::fetch(const double *src, bool src_on_device, double *dst, size_t nd)
+{
+    if (!nd)
+        return 0;
+    if (!src_on_device)
+    {
+        memcpy(dst, src, sizeof(double) * nd);
+        return 0;
+    }
+    GSLNLS_HIP_OK(hipMemcpyAsync(dst, src, sizeof(double) * nd, hipMemcpyDeviceToHost, fit.stream));
+    GSLNLS_HIP_OK(hipStreamSynchronize(fit.stream));
+    return 0;
+}
+inline int WideMsEvaluator::fetch_stream(const double *dev_src, double *dst, size_t nd)
+{
+    if (nd)
+        GSLNLS_HIP_OK(hipMemcpyAsync(dst, dev_src, sizeof(double) * nd, hipMemcpyDeviceToHost, fit.stream));
+    GSLNLS_HIP_OK(hipStreamSynchronize(fit.stream));
+    return 0;
+}
+inline int WideMsEvaluator::poke(double *dev_dst, double value)
+{
+    static double slot[4];
+    slot[0] = value;
+    GSLNLS_HIP_OK(hipMemcpyAsync(dev_dst, slot, sizeof(double), hipMemcpyHostToDevice, fit.stream));
+    GSLNLS_HIP_OK(hipStreamSynchronize(fit.stream));
+    return 0;
+}
+inline int WideMsEvaluator::run_async(MsBatch &b, int lo, int hi, double *dev_out)
+{
+    const size_t nd = (size_t)(hi - lo) * (3 * fit.p + 8);
+    staged.assign(nd, 0.0);
+    const int rc = run_host(b, lo, hi, staged.data());
+    if (rc)
+        return rc;
+    // (`staged` lives as long as the evaluator: the copy is complete before the collective that follows it on the stream)
+    GSLNLS_HIP_OK(hipMemcpyAsync(dev_out, staged.data(), sizeof(double) * nd, hipMemcpyHostToDevice, fit.stream));
+    return 0;
+}
 inline int WideMsEvaluator::run(MsBatch &b, int lo, int hi, double *out, bool out_on_device)
 {
-    if (out_on_device || !out)
-        return GSLNLS_E_UNSUPPORTED; // records are produced on the host
+    if (!out)
+        return GSLNLS_E_UNSUPPORTED; // (records are produced on the host: somebody has to take them)
+    if (!out_on_device)
+        return run_host(b, lo, hi, out);
+    const int rc = run_async(b, lo, hi, out);
+    if (rc)
+        return rc;
+    GSLNLS_HIP_OK(hipStreamSynchronize(fit.stream));
+    return 0;
+}
+inline int WideMsEvaluator::run_host(MsBatch &b, int lo, int hi, double *out)
+{
     const int p = fit.p, K = 3 * p + 8, NA = p * (p + 1) / 2;
     std::vector<double> st(p), tot((size_t)fit.NV);
     for (int idx = lo; idx < hi; ++idx)

@@ -569,3 +569,49 @@ def test_wide_path_on_very_few_rows(amd, gslref, n):
     assert fit["code_path"] == 3 and fit["conv"] == o["conv"] and fit["niter"] == o["niter"]
     assert np.allclose(fit["par"], o["par"], rtol=1e-6, atol=1e-8)
     assert abs(fit["ssr"] - o["ssr"]) <= 1e-8 * o["ssr"]
+
+
+def test_wide_multistart_through_the_in_library_collective(amd):
+    """one process per GPU: with an RCCL communicator in the library every multi-start gsl_nls() shards its points over
+    the ranks and all-gathers the records (capi.hip: ms_rccl_run_batch).  For p > 9 a rank fits its block one point after
+    the other on the host-driven wide path and stages the records into the shard buffer; here one rank with the
+    collective forced (GSLNLS_COMM_FORCE_COLLECTIVE): same bookkeeping and the same fit as without a communicator"""
+    import json
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import json, os, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import gslnls_amd as amd
+from gslnls_amd import _lib
+from test_gpu_wide import gaussians_problem
+L = _lib.lib()
+q = gaussians_problem(4, 0, 1500, seed=13, noise=0.02)
+lo = q["truth"] * np.where(np.arange(12) %% 3 == 1, 0.97, 0.8); hi = q["truth"] * np.where(np.arange(12) %% 3 == 1, 1.03, 1.2)
+start = {nm: [float(a), float(b)] for nm, a, b in zip(q["names"], lo, hi)}
+ctrl = dict(solver="cholesky", mstart_n=12, mstart_q=3, mstart_maxstart=40)
+def fit():
+    f = amd.gsl_nls(q["formula"], data=dict(x=q["x"], y=q["y"]), start=start, jac=True, control=ctrl)
+    return dict(par=list(map(float, f["par"])), conv=int(f["conv"]), niter=int(f["niter"]), ms={k: float(v) for k, v in f["mstart"].items()},
+                path=int(f["code_path"]))
+plain = fit()
+rc_init = L.gslnls_comm_init_file(sys.argv[1].encode(), 0, 1, 30)
+n0 = L.gslnls_comm_allgather_count()
+coll = fit()
+n1 = L.gslnls_comm_allgather_count()
+L.gslnls_comm_destroy()
+print(json.dumps(dict(plain=plain, coll=coll, rc_init=rc_init, collectives=n1 - n0)))
+""" % (root, root)
+    with tempfile.TemporaryDirectory() as td:
+        env = dict(os.environ, GSLNLS_COMM_FORCE_COLLECTIVE="1", GSLNLS_COMM_NONCE="wide-ms")
+        out = subprocess.run([sys.executable, "-c", code, os.path.join(td, "nccl_id")], capture_output=True, text=True,
+                             timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["rc_init"] == 0 and r["collectives"] >= 1
+    assert r["plain"]["path"] == r["coll"]["path"] == 3 and r["plain"]["conv"] == r["coll"]["conv"] == 0
+    assert r["plain"]["ms"] == r["coll"]["ms"] and r["plain"]["niter"] == r["coll"]["niter"]
+    assert r["plain"]["par"] == r["coll"]["par"]
