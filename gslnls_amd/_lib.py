@@ -47,6 +47,9 @@ class Sparse(C.Structure):
                 ("x", C.POINTER(C.c_double))]
 
 
+FN_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_void_p)
+JAC_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_void_p)
+FVV_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_void_p)
 LARGE_F_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_void_p)
 LARGE_JAC_CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(Sparse), C.c_void_p)
 
@@ -73,6 +76,9 @@ _SIGNATURES = {
     "gslnls_nls": (C.c_int, [C.POINTER(Model), C.c_void_p, C.c_int, C.c_int, C.c_int, DP, C.c_int, C.c_void_p,
                              C.c_int, DP, IP, DP, IP, C.c_int, DP, C.POINTER(Result)]),
     "gslnls_solver_served": (C.c_int, [IP, C.POINTER(Result)]),
+    "gslnls_last_call_profile": (C.c_int, [DP, C.c_int]),
+    "gslnls_nls_fn": (C.c_int, [C.c_int, C.c_int, C.c_void_p, FN_CB, JAC_CB, FVV_CB, C.c_void_p, DP, C.c_void_p, DP, IP, DP,
+                                C.POINTER(Result)]),
     "gslnls_dense_create": (C.c_void_p, [C.POINTER(Model), C.c_void_p, C.c_int, C.c_void_p, IP]),
     "gslnls_dense_destroy": (None, [C.c_void_p]),
     "gslnls_dense_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, DP, DP, IP, DP, C.c_int, C.POINTER(Result)]),

@@ -1,0 +1,773 @@
+// bd_host.hpp -- gsl_nls() with the Jacobian as a matrix in HBM: R `function` models of any size (the closures stay on the
+// host, as fn / jac / fvv are evaluated with Rf_eval on the R thread in the reference, src/nls.c:815-978) and formulas
+// with more than 64 parameters (rows evaluated by a kernel compiled in process for the formula).
+//
+// Replaces, for these inputs, the same functions as dense_host.hpp / wide_host.hpp: C_nls_internal's single-start branch
+// (src/nls.c:533-576, :598-608, :632-753), gsl_multifit_nlinear_driver2 (src/nls_fit.c:40-121), trust_init_LD /
+// trust_iterate_lu_LD / lm_step_LD / nielsen_* / trust_calc_rho (src/trust.c), eval_f / eval_df / eval_fvv with weights
+// (src/fdf.c:94-233), the difference Jacobians (src/fdjac.c) and fvv (src/fdfvv.c).  The order of operations of one
+// iteration is the one of lm_advance<P> (lm_core.hpp) and wide_advance (wide_core.hpp) -- the same state machine a third
+// time, with a run-time p up to 4096 and p-vectors on the host: a trial step has to come back to the host anyway when
+// the model is a closure, and for p > 64 the p x p factorisation (hundreds of microseconds) hides a round trip.
+// Every n x p and p x p operation is a device kernel (bd_kernels.hpp; mchol_device.hip from p = 400 on).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <vector>
+#include "../../include/gslnls_core.h"
+#include "bd_kernels.hpp"
+#include "dense_host.hpp"
+#include "large_host.hpp"
+
+namespace gslnls
+{
+
+// 2-norm condition number of the column-scaled normal matrix for any p: Cholesky of C = S A S, lambda_max by power
+// iteration, lambda_min by inverse iteration through the factor (the boundary's solver-routing diagnostic,
+// gslnls_solver_served; dense_host.hpp's Jacobi sweeps are cubic per sweep)
+inline double bd_scaled_cond(int p, const std::vector<double> &A)
+{
+    std::vector<double> C((size_t)p * p), s(p);
+    for (int i = 0; i < p; ++i)
+    {
+        const double d = A[(size_t)i * p + i];
+        if (!(d > 0.0) || !std::isfinite(d))
+            return INFINITY;
+        s[i] = 1.0 / sqrt(d);
+    }
+    for (int i = 0; i < p; ++i)
+        for (int j = 0; j < p; ++j)
+            C[(size_t)i * p + j] = A[(size_t)i * p + j] * s[i] * s[j];
+    std::vector<double> Lf(C);
+    if (!lg_chol(p, Lf))
+        return INFINITY;
+    std::vector<double> v(p, 1.0 / sqrt((double)p)), w(p);
+    double lmax = 0.0, lmin_inv = 0.0;
+    for (int it = 0; it < 60; ++it)
+    {
+        double nrm = 0.0;
+        for (int i = 0; i < p; ++i)
+        {
+            double t = 0.0;
+            for (int j = 0; j < p; ++j)
+                t += C[(size_t)i * p + j] * v[j];
+            w[i] = t;
+            nrm += t * t;
+        }
+        nrm = sqrt(nrm);
+        if (!(nrm > 0.0))
+            break;
+        lmax = nrm;
+        for (int i = 0; i < p; ++i)
+            v[i] = w[i] / nrm;
+    }
+    for (int i = 0; i < p; ++i)
+        v[i] = ((i & 1) ? -1.0 : 1.0) / sqrt((double)p);
+    for (int it = 0; it < 60; ++it)
+    {
+        // w = C^-1 v through L L^T (lg_chol leaves L in the lower triangle)
+        for (int i = 0; i < p; ++i)
+        {
+            double t = v[i];
+            for (int k = 0; k < i; ++k)
+                t -= Lf[(size_t)i * p + k] * w[k];
+            w[i] = t / Lf[(size_t)i * p + i];
+        }
+        for (int i = p - 1; i >= 0; --i)
+        {
+            double t = w[i];
+            for (int k = i + 1; k < p; ++k)
+                t -= Lf[(size_t)k * p + i] * w[k];
+            w[i] = t / Lf[(size_t)i * p + i];
+        }
+        double nrm = 0.0;
+        for (int i = 0; i < p; ++i)
+            nrm += w[i] * w[i];
+        nrm = sqrt(nrm);
+        if (!(nrm > 0.0) || !std::isfinite(nrm))
+            return INFINITY;
+        lmin_inv = nrm;
+        for (int i = 0; i < p; ++i)
+            v[i] = w[i] / nrm;
+    }
+    return lmax * lmin_inv;
+}
+
+// where the model comes from: host closures (R functions) or a kernel compiled for the formula
+struct BdModel
+{
+    virtual ~BdModel() {}
+    // model values m(theta) -> d_fval[n] on the device (NOT residuals).  Non-zero: the closure failed (EBADFUNC).
+    virtual int values(const double *theta, double *d_fval, hipStream_t st) = 0;
+    // analytic Jacobian dm/dtheta -> d_J, n x p column-major, unweighted.  Only called when has_jac.
+    virtual int jacobian(const double *theta, double *d_J, hipStream_t st) = 0;
+    // analytic second directional derivative D^2 m[v, v] -> d_out[n], unweighted.  Only called when has_fvv.
+    virtual int fvv(const double *theta, const double *v, double *d_out, hipStream_t st) = 0;
+    bool has_jac = false, has_fvv = false;
+};
+
+struct BdFit
+{
+    int n = 0, p = 0;
+    BdModel *model = nullptr;
+    hipStream_t st = nullptr;
+    double *d_y = nullptr, *d_sw = nullptr, *d_fval = nullptr, *d_f[2] = {nullptr, nullptr}, *d_fp = nullptr, *d_fm = nullptr,
+           *d_J = nullptr, *d_C = nullptr, *d_cpart = nullptr, *d_part = nullptr, *d_pv = nullptr, *d_u = nullptr;
+    std::vector<double> h_part;
+    int cur = 0;        // d_f[cur]: residual at the current point, d_f[cur ^ 1]: at the trial point
+    int npanel = 0, npair = 0, nslice = 1;
+    long nevalf = 0, nevaldf = 0, nevalfvv = 0;
+    int device_ordinal = -1;
+
+    ~BdFit() { release(); }
+    void release()
+    {
+        double *bufs[] = {d_y, d_sw, d_fval, d_f[0], d_f[1], d_fp, d_fm, d_J, d_C, d_cpart, d_part, d_pv, d_u};
+        for (double *b : bufs)
+            if (b)
+                (void)hipFree(b);
+        d_y = d_sw = d_fval = d_f[0] = d_f[1] = d_fp = d_fm = d_J = d_C = d_cpart = d_part = d_pv = d_u = nullptr;
+        if (st)
+            (void)hipStreamDestroy(st);
+        st = nullptr;
+    }
+
+    int init(int n_, int p_, const double *y, const double *swts, BdModel *m)
+    {
+        n = n_;
+        p = p_;
+        model = m;
+        if (n < 1 || p < 1 || p > 4096 || !y)
+            return GSLNLS_EINVAL;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        {
+            fprintf(stderr, "gslnls: no HIP device available -- the MI355X path cannot run (no CPU fallback exists)\n");
+            return GSLNLS_E_NODEVICE;
+        }
+        (void)hipGetDevice(&device_ordinal);
+        GSLNLS_HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        const size_t nb = sizeof(double) * (size_t)n;
+        npanel = (p + 63) / 64;
+        npair = npanel * (npanel + 1) / 2;
+        const long long ntile = ((long long)n + 63) / 64;
+        // enough workgroups for the chip (512 = two per CU), at most one slice per row tile and 32 partial blocks per block
+        long long sl = (512 + npair - 1) / npair;
+        sl = sl > ntile ? ntile : sl;
+        sl = sl > 32 ? 32 : (sl < 1 ? 1 : sl);
+        nslice = (int)sl;
+        GSLNLS_HIP_OK(hipMalloc(&d_y, nb));
+        GSLNLS_HIP_OK(hipMalloc(&d_fval, nb));
+        GSLNLS_HIP_OK(hipMalloc(&d_f[0], nb));
+        GSLNLS_HIP_OK(hipMalloc(&d_f[1], nb));
+        GSLNLS_HIP_OK(hipMalloc(&d_fp, nb));
+        GSLNLS_HIP_OK(hipMalloc(&d_fm, nb));
+        GSLNLS_HIP_OK(hipMalloc(&d_u, nb));
+        GSLNLS_HIP_OK(hipMalloc(&d_J, nb * p));
+        GSLNLS_HIP_OK(hipMalloc(&d_C, sizeof(double) * (size_t)p * p));
+        GSLNLS_HIP_OK(hipMalloc(&d_cpart, sizeof(double) * (size_t)nslice * npair * 4096));
+        GSLNLS_HIP_OK(hipMalloc(&d_part, sizeof(double) * BD_MAXG));
+        GSLNLS_HIP_OK(hipMalloc(&d_pv, sizeof(double) * (size_t)4 * p));
+        h_part.resize(BD_MAXG);
+        GSLNLS_HIP_OK(hipMemcpyAsync(d_y, y, nb, hipMemcpyHostToDevice, st));
+        if (swts)
+        {
+            GSLNLS_HIP_OK(hipMalloc(&d_sw, nb));
+            GSLNLS_HIP_OK(hipMemcpyAsync(d_sw, swts, nb, hipMemcpyHostToDevice, st));
+        }
+        GSLNLS_HIP_OK(hipStreamSynchronize(st));
+        return GSLNLS_SUCCESS;
+    }
+
+    int grid_n() const
+    {
+        long long g = ((long long)n + BD_T - 1) / BD_T;
+        return (int)(g < 1 ? 1 : (g > BD_MAXG ? BD_MAXG : g));
+    }
+    int sum_parts(int g, double *out)
+    {
+        GSLNLS_HIP_OK(hipMemcpyAsync(h_part.data(), d_part, sizeof(double) * g, hipMemcpyDeviceToHost, st));
+        GSLNLS_HIP_OK(hipStreamSynchronize(st));
+        double s = 0.0;
+        for (int k = 0; k < g; ++k)
+            s += h_part[k];
+        *out = s;
+        return GSLNLS_SUCCESS;
+    }
+
+    // weighted residual at theta into d_dst (and its sum of squares when ssr != nullptr)
+    int resid_at(const double *theta, double *d_dst, double *ssr)
+    {
+        if (model->values(theta, d_fval, st))
+            return GSLNLS_EBADFUNC;
+        const int g = grid_n();
+        hipLaunchKernelGGL(bd_resid_kernel, dim3(g), dim3(BD_T), 0, st, d_fval, d_y, d_sw, (long long)n, d_dst, ssr ? d_part : nullptr);
+        if (ssr)
+            return sum_parts(g, ssr);
+        return GSLNLS_SUCCESS;
+    }
+
+    // Jacobian at theta (residual at theta in d_fbase) -> d_J weighted, then J^T J -> d_C, g = J^T f_base, diag(J^T J).
+    // *badj != 0: an analytic Jacobian with a non-finite entry.  jtj_host (p x p row-major) is filled when not null.
+    int jac_at(const double *theta, const double *d_fbase, const LmParams &prm, double *g_out, double *djj_out, double *badj,
+               double *jtj_host)
+    {
+        *badj = 0.0;
+        if (prm.jac_analytic)
+        {
+            if (model->jacobian(theta, d_J, st))
+                return GSLNLS_EBADFUNC;
+            const long long tot = (long long)n * p;
+            long long gl = (tot + BD_T - 1) / BD_T;
+            const int g = (int)(gl > BD_MAXG ? BD_MAXG : gl);
+            hipLaunchKernelGGL(bd_weight_kernel, dim3(g), dim3(BD_T), 0, st, d_J, d_sw, (long long)n, p, d_part);
+            double b = 0.0;
+            if (int rc = sum_parts(g, &b))
+                return rc;
+            *badj = (b == 0.0) ? 0.0 : 1.0;
+        }
+        else
+        {
+            // src/fdjac.c: delta_j = h |x_j| (0 -> h); forward (f(x + delta e_j) - f(x)) / delta, central over +- delta / 2
+            std::vector<double> th(theta, theta + p);
+            const int g = grid_n();
+            for (int j = 0; j < p; ++j)
+            {
+                double d = prm.h_df * fabs(theta[j]);
+                if (d == 0.0)
+                    d = prm.h_df;
+                if (prm.fdtype == 0)
+                {
+                    th[j] = theta[j] + d;
+                    if (int rc = resid_at(th.data(), d_fp, nullptr))
+                        return rc;
+                    hipLaunchKernelGGL(bd_fdcol_kernel, dim3(g), dim3(BD_T), 0, st, d_fp, d_fbase, 1.0 / d, d_J + (size_t)j * n,
+                                       (long long)n);
+                }
+                else
+                {
+                    th[j] = theta[j] + 0.5 * d;
+                    if (int rc = resid_at(th.data(), d_fp, nullptr))
+                        return rc;
+                    th[j] = theta[j] - 0.5 * d;
+                    if (int rc = resid_at(th.data(), d_fm, nullptr))
+                        return rc;
+                    hipLaunchKernelGGL(bd_fdcol_kernel, dim3(g), dim3(BD_T), 0, st, d_fp, d_fm, 1.0 / d, d_J + (size_t)j * n,
+                                       (long long)n);
+                }
+                th[j] = theta[j];
+            }
+        }
+        hipLaunchKernelGGL(bd_syrk_kernel, dim3(npair, nslice), dim3(BD_T), 0, st, d_J, (long long)n, p, nslice, d_cpart);
+        hipLaunchKernelGGL(bd_syrk_reduce_kernel, dim3(npair), dim3(BD_T), 0, st, d_cpart, p, npair, nslice, d_C);
+        hipLaunchKernelGGL(bd_gemv_t_kernel, dim3(p), dim3(BD_T), 0, st, d_J, d_fbase, (long long)n, p, d_pv);
+        GSLNLS_HIP_OK(hipMemcpyAsync(g_out, d_pv, sizeof(double) * p, hipMemcpyDeviceToHost, st));
+        if (jtj_host)
+            GSLNLS_HIP_OK(hipMemcpyAsync(jtj_host, d_C, sizeof(double) * (size_t)p * p, hipMemcpyDeviceToHost, st));
+        else
+            GSLNLS_HIP_OK(hipMemcpy2DAsync(djj_out, sizeof(double), d_C, sizeof(double) * ((size_t)p + 1), sizeof(double), (size_t)p,
+                                           hipMemcpyDeviceToHost, st));
+        GSLNLS_HIP_OK(hipStreamSynchronize(st));
+        if (jtj_host)
+            for (int j = 0; j < p; ++j)
+                djj_out[j] = jtj_host[(size_t)j * p + j];
+        GSLNLS_HIP_OK(hipGetLastError());
+        return GSLNLS_SUCCESS;
+    }
+
+    // J^T fvv at x along v (src/fdf.c:200-233; by differences src/fdfvv.c:35-77); *bad != 0: non-finite analytic fvv
+    int fvv_at(const double *x, const double *v, const LmParams &prm, double *out, double *bad)
+    {
+        *bad = 0.0;
+        const int g = grid_n();
+        if (prm.fvv_analytic)
+        {
+            if (model->fvv(x, v, d_fp, st))
+                return GSLNLS_EBADFUNC;
+            hipLaunchKernelGGL(bd_weight_vec_kernel, dim3(g), dim3(BD_T), 0, st, d_fp, d_sw, (long long)n, d_part);
+            double b = 0.0;
+            if (int rc = sum_parts(g, &b))
+                return rc;
+            *bad = (b == 0.0) ? 0.0 : 1.0;
+        }
+        else
+        {
+            std::vector<double> xh(p);
+            for (int k = 0; k < p; ++k)
+                xh[k] = x[k] + prm.h_fvv * v[k];
+            if (int rc = resid_at(xh.data(), d_fm, nullptr))
+                return rc;
+            GSLNLS_HIP_OK(hipMemcpyAsync(d_pv + p, v, sizeof(double) * p, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(bd_gemv_n_kernel, dim3(g), dim3(BD_T), 0, st, d_J, d_pv + p, (long long)n, p, d_u);
+            hipLaunchKernelGGL(bd_fdfvv_kernel, dim3(g), dim3(BD_T), 0, st, d_fm, d_f[cur], d_u, prm.h_fvv, d_fp, (long long)n);
+        }
+        hipLaunchKernelGGL(bd_gemv_t_kernel, dim3(p), dim3(BD_T), 0, st, d_J, d_fp, (long long)n, p, d_pv);
+        GSLNLS_HIP_OK(hipMemcpyAsync(out, d_pv, sizeof(double) * p, hipMemcpyDeviceToHost, st));
+        GSLNLS_HIP_OK(hipStreamSynchronize(st));
+        return GSLNLS_SUCCESS;
+    }
+
+    // v^T (J^T J) v with J^T J on the device (p >= the device threshold)
+    int quad_device(const double *v, double *out)
+    {
+        GSLNLS_HIP_OK(hipMemcpyAsync(d_pv + p, v, sizeof(double) * p, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(bd_quad_kernel, dim3(p), dim3(BD_T), 0, st, d_C, d_pv + p, p, d_pv + 2 * p);
+        std::vector<double> r(p);
+        GSLNLS_HIP_OK(hipMemcpyAsync(r.data(), d_pv + 2 * p, sizeof(double) * p, hipMemcpyDeviceToHost, st));
+        GSLNLS_HIP_OK(hipStreamSynchronize(st));
+        double s = 0.0;
+        for (int i = 0; i < p; ++i)
+            s += r[i];
+        *out = s;
+        return GSLNLS_SUCCESS;
+    }
+
+    // The fit.  Same decisions in the same order as lm_advance<P> / wide_advance (which cite the reference line by line).
+    int solve(int jac, int fvv, const double *start, const double *lupars, const int *ci, const double *cd, gslnls_result *out)
+    {
+        if (ci[2] > 1)
+            return GSLNLS_E_UNSUPPORTED; // dogleg family: not lowered
+        if ((jac && !model->has_jac) || (fvv && !model->has_fvv))
+            return GSLNLS_EINVAL;
+        const LmParams prm = make_params(ci, cd, jac, fvv, lupars != nullptr, d_sw != nullptr);
+        const int maxiter = prm.maxiter;
+        const bool trace = ci[1] != 0 && out->ssrtrace && out->partrace;
+        static const int dev_min = [] {
+            const char *e = getenv("GSLNLS_LARGE_CHOL_DEVICE_MIN");
+            return e ? atoi(e) : 400;
+        }();
+        const bool dev_solve = dev_min > 0 && p >= dev_min;
+        std::vector<double> x(start, start + p), xt(p), dx(p, 0.0), vel(p, 0.0), acc(p, 0.0), g(p), gt(p), diag(p, 1.0), djj(p),
+            djjt(p), lo(p, -INFINITY), up(p, INFINITY), rhs(p), gfvv(p);
+        std::vector<double> A(dev_solve ? 0 : (size_t)p * p), Adamp;
+        if (lupars)
+            for (int k = 0; k < p; ++k)
+            {
+                lo[k] = std::isfinite(lupars[2 * k]) ? lupars[2 * k] : -INFINITY;
+                up[k] = std::isfinite(lupars[2 * k + 1]) ? lupars[2 * k + 1] : INFINITY;
+            }
+        nevalf = nevaldf = nevalfvv = 0;
+        double fnorm2 = INFINITY, mu = 0.0, nu = 2.0, delta = 0.0, avratio = 0.0, chisq0 = INFINITY, chisq1 = INFINITY,
+               chisq_init = INFINITY;
+        int niter = 0, status = ST_CONTINUE, info = ST_CONTINUE, bad_steps = 0;
+        const double t_begin = now_s();
+        if (trace)
+        {
+            for (int k = 0; k <= maxiter; ++k)
+                out->ssrtrace[k] = NAN;
+            for (size_t k = 0; k < (size_t)(maxiter + 1) * p; ++k)
+                out->partrace[k] = NAN;
+        }
+        auto scale = [&](bool init) { // GSL scaling.c
+            for (int j = 0; j < p; ++j)
+            {
+                if (prm.scale == 1)
+                {
+                    if (init)
+                        diag[j] = 1.0;
+                    continue;
+                }
+                double norm = sqrt(djj[j]);
+                if (norm == 0.0)
+                    norm = 1.0;
+                if (init || prm.scale == 2)
+                    diag[j] = norm;
+                else
+                    diag[j] = fmax(diag[j], norm);
+            }
+        };
+        // (J^T J + mu D^2) sol = b: gsl_linalg_mcholesky on the device from p = 400 on, the host routine below
+        auto damped_solve = [&](const std::vector<double> &b, std::vector<double> &sol) -> int {
+            sol.assign(p, 0.0);
+            if (dev_solve)
+            {
+                const int rc = mchol_device_solve_resident(p, d_C, diag.data(), mu, b.data(), sol.data());
+                if (rc != GSLNLS_E_UNSUPPORTED)
+                    return rc;
+                std::vector<double> Ah((size_t)p * p);
+                GSLNLS_HIP_OK(hipMemcpy(Ah.data(), d_C, sizeof(double) * (size_t)p * p, hipMemcpyDeviceToHost));
+                for (int i = 0; i < p; ++i)
+                    Ah[(size_t)i * p + i] += mu * diag[i] * diag[i];
+                lg_mchol_solve(p, Ah, b, sol);
+                return GSLNLS_SUCCESS;
+            }
+            Adamp = A;
+            for (int i = 0; i < p; ++i)
+                Adamp[(size_t)i * p + i] += mu * diag[i] * diag[i];
+            lg_mchol_solve(p, Adamp, b, sol);
+            return GSLNLS_SUCCESS;
+        };
+        auto test = [&](int *inf) -> int { // gsl_multifit_nlinear_test
+            bool small = true;
+            for (int i = 0; i < p && small; ++i)
+                if (!(fabs(dx[i]) < prm.xtol * prm.xtol + prm.xtol * fabs(x[i])))
+                    small = false;
+            if (small)
+            {
+                *inf = 1;
+                return ST_SUCCESS;
+            }
+            double gnorm = 0.0;
+            for (int i = 0; i < p; ++i)
+                gnorm = fmax(gnorm, fabs(fmax(x[i], 1.0) * g[i]));
+            if (gnorm <= prm.gtol * fmax(0.5 * fnorm2, 1.0))
+            {
+                *inf = 2;
+                return ST_SUCCESS;
+            }
+            *inf = 0;
+            return ST_CONTINUE;
+        };
+        bool done = false;
+        auto trace_row = [&](int row, double ssr) {
+            if (!trace)
+                return;
+            out->ssrtrace[row] = ssr;
+            for (int k = 0; k < p; ++k)
+                out->partrace[row + (size_t)(maxiter + 1) * k] = x[k];
+        };
+        auto end_iteration = [&](int itstatus) -> bool { // lm_end_iteration: true = another iteration follows
+            const int iter = niter;
+            niter += 1;
+            chisq1 = fnorm2;
+            if (itstatus == ST_EBADFUNC || (itstatus == ST_ENOPROG && iter == 0))
+            {
+                info = itstatus;
+                status = itstatus;
+                done = true;
+                return false;
+            }
+            trace_row(niter, chisq1);
+            int inf = 0;
+            const int t = test(&inf);
+            info = inf;
+            if (t == ST_SUCCESS)
+            {
+                status = ST_SUCCESS;
+                done = true;
+                return false;
+            }
+            if (niter >= maxiter)
+            {
+                status = ST_EMAXITER;
+                done = true;
+                return false;
+            }
+            chisq0 = chisq1;
+            bad_steps = 0;
+            return true;
+        };
+
+        // ---- trust_init_LD ----
+        int rc = resid_at(x.data(), d_f[cur], &fnorm2);
+        if (rc == GSLNLS_EBADFUNC)
+        {
+            status = info = ST_EBADFUNC;
+            done = true;
+        }
+        else if (rc)
+            return rc;
+        double badj = 0.0;
+        if (!done)
+        {
+            nevalf += 1;
+            rc = jac_at(x.data(), d_f[cur], prm, g.data(), djj.data(), &badj, dev_solve ? nullptr : A.data());
+            if (rc == GSLNLS_EBADFUNC)
+                badj = 1.0;
+            else if (rc)
+                return rc;
+            if (prm.jac_analytic)
+                nevaldf += 1;
+            else
+                nevalf += lm_fd_cost(prm, p);
+            if (badj != 0.0)
+            {
+                chisq_init = chisq0 = chisq1 = fnorm2;
+                status = info = ST_EBADFUNC;
+                done = true;
+            }
+        }
+        bool step = false;
+        if (!done)
+        {
+            scale(true);
+            double Dx2 = 0.0, mx = -1.0;
+            for (int j = 0; j < p; ++j)
+            {
+                const double u = diag[j] * x[j];
+                Dx2 += u * u;
+                mx = fmax(mx, sqrt(djj[j]) / diag[j]);
+            }
+            delta = 0.3 * fmax(1.0, sqrt(Dx2));
+            mu = 1.0e-3 * mx * mx;
+            nu = 2.0;
+            avratio = 0.0;
+            chisq_init = chisq0 = chisq1 = fnorm2;
+            niter = 0;
+            bad_steps = 0;
+            trace_row(0, chisq_init);
+            step = true;
+        }
+        // ---- driver2 / trust_iterate_lu_LD: one pass of the loop = one trial step ----
+        long steps = 0;
+        const long max_steps = ((long)maxiter * 17 + 2) * (prm.trs ? 2 : 1) + 2;
+        while (!done)
+        {
+            if (g_interrupt_hook && g_interrupt_hook())
+                return GSLNLS_E_INTERRUPTED;
+            if (++steps > max_steps)
+                return GSLNLS_FAILURE;
+            // lm_begin_step: velocity of the damped system
+            for (int k = 0; k < p; ++k)
+                rhs[k] = -g[k];
+            if ((rc = damped_solve(rhs, vel)))
+                return rc;
+            if (prm.trs == 1)
+            {
+                // geodesic acceleration (src/trust.c:252-286)
+                double badv = 0.0;
+                rc = fvv_at(x.data(), vel.data(), prm, gfvv.data(), &badv);
+                if (rc == GSLNLS_EBADFUNC)
+                    badv = 1.0;
+                else if (rc)
+                    return rc;
+                if (prm.fvv_analytic)
+                    nevalfvv += 1;
+                else
+                    nevalf += 1;
+                if (prm.fvv_analytic && badv != 0.0)
+                {
+                    // a failed fvv counts as a rejected step (src/trust.c:452-483, :530-545)
+                    delta /= prm.factor_down;
+                    mu *= nu;
+                    nu *= 2.0;
+                    const int itstatus = (++bad_steps > 15) ? ST_ENOPROG : ST_CONTINUE;
+                    if (itstatus != ST_CONTINUE)
+                        (void)end_iteration(itstatus);
+                    continue;
+                }
+                for (int k = 0; k < p; ++k)
+                    rhs[k] = -gfvv[k];
+                if ((rc = damped_solve(rhs, acc)))
+                    return rc;
+                double an = 0.0, vn = 0.0;
+                for (int k = 0; k < p; ++k)
+                {
+                    an += acc[k] * acc[k];
+                    vn += vel[k] * vel[k];
+                }
+                avratio = sqrt(an) / sqrt(vn);
+                for (int k = 0; k < p; ++k)
+                    dx[k] = vel[k] + 0.5 * acc[k];
+            }
+            else
+                for (int k = 0; k < p; ++k)
+                {
+                    acc[k] = 0.0;
+                    dx[k] = vel[k];
+                }
+            // trust_trial_step_lu (src/trust.c:9-32)
+            for (int k = 0; k < p; ++k)
+            {
+                double t = x[k] + dx[k];
+                if (prm.has_bounds)
+                {
+                    if (t < lo[k])
+                        t = x[k] + (dx[k] / fmax(fabs(dx[k]), delta) * fabs(x[k] - lo[k]));
+                    else if (t > up[k])
+                        t = x[k] + (dx[k] / fmax(fabs(dx[k]), delta) * fabs(x[k] - up[k]));
+                }
+                xt[k] = t;
+            }
+            // trust_eval_step + radius / mu updates (src/trust.c:474-545)
+            double ssr_t = INFINITY;
+            rc = resid_at(xt.data(), d_f[cur ^ 1], &ssr_t);
+            if (rc == GSLNLS_EBADFUNC)
+                ssr_t = INFINITY;
+            else if (rc)
+                return rc;
+            nevalf += 1;
+            double rho;
+            if (!(ssr_t < fnorm2))
+                rho = -1.0;
+            else
+            {
+                const double finv = 1.0 / fnorm2;
+                const double ared = 1.0 - ssr_t * finv;
+                double vAv = 0.0, Dv2 = 0.0;
+                if (dev_solve)
+                {
+                    if ((rc = quad_device(vel.data(), &vAv)))
+                        return rc;
+                }
+                else
+                    for (int i = 0; i < p; ++i)
+                    {
+                        double row = 0.0;
+                        for (int j = 0; j < p; ++j)
+                            row += A[(size_t)i * p + j] * vel[j];
+                        vAv += row * vel[i];
+                    }
+                for (int i = 0; i < p; ++i)
+                {
+                    const double ud = diag[i] * vel[i];
+                    Dv2 += ud * ud;
+                }
+                const double pred = vAv * finv + 2.0 * mu * (Dv2 * finv);
+                rho = (pred > 0.0) ? ared / pred : -1.0;
+            }
+            bool found = rho > 0.0;
+            if (prm.trs == 1 && avratio > prm.avmax)
+                found = false;
+            if (rho > 0.75)
+                delta *= prm.factor_up;
+            else if (rho < 0.25)
+                delta /= prm.factor_down;
+            int itstatus = ST_CONTINUE;
+            if (found)
+            {
+                itstatus = ST_SUCCESS;
+                rc = jac_at(xt.data(), d_f[cur ^ 1], prm, gt.data(), djjt.data(), &badj, dev_solve ? nullptr : A.data());
+                if (rc == GSLNLS_EBADFUNC)
+                    badj = 1.0;
+                else if (rc)
+                    return rc;
+                if (prm.jac_analytic)
+                {
+                    nevaldf += 1;
+                    if (badj != 0.0)
+                        itstatus = ST_EBADFUNC;
+                }
+                else
+                    nevalf += lm_fd_cost(prm, p);
+                if (itstatus == ST_SUCCESS)
+                {
+                    x = xt;
+                    g = gt;
+                    djj = djjt;
+                    cur ^= 1;
+                    fnorm2 = ssr_t;
+                    scale(false);
+                    double b = 2.0 * rho - 1.0;
+                    b = 1.0 - b * b * b;
+                    nu = 2.0;
+                    mu *= fmax(0.333333333333333, b);
+                    bad_steps = 0;
+                }
+            }
+            else
+            {
+                mu *= nu;
+                nu *= 2.0;
+                if (++bad_steps > 15)
+                    itstatus = ST_ENOPROG;
+            }
+            if (itstatus != ST_CONTINUE)
+                (void)end_iteration(itstatus);
+        }
+        (void)step;
+        const double loop_ms = 1e3 * (now_s() - t_begin);
+        // ---- result (src/nls.c:648-753) ----
+        const bool ok = (status == ST_SUCCESS || status == ST_EMAXITER);
+        for (int k = 0; k < p; ++k)
+            if (out->par)
+                out->par[k] = ok ? x[k] : start[k];
+        // NOTE: after a failed last Jacobian (EBADFUNC at an accepted point) d_J / d_C hold that point's matrices; the
+        // result is NaN-filled then, as the reference's is
+        std::vector<double> Afin;
+        if (ok && (out->covar || true))
+        {
+            Afin.resize((size_t)p * p);
+            if (dev_solve)
+                GSLNLS_HIP_OK(hipMemcpy(Afin.data(), d_C, sizeof(double) * (size_t)p * p, hipMemcpyDeviceToHost));
+            else
+                Afin = A;
+        }
+        if (out->covar)
+        {
+            bool good = ok;
+            std::vector<double> Ci;
+            if (good)
+            {
+                Ci = Afin;
+                good = lg_chol(p, Ci);
+                if (good)
+                    lg_chol_invert(p, Ci);
+            }
+            for (int i = 0; i < p; ++i)
+                for (int j = 0; j < p; ++j)
+                    out->covar[i + (size_t)p * j] = good ? Ci[(size_t)i * p + j] : NAN;
+        }
+        if (out->resid)
+        {
+            if (ok)
+                GSLNLS_HIP_OK(hipMemcpy(out->resid, d_f[cur], sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+            else
+                for (int i = 0; i < n; ++i)
+                    out->resid[i] = NAN;
+        }
+        if (out->grad)
+        {
+            if (ok)
+                GSLNLS_HIP_OK(hipMemcpy(out->grad, d_J, sizeof(double) * (size_t)n * p, hipMemcpyDeviceToHost));
+            else
+                for (size_t i = 0; i < (size_t)n * p; ++i)
+                    out->grad[i] = NAN;
+        }
+        out->niter = niter;
+        out->conv = status;
+        out->info = info;
+        out->ssr = chisq1;
+        out->ssrtol = chisq0 - chisq1;
+        out->neval[0] = (int)nevalf;
+        out->neval[1] = (int)nevaldf;
+        out->neval[2] = (int)nevalfvv;
+        out->chisq_init = chisq_init;
+        out->loop_ms = (float)loop_ms;
+        out->n_launches = 0;
+        out->n_steps = (int)steps;
+        out->jtj_cond = ok ? bd_scaled_cond(p, Afin) : NAN;
+        out->code_path = 4;
+        return status;
+    }
+};
+
+// host closures as the model: gslnls_nls_fn (capi.hip)
+struct BdCallbackModel : BdModel
+{
+    int n = 0, p = 0;
+    gslnls_fn_cb f = nullptr;
+    gslnls_jac_cb jac = nullptr;
+    gslnls_fvv_cb fv = nullptr;
+    void *user = nullptr;
+    std::vector<double> hbuf, hJ;
+    int values(const double *theta, double *d_fval, hipStream_t st) override
+    {
+        hbuf.resize(n);
+        if (f(theta, p, hbuf.data(), n, user))
+            return 1;
+        if (hipMemcpyAsync(d_fval, hbuf.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess)
+            return 1;
+        return hipStreamSynchronize(st) == hipSuccess ? 0 : 1; // (hbuf is rewritten by the next call)
+    }
+    int jacobian(const double *theta, double *d_J, hipStream_t st) override
+    {
+        hJ.resize((size_t)n * p);
+        if (jac(theta, p, hJ.data(), n, user))
+            return 1;
+        if (hipMemcpyAsync(d_J, hJ.data(), sizeof(double) * (size_t)n * p, hipMemcpyHostToDevice, st) != hipSuccess)
+            return 1;
+        return hipStreamSynchronize(st) == hipSuccess ? 0 : 1;
+    }
+    int fvv(const double *theta, const double *v, double *d_out, hipStream_t st) override
+    {
+        hbuf.resize(n);
+        if (fv(theta, v, p, hbuf.data(), n, user))
+            return 1;
+        if (hipMemcpyAsync(d_out, hbuf.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess)
+            return 1;
+        return hipStreamSynchronize(st) == hipSuccess ? 0 : 1;
+    }
+};
+
+} // namespace gslnls

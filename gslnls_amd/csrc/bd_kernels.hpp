@@ -1,0 +1,252 @@
+// bd_kernels.hpp -- device kernels of the "big dense" path: gsl_nls() with more than 64 parameters, and gsl_nls() on an
+// R function (any p), where the Jacobian is a MATRIX in HBM instead of rows recomputed in registers.
+//
+// The reference allocates an n x p workspace for any p (gsl_multifit_nlinear_alloc, src/nls.c:266) and fills it from the
+// closure's result (gsl_df, src/nls.c:864-916) or by finite differences (src/fdjac.c:24-128); GSL's Cholesky solver then
+// forms J^T J with dsyrk (multifit_nlinear/cholesky.c) and J^T f with dgemv (trust.c).  Here J lives column-major in HBM
+// (n x p, exactly the layout C_nls hands back as `grad`, src/nls.c:718) and
+//   bd_syrk_kernel     J^T J on the matrix cores: 64 x 64 blocks of the lower triangle, v_mfma_f64_16x16x4_f64, the two column
+//                      panels of a block staged through LDS 64 rows at a time (the tile layout of wide_kernels.hpp);
+//                      row slices in parallel, partial blocks summed in slice order by bd_syrk_reduce_kernel (no atomics:
+//                      bit-identical run to run), which also mirrors the upper triangle for the device factorisation;
+//   bd_gemv_t_kernel   J^T f, one workgroup per column (contiguous in memory);
+//   bd_resid_kernel    f = sqrt(w) (m - y) with the reference's non-finite rule (src/nls.c:843-849) + sum of squares;
+//   bd_weight_kernel   rows of an analytic Jacobian scaled by sqrt(w) (src/fdf.c:135-177) + non-finite check;
+//   bd_fdcol_kernel    one column of a forward / central difference Jacobian (src/fdjac.c:81-128, :147-168);
+//   bd_quad_kernel     rows of v^T (J^T J) v for the predicted reduction (GSL lm_preduction).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "lm_core.hpp"
+
+namespace gslnls
+{
+
+constexpr int BD_T = 256;
+constexpr int BD_LD = 68;   // leading dimension of a staged tile (doubles): conflict-free column writes, 2 lanes per bank on reads
+constexpr int BD_MAXG = 1024;
+
+typedef double bd_v4f64 __attribute__((ext_vector_type(4)));
+
+// fixed-shape workgroup sum (BD_T threads): wavefront xor butterflies, then the four wave sums in wave order
+__device__ __forceinline__ double bd_block_sum(double v, double *red_s)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+    {
+        const long long bits = __double_as_longlong(v);
+        const int lo = __shfl_xor((int)(bits & 0xffffffffll), m, 64), hi = __shfl_xor((int)(bits >> 32), m, 64);
+        v += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0)
+        red_s[wave] = v;
+    __syncthreads();
+    double s = red_s[0];
+    for (int w = 1; w < BD_T / 64; ++w)
+        s += red_s[w];
+    return s;
+}
+
+// f_i = sqrt(w_i) (m_i - y_i), +Inf where the model value is not finite (src/nls.c:843-849); part[block] = sum f_i^2
+__global__ __launch_bounds__(BD_T) void bd_resid_kernel(const double *fval, const double *y, const double *sw, long long n,
+                                                        double *f, double *part)
+{
+    __shared__ double red_s[BD_T / 64];
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * BD_T + threadIdx.x; i < n; i += (long long)gridDim.x * BD_T)
+    {
+        const double m = fval[i];
+        double r = isfinite(m) ? m - y[i] : INFINITY;
+        if (sw)
+            r *= sw[i];
+        f[i] = r;
+        s += r * r;
+    }
+    s = bd_block_sum(s, red_s);
+    if (threadIdx.x == 0 && part)
+        part[blockIdx.x] = s;
+}
+
+// rows of J (n x p column-major) scaled by sqrt(w); part[block] = NaN when an entry of J is not finite, else 0
+__global__ __launch_bounds__(BD_T) void bd_weight_kernel(double *J, const double *sw, long long n, int p, double *part)
+{
+    __shared__ double red_s[BD_T / 64];
+    double bad = 0.0;
+    const long long tot = n * (long long)p;
+    for (long long e = (long long)blockIdx.x * BD_T + threadIdx.x; e < tot; e += (long long)gridDim.x * BD_T)
+    {
+        const double v = J[e];
+        bad = fma(v, 0.0, bad);
+        if (sw)
+            J[e] = v * sw[e % n];
+    }
+    bad = bd_block_sum(bad, red_s);
+    if (threadIdx.x == 0)
+        part[blockIdx.x] = bad;
+}
+
+// column of a difference Jacobian: (fa - fb) * dinv (forward: fa = f(x + d e_j), fb = f(x); central: f(x +- d/2 e_j))
+__global__ __launch_bounds__(BD_T) void bd_fdcol_kernel(const double *fa, const double *fb, double dinv, double *col, long long n)
+{
+    for (long long i = (long long)blockIdx.x * BD_T + threadIdx.x; i < n; i += (long long)gridDim.x * BD_T)
+        col[i] = (fa[i] - fb[i]) * dinv;
+}
+
+// g_j = sum_i J[i][j] f_i: one workgroup per column
+__global__ __launch_bounds__(BD_T) void bd_gemv_t_kernel(const double *J, const double *f, long long n, int p, double *g)
+{
+    __shared__ double red_s[BD_T / 64];
+    const double *col = J + (size_t)blockIdx.x * n;
+    double s = 0.0;
+    for (long long i = threadIdx.x; i < n; i += BD_T)
+        s += col[i] * f[i];
+    s = bd_block_sum(s, red_s);
+    if (threadIdx.x == 0)
+        g[blockIdx.x] = s;
+}
+
+// u_i = sum_k J[i][k] v_k (row i of J v), for the second directional derivative by differences (src/fdfvv.c:35-77)
+__global__ __launch_bounds__(BD_T) void bd_gemv_n_kernel(const double *J, const double *v, long long n, int p, double *u)
+{
+    for (long long i = (long long)blockIdx.x * BD_T + threadIdx.x; i < n; i += (long long)gridDim.x * BD_T)
+    {
+        double s = 0.0;
+        for (int k = 0; k < p; ++k)
+            s += J[(size_t)k * n + i] * v[k];
+        u[i] = s;
+    }
+}
+
+// fvv_i = (2 / h) ((f_i(x + h v) - f_i(x)) / h - (J v)_i)   (src/fdfvv.c:60-72)
+__global__ __launch_bounds__(BD_T) void bd_fdfvv_kernel(const double *fp, const double *f, const double *u, double h, double *out,
+                                                        long long n)
+{
+    const double hinv = 1.0 / h;
+    for (long long i = (long long)blockIdx.x * BD_T + threadIdx.x; i < n; i += (long long)gridDim.x * BD_T)
+        out[i] = (2.0 * hinv) * ((fp[i] - f[i]) * hinv - u[i]);
+}
+
+// analytic fvv from a closure: weighted, non-finite -> flag (part[block] NaN)
+__global__ __launch_bounds__(BD_T) void bd_weight_vec_kernel(double *v, const double *sw, long long n, double *part)
+{
+    __shared__ double red_s[BD_T / 64];
+    double bad = 0.0;
+    for (long long i = (long long)blockIdx.x * BD_T + threadIdx.x; i < n; i += (long long)gridDim.x * BD_T)
+    {
+        const double r = v[i];
+        bad = fma(r, 0.0, bad);
+        if (sw)
+            v[i] = r * sw[i];
+    }
+    bad = bd_block_sum(bad, red_s);
+    if (threadIdx.x == 0)
+        part[blockIdx.x] = bad;
+}
+
+// out[i] = (sum_j C[i][j] v_j) v_i: the rows of v^T C v (C p x p row-major, symmetric); the host adds them in index order
+__global__ __launch_bounds__(BD_T) void bd_quad_kernel(const double *C, const double *v, int p, double *out)
+{
+    __shared__ double red_s[BD_T / 64];
+    const int i = blockIdx.x;
+    const double *row = C + (size_t)i * p;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < p; j += BD_T)
+        s += row[j] * v[j];
+    s = bd_block_sum(s, red_s);
+    if (threadIdx.x == 0)
+        out[i] = s * v[i];
+}
+
+// ---- J^T J ------------------------------------------------------------------------------------------------------------
+// Block (I, Jb), I >= Jb, of the lower triangle in units of 64 columns; `slice` of the row tiles.  The four wavefronts of a
+// workgroup share the two staged panels (64 rows x 64 columns each, tile[column][row]); wavefront w owns block row w of the
+// 4 x 4 grid of 16 x 16 products: per 4-row chunk one A' operand (panel I, columns 16 w ..) and four B operands (panel
+// Jb), four MFMAs.  Operand / result layout of v_mfma_f64_16x16x4_f64 as in wide_kernels.hpp: lane l supplies
+// A'[l % 16][l / 16] and B[l / 16][l % 16] and holds D[4 r + l / 16][l % 16] in result register r.
+// cpart: [slice][pair][64 x 64] partial blocks.
+__global__ __launch_bounds__(BD_T, 2) void bd_syrk_kernel(const double *J, long long n, int p, int nslice, double *cpart)
+{
+    __shared__ double tile[2][64 * BD_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kk = lane >> 4, ii = lane & 15;
+    // pair index -> (I, Jb), Jb <= I
+    const int pair = blockIdx.x;
+    int I = (int)((sqrt(8.0 * pair + 1.0) - 1.0) * 0.5);
+    while (I * (I + 1) / 2 > pair)
+        --I;
+    while ((I + 1) * (I + 2) / 2 <= pair)
+        ++I;
+    const int Jb = pair - I * (I + 1) / 2;
+    const int slice = blockIdx.y;
+    const bool diagblk = I == Jb;
+    bd_v4f64 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        acc[b] = (bd_v4f64){0.0, 0.0, 0.0, 0.0};
+    const long long ntile = (n + 63) / 64;
+    for (long long t = slice; t < ntile; t += nslice)
+    {
+        const long long r0 = t * 64;
+        __syncthreads(); // the previous tile has been consumed
+        // stage: wavefront w loads columns w, w + 4, ... of each panel, lane = row (512 contiguous bytes per instruction)
+        for (int c = wave; c < 64; c += 4)
+        {
+            const long long r = r0 + lane;
+            const int cI = I * 64 + c, cJ = Jb * 64 + c;
+            tile[0][c * BD_LD + lane] = (r < n && cI < p) ? J[(size_t)cI * n + r] : 0.0;
+            if (!diagblk)
+                tile[1][c * BD_LD + lane] = (r < n && cJ < p) ? J[(size_t)cJ * n + r] : 0.0;
+        }
+        __syncthreads();
+        const double *tA = tile[0], *tB = diagblk ? tile[0] : tile[1];
+#pragma unroll 4
+        for (int c = 0; c < 16; ++c)
+        {
+            const double va = tA[(wave * 16 + ii) * BD_LD + c * 4 + kk];
+            double vb[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                vb[b] = tB[(b * 16 + ii) * BD_LD + c * 4 + kk];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va, vb[b], acc[b], 0, 0, 0);
+        }
+    }
+    // block row `wave`: element (16 wave + 4 r + kk, 16 b + ii)
+    double *out = cpart + ((size_t)slice * gridDim.x + pair) * 4096;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            out[(wave * 16 + 4 * r + kk) * 64 + b * 16 + ii] = acc[b][r];
+}
+
+// C[i][j] = sum over the slices (in slice order) of the partial blocks; both triangles are written (C p x p row-major)
+__global__ __launch_bounds__(BD_T) void bd_syrk_reduce_kernel(const double *cpart, int p, int npair, int nslice, double *C)
+{
+    const int pair = blockIdx.x;
+    int I = (int)((sqrt(8.0 * pair + 1.0) - 1.0) * 0.5);
+    while (I * (I + 1) / 2 > pair)
+        --I;
+    while ((I + 1) * (I + 2) / 2 <= pair)
+        ++I;
+    const int Jb = pair - I * (I + 1) / 2;
+    for (int e = threadIdx.x; e < 4096; e += BD_T)
+    {
+        const int r = e >> 6, c = e & 63;
+        const int gi = I * 64 + r, gj = Jb * 64 + c;
+        if (gi >= p || gj >= p)
+            continue;
+        double s = cpart[(size_t)pair * 4096 + e];
+        for (int sl = 1; sl < nslice; ++sl)
+            s += cpart[((size_t)sl * npair + pair) * 4096 + e];
+        if (I != Jb || gj <= gi)
+        {
+            C[(size_t)gi * p + gj] = s;
+            C[(size_t)gj * p + gi] = s;
+        }
+    }
+}
+
+} // namespace gslnls

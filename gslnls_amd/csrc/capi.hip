@@ -84,6 +84,11 @@ int ms_rccl_run_batch(MsEvaluator &ev, const MsComm &comm, MsBatch &b, int per, 
 namespace gslnls
 {
 DenseBase *make_dense_expr(const gslnls_model *fn, const double *y, int n, const double *swts, int *err); // vm_models.hip
+int bd_formula_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv, const double *start, const double *swts,
+                   const double *lupars, const int *ci, const double *cd, gslnls_result *out); // bd_models.hip
+int bd_callback_nls(int n, int p, const double *y, gslnls_fn_cb f, gslnls_jac_cb jac, gslnls_fvv_cb fvv, void *user,
+                    const double *start, const double *swts, const double *lupars, const int *ci, const double *cd,
+                    gslnls_result *out); // bd_models.hip
 void trim_dense_expr();                                                                                         // vm_models.hip
 }
 
@@ -1004,10 +1009,30 @@ int gslnls_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv,
 {
     if (swts && swts_is_matrix)
         return GSLNLS_E_UNSUPPORTED; // GLS: n x n factor, not lowered
+    g_call_prof = CallProfile();
+    const double t0 = now_s();
+#ifndef GSLNLS_NO_EXPR
+    if (fn && fn->id == GSLNLS_MODEL_EXPR && fn->p > 64) // (WIDE_MAX_P, vm_program.hpp)
+    {
+        // more than 64 parameters: the Jacobian is a matrix in HBM (csrc/bd_host.hpp); single start, default loss
+        if (start_is_matrix || loss_rho != 0)
+            return GSLNLS_E_UNSUPPORTED;
+        const int rcb = bd_formula_nls(fn, y, n, jac, fvv, start, swts, lupars, control_int, control_dbl, out);
+        g_call_prof.total_ms = 1e3 * (now_s() - t0);
+        return rcb;
+    }
+#endif
+    // the result vectors are usually pages the process has never touched (a large Rf_allocVector is a fresh mmap): fault
+    // them in on a helper thread while the data uploads and the fit runs, instead of under the device-to-host copy
+    OutputPrefault pre;
+    if (out)
+        pre.start(out->resid, (size_t)n * sizeof(double), out->grad, fn ? (size_t)n * fn->p * sizeof(double) : 0);
     int err = 0;
     DenseBase *b = make_dense(fn, y, n, swts, &err);
     if (!b)
         return err;
+    const double t1 = now_s();
+    b->prefault = &pre;
     int rc;
     if (start_is_matrix)
         rc = b->mstart(jac, fvv, start, lupars, control_int, control_dbl, has_start, g_comm, loss_rho, loss_cc, out);
@@ -1015,8 +1040,38 @@ int gslnls_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv,
         rc = b->irls(jac, fvv, start, lupars, control_int, control_dbl, loss_rho, loss_cc, out);
     else
         rc = b->solve(jac, fvv, start, lupars, control_int, control_dbl, 0, out);
+    b->prefault = nullptr;
+    pre.join();
+    const double t2 = now_s();
     release_dense(b);
+    const double t3 = now_s();
+    g_call_prof.create_ms = 1e3 * (t1 - t0) - g_call_prof.h2d_ms;
+    g_call_prof.loop_ms = 1e3 * (t2 - t1) - g_call_prof.finalize_ms - g_call_prof.d2h_ms;
+    g_call_prof.destroy_ms = 1e3 * (t3 - t2);
+    g_call_prof.total_ms = 1e3 * (t3 - t0);
     return rc;
+}
+
+int gslnls_nls_fn(int n, int p, const double *y, gslnls_fn_cb f, gslnls_jac_cb jac, gslnls_fvv_cb fvv, void *user,
+                  const double *start, const double *swts, const double *lupars, const int *control_int,
+                  const double *control_dbl, gslnls_result *out)
+{
+    if (!f || !y || !start || !control_int || !control_dbl || !out || n < 1 || p < 1)
+        return GSLNLS_EINVAL;
+    if (p > 4096)
+        return GSLNLS_E_UNSUPPORTED;
+    return bd_callback_nls(n, p, y, f, jac, fvv, user, start, swts, lupars, control_int, control_dbl, out);
+}
+
+int gslnls_last_call_profile(double *ms, int cap)
+{
+    const double v[7] = {g_call_prof.create_ms, g_call_prof.h2d_ms,     g_call_prof.loop_ms, g_call_prof.finalize_ms,
+                         g_call_prof.d2h_ms,    g_call_prof.destroy_ms, g_call_prof.total_ms};
+    if (!ms)
+        return GSLNLS_EINVAL;
+    for (int k = 0; k < cap && k < 7; ++k)
+        ms[k] = v[k];
+    return 7;
 }
 
 int gslnls_solver_served(const int *control_int, const gslnls_result *res)

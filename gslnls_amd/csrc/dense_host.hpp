@@ -12,6 +12,8 @@
 #include <stdio.h>
 #include <string.h>
 #include <vector>
+#include <thread>
+#include <sys/mman.h>
 #include "../../include/gslnls_core.h"
 #include "dense_kernels.hpp"
 #include "dense_persist.hpp"
@@ -119,6 +121,95 @@ inline double scaled_jtj_cond(const double *Ap, int P)
     return (emin > 0.0) ? emax / emin : INFINITY;
 }
 
+// where the milliseconds of the last one-shot gslnls_nls() went (gslnls_last_call_profile): the number .Call(C_nls)
+// delivers is create + H2D + loop + finalize + D2H + destroy, not the resident loop alone
+struct CallProfile
+{
+    double create_ms = 0, h2d_ms = 0, loop_ms = 0, finalize_ms = 0, d2h_ms = 0, destroy_ms = 0, total_ms = 0;
+};
+inline CallProfile g_call_prof;
+
+// Result vectors of a one-shot call (resid: n, grad: n x p doubles) are as a rule pages their process has not touched yet --
+// a large Rf_allocVector / malloc is a fresh mmap -- and a device-to-host copy into such pages runs at the speed of the
+// page faults it raises (scripts/pcie_probe/fresh_pages.hip: 1-12 GB/s against 55 GB/s into resident pages).  A helper
+// thread faults them in while the data uploads and the fit runs.  MADV_POPULATE_WRITE leaves the contents alone, so it may
+// still be running when the copy starts; where the kernel does not know it (< 5.14) the pages are touched with an atomic
+// `or 0` (a write fault that changes nothing), and the copy waits for that to finish.
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+struct OutputPrefault
+{
+    std::thread th;
+    bool running = false, touching = false;
+    static constexpr size_t MIN_BYTES = (size_t)1 << 20;
+    // does this kernel know MADV_POPULATE_WRITE (Linux >= 5.14)?  asked once, on a page of our own
+    static bool populate_supported()
+    {
+        static const bool ok = [] {
+            void *q = mmap(nullptr, 4096, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (q == MAP_FAILED)
+                return false;
+            const bool r = madvise(q, 4096, MADV_POPULATE_WRITE) == 0;
+            munmap(q, 4096);
+            return r;
+        }();
+        return ok;
+    }
+    static void populate(char *p, size_t bytes, bool touch)
+    {
+        const uintptr_t a = ((uintptr_t)p + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)p + bytes) & ~(uintptr_t)4095;
+        if (e <= a)
+            return;
+        if (!touch && madvise((void *)a, e - a, MADV_POPULATE_WRITE) == 0)
+            return;
+        if (!touch)
+            return; // (refused for this range: leave the pages to the copy)
+        for (uintptr_t q = a; q < e; q += 4096)
+            (void)__atomic_fetch_or((unsigned char *)q, (unsigned char)0, __ATOMIC_RELAXED);
+    }
+    void start(double *a, size_t na, double *b, size_t nb)
+    {
+        // Measured on the MI355X host (scripts/pcie_probe, gpurun_out r04a): populating 32 MB while the upload and the fit
+        // run takes 6 ms instead of 1.5 (the populate and the driver's own page pinning serialise on the address space's
+        // lock), and a copy that starts before it has finished drops from 3.6 ms to 10 ms.  Off unless asked for.
+        static const bool on = getenv("GSLNLS_PREFAULT") && getenv("GSLNLS_PREFAULT")[0] == '1';
+        if (!on || running)
+            return;
+        if (!a || na < MIN_BYTES)
+            na = 0;
+        if (!b || nb < MIN_BYTES)
+            nb = 0;
+        if (na + nb == 0)
+            return;
+        running = true;
+        touching = !populate_supported();
+        const bool touch = touching;
+        th = std::thread([=] {
+            if (na)
+                populate((char *)a, na, touch);
+            if (nb)
+                populate((char *)b, nb, touch);
+        });
+    }
+    void join()
+    {
+        if (running)
+        {
+            th.join();
+            running = false;
+        }
+    }
+    // the touching fallback modifies (rewrites) bytes: it must be over before a copy engine writes the same pages
+    void before_d2h()
+    {
+        static const bool wait = getenv("GSLNLS_PREFAULT_WAIT") != nullptr;
+        if (running && (wait || touching))
+            join();
+    }
+    ~OutputPrefault() { join(); }
+};
+
 struct LargeOps; // large_host.hpp
 
 struct DenseBase
@@ -151,6 +242,7 @@ struct DenseBase
                              double *records, int records_on_device, float *kernel_ms) = 0;
     virtual int debug_stamps(int jac, const double *theta, int warm, unsigned long long *out, int *nrows) = 0;
     int n = 0, p = 0;
+    OutputPrefault *prefault = nullptr; // set by gslnls_nls() around its solve: pack() consults it before the D2H copies
     const MsComm *batch_comm = nullptr; // communicator of mstart_batch's gathered form (set by the C entry point)
 };
 
@@ -333,17 +425,19 @@ struct DenseFit : DenseBase
                 cap_rows = n;
             }
             owns_data = true;
-            GSLNLS_HIP_OK(hipMemcpy(d_x, fn->x, nb * M::NX, hipMemcpyHostToDevice));
-            GSLNLS_HIP_OK(hipMemcpy(d_y, y, nb, hipMemcpyHostToDevice));
-            if (swts)
+            if (swts && !sw_owned)
             {
-                if (!sw_owned)
-                {
-                    GSLNLS_HIP_OK(hipMalloc(&d_sw, sizeof(double) * (size_t)cap_rows));
-                    sw_owned = true;
-                }
-                GSLNLS_HIP_OK(hipMemcpy(d_sw, swts, nb, hipMemcpyHostToDevice));
+                GSLNLS_HIP_OK(hipMalloc(&d_sw, sizeof(double) * (size_t)cap_rows));
+                sw_owned = true;
             }
+            // the three uploads go out back to back on the problem's stream and are waited for once
+            const double t_h2d = now_s();
+            GSLNLS_HIP_OK(hipMemcpyAsync(d_x, fn->x, nb * M::NX, hipMemcpyHostToDevice, stream));
+            GSLNLS_HIP_OK(hipMemcpyAsync(d_y, y, nb, hipMemcpyHostToDevice, stream));
+            if (swts)
+                GSLNLS_HIP_OK(hipMemcpyAsync(d_sw, swts, nb, hipMemcpyHostToDevice, stream));
+            GSLNLS_HIP_OK(hipStreamSynchronize(stream));
+            g_call_prof.h2d_ms = 1e3 * (now_s() - t_h2d);
         }
         for (int c = 0; c < M::NX; ++c)
             ctx.x[c] = d_x + (size_t)c * n;
@@ -934,14 +1028,20 @@ struct DenseFit : DenseBase
         const int maxiter = ctx.prm.maxiter;
         const bool ok = (s.status == ST_SUCCESS || s.status == ST_EMAXITER);
         const bool want_vecs = ok && (out->resid || out->grad);
+        double t_fin = 0.0;
         if (want_vecs || (ok && out->covar))
         {
             if (out->resid && !d_resid)
                 GSLNLS_HIP_OK(hipMalloc(&d_resid, sizeof(double) * (size_t)n));
             if (out->grad && !d_grad)
                 GSLNLS_HIP_OK(hipMalloc(&d_grad, sizeof(double) * (size_t)n * P));
+            if (prefault)
+                prefault->before_d2h();
+            t_fin = now_s();
+            hipEventRecord(ev0, stream);
             launch_finalize(jacmode, last_parity, out->resid ? d_resid : nullptr, out->grad ? d_grad : nullptr,
                             d_covar);
+            hipEventRecord(ev1, stream);
             if (out->resid)
                 GSLNLS_HIP_OK(hipMemcpyAsync(out->resid, d_resid, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost,
                                              stream));
@@ -961,6 +1061,13 @@ struct DenseFit : DenseBase
         }
         if (trace || want_vecs || (ok && out->covar))
             GSLNLS_HIP_OK(hipStreamSynchronize(stream)); // only when something n- or trace-sized was requested
+        if (t_fin > 0.0)
+        {
+            float fms = 0.f;
+            (void)hipEventElapsedTime(&fms, ev0, ev1);
+            g_call_prof.finalize_ms = fms;
+            g_call_prof.d2h_ms = 1e3 * (now_s() - t_fin) - fms;
+        }
         for (int k = 0; k < P; ++k)
             if (out->par)
                 out->par[k] = ok ? s.x[k] : start[k];

@@ -25,6 +25,7 @@ GSLNLS_EMBED(rowops, "rowops.hpp")
 GSLNLS_EMBED(dense_kernels, "dense_kernels.hpp")
 GSLNLS_EMBED(wide_core, "wide_core.hpp")
 GSLNLS_EMBED(wide_kernels, "wide_kernels.hpp")
+GSLNLS_EMBED(bd_model_kernels, "bd_model_kernels.hpp")
 
 namespace gslnls
 {
@@ -39,6 +40,7 @@ const RtcHeader *rtc_embedded_headers(int *count)
         {"dense_kernels.hpp", gslnls_rtc_dense_kernels_begin, gslnls_rtc_dense_kernels_end},
         {"wide_core.hpp", gslnls_rtc_wide_core_begin, gslnls_rtc_wide_core_end},
         {"wide_kernels.hpp", gslnls_rtc_wide_kernels_begin, gslnls_rtc_wide_kernels_end},
+        {"bd_model_kernels.hpp", gslnls_rtc_bd_model_kernels_begin, gslnls_rtc_bd_model_kernels_end},
     };
     *count = (int)(sizeof h / sizeof h[0]);
     return h;

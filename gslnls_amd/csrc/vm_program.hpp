@@ -68,6 +68,10 @@ using VmProgram = VmProgramT<VM_MAX_OPS, VM_MAX_CONST, VM_MAX_P, true>;
 // as C++ for the in-process compiler (rtc_host.hpp), so its size is bounded by compile time, not by constant memory
 constexpr int WIDE_MAX_P = 64, WIDE_NX = 8, WIDE_MAX_OPS = 8192, WIDE_MAX_CONST = 256;
 using WideProgram = VmProgramT<WIDE_MAX_OPS, WIDE_MAX_CONST, WIDE_MAX_P, false>;
+// formulas with more than 64 parameters (csrc/bd_host.hpp: the Jacobian as a matrix in HBM): slot numbers are 16 bits
+constexpr int BIG_MAX_P = 512, BIG_MAX_OPS = 49152, BIG_MAX_CONST = 2048;
+using BigProgram = VmProgramT<BIG_MAX_OPS, BIG_MAX_CONST, BIG_MAX_P, false>;
+static_assert(2 * BIG_MAX_P + WIDE_NX + BIG_MAX_CONST + BIG_MAX_OPS < 65536, "slot numbers are unsigned short");
 static_assert(VM_MAX_SLOTS < 4096, "slot numbers are packed in 12 bits");
 
 GSLNLS_HD bool vm_is_binary(unsigned op) { return op <= VM_DIV || op == VM_POW; }

@@ -51,6 +51,7 @@ struct WAdvanceArgs
     unsigned int seq;
     int launch_idx;
     int p; // (the same as state->p: the loads of a call are issued at once instead of after a first round trip for p)
+    int pivoted; // 1: always the reference's pivoted, modified Cholesky (GSLNLS_WIDE_PIVOTED=1); 0: natural order first
 };
 
 #if defined(__HIPCC__) || defined(__HIPCC_RTC__)
@@ -509,27 +510,216 @@ __device__ __forceinline__ void wide_solve_reg(WideLds &L, int p, double mu, con
     wide_lds_sync();
 }
 
-__device__ __forceinline__ void wide_solve(WideLds &L, int p, double mu, const double *rhs, double *sol, int lane)
+// v of row 16 g + l % 16 in lane l, g = 0 .. R - 1: the operands of the DPP row broadcasts of a rank-one update
+template <int R>
+__device__ __forceinline__ void wide_row_copies(double v, double (&vb)[R])
+{
+    vb[0] = v;
+    if constexpr (R > 1)
+    {
+        const long long bits = __double_as_longlong(v);
+        const unsigned int lo = (unsigned int)(bits & 0xffffffffll), hi = (unsigned int)(bits >> 32);
+        const auto l16 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto h16 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        // l16[0] = rows [0, 0, 2, 2], l16[1] = rows [1, 1, 3, 3]
+        if constexpr (R == 2)
+        {
+            vb[0] = __longlong_as_double(((long long)h16[0] << 32) | l16[0]);
+            vb[1] = __longlong_as_double(((long long)h16[1] << 32) | l16[1]);
+        }
+        else
+        {
+            const auto l0 = __builtin_amdgcn_permlane32_swap(l16[0], l16[0], false, false);
+            const auto h0 = __builtin_amdgcn_permlane32_swap(h16[0], h16[0], false, false);
+            const auto l1 = __builtin_amdgcn_permlane32_swap(l16[1], l16[1], false, false);
+            const auto h1 = __builtin_amdgcn_permlane32_swap(h16[1], h16[1], false, false);
+            vb[0] = __longlong_as_double(((long long)h0[0] << 32) | l0[0]); // rows [0, 0, 0, 0]
+            vb[2] = __longlong_as_double(((long long)h0[1] << 32) | l0[1]); // rows [2, 2, 2, 2]
+            vb[1] = __longlong_as_double(((long long)h1[0] << 32) | l1[0]);
+            if constexpr (R > 3)
+                vb[3] = __longlong_as_double(((long long)h1[1] << 32) | l1[1]);
+        }
+    }
+    // (a DPP operand written by the instruction before: 2 wait states)
+    if constexpr (R == 1)
+        asm volatile("s_nop 1" : "+v"(vb[0]));
+    else if constexpr (R == 2)
+        asm volatile("s_nop 1" : "+v"(vb[0]), "+v"(vb[1]));
+    else if constexpr (R == 3)
+        asm volatile("s_nop 1" : "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]));
+    else
+        asm volatile("s_nop 1" : "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]));
+}
+
+// columns K .. PW - 1 of the rank-one update S -= t v^T (K a literal: the DPP control and the register are immediates)
+template <int K, int PW, int R>
+__device__ __forceinline__ void wide_chol_update(double (&m)[PW], const double (&vb)[R], double tn)
+{
+    if constexpr (K < PW)
+    {
+        wide_fmac_rowbcast<(K & 15)>(m[K], vb[K >> 4], tn);
+        wide_chol_update<K + 1, PW, R>(m, vb, tn);
+    }
+}
+
+// The same system WITHOUT the pivot search, for the matrices an LM step actually meets: J^T J + mu D^2 with mu > 0 is
+// positive definite, and on a numerically positive definite matrix gsl_linalg_mcholesky never modifies anything (with the
+// largest diagonal as pivot, theta^2 / beta <= d_jj always) -- its pivoting only decides the ORDER in which the same L D L^T
+// is rounded.  Taking the rows in their natural order makes every register index a literal: no search (25 instructions
+// of the ~145 a pivoted step issues), no computed jump for the pivot column, no permutation to keep, and the rank-one
+// update of step j touches only the columns behind j -- ~42 instructions per step instead of ~145 on the lone wavefront
+// that is the critical path of every trial step.  Same arithmetic per element as wide_solve_reg (t = v / alpha as
+// (1 / alpha) v, S -= t v^T, the forward substitution riding along, D^-1, then L^T by columns): when the largest diagonal
+// happens to come first at every step the two give the same bits.
+// Returns false -- nothing written -- as soon as a pivot is not safely positive (d_jj <= 1e-12 of the entry it started
+// as, or NaN): the matrix is not numerically positive definite, the caller runs the modified, pivoted factorisation.
+template <int PW>
+__device__ __forceinline__ bool wide_chol_reg(WideLds &L, int p, double mu, const double *rhs, double *sol, int lane)
+{
+    constexpr int R = PW / 16;
+    constexpr int LD = WP + 1;
+    double *T = L.M;
+    const bool mine = lane < p;
+    double m[PW];
+    {
+        const int base = lane * (lane + 1) / 2;
+#pragma unroll
+        for (int k = 0; k < PW; ++k)
+        {
+            const int idx = k < lane ? base + k : k * (k + 1) / 2 + lane;
+            const double a = L.A[(mine && k < p) ? idx : 0];
+            m[k] = (mine && k < p && k != lane) ? a : 0.0; // (the diagonal lives in dg)
+        }
+    }
+    double dg = 0.0, b = 0.0;
+    if (mine)
+    {
+        dg = L.A[tri(lane, lane)] + mu * L.diag[lane] * L.diag[lane];
+        b = rhs[lane];
+    }
+    const double thr = 1e-12 * dg;
+    double dinv = 0.0;
+    // step j with j a LITERAL (a recursion over WideInt<j>, not a loop the compiler may or may not unroll: with a run-time
+    // j the rows m[] are indexed dynamically and live in scratch memory)
+    auto step = [&](auto self, auto jj) __attribute__((always_inline)) -> bool {
+        constexpr int j = decltype(jj)::value;
+        if constexpr (j >= PW)
+            return true;
+        else
+        {
+            if (j >= p)
+                return true;
+            const double dj = wide_bcast(dg, j), tj = wide_bcast(thr, j);
+            if (!(dj > tj))
+                return false;
+            const double ainv = 1.0 / dj;
+            const bool below = lane > j;
+            const double v = below ? m[j] : 0.0; // S[i][j] of the rows still to be eliminated
+            const double t = ainv * v;           // the multiplier l_i
+            dg -= t * v;
+            const double bj = wide_bcast(b, j);
+            b = below ? b - t * bj : b;
+            dinv = lane == j ? ainv : dinv;
+            T[j * LD + lane] = t;
+            if constexpr (j + 1 < PW)
+            {
+                double vb[R];
+                wide_row_copies<R>(v, vb);
+                wide_chol_update<j + 1, PW, R>(m, vb, -t);
+            }
+            return self(self, WideInt<j + 1>{});
+        }
+    };
+    const bool ok = step(step, WideInt<0>{});
+    if (!ok)
+        return false;
+    b *= dinv;
+    wide_lds_sync();
+    // L^T w = z by columns, the last one first: row i needs L[j][i] = the multiplier lane j stored at step i, T[i][j]
+    {
+        const double *Trow = T + lane * LD;
+        int j = p - 1;
+        for (; j >= 4; j -= 4)
+        {
+            const double t0 = Trow[j], t1 = Trow[j - 1], t2 = Trow[j - 2], t3 = Trow[j - 3];
+            double w = wide_bcast(b, j);
+            if (lane < j)
+                b -= t0 * w;
+            w = wide_bcast(b, j - 1);
+            if (lane < j - 1)
+                b -= t1 * w;
+            w = wide_bcast(b, j - 2);
+            if (lane < j - 2)
+                b -= t2 * w;
+            w = wide_bcast(b, j - 3);
+            if (lane < j - 3)
+                b -= t3 * w;
+        }
+        for (; j >= 1; --j)
+        {
+            const double w = wide_bcast(b, j);
+            if (lane < j)
+                b -= Trow[j] * w;
+        }
+    }
+    if (mine)
+        sol[lane] = b;
+    wide_lds_sync();
+    return true;
+}
+
+// the damped solve of one LM step: natural-order L D L^T first, gsl_linalg_mcholesky (modified, pivoted) when the matrix
+// is not numerically positive definite -- or always, when `pivoted` asks for the reference's order of operations
+template <int PW>
+__device__ __forceinline__ void wide_solve_pw(WideLds &L, int p, double mu, const double *rhs, double *sol, int lane, int pivoted)
+{
+    if (!pivoted && wide_chol_reg<PW>(L, p, mu, rhs, sol, lane))
+        return;
+    wide_solve_reg<PW>(L, p, mu, rhs, sol, lane);
+}
+
+__device__ __forceinline__ void wide_solve(WideLds &L, int p, double mu, const double *rhs, double *sol, int lane, int pivoted = 0)
 {
     // (noinline-sized bodies, one per register-file width; the caller has ONE call site)
     if (p <= 16)
-        wide_solve_reg<16>(L, p, mu, rhs, sol, lane);
+        wide_solve_pw<16>(L, p, mu, rhs, sol, lane, pivoted);
     else if (p <= 32)
-        wide_solve_reg<32>(L, p, mu, rhs, sol, lane);
+        wide_solve_pw<32>(L, p, mu, rhs, sol, lane, pivoted);
     else if (p <= 48)
-        wide_solve_reg<48>(L, p, mu, rhs, sol, lane);
+        wide_solve_pw<48>(L, p, mu, rhs, sol, lane, pivoted);
     else
-        wide_solve_reg<64>(L, p, mu, rhs, sol, lane);
+        wide_solve_pw<64>(L, p, mu, rhs, sol, lane, pivoted);
 }
+
+// the scalars of the state while a call works on them (registers, identical in every lane) + what the call decided
+struct WideCtx
+{
+    double fnorm2, mu, nu, delta, avratio, chisq0, chisq1, chisq_init;
+    int bad_steps, niter, phase, status, info, nevalf, nevaldf, nevalfvv;
+    int niter_before, phase_before;
+    int want;      // the damped solve this call needs: 0 none, 1 acceleration (rhs = -J^T fvv), 2 velocity (rhs = -g)
+    bool rejected; // the velocity solve follows a rejected trial: same J^T J, D, g as before the pass, mu <- mu nu
+    bool active;   // false: a launch enqueued past the end of the fit (nothing to do, nothing written)
+};
 
 // ONE wavefront (64 lanes >= p: lane k owns component k of every p-vector); all 64 lanes call.  Scalars of the state live
 // in registers, identical in every lane; LDS traffic between lanes is ordered by wide_lds_sync().
-__device__ __forceinline__ void wide_advance(const WAdvanceArgs &a, WideLds &L)
+// A call is three pieces: wide_advance_pre (state -> LDS, the decision of trust_iterate_lu_LD, right-hand side of the
+// damped system in L.rhs), the solve (wide_solve / wide_solve_reg<PW>: into L.acc when c.want == 1, L.vel when 2), and
+// wide_advance_post (trial point, state -> memory).  Kernels that carry a second user of the solve (the speculative
+// solve of wide_kernels.hpp) put ONE call site of it between the two.
+// PFIX > 0: p is known when the kernel is compiled (the formula's kernels, wide_kernels.hpp): the staging loops and the
+// sums are cut to size and the other sizes are not compiled at all.
+template <int PFIX = 0>
+__device__ __forceinline__ void wide_advance_pre(const WAdvanceArgs &a, WideLds &L, WideCtx &c)
 {
     const int lane = threadIdx.x & 63;
     WState *S = a.state;
-    const int p = a.p, NA = p * (p + 1) / 2;
+    const int p = PFIX > 0 ? PFIX : a.p, NA = p * (p + 1) / 2;
     const LmParams prm = a.prm;
+    c.want = 0;
+    c.rejected = false;
+    c.active = true;
     const int phase_in = S->phase; // (checked below, after every load of the call is in flight)
     const double *tot = a.totals;
     const double *rA = tot + 2;
@@ -573,7 +763,9 @@ __device__ __forceinline__ void wide_advance(const WAdvanceArgs &a, WideLds &L)
             }
         }
     };
-    if (NA <= 64 * 3)
+    if constexpr (PFIX > 0)
+        stage_matrices(WideInt<(PFIX * (PFIX + 1) / 2 + 63) / 64>{});
+    else if (NA <= 64 * 3)
         stage_matrices(WideInt<3>{});
     else if (NA <= 64 * 9)
         stage_matrices(WideInt<9>{});
@@ -582,7 +774,10 @@ __device__ __forceinline__ void wide_advance(const WAdvanceArgs &a, WideLds &L)
     else
         stage_matrices(WideInt<(WNA + 63) / 64>{});
     if (phase_in == PH_DONE)
-        return; // (a launch enqueued past the end of the fit: nothing was written)
+    {
+        c.active = false;
+        return; // (a launch enqueued past the end of the fit: nothing is written)
+    }
     if (mine)
     {
         L.x[lane] = sv[0];
@@ -677,23 +872,6 @@ __device__ __forceinline__ void wide_advance(const WAdvanceArgs &a, WideLds &L)
         bad_steps = 0;
         return true;
     };
-    auto set_trial = [&]() { // trust_trial_step_lu
-        if (mine)
-        {
-            const double dxi = L.dx[lane], xi = L.x[lane];
-            double xt = xi + dxi;
-            if (prm.has_bounds)
-            {
-                if (xt < L.lo[lane])
-                    xt = xi + (dxi / fmax(fabs(dxi), delta) * fabs(xi - L.lo[lane]));
-                else if (xt > L.up[lane])
-                    xt = xi + (dxi / fmax(fabs(dxi), delta) * fabs(xi - L.up[lane]));
-            }
-            L.xt[lane] = xt;
-        }
-        wide_lds_sync();
-    };
-
     bool step = false;
     int want = 0; // which damped solve this call ends with: 1 acceleration, 2 velocity
     if (phase == PH_INIT)
@@ -810,6 +988,7 @@ __device__ __forceinline__ void wide_advance(const WAdvanceArgs &a, WideLds &L)
             nu *= 2.0;
             if (++bad_steps > 15)
                 itstatus = ST_ENOPROG;
+            c.rejected = itstatus == ST_CONTINUE;
         }
         step = (itstatus == ST_CONTINUE) ? true : end_iteration(itstatus);
     }
@@ -821,8 +1000,46 @@ __device__ __forceinline__ void wide_advance(const WAdvanceArgs &a, WideLds &L)
         if (mine)
             L.rhs[lane] = want == 1 ? -r_g : -L.g[lane];
         wide_lds_sync();
-        wide_solve(L, p, mu, L.rhs, want == 1 ? L.acc : L.vel, lane);
     }
+    c.fnorm2 = fnorm2, c.mu = mu, c.nu = nu, c.delta = delta, c.avratio = avratio, c.chisq0 = chisq0, c.chisq1 = chisq1,
+    c.chisq_init = chisq_init;
+    c.bad_steps = bad_steps, c.niter = niter, c.phase = phase, c.status = status, c.info = info, c.nevalf = nevalf,
+    c.nevaldf = nevaldf, c.nevalfvv = nevalfvv;
+    c.niter_before = niter_before, c.phase_before = phase_before;
+    c.want = want;
+}
+
+template <int PFIX = 0>
+__device__ __forceinline__ void wide_advance_post(const WAdvanceArgs &a, WideLds &L, const WideCtx &c)
+{
+    if (!c.active)
+        return;
+    const int lane = threadIdx.x & 63;
+    WState *S = a.state;
+    const int p = PFIX > 0 ? PFIX : a.p, NA = p * (p + 1) / 2;
+    const LmParams prm = a.prm;
+    const bool mine = lane < p;
+    double fnorm2 = c.fnorm2, mu = c.mu, nu = c.nu, delta = c.delta, avratio = c.avratio, chisq0 = c.chisq0, chisq1 = c.chisq1,
+           chisq_init = c.chisq_init;
+    int bad_steps = c.bad_steps, niter = c.niter, phase = c.phase, status = c.status, info = c.info, nevalf = c.nevalf,
+        nevaldf = c.nevaldf, nevalfvv = c.nevalfvv;
+    const int niter_before = c.niter_before, phase_before = c.phase_before, want = c.want;
+    auto set_trial = [&]() { // trust_trial_step_lu
+        if (mine)
+        {
+            const double dxi = L.dx[lane], xi = L.x[lane];
+            double xt = xi + dxi;
+            if (prm.has_bounds)
+            {
+                if (xt < L.lo[lane])
+                    xt = xi + (dxi / fmax(fabs(dxi), delta) * fabs(xi - L.lo[lane]));
+                else if (xt > L.up[lane])
+                    xt = xi + (dxi / fmax(fabs(dxi), delta) * fabs(xi - L.up[lane]));
+            }
+            L.xt[lane] = xt;
+        }
+        wide_lds_sync();
+    };
     if (want == 1)
     {
         const double ai = mine ? L.acc[lane] : 0.0, vi = mine ? L.vel[lane] : 0.0;
@@ -925,6 +1142,15 @@ __device__ __forceinline__ void wide_advance(const WAdvanceArgs &a, WideLds &L)
         if (lane == 0)
             __hip_atomic_store(a.done_seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+__device__ __forceinline__ void wide_advance(const WAdvanceArgs &a, WideLds &L)
+{
+    WideCtx c;
+    wide_advance_pre(a, L, c);
+    if (c.active && c.want)
+        wide_solve(L, a.p, c.mu, L.rhs, c.want == 1 ? L.acc : L.vel, threadIdx.x & 63, a.pivoted);
+    wide_advance_post(a, L, c);
 }
 
 #endif // __HIPCC__

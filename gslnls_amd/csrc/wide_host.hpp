@@ -29,7 +29,7 @@ namespace gslnls
 // by other XCDs, a load is a ~2 us fabric round trip, and 256 of them one after the other took 57 us), then the 16
 // group sums are added in group order.  Fixed order => bit-identical results run to run.
 constexpr int WIDE_RED_T = 1024;
-__global__ __launch_bounds__(WIDE_RED_T) void wide_reduce_kernel(const double *partials, int G, int NV, double *totals,
+__global__ __launch_bounds__(WIDE_RED_T) void wide_reduce_kernel(const double *partials, int G, int NV, int NVP, double *totals,
                                                                  const WState *state)
 {
     __shared__ double part[16][64];
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(WIDE_RED_T) void wide_reduce_kernel(const double *p
         for (int k = 0; k < PER; ++k)
         {
             const int g = q + 16 * k;
-            t[k] = g < G ? partials[(size_t)g * NV + v] : 0.0;
+            t[k] = g < G ? partials[(size_t)g * NVP + v] : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < PER; ++k)
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void wide_cooks_kernel(const double *resid, co
 
 // test hook: the damped solve alone (tests compare it with the oracle's modified Cholesky)
 __global__ __launch_bounds__(64) void wide_solve_debug_kernel(int p, const double *Ap, const double *diag, double mu,
-                                                              const double *rhs, double *sol)
+                                                              const double *rhs, double *sol, int pivoted)
 {
     __shared__ WideLds L;
     const int lane = threadIdx.x;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64) void wide_solve_debug_kernel(int p, const doubl
         L.rhs[lane] = rhs[lane];
     }
     wide_lds_sync();
-    wide_solve(L, p, mu, L.rhs, L.sol, lane);
+    wide_solve(L, p, mu, L.rhs, L.sol, lane, pivoted);
     if (lane < p)
         sol[lane] = L.sol[lane];
 }
@@ -150,6 +150,10 @@ inline std::string rtc_wide_source(const WideProgram &pr, int nx_model)
 inline std::string rtc_wide_pass_expr(int jacmode, int PW)
 {
     return "&gslnls::wide_pass_kernel<gslnls::ModelJit, " + std::to_string(jacmode) + ", " + std::to_string(PW) + ">";
+}
+inline std::string rtc_wide_step_expr(int jacmode, int PW)
+{
+    return "&gslnls::wide_step_kernel<gslnls::ModelJit, " + std::to_string(jacmode) + ", " + std::to_string(PW) + ">";
 }
 inline std::string rtc_wide_finalize_expr(int jacmode)
 {
@@ -214,21 +218,34 @@ struct WideMsEvaluator : MsEvaluator
 struct WideFit : DenseBase
 {
     WideProgram *prog = nullptr; // (45 KB: on the heap)
-    int nx = 1, PW = 16, G = 1, NV = 0;
+    int nx = 1, PW = 16, G = 1, NV = 0, NVP = 0; // NVP: doubles from one partial set to the next (NV rounded up to even)
     bool owns_data = false, sw_owned = false;
     double *d_x = nullptr, *d_y = nullptr, *d_sw = nullptr;
     const double *cur_sw = nullptr;
     WState *d_state = nullptr, *h_state = nullptr; // h_state: pinned + mapped, [0] staging of the start, [1] final state
     volatile unsigned int *h_done = nullptr;
     double *d_partials = nullptr, *d_totals = nullptr;
+    // one launch per trial step (wide_kernels.hpp): level-1 sums and hand-off words of the in-launch reduction
+    double *d_gsums = nullptr;
+    WFuseBuf *d_fb = nullptr;
+    unsigned long long *d_stamps = nullptr; // GSLNLS_WIDE_STAMPS=1 (developer): phase stamps of the fused kernel
+    int fuse = WIDE_FUSE_STEP; // GSLNLS_WIDE_FUSE = 0: pass, reduce and advance as three launches (the round-3 chain)
+    int spec = 1;              // GSLNLS_WIDE_SPEC = 0: no speculative solve of the step that follows a rejection
+    int pivoted = 0;           // GSLNLS_WIDE_PIVOTED = 1: every damped solve by the reference's pivoted modified Cholesky
     double *d_ssrtrace = nullptr, *d_partrace = nullptr, *d_resid = nullptr, *d_grad = nullptr;
     int trace_cap = 0;
     unsigned int seq = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string rtc_src;
-    std::shared_ptr<RtcEntry> rtc[3];
+    std::shared_ptr<RtcEntry> rtc[3], rtc_step[3];
     hipFunction_t fn_pass[3] = {nullptr, nullptr, nullptr}, fn_final[3] = {nullptr, nullptr, nullptr};
+    // the one-launch-per-step kernel of the formula: several seconds of compiler, so it is built on the background thread
+    // (GSLNLS_LOWER_JIT: now) while fits run pass | reduce | advance as three launches, and bound when it is ready --
+    // same sums in the same order, same LM step: the switch changes no bit of any result
+    hipFunction_t fn_step[3] = {nullptr, nullptr, nullptr};
+    bool step_failed[3] = {false, false, false};
+    int lowering = GSLNLS_LOWER_AUTO;
     double ev_ms_total = 0.0;
     long long ev_launches_total = 0;
     float last_ms = 0.f;
@@ -256,6 +273,9 @@ struct WideFit : DenseBase
             (void)hipHostFree(h_state);
         hipFree(d_partials);
         hipFree(d_totals);
+        hipFree(d_gsums);
+        hipFree(d_fb);
+        hipFree(d_stamps);
         hipFree(d_ssrtrace);
         hipFree(d_partrace);
         hipFree(d_resid);
@@ -276,6 +296,7 @@ struct WideFit : DenseBase
         nx = fn->nx > 0 ? fn->nx : 1;
         PW = 16 * ((p + 15) / 16);
         NV = 2 + p * (p + 1) / 2 + p;
+        NVP = (NV + 1) & ~1;
         const long long tiles = ((long long)n + 63) / 64;
         long long g = (tiles + (WIDE_T / 64) - 1) / (WIDE_T / 64);
         // one workgroup per CU for the wide tiles (PW >= 48: LDS), two below
@@ -298,25 +319,44 @@ struct WideFit : DenseBase
             owns_data = true;
             GSLNLS_HIP_OK(hipMalloc(&d_x, nb * nx));
             GSLNLS_HIP_OK(hipMalloc(&d_y, nb));
-            if (fn->nx > 0)
-                GSLNLS_HIP_OK(hipMemcpy(d_x, fn->x, nb * nx, hipMemcpyHostToDevice));
-            else
-                GSLNLS_HIP_OK(hipMemset(d_x, 0, nb));
-            GSLNLS_HIP_OK(hipMemcpy(d_y, y, nb, hipMemcpyHostToDevice));
             if (swts)
             {
                 GSLNLS_HIP_OK(hipMalloc(&d_sw, nb));
                 sw_owned = true;
-                GSLNLS_HIP_OK(hipMemcpy(d_sw, swts, nb, hipMemcpyHostToDevice));
             }
+            const double t_h2d = now_s();
+            if (fn->nx > 0)
+                GSLNLS_HIP_OK(hipMemcpyAsync(d_x, fn->x, nb * nx, hipMemcpyHostToDevice, stream));
+            else
+                GSLNLS_HIP_OK(hipMemsetAsync(d_x, 0, nb, stream));
+            GSLNLS_HIP_OK(hipMemcpyAsync(d_y, y, nb, hipMemcpyHostToDevice, stream));
+            if (swts)
+                GSLNLS_HIP_OK(hipMemcpyAsync(d_sw, swts, nb, hipMemcpyHostToDevice, stream));
+            GSLNLS_HIP_OK(hipStreamSynchronize(stream));
+            g_call_prof.h2d_ms = 1e3 * (now_s() - t_h2d);
         }
         cur_sw = swts ? d_sw : nullptr;
         GSLNLS_HIP_OK(hipMalloc(&d_state, sizeof(WState)));
         GSLNLS_HIP_OK(hipHostMalloc(&h_state, sizeof(WState) * 2 + 64, hipHostMallocMapped));
         memset(h_state, 0, sizeof(WState) * 2 + 64);
         h_done = reinterpret_cast<volatile unsigned int *>(reinterpret_cast<char *>(h_state) + sizeof(WState) * 2);
-        GSLNLS_HIP_OK(hipMalloc(&d_partials, sizeof(double) * (size_t)G * NV));
-        GSLNLS_HIP_OK(hipMalloc(&d_totals, sizeof(double) * (size_t)NV));
+        GSLNLS_HIP_OK(hipMalloc(&d_partials, sizeof(double) * (size_t)G * NVP));
+        GSLNLS_HIP_OK(hipMalloc(&d_totals, sizeof(double) * (size_t)NVP));
+        GSLNLS_HIP_OK(hipMalloc(&d_gsums, sizeof(double) * (size_t)WIDE_NGRP * NVP));
+        GSLNLS_HIP_OK(hipMalloc(&d_fb, sizeof(WFuseBuf)));
+        GSLNLS_HIP_OK(hipMemset(d_fb, 0, sizeof(WFuseBuf)));
+        if (const char *e = getenv("GSLNLS_WIDE_FUSE"))
+            fuse = atoi(e) <= 0 ? WIDE_FUSE_NONE : WIDE_FUSE_STEP;
+        if (const char *e = getenv("GSLNLS_WIDE_SPEC"))
+            spec = atoi(e) != 0;
+        if (const char *e = getenv("GSLNLS_WIDE_PIVOTED"))
+            pivoted = atoi(e) != 0;
+        if (getenv("GSLNLS_WIDE_STAMPS"))
+        {
+            GSLNLS_HIP_OK(hipMalloc(&d_stamps, sizeof(unsigned long long) * 10 * 1024));
+            GSLNLS_HIP_OK(hipMemset(d_stamps, 0, sizeof(unsigned long long) * 10 * 1024));
+        }
+        lowering = fn->lowering;
         rtc_src = rtc_wide_source(*prog, nx);
         return GSLNLS_SUCCESS;
     }
@@ -325,7 +365,10 @@ struct WideFit : DenseBase
     int bind(int jm)
     {
         if (fn_pass[jm])
+        {
+            bind_step(jm, false);
             return 0;
+        }
         const std::string ep = rtc_wide_pass_expr(jm, PW), ef = rtc_wide_finalize_expr(jm);
         rtc[jm] = rtc_request(rtc_src, {ep, ef}, true);
         std::string msg;
@@ -343,7 +386,28 @@ struct WideFit : DenseBase
                     p, msg.c_str());
             return GSLNLS_E_UNSUPPORTED;
         }
+        bind_step(jm, lowering == GSLNLS_LOWER_JIT);
         return 0;
+    }
+
+    // ask for / pick up the fused kernel; a failed build leaves the three-launch chain in place (it is complete by itself)
+    void bind_step(int jm, bool wait)
+    {
+        if (!fuse || fn_step[jm] || step_failed[jm])
+            return;
+        const std::string es = rtc_wide_step_expr(jm, PW);
+        if (!rtc_step[jm] || wait)
+            rtc_step[jm] = rtc_request(rtc_src, {es}, wait);
+        const int st = rtc_step[jm]->state.load(std::memory_order_acquire);
+        if (st == RTC_READY)
+        {
+            std::string msg;
+            fn_step[jm] = rtc_function(*rtc_step[jm], es, msg);
+            if (!fn_step[jm])
+                step_failed[jm] = true;
+        }
+        else if (st == RTC_FAILED)
+            step_failed[jm] = true;
     }
 
     WPassArgs pass_args(const LmParams &prm) const
@@ -359,17 +423,50 @@ struct WideFit : DenseBase
         a.h_fvv = prm.h_fvv;
         a.fvv_analytic = prm.fvv_analytic;
         a.wf_only = wf_only;
+        a.fuse = WIDE_FUSE_NONE;
+        a.G = G;
+        a.spec = 0;
+        a.gsums = d_gsums;
+        a.totals = d_totals;
+        a.fb = d_fb;
+        a.stamps = d_stamps;
+        memset(&a.adv, 0, sizeof a.adv);
         return a;
     }
 
+    // one pass at the state's trial point -> d_totals (sums_at, the gsl_nls_large operators): one launch, or two
+    void launch_pass_totals(int jm, const LmParams &prm)
+    {
+        WPassArgs pa = pass_args(prm);
+        const bool fused = fuse && fn_step[jm];
+        pa.fuse = fused ? WIDE_FUSE_REDUCE : WIDE_FUSE_NONE;
+        void *args[] = {(void *)&pa};
+        (void)hipModuleLaunchKernel(fused ? fn_step[jm] : fn_pass[jm], G, 1, 1, WIDE_T, 1, 1, 0, stream, args, nullptr);
+        if (!fused)
+            hipLaunchKernelGGL(wide_reduce_kernel, dim3((NV + 63) / 64), dim3(WIDE_RED_T), 0, stream, d_partials, G, NV, NVP,
+                               d_totals, d_state);
+    }
+
+    int launches_per_step(int jm) const { return fuse && fn_step[jm] ? 1 : 3; }
+
+    // one trial step of trust_iterate_lu_LD (src/trust.c:445-546): rows -> sums -> LM step.  ONE launch: the workgroup
+    // that completes the totals runs the step, workgroup 0 (no rows) solves ahead for the case that the step rejects.
     void launch_step(int jm, const LmParams &prm, WAdvanceArgs &adv, int index)
     {
         WPassArgs pa = pass_args(prm);
-        void *args[] = {(void *)&pa};
-        (void)hipModuleLaunchKernel(fn_pass[jm], G, 1, 1, WIDE_T, 1, 1, 0, stream, args, nullptr);
-        hipLaunchKernelGGL(wide_reduce_kernel, dim3((NV + 63) / 64), dim3(WIDE_RED_T), 0, stream, d_partials, G, NV, d_totals,
-                           d_state);
         adv.launch_idx = index;
+        void *args[] = {(void *)&pa};
+        if (fuse && fn_step[jm])
+        {
+            pa.fuse = WIDE_FUSE_STEP;
+            pa.spec = spec;
+            pa.adv = adv;
+            (void)hipModuleLaunchKernel(fn_step[jm], G + pa.spec, 1, 1, WIDE_T, 1, 1, 0, stream, args, nullptr);
+            return;
+        }
+        (void)hipModuleLaunchKernel(fn_pass[jm], G, 1, 1, WIDE_T, 1, 1, 0, stream, args, nullptr);
+        hipLaunchKernelGGL(wide_reduce_kernel, dim3((NV + 63) / 64), dim3(WIDE_RED_T), 0, stream, d_partials, G, NV, NVP, d_totals,
+                           d_state);
         hipLaunchKernelGGL(wide_advance_kernel, dim3(1), dim3(WT_ADV), 0, stream, adv);
     }
 
@@ -411,6 +508,7 @@ struct WideFit : DenseBase
         GSLNLS_HIP_OK(hipMemcpyAsync(d_state, &s0, sizeof(WState), hipMemcpyHostToDevice, stream));
         seq += 1;
         WAdvanceArgs adv;
+        adv.pivoted = pivoted;
         adv.state = d_state;
         adv.totals = d_totals;
         adv.prm = prm;
@@ -475,17 +573,47 @@ struct WideFit : DenseBase
         }
         __sync_synchronize();
         last_ms = (float)(1e3 * (now_s() - t_begin));
-        last_launches = 3 * steps;
+        last_launches = launches_per_step(jm) * steps;
         pred_kind = kind;
         pred_steps = h_state[1].end_launch + 1;
         if (pred_steps < 1 || pred_steps > 4096)
             pred_steps = 0;
         GSLNLS_HIP_OK(hipStreamSynchronize(stream)); // trailing steps (no-ops) + the event pair
+        if (d_stamps && fuse && fn_step[jm])
+        {
+            const int ns = pred_steps > 0 && pred_steps < 1024 ? pred_steps : 0;
+            std::vector<unsigned long long> hs((size_t)10 * 1024);
+            (void)hipMemcpy(hs.data(), d_stamps, sizeof(unsigned long long) * hs.size(), hipMemcpyDeviceToHost);
+            static const char *nm[8] = {"rows", "partial+arrive1", "reduce1", "arrive2", "reduce2", "advance_pre", "solve/spec", "post"};
+            for (int kind = 0; kind < 2; ++kind)
+            {
+                double acc[8] = {0}, gap = 0;
+                int cnt = 0;
+                for (int k = 1; k < ns; ++k)
+                {
+                    const unsigned long long *o = &hs[(size_t)k * 10];
+                    const bool rej = (o[9] >> 16) & 1;
+                    if ((int)rej != kind || o[0] == 0)
+                        continue;
+                    for (int j = 0; j < 8; ++j)
+                        acc[j] += (double)(o[j + 1] - o[j]) * 0.01;
+                    gap += (double)(o[0] - hs[(size_t)(k - 1) * 10 + 8]) * 0.01;
+                    cnt += 1;
+                }
+                if (cnt)
+                {
+                    fprintf(stderr, "[wide stamps] %s steps (%d): end of previous step -> start %.2f us |", kind ? "rejected" : "accepted", cnt, gap / cnt);
+                    for (int j = 0; j < 8; ++j)
+                        fprintf(stderr, " %s %.2f", nm[j], acc[j] / cnt);
+                    fprintf(stderr, "\n");
+                }
+            }
+        }
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess)
         {
             ev_ms_total += ms;
-            ev_launches_total += 3 * steps;
+            ev_launches_total += launches_per_step(jm) * steps;
         }
         return GSLNLS_SUCCESS;
     }
@@ -514,6 +642,7 @@ struct WideFit : DenseBase
     {
         const WState &s = h_state[1];
         const bool ok = (s.status == ST_SUCCESS || s.status == ST_EMAXITER);
+        double t_fin = 0.0;
         if (ok && (out->resid || out->grad))
         {
             if (out->resid && !d_resid)
@@ -525,7 +654,12 @@ struct WideFit : DenseBase
             void *args[] = {(void *)&pa, (void *)&r, (void *)&g};
             int gf = (int)(((long long)n + 255) / 256);
             gf = gf > 2048 ? 2048 : (gf < 1 ? 1 : gf);
+            if (prefault)
+                prefault->before_d2h();
+            t_fin = now_s();
+            hipEventRecord(ev0, stream);
             (void)hipModuleLaunchKernel(fn_final[jm], gf, 1, 1, 256, 1, 1, 0, stream, args, nullptr);
+            hipEventRecord(ev1, stream);
             if (out->resid)
                 GSLNLS_HIP_OK(hipMemcpyAsync(out->resid, d_resid, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream));
             if (out->grad)
@@ -538,6 +672,13 @@ struct WideFit : DenseBase
                                          hipMemcpyDeviceToHost, stream));
         }
         GSLNLS_HIP_OK(hipStreamSynchronize(stream));
+        if (t_fin > 0.0)
+        {
+            float fms = 0.f;
+            (void)hipEventElapsedTime(&fms, ev0, ev1);
+            g_call_prof.finalize_ms = fms;
+            g_call_prof.d2h_ms = 1e3 * (now_s() - t_fin) - fms;
+        }
         for (int k = 0; k < p; ++k)
             if (out->par)
                 out->par[k] = ok ? s.x[k] : start[k];
@@ -601,11 +742,7 @@ struct WideFit : DenseBase
         s0.phase = PH_TRIAL;
         s0.p = p;
         GSLNLS_HIP_OK(hipMemcpyAsync(d_state, &s0, sizeof(WState), hipMemcpyHostToDevice, stream));
-        WPassArgs pa = pass_args(prm);
-        void *args[] = {(void *)&pa};
-        (void)hipModuleLaunchKernel(fn_pass[jm], G, 1, 1, WIDE_T, 1, 1, 0, stream, args, nullptr);
-        hipLaunchKernelGGL(wide_reduce_kernel, dim3((NV + 63) / 64), dim3(WIDE_RED_T), 0, stream, d_partials, G, NV, d_totals,
-                           d_state);
+        launch_pass_totals(jm, prm);
         GSLNLS_HIP_OK(hipMemcpyAsync(totals, d_totals, sizeof(double) * (size_t)NV, hipMemcpyDeviceToHost, stream));
         GSLNLS_HIP_OK(hipStreamSynchronize(stream));
         return hipGetLastError() == hipSuccess ? GSLNLS_SUCCESS : GSLNLS_E_NODEVICE;
@@ -641,6 +778,7 @@ struct WideFit : DenseBase
         seq += 1;
         WAdvanceArgs adv;
         memset(&adv, 0, sizeof adv);
+        adv.pivoted = pivoted;
         adv.state = d_state;
         adv.totals = d_totals;
         adv.prm = prm;

@@ -35,6 +35,23 @@ constexpr int WIDE_LD = 68;     // leading dimension of the tile (doubles)
 constexpr int WIDE_T = 256;     // threads per workgroup of the pass
 constexpr int WIDE_MAX_G = 512; // workgroups == partial sets (two per CU where registers and LDS allow)
 
+// what one launch of the pass does beyond the per-workgroup partial sets
+constexpr int WIDE_FUSE_NONE = 0;   // partial sets only (wide_reduce_kernel / wide_advance_kernel follow as launches)
+constexpr int WIDE_FUSE_REDUCE = 1; // + the sets are reduced in the launch: totals[NV] in HBM when it ends
+constexpr int WIDE_FUSE_STEP = 2;   // + the workgroup that completes the totals runs the LM step: ONE launch per trial step
+constexpr int WIDE_NGRP = 16;       // level-1 groups of the in-launch reduction: group q = sets q, q + 16, q + 32, ...
+
+// hand-off words of the in-launch reduction and of the speculative solve (one allocation, zeroed when it is made)
+struct WFuseBuf
+{
+    unsigned int tickets[WIDE_NGRP]; // level 1: arrivals of group q's workgroups
+    unsigned int ticket2;            // level 2: arrivals of the group reducers
+    unsigned int pad[15];
+    unsigned long long spec_tag;     // {launch epoch, fold of the payload}: the speculative solve of this launch is complete
+    double spec_mu;                  // the damping it was computed for
+    double spec_vel[64];             // (WP; wide_core.hpp)
+};
+
 struct WPassArgs
 {
     const double *x;  // n x NX column-major
@@ -46,6 +63,15 @@ struct WPassArgs
     double h_df, h_fvv;
     int fvv_analytic;
     int wf_only; // gsl_nls_large: the weights scale f only -- the reference's callback never weights J (src/nls_large.c:629-633)
+    // ---- one launch per trial step ----
+    int fuse;       // WIDE_FUSE_*
+    int G;          // workgroups that own rows (the grid has spec more: workgroup 0 is then the speculator)
+    int spec;       // 1: workgroup 0 solves the damped system of the step that FOLLOWS A REJECTION of this launch's trial
+    double *gsums;  // [WIDE_NGRP][NV] level-1 sums
+    double *totals; // [NV]
+    WFuseBuf *fb;
+    unsigned long long *stamps; // developer diagnostic (GSLNLS_WIDE_STAMPS=1): [launch][8] 100 MHz stamps of the stepping workgroup
+    WAdvanceArgs adv; // WIDE_FUSE_STEP
 };
 
 typedef double wide_v4f64 __attribute__((ext_vector_type(4)));
@@ -102,33 +128,151 @@ __device__ __forceinline__ double wide_resid(const TH &th, const XR &xr, double 
 #ifndef GSLNLS_WIDE_WAVES
 #define GSLNLS_WIDE_WAVES(PW) ((PW) <= 32 ? 2 : 1) // workgroups per CU the register budget is cut for (LDS allows 2 up to PW = 32)
 #endif
-template <class M, int JAC, int PW>
-__global__ __launch_bounds__(WIDE_T, GSLNLS_WIDE_WAVES(PW)) void wide_pass_kernel(WPassArgs a)
+// ---- hand-off helpers of the in-launch reduction (cdna_hip_programming.md guideline 16) ----------------------------------
+// payload stores are write-through (sc1: relaxed agent-scope atomic stores), so the producer needs no release fence: every
+// storing wave drains its stores, the workgroup meets at a barrier, ONE lane adds to the arrival counter; the workgroup
+// whose add came last acquires (agent scope: its L1 may hold lines of an earlier launch) and reads with plain loads.
+__device__ __forceinline__ void wide_store_wt(double *p, double v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// true in every thread of the ONE workgroup whose arrival is number `members` of counter `ctr` (all threads call)
+__device__ __forceinline__ bool wide_arrive_last(unsigned int *ctr, unsigned int members, int *flag_s)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: its payload has left
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        const unsigned int old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old + 1u == members;
+        if (last)
+        {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *flag_s = last;
+    }
+    __syncthreads();
+    return *flag_s != 0;
+}
+
+// FUSED = false: rows -> one partial set per workgroup, nothing else is compiled (about a second in the in-process
+// compiler: what the first fit of a formula waits for).  FUSED = true: the same pass + the in-launch reduction + the LM
+// step + the speculative solve (several seconds: built in the background, bound when ready -- wide_host.hpp).
+template <class M, int JAC, int PW, bool FUSED>
+__device__ __forceinline__ void wide_pass_body(const WPassArgs &a)
 {
     constexpr int P = M::P, NX = M::NX, NB = PW / 16, NW = WIDE_T / 64, NQ = NB * (NB + 1) / 2;
-    constexpr int NA = P * (P + 1) / 2, NV = 2 + NA + P;
+    constexpr int NA = P * (P + 1) / 2, NV = 2 + NA + P, NVP = (NV + 1) & ~1; // NVP: doubles from one set to the next
     static_assert(P <= PW && PW <= 64 && PW % 16 == 0, "PW = 16 ceil(p / 16)");
-    __shared__ double tile[NW][PW * WIDE_LD];
+    // one LDS region, two tenants: the tiles of the pass, then (in the one workgroup that runs the LM step, and in the
+    // speculator) the working set of wide_advance followed by the totals of the pass
+    constexpr int TILE_D = NW * PW * WIDE_LD, ADV_D = (int)(sizeof(WideLds) / sizeof(double)) + ((NV + 1) & ~1);
+    constexpr int LDS_D = (!FUSED || TILE_D > ADV_D) ? TILE_D : ADV_D;
+    __shared__ __attribute__((aligned(16))) double lds_raw[LDS_D];
     __shared__ double ftile[NW][64];
     __shared__ double th_s[P], vel_s[P], delta_s[P];
     __shared__ double red_s[NW][2];
+    __shared__ int flag_s;
+    double(*const tile)[PW * WIDE_LD] = reinterpret_cast<double(*)[PW * WIDE_LD]>(lds_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const WState *S = a.state;
+    // everything this workgroup needs from the previous launch is asked for at once (the state was written on another
+    // XCD: a load is most of two microseconds, and phase -> theta -> rows one after the other was six)
+    double st_x = 0.0, st_xt = 0.0, st_vel = 0.0;
+    if (tid < P)
+    {
+        st_x = S->x[tid];
+        st_xt = S->xt[tid];
+        st_vel = S->vel[tid];
+    }
     const int phase = S->phase;
+    const int rb = FUSED ? (int)blockIdx.x - a.spec : (int)blockIdx.x; // row-block index; -1: the speculator
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int k) {
+        if (FUSED && a.stamps)
+            st[k] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
+    // ---- roles that end in the damped solve: the speculator now, the workgroup that completes the totals later ----
+    bool solver = false;       // this wavefront runs the solve below
+    const bool is_spec = FUSED && rb < 0;
+    WideLds &L = *reinterpret_cast<WideLds *>(lds_raw);
+    double *const totals_s = lds_raw + sizeof(WideLds) / sizeof(double);
+    WideCtx ctx;
+    double mu_solve = 0.0;
+    double *sol_dst = nullptr;
+    WAdvanceArgs adv = a.adv;
+    if (is_spec)
+    {
+        // A rejected trial leaves x, J^T J, D, g as they are and multiplies mu by nu (src/trust.c:530-545): the damped
+        // system of the step after a rejection is known before the pass has run.  This workgroup solves it while the
+        // others stream the rows; the LM step takes the solution if it rejects (bit for bit what it would compute).
+        if (wave != 0 || phase != PH_TRIAL) // (PH_DONE included: a launch past the end of the fit)
+            return;
+        const int p = P;
+        const bool mine = lane < p;
+        {
+            constexpr int IT = (NA + 63) / 64;
+            double ba[IT];
+#pragma unroll
+            for (int i = 0; i < IT; ++i)
+                ba[i] = lane + 64 * i < NA ? S->A[lane + 64 * i] : 0.0;
+            const double dg = mine ? S->diag[lane] : 0.0, gg = mine ? S->g[lane] : 0.0;
+            mu_solve = S->mu * S->nu;
+#pragma unroll
+            for (int i = 0; i < IT; ++i)
+                if (lane + 64 * i < NA)
+                    L.A[lane + 64 * i] = ba[i];
+            if (mine)
+            {
+                L.diag[lane] = dg;
+                L.rhs[lane] = -gg;
+            }
+        }
+        wide_lds_sync();
+        solver = true;
+        sol_dst = L.sol;
+    }
+    else
+    {
+    // the rows of this wavefront's first tile: requested before the state is waited for
+    const long long ntile = (a.n + 63) / 64;
+    const int nrb = FUSED ? (int)gridDim.x - a.spec : (int)gridDim.x;
+    const long long tstride = (long long)nrb * NW;
+    long long t = (long long)rb * NW + wave;
+    double xr_n[NX], yy_n = 0.0, sw_n = 0.0;
+    auto load_rows = [&](long long tt) {
+        const long long i = tt * 64 + lane;
+        const bool live = i < a.n;
+        const long long ic = live ? i : a.n - 1;
+#pragma unroll
+        for (int c = 0; c < NX; ++c)
+            xr_n[c] = a.x[(size_t)c * a.n + ic];
+        yy_n = a.y[ic];
+        sw_n = live ? (a.sw ? a.sw[ic] : 1.0) : 0.0;
+    };
+#pragma unroll
+    for (int c = 0; c < NX; ++c)
+        xr_n[c] = 0.0;
+    if (t < ntile)
+        load_rows(t);
     if (phase == PH_DONE)
         return;
-    for (int k = tid; k < P; k += WIDE_T)
+    if (tid < P)
     {
-        const double t = (phase == PH_FVV) ? S->x[k] : S->xt[k];
-        th_s[k] = t;
-        vel_s[k] = S->vel[k];
-        double d = a.h_df * fabs(t); // src/fdjac.c:36-38
+        const double t0 = (phase == PH_FVV) ? st_x : st_xt;
+        th_s[tid] = t0;
+        vel_s[tid] = st_vel;
+        double d = a.h_df * fabs(t0); // src/fdjac.c:36-38
         if (d == 0.0)
             d = a.h_df;
-        delta_s[k] = d;
+        delta_s[tid] = d;
     }
-    for (int e = tid; e < NW * PW * WIDE_LD; e += WIDE_T)
-        (&tile[0][0])[e] = 0.0;
+    // the padding columns of the tiles (P .. PW - 1) are zeroed once; the row phase writes every other entry
+    if constexpr (P < PW)
+        for (int e = lane; e < (PW - P) * WIDE_LD; e += 64)
+            tile[wave][P * WIDE_LD + e] = 0.0;
     __syncthreads();
     const WideTheta th{th_s};
     double *const mytile = tile[wave];
@@ -144,19 +288,19 @@ __global__ __launch_bounds__(WIDE_T, GSLNLS_WIDE_WAVES(PW)) void wide_pass_kerne
         gacc[b] = 0.0;
     double ssr = 0.0, bad = 0.0;
 
-    const long long ntile = (a.n + 63) / 64;
-    for (long long t = (long long)blockIdx.x * NW + wave; t < ntile; t += (long long)gridDim.x * NW)
+    for (; t < ntile; t += tstride)
     {
         // ---------------- row phase: lane = row ----------------
         const long long i = t * 64 + lane;
         const bool live = i < a.n;
-        const long long ic = live ? i : a.n - 1;
         double xr[NX];
 #pragma unroll
         for (int c = 0; c < NX; ++c)
-            xr[c] = a.x[(size_t)c * a.n + ic];
-        const double yy = a.y[ic];
-        const double sw = live ? (a.sw ? a.sw[ic] : 1.0) : 0.0;
+            xr[c] = xr_n[c];
+        const double yy = yy_n;
+        const double sw = sw_n;
+        if (t + tstride < ntile)
+            load_rows(t + tstride); // (in flight while this tile is evaluated and contracted)
         double f;
         if constexpr (JAC == JAC_ANALYTIC)
         {
@@ -278,7 +422,9 @@ __global__ __launch_bounds__(WIDE_T, GSLNLS_WIDE_WAVES(PW)) void wide_pass_kerne
         }
         __syncthreads();
     }
-    double *out = a.partials + (size_t)blockIdx.x * NV;
+    stamp(1); // rows done, workgroup sums staged
+    double *out = a.partials + (size_t)rb * NVP;
+    const bool fuse = FUSED && a.fuse != WIDE_FUSE_NONE;
     if (tid == 0)
     {
         double s0 = red_s[0][0], s1 = red_s[0][1];
@@ -287,8 +433,16 @@ __global__ __launch_bounds__(WIDE_T, GSLNLS_WIDE_WAVES(PW)) void wide_pass_kerne
             s0 += red_s[w][0];
             s1 += red_s[w][1];
         }
-        out[0] = s0;
-        out[1] = s1;
+        if (fuse)
+        {
+            wide_store_wt(out, s0);
+            wide_store_wt(out + 1, s1);
+        }
+        else
+        {
+            out[0] = s0;
+            out[1] = s1;
+        }
     }
     for (int e = tid; e < NA; e += WIDE_T)
     {
@@ -299,10 +453,222 @@ __global__ __launch_bounds__(WIDE_T, GSLNLS_WIDE_WAVES(PW)) void wide_pass_kerne
         while ((i + 1) * (i + 2) / 2 <= e)
             ++i;
         const int j = e - i * (i + 1) / 2;
-        out[2 + e] = full[i * PW + j];
+        if (fuse)
+            wide_store_wt(out + 2 + e, full[i * PW + j]);
+        else
+            out[2 + e] = full[i * PW + j];
     }
     for (int k = tid; k < P; k += WIDE_T)
-        out[2 + NA + k] = gfull[k];
+    {
+        if (fuse)
+            wide_store_wt(out + 2 + NA + k, gfull[k]);
+        else
+            out[2 + NA + k] = gfull[k];
+    }
+    if (fuse && NVP != NV && tid == 0)
+        wide_store_wt(out + NV, 0.0); // (the pad of an odd set: read, never used)
+    if (!fuse)
+        return;
+    if constexpr (FUSED)
+    {
+    // ---------------- the G partial sets -> one, inside the launch ----------------
+    // Two levels, the summation order of wide_reduce_kernel (group q adds the sets q, q + 16, ... in index order, then the
+    // group sums are added in group order): the LAST workgroup of group q to arrive adds the group's sets, the last of
+    // those group reducers adds the group sums.  Fixed order => bit-identical totals whichever workgroups do the adding.
+    const int G = a.G, q = rb % WIDE_NGRP, ngrp = G < WIDE_NGRP ? G : WIDE_NGRP;
+    const unsigned int members = (unsigned int)((G - q + WIDE_NGRP - 1) / WIDE_NGRP);
+    if (!wide_arrive_last(&a.fb->tickets[q], members, &flag_s))
+        return;
+    stamp(2); // last of its group: acquired
+    // (sets and group sums are NVP = NV rounded up to even doubles apart: every load below moves two values, 16 bytes,
+    // and the loads of a round are all in flight before the first is added)
+    typedef double wide_v2f64 __attribute__((ext_vector_type(2)));
+    for (int v0 = 0; v0 < NVP / 2; v0 += 2 * WIDE_T)
+    {
+        // two value pairs per thread per trip: 2 x 32 loads of 16 bytes in flight
+        const int va = v0 + tid, vb = va + WIDE_T;
+        constexpr int PER = WIDE_MAX_G / WIDE_NGRP;
+        wide_v2f64 ta[PER], tb[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+        {
+            const int g = q + WIDE_NGRP * k;
+            ta[k] = (va < NVP / 2 && g < G) ? *reinterpret_cast<const wide_v2f64 *>(a.partials + (size_t)g * NVP + 2 * va)
+                                            : (wide_v2f64){0.0, 0.0};
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+        {
+            const int g = q + WIDE_NGRP * k;
+            tb[k] = (vb < NVP / 2 && g < G) ? *reinterpret_cast<const wide_v2f64 *>(a.partials + (size_t)g * NVP + 2 * vb)
+                                            : (wide_v2f64){0.0, 0.0};
+        }
+        wide_v2f64 sa = {0.0, 0.0}, sb = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            sa += ta[k];
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            sb += tb[k];
+        if (va < NVP / 2)
+        {
+            wide_store_wt(a.gsums + (size_t)q * NVP + 2 * va, sa[0]);
+            wide_store_wt(a.gsums + (size_t)q * NVP + 2 * va + 1, sa[1]);
+        }
+        if (vb < NVP / 2)
+        {
+            wide_store_wt(a.gsums + (size_t)q * NVP + 2 * vb, sb[0]);
+            wide_store_wt(a.gsums + (size_t)q * NVP + 2 * vb + 1, sb[1]);
+        }
+    }
+    stamp(3); // group sums stored
+    if (!wide_arrive_last(&a.fb->ticket2, (unsigned int)ngrp, &flag_s))
+        return;
+    stamp(4); // last group reducer: acquired
+    for (int v0 = 0; v0 < NVP / 2; v0 += 2 * WIDE_T)
+    {
+        const int va = v0 + tid, vb = va + WIDE_T;
+        wide_v2f64 ta[WIDE_NGRP], tb[WIDE_NGRP];
+#pragma unroll
+        for (int k = 0; k < WIDE_NGRP; ++k)
+            ta[k] = (va < NVP / 2 && k < ngrp) ? *reinterpret_cast<const wide_v2f64 *>(a.gsums + (size_t)k * NVP + 2 * va)
+                                               : (wide_v2f64){0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < WIDE_NGRP; ++k)
+            tb[k] = (vb < NVP / 2 && k < ngrp) ? *reinterpret_cast<const wide_v2f64 *>(a.gsums + (size_t)k * NVP + 2 * vb)
+                                               : (wide_v2f64){0.0, 0.0};
+        wide_v2f64 ra = ta[0], rb2 = tb[0];
+#pragma unroll
+        for (int k = 1; k < WIDE_NGRP; ++k)
+            ra += ta[k];
+#pragma unroll
+        for (int k = 1; k < WIDE_NGRP; ++k)
+            rb2 += tb[k];
+        auto put = [&](int v, wide_v2f64 r) {
+            if (v >= NVP / 2)
+                return;
+            if (a.fuse == WIDE_FUSE_STEP)
+            {
+                totals_s[2 * v] = r[0]; // (behind the working set of the step: the tiles are dead)
+                totals_s[2 * v + 1] = r[1];
+            }
+            else
+            {
+                a.totals[2 * v] = r[0];
+                if (2 * v + 1 < NV)
+                    a.totals[2 * v + 1] = r[1];
+            }
+        };
+        put(va, ra);
+        put(vb, rb2);
+    }
+    // the counters go back to zero for the next launch (which starts after this one has ended)
+    if (tid <= WIDE_NGRP)
+        __hip_atomic_store(tid < WIDE_NGRP ? &a.fb->tickets[tid] : &a.fb->ticket2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (a.fuse != WIDE_FUSE_STEP || wave != 0)
+        return;
+    // ---------------- the LM step, by the first wavefront of this workgroup ----------------
+    stamp(5); // totals in LDS
+    adv.totals = totals_s;
+    wide_advance_pre<P>(adv, L, ctx);
+    if (!ctx.active)
+        return;
+    stamp(6); // decision taken, right-hand side ready
+    if (ctx.want)
+    {
+        solver = true;
+        mu_solve = ctx.mu;
+        sol_dst = ctx.want == 1 ? L.acc : L.vel;
+        if (a.spec && ctx.want == 2 && ctx.rejected && ctx.phase_before == PH_TRIAL)
+        {
+            // the speculator has had the whole pass for this solve: take its result when it is there (bounded wait: it
+            // started before this workgroup did), else solve here.  {epoch, fold} guards against a payload that is not this
+            // launch's: a mismatch of either is treated as "not there".
+            const unsigned int epoch = ((unsigned int)adv.seq << 16) ^ (unsigned int)(adv.launch_idx + 1);
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            bool got = false;
+            unsigned long long tag = 0;
+            for (;;)
+            {
+                tag = __hip_atomic_load(&a.fb->spec_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned int)(tag >> 32) == epoch)
+                {
+                    got = true;
+                    break;
+                }
+                if (__builtin_readcyclecounter() - t0 > 200000ull) // ~100 us: the speculator is not coming
+                    break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (got)
+            {
+                const double sv = lane < P ? __hip_atomic_load(&a.fb->spec_vel[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                const double smu = __hip_atomic_load(&a.fb->spec_mu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long h = lane < P ? (unsigned long long)__double_as_longlong(sv) : 0ull;
+                h = (h >> 32) ^ (h & 0xffffffffull);
+                unsigned int f = (unsigned int)h;
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1)
+                    f ^= (unsigned int)__shfl_xor((int)f, m, 64);
+                if (f == (unsigned int)(tag & 0xffffffffull) && __double_as_longlong(smu) == __double_as_longlong(ctx.mu))
+                {
+                    if (lane < P)
+                        L.vel[lane] = sv;
+                    wide_lds_sync();
+                    solver = false;
+                }
+            }
+        }
+    }
+    }
+    }
+    if constexpr (FUSED)
+    {
+    // ---------------- ONE call site of the damped solve: the LM step's, or the speculator's ----------------
+    if (solver)
+        wide_solve_pw<PW>(L, P, mu_solve, L.rhs, sol_dst, lane, adv.pivoted);
+    if (is_spec)
+    {
+        const double sv = lane < P ? L.sol[lane] : 0.0;
+        unsigned long long h = lane < P ? (unsigned long long)__double_as_longlong(sv) : 0ull;
+        h = (h >> 32) ^ (h & 0xffffffffull);
+        unsigned int f = (unsigned int)h;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1)
+            f ^= (unsigned int)__shfl_xor((int)f, m, 64);
+        if (lane < P)
+            wide_store_wt(&a.fb->spec_vel[lane], sv);
+        if (lane == 0)
+            wide_store_wt(&a.fb->spec_mu, mu_solve);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the payload has left before the tag says so
+        const unsigned int epoch = ((unsigned int)adv.seq << 16) ^ (unsigned int)(adv.launch_idx + 1);
+        if (lane == 0)
+            __hip_atomic_store(&a.fb->spec_tag, ((unsigned long long)epoch << 32) | f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    stamp(7); // solve done (or the speculator's result taken)
+    wide_advance_post<P>(adv, L, ctx);
+    if (a.stamps && lane == 0)
+    {
+        unsigned long long *o = a.stamps + (size_t)(adv.launch_idx & 1023) * 10;
+        for (int k = 0; k < 8; ++k)
+            o[k] = st[k];
+        o[8] = __builtin_amdgcn_s_memrealtime();
+        o[9] = (unsigned long long)ctx.want | ((unsigned long long)(solver ? 1 : 0) << 8) | ((unsigned long long)ctx.rejected << 16);
+    }
+    }
+}
+
+template <class M, int JAC, int PW>
+__global__ __launch_bounds__(WIDE_T, GSLNLS_WIDE_WAVES(PW)) void wide_pass_kernel(WPassArgs a)
+{
+    wide_pass_body<M, JAC, PW, false>(a);
+}
+template <class M, int JAC, int PW>
+__global__ __launch_bounds__(WIDE_T, GSLNLS_WIDE_WAVES(PW)) void wide_step_kernel(WPassArgs a)
+{
+    wide_pass_body<M, JAC, PW, true>(a);
 }
 
 // After the fit: weighted residual and Jacobian at the final point in the layout C_nls returns them (resid n; grad

@@ -57,6 +57,13 @@ int wide_expr_build(const gslnls_model *fn, std::string &first_path)
         }
         if (jm == 0)
             first_path = ent->cache_path;
+        // the one-launch-per-step kernel (wide_kernels.hpp): the unit fits otherwise wait for in the background
+        auto step = rtc_request(src, {rtc_wide_step_expr(jm, PW)}, true);
+        if (step->state.load() != RTC_READY)
+        {
+            fprintf(stderr, "gslnls: native lowering (step kernel) failed: %s\n", step->log.c_str());
+            return GSLNLS_E_UNSUPPORTED;
+        }
     }
     return GSLNLS_SUCCESS;
 }
@@ -82,6 +89,8 @@ extern "C" int gslnls_debug_wide_solve(int p, const double *Ap, const double *di
     if (p < 1 || p > WP || !Ap || !diag || !rhs || !sol)
         return GSLNLS_EINVAL;
     const int na = p * (p + 1) / 2;
+    // (read at every call: the tests exercise both orders of elimination)
+    const int pivoted = getenv("GSLNLS_WIDE_PIVOTED") && atoi(getenv("GSLNLS_WIDE_PIVOTED")) != 0;
     double *d = nullptr;
     GSLNLS_HIP_OK(hipMalloc(&d, sizeof(double) * (size_t)(na + 3 * p)));
     hipError_t he = hipMemcpy(d, Ap, sizeof(double) * na, hipMemcpyHostToDevice);
@@ -91,7 +100,7 @@ extern "C" int gslnls_debug_wide_solve(int p, const double *Ap, const double *di
         he = hipMemcpy(d + na + p, rhs, sizeof(double) * p, hipMemcpyHostToDevice);
     if (he == hipSuccess)
     {
-        hipLaunchKernelGGL(wide_solve_debug_kernel, dim3(1), dim3(64), 0, 0, p, d, d + na, mu, d + na + p, d + na + 2 * p);
+        hipLaunchKernelGGL(wide_solve_debug_kernel, dim3(1), dim3(64), 0, 0, p, d, d + na, mu, d + na + p, d + na + 2 * p, pivoted);
         he = hipMemcpy(sol, d + na + 2 * p, sizeof(double) * p, hipMemcpyDeviceToHost);
     }
     if (he != hipSuccess)
@@ -108,7 +117,7 @@ extern "C" int gslnls_debug_wide_solve(int p, const double *Ap, const double *di
         GSLNLS_HIP_OK(hipEventCreate(&e1));
         (void)hipEventRecord(e0, 0);
         for (int r = 0; r < reps; ++r)
-            hipLaunchKernelGGL(wide_solve_debug_kernel, dim3(1), dim3(64), 0, 0, p, d, d + na, mu, d + na + p, d + na + 2 * p);
+            hipLaunchKernelGGL(wide_solve_debug_kernel, dim3(1), dim3(64), 0, 0, p, d, d + na, mu, d + na + p, d + na + 2 * p, pivoted);
         (void)hipEventRecord(e1, 0);
         (void)hipEventSynchronize(e1);
         float ms = 0.f;

@@ -203,6 +203,111 @@ def _finish(out, res, trace, algorithm, n):
     return GslNlsFit(out)
 
 
+def _gsl_nls_function(fn, y, start, algorithm, control, jac, fvv, trace, weights, lower, upper, loss):
+    """gsl_nls.function (R/nls.R:778-1060): `fn(par)` returns the n model values -- or (values, gradient), the analogue of
+    the "gradient" attribute README example 4 uses --, `y` the response, `jac` / `fvv` optional functions jac(par) -> n x p,
+    fvv(par, v) -> n.  The closures run on this thread, where the reference runs them (src/nls.c:815-978); every n x p and
+    p x p operation of the fit runs on the device (csrc/bd_host.hpp).  Any p <= 4096."""
+    if y is None:
+        raise ValueError("'y' is required when 'fn' is a function")
+    if algorithm not in ALGORITHMS:
+        raise ValueError("'algorithm' should be one of %s" % ", ".join(ALGORITHMS))
+    loss_cfg = gsl_nls_loss(loss) if isinstance(loss, str) else gsl_nls_loss(**loss)
+    if loss_cfg["rho"] != "default":
+        raise NotImplementedError("robust loss functions with a function model are not lowered to the device")
+    ctrl = control if (control is not None and len(control) >= 23) else gsl_nls_control(**(control or {}))
+    if isinstance(start, dict):
+        names, vec = list(start.keys()), np.asarray([float(np.asarray(v).reshape(-1)[0]) for v in start.values()])
+        if any(np.asarray(v).size != 1 for v in start.values()):
+            raise NotImplementedError("multi-start with a function model is not lowered to the device")
+    else:
+        vec = np.asarray(start, dtype=np.float64).reshape(-1)
+        names = ["par%d" % (k + 1) for k in range(len(vec))]
+    p = len(vec)
+    yv = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
+    n = len(yv)
+    first = fn(vec.copy())
+    grad_in_fn = isinstance(first, tuple)
+    if jac is True and not grad_in_fn:
+        raise ValueError("jac = True needs a model function that returns (values, gradient)")
+    jac_fn = jac if callable(jac) else ((lambda th: fn(th)[1]) if (grad_in_fn and jac is not False) else None)
+    fvv_fn = fvv if callable(fvv) else None
+    errors = []
+
+    def f_cb(theta, pp, out, nn, _user):
+        try:
+            v = fn(np.ctypeslib.as_array(theta, shape=(pp,)).copy())
+            v = np.asarray(v[0] if isinstance(v, tuple) else v, dtype=np.float64).reshape(-1)
+            if v.size != nn:
+                return 1
+            np.ctypeslib.as_array(out, shape=(nn,))[:] = v
+            return 0
+        except Exception as e:  # noqa: BLE001 -- a Python exception must not unwind through the C frames
+            errors.append(e)
+            return 1
+
+    def jac_cb(theta, pp, out, nn, _user):
+        try:
+            Jm = np.asarray(jac_fn(np.ctypeslib.as_array(theta, shape=(pp,)).copy()), dtype=np.float64)
+            if hasattr(Jm, "toarray"):
+                Jm = Jm.toarray()
+            if Jm.shape != (nn, pp):
+                return 1
+            np.ctypeslib.as_array(out, shape=(nn * pp,))[:] = np.asfortranarray(Jm).reshape(-1, order="F")
+            return 0
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            return 1
+
+    def fvv_cb(theta, v, pp, out, nn, _user):
+        try:
+            r = np.asarray(fvv_fn(np.ctypeslib.as_array(theta, shape=(pp,)).copy(),
+                                  np.ctypeslib.as_array(v, shape=(pp,)).copy()), dtype=np.float64).reshape(-1)
+            if r.size != nn:
+                return 1
+            np.ctypeslib.as_array(out, shape=(nn,))[:] = r
+            return 0
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            return 1
+
+    sw = None
+    if weights is not None:
+        w = np.asarray(weights, dtype=np.float64)
+        if w.ndim != 1 or len(w) != n or np.any(~(w > 0)):
+            raise ValueError("weights of a function model: a vector of n positive values")
+        sw = np.ascontiguousarray(np.sqrt(w))
+    lu = _bounds(lower, upper, names)
+    if lu is not None:
+        lo_b, up_b = lu.reshape(p, 2)[:, 0], lu.reshape(p, 2)[:, 1]
+        if np.any(lo_b > up_b):
+            raise ValueError("Parameter lower bounds cannot be larger than upper bounds")
+        if np.any(vec < lo_b) or np.any(vec > up_b):
+            raise ValueError("Starting parameters must be contained within 'lower' and/or 'upper' bounds")
+    ci, cd = pack_control(ctrl, algorithm, trace, True, False)
+    out = dict(par=np.zeros(p), covar=np.zeros((p, p), order="F"), resid=np.zeros(n), grad=np.zeros((n, p), order="F"))
+    res = _lib.Result()
+    res.par, res.covar, res.resid, res.grad = _dp(out["par"]), _dp(out["covar"]), _dp(out["resid"]), _dp(out["grad"])
+    if trace:
+        out["partrace"] = np.full((ctrl["maxiter"] + 1, p), np.nan, order="F")
+        out["ssrtrace"] = np.full(ctrl["maxiter"] + 1, np.nan)
+        res.partrace, res.ssrtrace = _dp(out["partrace"]), _dp(out["ssrtrace"])
+    # (a function-pointer type called without arguments is the NULL pointer)
+    cbs = (_lib.FN_CB(f_cb), _lib.JAC_CB(jac_cb) if jac_fn else _lib.JAC_CB(), _lib.FVV_CB(fvv_cb) if fvv_fn else _lib.FVV_CB())
+    st = np.ascontiguousarray(vec, dtype=np.float64)
+    rc = _lib.lib().gslnls_nls_fn(n, p, yv.ctypes.data_as(C.c_void_p), cbs[0], cbs[1], cbs[2], None, _dp(st),
+                                  None if sw is None else sw.ctypes.data_as(C.c_void_p), _dp(lu), ci.ctypes.data_as(IP), _dp(cd),
+                                  C.byref(res))
+    if errors:
+        raise errors[0]
+    _lib.check(rc)
+    fit = _finish(out, res, trace, algorithm, n)
+    fit["solver_served"] = bool(_lib.lib().gslnls_solver_served(ci.ctypes.data_as(IP), C.byref(res)))
+    fit["parnames"] = names
+    fit["weights"] = weights
+    return fit
+
+
 def gsl_nls(fn, data=None, start=None, algorithm="lm", control=None, jac=None, fvv=None, trace=False,
             weights=None, lower=None, upper=None, loss="default", y=None, lowering="auto"):
     """gsl_nls(fn = y ~ f(x, theta), data, start, ...) -- same arguments as R/nls.R:306-316.
@@ -218,6 +323,8 @@ def gsl_nls(fn, data=None, start=None, algorithm="lm", control=None, jac=None, f
     """
     if start is None:
         raise ValueError("starting values 'start' are required")
+    if callable(fn):
+        return _gsl_nls_function(fn, y, start, algorithm, control, jac, fvv, trace, weights, lower, upper, loss)
     _ = ALGORITHMS.index(algorithm) if algorithm in ALGORITHMS else (_ for _ in ()).throw(
         ValueError("'algorithm' should be one of %s" % ", ".join(ALGORITHMS)))
     ctrl = control if (control is not None and len(control) >= 23) else gsl_nls_control(**(control or {}))
@@ -238,8 +345,8 @@ def gsl_nls(fn, data=None, start=None, algorithm="lm", control=None, jac=None, f
             missing = [v for v in xnames if v not in data]
             if missing:
                 raise ValueError("formula symbols %s are neither parameters nor data columns" % missing)
-            if p > 64 or len(xnames) > 8:
-                raise NotImplementedError("expression models support p <= 64 and <= 8 data columns: %s" % fn)
+            if p > 512 or len(xnames) > 8:
+                raise NotImplementedError("expression models support p <= 512 and <= 8 data columns: %s" % fn)
             mid, order = _lib.MODEL_EXPR, list(range(p))
             expr_text = fn.split("~", 1)[1].strip()
         else:

@@ -34,8 +34,9 @@ extern "C" {
 #define GSLNLS_MODEL_GAUSSPK 3  /* a*exp(-(x-b)^2/(2c^2))    p=3  README.md:545 */
 #define GSLNLS_MODEL_GAUSS1 4   /* NIST Gauss1 family        p=8  R/nls_test.R:301 */
 #define GSLNLS_MODEL_EXPR 100  /* any formula right-hand side: compiled to a device program with symbolic
-                                   gradient (csrc/expr_compile.hpp); p <= 64, at most 8 regressor columns (beyond 9
-                                   parameters or 3 columns: the wide path) */
+                                   gradient (csrc/expr_compile.hpp); p <= 512, at most 8 regressor columns (beyond 9
+                                   parameters or 3 columns: the wide path; beyond 64 parameters, single start and default
+                                   loss only: the Jacobian as a matrix in HBM, csrc/bd_host.hpp) */
 #define GSLNLS_MODEL_GLMEXP 5   /* exp(a_i . theta), dense A n x p ROW-major in `x`, nx = p in {16,32,64};
                                    gsl_nls_large only */
 
@@ -128,7 +129,7 @@ typedef struct gslnls_result
                          n_launches on the launch-per-step kernel, while the one-launch-per-fit kernel has n_launches = 1 */
     int code_path;    /* which device code evaluated the model rows of the (last) solve: 0 hand-written row model,
                          1 interpreted expression, 2 expression compiled in process (hiprtc), 3 the same on the wide path
-                         (p > 9: MFMA J^T J tiles) */
+                         (p > 9: MFMA J^T J tiles), 4 Jacobian as a matrix in HBM (function models, p > 64: csrc/bd_host.hpp) */
 } gslnls_result;
 
 /* Solver routing rule of the boundary.  control_int[4]: 0 qr (the R default), 1 cholesky, 2 svd (R/nls.R:702).
@@ -157,6 +158,36 @@ int gslnls_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv,
                int start_is_matrix, const double *swts, int swts_is_matrix, const double *lupars,
                const int *control_int, const double *control_dbl, const int *has_start, int loss_rho,
                const double *loss_cc, gslnls_result *out);
+
+/*
+ * gslnls_nls_fn -- gsl_nls() on an R `function` (gsl_nls.function, R/nls.R:778; the reference's unit tests 2.2-2.3 and
+ * README example 4 call it this way): the model, its Jacobian and its second directional derivative stay HOST callbacks,
+ * evaluated on the calling thread exactly where the reference evaluates the closures (gsl_f / gsl_df / gsl_fvv,
+ * src/nls.c:815-978); everything after them runs on the device: weighting, ||f||^2, the difference Jacobian's columns
+ * (p + 1 calls of f, src/fdjac.c) , J^T J on the matrix cores, J^T f, the damped solve, rho -- csrc/bd_host.hpp.  Any
+ * p <= 4096 (the reference's n x p workspace has no limit, src/nls.c:266).
+ *   f    : model values m(theta) into fval[n] (NOT residuals: the core subtracts y); non-zero return = EBADFUNC
+ *   jac  : n x p column-major dm/dtheta as an R matrix is laid out, or NULL for finite differences (control_int[5])
+ *   fvv  : D^2 m[v, v] into out[n], or NULL (lmaccel then differences f, src/fdfvv.c)
+ *   start p values; swts sqrt(weights) [n] or NULL; lupars 2 x p or NULL; control_int / control_dbl as gslnls_nls.
+ * Single start, default loss (multi-start and IRLS of function models keep the GSL path: GSLNLS_E_UNSUPPORTED).
+ * out->code_path = 4.
+ */
+typedef int (*gslnls_fn_cb)(const double *theta, int p, double *fval, int n, void *user);
+typedef int (*gslnls_jac_cb)(const double *theta, int p, double *J, int n, void *user);
+typedef int (*gslnls_fvv_cb)(const double *theta, const double *v, int p, double *out, int n, void *user);
+int gslnls_nls_fn(int n, int p, const double *y, gslnls_fn_cb f, gslnls_jac_cb jac, gslnls_fvv_cb fvv, void *user,
+                  const double *start, const double *swts, const double *lupars, const int *control_int,
+                  const double *control_dbl, gslnls_result *out);
+
+/* Where the wall time of the last gslnls_nls() call of this process went, milliseconds:
+ *   ms[0] create (allocation / re-binding of a parked problem), [1] H2D of x, y, swts, [2] the solve loop (plus
+ *   multi-start / IRLS driver work), [3] the finalize kernel (resid, grad, covar), [4] D2H of the result vectors,
+ *   [5] destroy / parking, [6] total.  Returns the number of values (7) and writes min(cap, 7).  What .Call(C_nls)
+ *   delivers is the total, not the resident loop ("also report end-to-end"); the copies the reference
+ *   itself makes are src/nls.c:695-720.  (GSLNLS_PREFAULT=1: result vectors of >= 1 MB are faulted in by a helper thread
+ *   while the data uploads -- measured slower on the MI355X host, see csrc/dense_host.hpp; off by default.) */
+int gslnls_last_call_profile(double *ms, int cap);
 
 /*
  * Model lowering: match the deparsed right-hand side of the model formula (formula[[3]], R/nls.R:565)

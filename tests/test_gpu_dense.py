@@ -430,3 +430,51 @@ print(json.dumps(out))
             assert np.allclose(a["resid"], b["resid"], rtol=1e-9, atol=1e-12), tag
         if a["ssrtrace"] is not None:
             assert np.allclose(a["ssrtrace"], b["ssrtrace"], rtol=1e-12), tag
+
+
+@pytest.mark.parametrize("jac", [True, False])
+def test_one_shot_call_equals_the_resident_path_and_reports_where_its_time_went(amd, jac):
+    """What .Call(C_nls) gets is ONE gslnls_nls(): create, H2D, fit, finalize, D2H, destroy (src/nls.c:54-813; its own copies
+    :695-720).  The result must be bit for bit what the resident-data API gives on the same problem -- into recycled
+    result buffers and into pages the process has never touched (a fresh anonymous mapping, what a large Rf_allocVector
+    is) -- and gslnls_last_call_profile must account for the call: the seven parts are non-negative, the first six add up to
+    the total, and at this size the two copies are the bulk of it."""
+    import ctypes as C
+    import mmap
+    from gslnls_amd import _lib
+    from gslnls_amd.control import pack_control
+    L = _lib.lib()
+    n = 1_000_000
+    x, y = c2_data(n)
+    ctrl = amd.gsl_nls_control(solver="cholesky")
+    prob = amd.DenseProblem(1, 3, x, y)
+    ref = prob.solve([1.0, 1.0, 0.0], jac=jac, control=ctrl)
+    prob.close()
+    ci, cd = pack_control(ctrl)
+    ci, cd = (C.c_int * 15)(*ci), (C.c_double * 11)(*cd)
+    start = (C.c_double * 3)(1.0, 1.0, 0.0)
+    for fresh in (False, True, False):
+        if fresh:
+            m1, m2 = mmap.mmap(-1, 8 * n), mmap.mmap(-1, 24 * n)
+            resid, grad = np.frombuffer(m1, dtype=np.float64), np.frombuffer(m2, dtype=np.float64)
+        else:
+            resid, grad = np.full(n, -7.0), np.full(3 * n, -7.0)
+        par, covar, res = np.empty(3), np.empty(9), _lib.Result()
+        res.par, res.covar = par.ctypes.data_as(_lib.DP), covar.ctypes.data_as(_lib.DP)
+        res.resid, res.grad = resid.ctypes.data_as(_lib.DP), grad.ctypes.data_as(_lib.DP)
+        model = _lib.Model(1, 3, 1, x.ctypes.data_as(C.c_void_p), 0)
+        rc = L.gslnls_nls(C.byref(model), y.ctypes.data_as(C.c_void_p), n, int(jac), 0, start, 0, None, 0, None, ci, cd, None,
+                          0, None, C.byref(res))
+        assert rc == 0 and res.conv == 0 and res.niter == ref["niter"]
+        assert np.array_equal(par, ref["par"]) and res.ssr == ref["ssr"]
+        assert np.array_equal(covar.reshape(3, 3), np.asarray(ref["covar"]).reshape(3, 3))
+        assert np.array_equal(resid, ref["resid"])
+        assert np.array_equal(grad.reshape(3, n).T, ref["grad"])
+        pr = (C.c_double * 8)()
+        assert L.gslnls_last_call_profile(pr, 8) == 7
+        parts = np.array(pr[:6])
+        assert np.all(parts >= -1e-6) and abs(parts.sum() - pr[6]) <= 1e-6 * max(1.0, pr[6])
+        assert pr[1] > 0.05 and pr[4] > 0.1          # 16 MB in, 32 MB out: never free
+        print("one-shot C2 jac=%d fresh=%d: total %.3f ms = create %.3f + h2d %.3f + loop %.3f + finalize %.3f + d2h %.3f + "
+              "destroy %.3f" % (jac, fresh, pr[6], pr[0], pr[1], pr[2], pr[3], pr[4], pr[5]))
+        del resid, grad

@@ -24,11 +24,16 @@ def _packed(A):
     return np.ascontiguousarray(np.concatenate([A[i, :i + 1] for i in range(p)]))
 
 
+@pytest.mark.parametrize("pivoted", ["0", "1"])
 @pytest.mark.parametrize("p", [1, 2, 10, 16, 17, 33, 48, 64])
-def test_wide_damped_solve_matches_the_oracles_modified_cholesky(amd, gslref, p):
+def test_wide_damped_solve_matches_the_oracles_modified_cholesky(amd, gslref, p, pivoted, monkeypatch):
     """(J^T J + mu D^2) v = -g on one wavefront against gsl_linalg_mcholesky as restated by the oracle: well
-    conditioned, rank deficient (the modification kicks in) and badly scaled (pivoting matters) matrices"""
+    conditioned, rank deficient (the modification kicks in) and badly scaled (pivoting matters) matrices.  Both routes of
+    the device: the natural-order L D L^T that serves numerically positive definite systems (and hands everything else to
+    the pivoted routine: the rank-deficient and zero-column cases end there) and the pivoted, modified factorisation alone
+    (GSLNLS_WIDE_PIVOTED=1)."""
     from gslnls_amd import _lib
+    monkeypatch.setenv("GSLNLS_WIDE_PIVOTED", pivoted)
     L = _lib.lib()
     rng = np.random.Generator(np.random.PCG64(100 + p))
     for case in ("spd", "rank_deficient", "badly_scaled", "zero_column"):
@@ -65,14 +70,16 @@ def test_wide_damped_solve_matches_the_oracles_modified_cholesky(amd, gslref, p)
             assert np.max(np.abs(sol - ref)) <= tol * scale, (case, p, np.max(np.abs(sol - ref)) / scale)
 
 
+@pytest.mark.parametrize("pivoted", ["0", "1"])
 @pytest.mark.parametrize("p", [2, 7, 16, 31, 32, 64])
-def test_wide_solve_pivot_rules_ties_near_ties_and_nans(amd, gslref, p):
+def test_wide_solve_pivot_rules_ties_near_ties_and_nans(amd, gslref, p, pivoted, monkeypatch):
     """The pivot search of the register-resident factorisation reduces the HIGH words of the diagonal first and only
     then compares whole values: exact ties (identical blocks: the reference's scan keeps the FIRST position), diagonals
     that differ below the 20th mantissa bit (the full comparison has to find the true maximum, which sits last), and a
     NaN on the diagonal (the call must come back) -- permutation decisions identical to the oracle's give solutions
     equal to round-off"""
     from gslnls_amd import _lib
+    monkeypatch.setenv("GSLNLS_WIDE_PIVOTED", pivoted)  # ("0": positive definite cases take the natural order, NaN the pivoted routine)
     L = _lib.lib()
     G = gslref.lib()
     rng = np.random.Generator(np.random.PCG64(900 + p))
