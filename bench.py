@@ -417,9 +417,92 @@ def wide_dense_bench(_lib, n=100_000, ng=10):
                             "rows_per_s_one_step": nn / (ms_step * 1e-3),
                             "mfma_tile_GFLOPs_per_step": nq * 512.0 * nn / (ms_step * 1e-3) / 1e9,
                             "max_rel_err_vs_truth": float(np.max(np.abs(fit["par"] - truth) / np.abs(truth)))}
-    out["note"] = ("a row costs ten fp64 exp + the 32 gradient entries (vector pipe) and 3 MFMA tiles per four rows; "
-                   "ms_per_trial_step is pass + reduce + advance (the p x p modified Cholesky runs on one wavefront)")
+    out["note"] = ("a row costs ten fp64 exp + the 32 gradient entries (vector pipe) and 3 MFMA tiles per four rows; one trial "
+                   "step = ONE launch: rows -> per-workgroup sums -> two-level in-launch reduction (arrival tickets) -> the LM step "
+                   "by the workgroup that completes the totals, natural-order L D L^T of the damped system on one wavefront "
+                   "(gsl_linalg_mcholesky's pivoted form when a pivot is not safely positive), a speculative solve for the "
+                   "rejected case by workgroup 0 while the rows stream.  ms_per_trial_step: back-to-back steps held at the "
+                   "converged point (mostly rejected steps); fit_loop_ms / steps: the real fit's mix")
     return out
+
+
+def wide_multistart_bench(L, _lib, npts=4096):
+    """Multi-start for 10 <= p <= 64 (src/nls_mstart.c:42-128 at p = 12): one concentration batch of 4096 Sobol points on a
+    sum of four Gaussians, n = 200, 5 LM iterations each -- every point at once, one workgroup per point
+    (wide_fit_kernel), against the round-3 form that fitted them one after the other through the launch-per-step chain."""
+    import gslnls_amd as A
+    from gslnls_amd.control import gsl_nls_control, pack_control
+    rng = np.random.Generator(np.random.PCG64(20250931))
+    ng, n = 4, 200
+    names, terms = [], []
+    for k in range(1, ng + 1):
+        names += ["a%d" % k, "m%d" % k, "s%d" % k]
+        terms.append("a%d*exp(-(x-m%d)^2/s%d^2)" % (k, k, k))
+    rhs = " + ".join(terms)
+    amp, mid, wid = rng.uniform(2.0, 6.0, ng), 10.0 * np.arange(ng) + rng.uniform(3.0, 7.0, ng), rng.uniform(1.2, 2.4, ng)
+    truth = np.stack([amp, mid, wid], axis=1).reshape(-1)
+    p = len(truth)
+    x = np.linspace(0.0, 10.0 * ng, n)
+    y = sum(truth[3 * k] * np.exp(-(x - truth[3 * k + 1]) ** 2 / truth[3 * k + 2] ** 2) for k in range(ng)) + 0.05 * rng.standard_normal(n)
+    prob = A.DenseProblem(_lib.MODEL_EXPR, p, x, y, expr=rhs, parnames=names, xnames=["x"], lowering="jit")
+    prob.solve(truth * 1.02, jac=True, control=A.gsl_nls_control(solver="cholesky"), want_vectors=False)  # builds the kernels
+    ci, cd = pack_control(gsl_nls_control(solver="cholesky"), "lm")
+    ranges = np.stack([truth * 0.8, truth * 1.2], axis=1).reshape(-1).copy()
+    kd = np.full(p, 0.75)
+    K = L.gslnls_mstart_record_size(p)
+    out = {"workload": "one concentration batch of %d Sobol points, sum of %d Gaussians (p = %d), n = %d, 5 LM iterations each, "
+                       "analytic Jacobian" % (npts, ng, p, n)}
+    recs = {}
+    for label, env, count in (("batch_kernel", "1", npts), ("one_after_the_other", "0", 256)):
+        os.environ["GSLNLS_WIDE_MS_BATCH"] = env
+        rec = np.zeros((count, K))
+        ms = C.c_float(0)
+        args = (prob._h, 1, ranges.ctypes.data_as(_lib.DP), kd.ctypes.data_as(_lib.DP), 0, count, 0, count, 5, 1e-6,
+                ci.ctypes.data_as(_lib.IP), cd.ctypes.data_as(_lib.DP), None, rec.ctypes.data_as(C.c_void_p), 0, C.byref(ms))
+        rc = L.gslnls_mstart_batch(*args)
+        if rc != 0:
+            raise RuntimeError("gslnls_mstart_batch (%s) failed with %d" % (label, rc))
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            L.gslnls_mstart_batch(*args)
+        el = (time.perf_counter() - t0) / reps
+        out[label] = {"points": count, "ms_per_batch": 1e3 * el, "us_per_point": 1e6 * el / count, "fits_per_s": count / el,
+                      "points_fitted": int(np.sum(rec[:, 3 * p + 5] > 0))}
+        recs[label] = rec
+    os.environ.pop("GSLNLS_WIDE_MS_BATCH", None)
+    out["speedup_per_point"] = out["one_after_the_other"]["us_per_point"] / out["batch_kernel"]["us_per_point"]
+    a, b = recs["batch_kernel"][:256], recs["one_after_the_other"]
+    out["max_rel_diff_of_the_first_256_records"] = float(np.max(np.abs(a[:, :p] - b[:, :p]) / np.maximum(np.abs(b[:, :p]), 1e-300)))
+    prob.close()
+    return out
+
+
+def function_model_bench():
+    """gsl_nls() on `function` models (gslnls_nls_fn: the closures stay on the host, csrc/bd_host.hpp): README example 4 exactly
+    as the README calls it -- gsl_nls(fn = f, y = rep(0, p + 1), start = 1:p, control = list(maxiter = 500)), p = 500, the
+    reference's own dense benchmark (36.66 s there on unstated hardware: context, not a baseline) -- and a p = 199 sum of
+    Gaussians."""
+    import gslnls_amd as A
+    p = 500
+    a = np.sqrt(1e-5)
+
+    def f(th):
+        return np.concatenate([a * (th - 1.0), [np.sum(th ** 2) - 0.25]]), np.vstack([a * np.eye(p), 2.0 * th[None, :]])
+    out = {"workload": "README Example 4 through gsl_nls(): penalty function I, p = 500, n = 501, dense Jacobian from a Python "
+                       "closure, LM", "reference_readme_quotes_s": 36.66}
+    for _ in range(2):
+        t0 = time.perf_counter()
+        fit = A.gsl_nls(f, y=np.zeros(p + 1), start=np.arange(1.0, p + 1.0), control=dict(maxiter=500, solver="cholesky"))
+        el = time.perf_counter() - t0
+    out["readme_example_4"] = {"wall_ms": 1e3 * el, "niter": int(fit["niter"]), "conv": int(fit["conv"]), "ssr": float(fit["ssr"]),
+                               "ssr_target": 0.004778845, "neval_f": int(fit["neval"]["f"]), "neval_J": int(fit["neval"]["J"]),
+                               "code_path": int(fit["code_path"])}
+    return out
+
+
+def _unused():
+    return None
 
 
 def sparse_readme_bench():
@@ -1032,6 +1115,8 @@ def main():
             side("large_cgst", large_bench, L, _lib)
             side("large_sparse_readme", sparse_readme_bench)
             side("wide_dense", wide_dense_bench, _lib)
+            side("wide_multistart", wide_multistart_bench, L, _lib)
+            side("function_models", function_model_bench)
     if world > 1:
         L.gslnls_comm_destroy()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

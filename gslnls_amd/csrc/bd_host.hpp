@@ -332,10 +332,9 @@ struct BdFit
         const LmParams prm = make_params(ci, cd, jac, fvv, lupars != nullptr, d_sw != nullptr);
         const int maxiter = prm.maxiter;
         const bool trace = ci[1] != 0 && out->ssrtrace && out->partrace;
-        static const int dev_min = [] {
-            const char *e = getenv("GSLNLS_LARGE_CHOL_DEVICE_MIN");
-            return e ? atoi(e) : 400;
-        }();
+        // (read per fit: the tests run one problem through both factorisations)
+        const char *dev_env = getenv("GSLNLS_LARGE_CHOL_DEVICE_MIN");
+        const int dev_min = dev_env ? atoi(dev_env) : 400;
         const bool dev_solve = dev_min > 0 && p >= dev_min;
         std::vector<double> x(start, start + p), xt(p), dx(p, 0.0), vel(p, 0.0), acc(p, 0.0), g(p), gt(p), diag(p, 1.0), djj(p),
             djjt(p), lo(p, -INFINITY), up(p, INFINITY), rhs(p), gfvv(p);

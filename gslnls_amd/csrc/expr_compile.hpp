@@ -174,16 +174,35 @@ struct ExprCompiler
         }
         case FNode::CALL:
         {
+            // the functions stats::deriv knows (R/nls.R:588-599 builds the Jacobian with it): primitives of the program, or
+            // -- where that costs no accuracy -- compositions of them
             static const std::map<std::string, unsigned char> f1 = {
                 {"exp", VM_EXP}, {"log", VM_LOG}, {"sin", VM_SIN}, {"cos", VM_COS}, {"tan", VM_TAN},
-                {"atan", VM_ATAN}, {"sqrt", VM_SQRT}, {"abs", VM_ABS}, {"tanh", VM_TANH}};
+                {"atan", VM_ATAN}, {"sqrt", VM_SQRT}, {"abs", VM_ABS}, {"tanh", VM_TANH}, {"sinh", VM_SINH},
+                {"cosh", VM_COSH}, {"asin", VM_ASIN}, {"acos", VM_ACOS}, {"log1p", VM_LOG1P}, {"expm1", VM_EXPM1},
+                {"pnorm", VM_PNORM}};
+            if (t->args.size() != 1)
+            {
+                error = "unsupported function " + t->name + " (one argument expected)";
+                return cst(NAN);
+            }
+            const int arg = build(t->args[0], parnames, varnames);
+            if (t->name == "log2")
+                return op2(VM_DIV, op1(VM_LOG, arg), cst(0.69314718055994530942));
+            if (t->name == "log10")
+                return op2(VM_DIV, op1(VM_LOG, arg), cst(2.30258509299404568402));
+            if (t->name == "dnorm") // exp(-x^2 / 2) / sqrt(2 pi)
+                return op2(VM_MUL, op1(VM_EXP, op2(VM_MUL, cst(-0.5), op2(VM_MUL, arg, arg))), cst(0.39894228040143267794));
+            if (t->name == "sinpi" || t->name == "cospi" || t->name == "tanpi")
+                return op1(t->name == "sinpi" ? VM_SIN : (t->name == "cospi" ? VM_COS : VM_TAN),
+                           op2(VM_MUL, cst(3.14159265358979323846), arg));
             auto it = f1.find(t->name);
-            if (it == f1.end() || t->args.size() != 1)
+            if (it == f1.end())
             {
                 error = "unsupported function " + t->name;
                 return cst(NAN);
             }
-            return op1(it->second, build(t->args[0], parnames, varnames));
+            return op1(it->second, arg);
         }
         }
         return cst(NAN);
@@ -277,6 +296,28 @@ struct ExprCompiler
                 break;
             case VM_TANH:
                 r = op2(VM_MUL, op2(VM_SUB, cst(1.0), op2(VM_MUL, n, n)), diff(a, k, dcache, dep));
+                break;
+            case VM_SINH:
+                r = op2(VM_MUL, op1(VM_COSH, a), diff(a, k, dcache, dep));
+                break;
+            case VM_COSH:
+                r = op2(VM_MUL, op1(VM_SINH, a), diff(a, k, dcache, dep));
+                break;
+            case VM_ASIN: // 1 / sqrt(1 - a^2)
+                r = op2(VM_DIV, diff(a, k, dcache, dep), op1(VM_SQRT, op2(VM_SUB, cst(1.0), op2(VM_MUL, a, a))));
+                break;
+            case VM_ACOS:
+                r = op1(VM_NEG, op2(VM_DIV, diff(a, k, dcache, dep), op1(VM_SQRT, op2(VM_SUB, cst(1.0), op2(VM_MUL, a, a)))));
+                break;
+            case VM_LOG1P:
+                r = op2(VM_DIV, diff(a, k, dcache, dep), op2(VM_ADD, cst(1.0), a));
+                break;
+            case VM_EXPM1:
+                r = op2(VM_MUL, op1(VM_EXP, a), diff(a, k, dcache, dep));
+                break;
+            case VM_PNORM: // dnorm(a) a'
+                r = op2(VM_MUL, op2(VM_MUL, op1(VM_EXP, op2(VM_MUL, cst(-0.5), op2(VM_MUL, a, a))), cst(0.39894228040143267794)),
+                        diff(a, k, dcache, dep));
                 break;
             default:
                 r = cst(NAN);

@@ -502,12 +502,304 @@ __global__ __launch_bounds__(MC_T) void mchol_backsub_kernel(MCholArgs a, double
         sol[r] = w[r];
 }
 
+// ---- natural-order blocked Cholesky: the factorisation that serves the matrices an LM step actually meets ----------------
+// J^T J + mu D^2 with mu > 0 is positive definite, and on a numerically positive definite matrix gsl_linalg_mcholesky
+// never modifies anything: its pivoting only decides the ORDER in which the same factor is rounded.  Without the pivot
+// search the factorisation is level 3: 64 columns per step --
+//   cholb_panel_kernel   every workgroup factors the 64 x 64 diagonal block of the step in LDS (redundantly: same bits,
+//                        no hand-off), workgroup 0 stores it, workgroup b > 0 solves its 64 rows of the panel against it
+//                        (X L11^T = W21);
+//   cholb_trail_kernel   W22 -= L21 L21^T on the matrix cores (v_mfma_f64_16x16x4_f64), one 64 x 64 tile per workgroup;
+//   the right-hand side rides through both as one more row of the matrix (L y = b happens inside the factorisation);
+//   cholb_back_kernel    L^T x = y, one launch per block from the last to the first.
+// A pivot that is not safely positive (<= 1e-12 of the diagonal entry it started as, or NaN) raises a flag: the matrix
+// is not numerically positive definite and the caller runs the pivoted, modified factorisation above on it.
+constexpr int CB = 64;
+constexpr int CB_LD = CB + 1; // LDS rows: conflict-free column walks
+constexpr int CBT_LD = 68;    // MFMA staging tiles (as BD_LD)
+typedef double cb_v4f64 __attribute__((ext_vector_type(4)));
+
+// X L11^T = W21 for 64 rows, thread (row = lane, column class = wave) with its 16 columns wave, wave + 4, ... of the row in
+// REGISTERS for all 64 steps.  Step J: the thread that owns column J scales it (x_J = r / L_JJ) and shows it to the other
+// three classes through LDS (two buffers in turn: one barrier per step), then every thread takes x_J L[c][J] out of its
+// columns c > J -- L[c][J] is the same for a whole wavefront, an LDS broadcast.  J is a literal (a recursion, not a loop):
+// every register index is static.
+template <int Q, int J>
+__device__ __forceinline__ void cholb_trsm_update(double (&r)[16], double xj, const double *Lt, int wave)
+{
+    if constexpr (Q < 16)
+    {
+        constexpr int QJ = J >> 2;
+        if constexpr (Q > QJ)
+            r[Q] -= xj * Lt[(wave + 4 * Q) * CB_LD + J];
+        else if constexpr (Q == QJ)
+        {
+            if (wave > (J & 3))
+                r[Q] -= xj * Lt[(wave + 4 * Q) * CB_LD + J];
+        }
+        cholb_trsm_update<Q + 1, J>(r, xj, Lt, wave);
+    }
+}
+template <int J>
+__device__ __forceinline__ void cholb_trsm_steps(double (&r)[16], const double *Lt, const double *invd, double (*xs)[CB], int lane,
+                                                 int wave)
+{
+    if constexpr (J < CB)
+    {
+        if (wave == (J & 3))
+        {
+            r[J >> 2] *= invd[J];
+            xs[J & 1][lane] = r[J >> 2];
+        }
+        __syncthreads();
+        const double xj = xs[J & 1][lane];
+        cholb_trsm_update<0, J>(r, xj, Lt, wave);
+        cholb_trsm_steps<J + 1>(r, Lt, invd, xs, lane, wave);
+    }
+}
+
+// One step of 64 columns.  The first wavefront of EVERY workgroup factors the 64 x 64 diagonal block in its registers
+// (lane = row, the rank-one update of a step as DPP row broadcasts: the natural-order form of wide_chol_reg, wide_core.hpp;
+// redundantly in every workgroup: same bits, no hand-off) and leaves L11 in LDS; then workgroup b > 0 solves its 64 rows of
+// the panel against it (cholb_trsm_steps; the rows are requested before the factorisation starts and arrive behind it).
+// Workgroup 0 stores L11 and carries the right-hand side (one more row of the matrix).
+__global__ __launch_bounds__(256) void cholb_panel_kernel(const double *W, double *Lf, int p, int k0, const double *dorig, int *flag,
+                                                          double *yv, double *dinvg)
+{
+    __shared__ double Lt[CB * CB_LD], invd[CB];
+    __shared__ int bad_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nb = p - k0 < CB ? p - k0 : CB;
+    if (tid == 0)
+        bad_s = 0;
+    // this workgroup's rows of the panel (workgroup b > 0: rows r0 .. r0 + 63): thread (lane, wave) holds columns
+    // wave, wave + 4, ... of row r0 + lane
+    const int r0 = k0 + CB * (int)blockIdx.x;
+    double rr[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+    {
+        const int c = wave + 4 * q;
+        rr[q] = (blockIdx.x > 0 && r0 + lane < p && c < nb) ? W[(size_t)(r0 + lane) * p + k0 + c] : 0.0;
+    }
+    // the diagonal block, lower triangle, identity beyond nb (a partial last block)
+    for (int e = tid; e < CB * CB; e += 256)
+    {
+        const int i = e >> 6, j = e & 63;
+        Lt[i * CB_LD + j] = (i < nb && j <= i) ? W[(size_t)(k0 + i) * p + k0 + j] : (i == j ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (wave == 0)
+    {
+        constexpr int R = CB / 16;
+        double m[CB];
+#pragma unroll
+        for (int k = 0; k < CB; ++k)
+            m[k] = k < lane ? Lt[lane * CB_LD + k] : (k > lane ? Lt[k * CB_LD + lane] : 0.0);
+        double dg = Lt[lane * CB_LD + lane];
+        const double thr = lane < nb ? fmax(1e-12 * dorig[k0 + lane], DBL_EPSILON) : 0.0;
+        wide_lds_sync(); // every lane has its row before the factor overwrites the block
+        auto step = [&](auto self, auto jj) __attribute__((always_inline)) -> bool {
+            constexpr int j = decltype(jj)::value;
+            if constexpr (j >= CB)
+                return true;
+            else
+            {
+                const double dj = wide_bcast(dg, j), tj = wide_bcast(thr, j);
+                if (!(dj > tj)) // (below eps the reference's alpha = max(eps, |d|, ..) replaces the pivot; NaN ends here too)
+                    return false;
+                const double rs = 1.0 / sqrt(dj), ainv = rs * rs; // (one division per step: 1 / d_j as (1 / sqrt d_j)^2)
+                const double v = lane > j ? m[j] : 0.0;
+                const double t = ainv * v;
+                dg -= t * v;
+                Lt[lane * CB_LD + j] = lane == j ? dj * rs : v * rs; // column j of L11 (0 above the diagonal)
+                if (lane == j)
+                    invd[j] = rs;
+                if constexpr (j + 1 < CB)
+                {
+                    double vb[R];
+                    wide_row_copies<R>(v, vb);
+                    wide_chol_update<j + 1, CB, R>(m, vb, -t);
+                }
+                return self(self, WideInt<j + 1>{});
+            }
+        };
+        const bool ok = step(step, WideInt<0>{});
+        if (!ok && lane == 0)
+        {
+            bad_s = 1;
+            if (blockIdx.x == 0)
+                *flag = 1;
+        }
+    }
+    __syncthreads();
+    if (bad_s)
+        return;
+    if (blockIdx.x == 0)
+    {
+        for (int e = tid; e < CB * CB; e += 256)
+        {
+            const int i = e >> 6, j = e & 63;
+            if (i < nb && j <= i)
+                Lf[(size_t)(k0 + i) * p + k0 + j] = Lt[i * CB_LD + j];
+        }
+        if (tid < nb)
+            dinvg[k0 + tid] = invd[tid]; // 1 / L_jj for the back substitution
+    }
+    if (blockIdx.x == 0)
+    {
+        // the right-hand side rides along as one more row of the matrix: its slice of this step, L11 y = b (forward
+        // substitution block by block; the trailing update of the vector is cholb_trail_kernel's last workgroups)
+        if (wave == 0)
+        {
+            double v = lane < nb ? yv[k0 + lane] : 0.0;
+            for (int j = 0; j < nb; ++j)
+            {
+                const double yj = wide_bcast(v, j) * invd[j];
+                if (lane == j)
+                    v = yj;
+                else if (lane > j && lane < nb)
+                    v -= Lt[lane * CB_LD + j] * yj;
+            }
+            if (lane < nb)
+                yv[k0 + lane] = v;
+        }
+        return;
+    }
+    // rows r0 .. r0 + 63 of the panel: X L11^T = W21
+    __shared__ double xs[2][CB];
+    cholb_trsm_steps<0>(rr, Lt, invd, xs, lane, wave);
+    if (r0 + lane < p)
+    {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+        {
+            const int c = wave + 4 * q;
+            if (c < nb)
+                Lf[(size_t)(r0 + lane) * p + k0 + c] = rr[q];
+        }
+    }
+}
+
+// W[I][J] -= L[I][kblk] L[J][kblk]^T for the tiles I >= J behind the panel (tile index from blockIdx.x, lower triangle)
+__global__ __launch_bounds__(256, 2) void cholb_trail_kernel(double *W, const double *Lf, int p, int k0, int ntile, double *yv)
+{
+    __shared__ double tI[CB * CBT_LD], tJ[CB * CBT_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, ii = lane & 15;
+    const int t = blockIdx.x;
+    if (t >= ntile)
+    {
+        // y[i] -= L[i][k-block] . y[k-block] for the rows behind the panel: 256 rows per workgroup, one per thread
+        __shared__ double yk[CB];
+        if (tid < CB)
+            yk[tid] = yv[k0 + tid];
+        __syncthreads();
+        const int i = k0 + CB + (t - ntile) * 256 + tid;
+        if (i < p)
+        {
+            const double *row = Lf + (size_t)i * p + k0;
+            double s0 = 0.0;
+#pragma unroll 8
+            for (int c = 0; c < CB; ++c)
+                s0 += row[c] * yk[c];
+            yv[i] -= s0;
+        }
+        return;
+    }
+    int I = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while (I * (I + 1) / 2 > t)
+        --I;
+    while ((I + 1) * (I + 2) / 2 <= t)
+        ++I;
+    const int J = t - I * (I + 1) / 2;
+    const int base = k0 + CB, ri = base + CB * I, rj = base + CB * J;
+    // (k0 + 64 <= p here: the last panel has no trailing matrix)
+    for (int e = tid; e < CB * CB; e += 256)
+    {
+        const int r = e >> 6, c = e & 63;
+        tI[r * CBT_LD + c] = ri + r < p ? Lf[(size_t)(ri + r) * p + k0 + c] : 0.0;
+        tJ[r * CBT_LD + c] = rj + r < p ? Lf[(size_t)(rj + r) * p + k0 + c] : 0.0;
+    }
+    __syncthreads();
+    cb_v4f64 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        acc[b] = (cb_v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int c = 0; c < 16; ++c)
+    {
+        // lane l supplies A'[l % 16][l / 16] = L_I[16 wave + ii][4 c + kk] and B[l / 16][l % 16] = L_J[16 b + ii][4 c + kk]
+        const double va = tI[(wave * 16 + ii) * CBT_LD + c * 4 + kk];
+        double vb[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            vb[b] = tJ[(b * 16 + ii) * CBT_LD + c * 4 + kk];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va, vb[b], acc[b], 0, 0, 0);
+    }
+    // result register r of block b: element (16 wave + 4 r + kk, 16 b + ii) of the tile
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+        {
+            const int gi = ri + wave * 16 + 4 * r + kk, gj = rj + b * 16 + ii;
+            if (gi < p && gj < p && gj <= gi)
+                W[(size_t)gi * p + gj] -= acc[b][r];
+        }
+}
+
+// One block of the back substitution L^T x = y (blocks from the last to the first): every workgroup solves the block's
+// 64 x 64 transposed triangle for x_k (redundantly: same bits, no hand-off); workgroup 0 stores x_k, workgroup g > 0
+// takes x_k out of 256 of the components in front of the block: y[j] -= sum_r L[k0 + r][j] x_r (coalesced over j).
+__global__ __launch_bounds__(256) void cholb_back_kernel(const double *Lf, int p, int k0, double *yv, double *sol, const double *dinvg)
+{
+    __shared__ double Ld[CB * CB_LD], xk[CB];
+    const int tid = threadIdx.x, nb = p - k0 < CB ? p - k0 : CB;
+    for (int e = tid; e < nb * nb; e += 256)
+    {
+        const int i = e / nb, j = e - i * nb;
+        Ld[i * CB_LD + j] = j <= i ? Lf[(size_t)(k0 + i) * p + k0 + j] : 0.0;
+    }
+    __syncthreads();
+    if (tid < 64)
+    {
+        double v = tid < nb ? yv[k0 + tid] : 0.0;
+        const double di = tid < nb ? dinvg[k0 + tid] : 0.0;
+        for (int j = nb - 1; j >= 0; --j)
+        {
+            const double xj = wide_bcast(v, j) * wide_bcast(di, j);
+            if (tid == j)
+                v = xj;
+            else if (tid < j)
+                v -= Ld[j * CB_LD + tid] * xj;
+        }
+        if (tid < nb)
+            xk[tid] = v;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0)
+    {
+        if (tid < nb)
+            sol[k0 + tid] = xk[tid];
+        return;
+    }
+    const int j = (blockIdx.x - 1) * 256 + tid;
+    if (j < k0)
+    {
+        double s0 = 0.0;
+        for (int r = 0; r < nb; ++r)
+            s0 += Lf[(size_t)(k0 + r) * p + j] * xk[r];
+        yv[j] -= s0;
+    }
+}
+
 struct MCholBuffers
 {
     std::mutex mu;
     int cap = 0, device = -1;
     double *A = nullptr, *Lg = nullptr, *Cg = nullptr, *vec = nullptr; // vec: ainvg | dcur | b | dinv | scal | rhs | sol
-    int *ivec = nullptr;                                              // pos | ord
+    int *ivec = nullptr;                                              // pos | ord | flag of the natural-order factorisation
     bool attr_set = false;
 };
 static MCholBuffers &mchol_buffers()
@@ -543,8 +835,8 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
         const size_t pp = (size_t)p * p;
         if (hipMalloc(&B.A, sizeof(double) * pp) != hipSuccess || hipMalloc(&B.Lg, sizeof(double) * pp) != hipSuccess ||
             hipMalloc(&B.Cg, sizeof(double) * (size_t)MC_NB_MAX * p) != hipSuccess ||
-            hipMalloc(&B.vec, sizeof(double) * ((size_t)6 * p + MC_NB_MAX + 8)) != hipSuccess ||
-            hipMalloc(&B.ivec, sizeof(int) * (size_t)2 * p) != hipSuccess)
+            hipMalloc(&B.vec, sizeof(double) * ((size_t)7 * p + MC_NB_MAX + 8)) != hipSuccess ||
+            hipMalloc(&B.ivec, sizeof(int) * ((size_t)2 * p + 4)) != hipSuccess)
         {
             (void)hipGetLastError();
             return GSLNLS_E_NODEVICE;
@@ -594,6 +886,49 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
         long long g = ((long long)p * p + 256 * 8 - 1) / (256 * 8);
         g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
         hipLaunchKernelGGL(mchol_init_kernel, dim3((unsigned)g), dim3(256), 0, 0, a, d_rhs, A_host ? nullptr : jtj_dev, d_dmp, mu);
+    }
+    // natural order first (level 3, no pivot search); the pivoted, modified factorisation below when it reports a pivot
+    // that is not safely positive, or always under GSLNLS_LARGE_CHOL_PIVOTED=1
+    {
+        const char *pe = getenv("GSLNLS_LARGE_CHOL_PIVOTED");
+        if (!(pe && atoi(pe) != 0))
+        {
+            int *d_flag = B.ivec + 2 * p;
+            double *d_work = d_dmp + p;
+            GSLNLS_HIP_OK(hipMemsetAsync(d_flag, 0, sizeof(int), 0));
+            // the right-hand side is one more row of the matrix: L y = b happens inside the factorisation
+            GSLNLS_HIP_OK(hipMemcpyAsync(d_work, d_rhs, sizeof(double) * p, hipMemcpyDeviceToDevice, 0));
+            for (int k0 = 0; k0 < p; k0 += CB)
+            {
+                const int nrb = (p - k0 + CB - 1) / CB; // row blocks from the diagonal block down
+                // (workgroup 0: the diagonal block and the right-hand side; workgroup b: row block b of the panel)
+                hipLaunchKernelGGL(cholb_panel_kernel, dim3(nrb), dim3(256), 0, 0, B.A, B.Lg, p, k0, a.dcur, d_flag, d_work, a.dinv);
+                if (nrb > 1)
+                {
+                    const int nt = (nrb - 1) * nrb / 2, nrhs = (p - k0 - CB + 255) / 256;
+                    hipLaunchKernelGGL(cholb_trail_kernel, dim3(nt + nrhs), dim3(256), 0, 0, B.A, B.Lg, p, k0, nt, d_work);
+                }
+            }
+            for (int k0 = ((p - 1) / CB) * CB; k0 >= 0; k0 -= CB)
+                hipLaunchKernelGGL(cholb_back_kernel, dim3(1 + (k0 + 255) / 256), dim3(256), 0, 0, B.Lg, p, k0, d_work, d_sol, a.dinv);
+            int h_flag = 0;
+            GSLNLS_HIP_OK(hipMemcpy(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost));
+            if (!h_flag)
+            {
+                GSLNLS_HIP_OK(hipMemcpy(sol_host, d_sol, sizeof(double) * p, hipMemcpyDeviceToHost));
+                GSLNLS_HIP_OK(hipGetLastError());
+                return GSLNLS_SUCCESS;
+            }
+            if (getenv("GSLNLS_LARGE_PROF"))
+                fprintf(stderr, "[mchol] p = %d: the natural-order factorisation met a pivot that is not safely positive; the pivoted routine runs\n", p);
+            // not numerically positive definite: the matrix (overwritten by the trailing updates) is formed again
+            if (A_host)
+                GSLNLS_HIP_OK(hipMemcpy(B.A, A_host, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice));
+            GSLNLS_HIP_OK(hipMemsetAsync(a.scal, 0, sizeof(double) * 8, 0));
+            long long g = ((long long)p * p + 256 * 8 - 1) / (256 * 8);
+            g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
+            hipLaunchKernelGGL(mchol_init_kernel, dim3((unsigned)g), dim3(256), 0, 0, a, d_rhs, A_host ? nullptr : jtj_dev, d_dmp, mu);
+        }
     }
     // the panel workgroup is sized to p (a wavefront without rows still pays for every barrier and reduction)
     int T = 64 * ((p + 63) / 64);

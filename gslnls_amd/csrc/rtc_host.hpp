@@ -80,7 +80,8 @@ inline std::string rtc_emit_ops(const Prog &pr, int upto)
             return rtc_fmt_double(pr.consts[slot - 2 * pr.p - pr.nx]);
         return "v" + std::to_string(slot - base);
     };
-    static const char *fn1[] = {"", "", "", "", "", "", "", "gexp", "log", "sin", "cos", "tan", "atan", "sqrt", "fabs", "tanh", ""};
+    static const char *fn1[] = {"", "", "", "", "", "", "", "gexp", "log", "sin", "cos", "tan", "atan", "sqrt", "fabs", "tanh", "",
+                                "sinh", "cosh", "asin", "acos", "log1p", "expm1", ""};
     std::string s;
     for (int i = 0; i < upto; ++i)
     {
@@ -95,6 +96,7 @@ inline std::string rtc_emit_ops(const Prog &pr, int upto)
         case VM_NEG: e = "-" + a; break;
         case VM_POW: e = "pow(" + a + ", " + b + ")"; break;
         case VM_SIGN: e = "(" + a + " > 0.0 ? 1.0 : (" + a + " < 0.0 ? -1.0 : 0.0))"; break;
+        case VM_PNORM: e = "0.5 * erfc(-" + a + " * 0.70710678118654752440)"; break;
         default: e = std::string(fn1[pr.op[i]]) + "(" + a + ")"; break;
         }
         s += "        const double v" + std::to_string(i) + " = " + e + ";\n";

@@ -44,7 +44,15 @@ enum VmOp : unsigned char
     VM_SQRT,
     VM_ABS,
     VM_TANH,
-    VM_SIGN
+    VM_SIGN,
+    // the rest of stats::deriv's table (R/nls.R:588-599 differentiates the formula with it): functions of one argument
+    VM_SINH,
+    VM_COSH,
+    VM_ASIN,
+    VM_ACOS,
+    VM_LOG1P,
+    VM_EXPM1,
+    VM_PNORM // standard normal distribution function: 0.5 erfc(-x / sqrt(2))
 };
 
 template <int MAX_OPS, int MAX_CONST, int MAX_P, bool PACKED>
@@ -95,6 +103,13 @@ inline double vm_apply_long(unsigned int op, double x, double y)
     case VM_TAN: return tan(x);
     case VM_ATAN: return atan(x);
     case VM_TANH: return tanh(x);
+    case VM_SINH: return sinh(x);
+    case VM_COSH: return cosh(x);
+    case VM_ASIN: return asin(x);
+    case VM_ACOS: return acos(x);
+    case VM_LOG1P: return log1p(x);
+    case VM_EXPM1: return expm1(x);
+    case VM_PNORM: return 0.5 * erfc(-x * 0.70710678118654752440);
     default: return NAN;
     }
 }

@@ -572,7 +572,7 @@ __device__ __forceinline__ void wide_chol_update(double (&m)[PW], const double (
 // (1 / alpha) v, S -= t v^T, the forward substitution riding along, D^-1, then L^T by columns): when the largest diagonal
 // happens to come first at every step the two give the same bits.
 // Returns false -- nothing written -- as soon as a pivot is not safely positive (d_jj <= 1e-12 of the entry it started
-// as, or NaN): the matrix is not numerically positive definite, the caller runs the modified, pivoted factorisation.
+// as, d_jj <= DBL_EPSILON -- where the reference's alpha = max(eps, |d|, ..) would replace it --, or NaN): the matrix is not numerically positive definite, the caller runs the modified, pivoted factorisation.
 template <int PW>
 __device__ __forceinline__ bool wide_chol_reg(WideLds &L, int p, double mu, const double *rhs, double *sol, int lane)
 {
@@ -597,7 +597,8 @@ __device__ __forceinline__ bool wide_chol_reg(WideLds &L, int p, double mu, cons
         dg = L.A[tri(lane, lane)] + mu * L.diag[lane] * L.diag[lane];
         b = rhs[lane];
     }
-    const double thr = 1e-12 * dg;
+    // (DBL_EPSILON: below it gsl_linalg_mcholesky replaces the pivot, alpha = max(eps, |d|, theta^2 / beta) -- the pivoted routine's case)
+    const double thr = fmax(1e-12 * dg, DBL_EPSILON);
     double dinv = 0.0;
     // step j with j a LITERAL (a recursion over WideInt<j>, not a loop the compiler may or may not unroll: with a run-time
     // j the rows m[] are indexed dynamically and live in scratch memory)
@@ -666,6 +667,54 @@ __device__ __forceinline__ bool wide_chol_reg(WideLds &L, int p, double mu, cons
         sol[lane] = b;
     wide_lds_sync();
     return true;
+}
+
+// det(A) of the packed lower triangle in L.A by the same natural-order elimination (no damping, no right-hand side):
+// the product of the pivots d_0 d_1 ... -- what det_cholesky_jtj returns as (prod L_ii)^2 (src/nls_utils.c:55-73) -- or 0
+// as soon as a pivot is not positive (the reference: gsl_linalg_cholesky_decomp1 fails -> 0).  All 64 lanes call.
+template <int PW>
+__device__ __forceinline__ double wide_det_reg(const double *Ap, int p, int lane)
+{
+    constexpr int R = PW / 16;
+    const bool mine = lane < p;
+    double m[PW];
+    {
+        const int base = lane * (lane + 1) / 2;
+#pragma unroll
+        for (int k = 0; k < PW; ++k)
+        {
+            const int idx = k < lane ? base + k : k * (k + 1) / 2 + lane;
+            const double a = Ap[(mine && k < p) ? idx : 0];
+            m[k] = (mine && k < p && k != lane) ? a : 0.0;
+        }
+    }
+    double dg = mine ? Ap[tri(lane, lane)] : 0.0, det = 1.0;
+    auto step = [&](auto self, auto jj) __attribute__((always_inline)) -> bool {
+        constexpr int j = decltype(jj)::value;
+        if constexpr (j >= PW)
+            return true;
+        else
+        {
+            if (j >= p)
+                return true;
+            const double dj = wide_bcast(dg, j);
+            if (!(dj > 0.0))
+                return false;
+            det *= dj;
+            const double ainv = 1.0 / dj;
+            const double v = lane > j ? m[j] : 0.0;
+            const double t = ainv * v;
+            dg -= t * v;
+            if constexpr (j + 1 < PW)
+            {
+                double vb[R];
+                wide_row_copies<R>(v, vb);
+                wide_chol_update<j + 1, PW, R>(m, vb, -t);
+            }
+            return self(self, WideInt<j + 1>{});
+        }
+    };
+    return step(step, WideInt<0>{}) ? det : 0.0;
 }
 
 // the damped solve of one LM step: natural-order L D L^T first, gsl_linalg_mcholesky (modified, pivoted) when the matrix
@@ -1078,7 +1127,7 @@ __device__ __forceinline__ void wide_advance_post(const WAdvanceArgs &a, WideLds
     }
     // ---- LDS / registers -> state (+ trace rows, + the host's copy when the fit has ended) ----
     const bool done = phase == PH_DONE;
-    for (int rep = 0; rep < (done ? 2 : 1); ++rep)
+    for (int rep = 0; rep < (done && a.host_mirror ? 2 : 1); ++rep)
     {
         WState *D = rep == 0 ? S : a.host_mirror;
         if (mine)
@@ -1135,7 +1184,7 @@ __device__ __forceinline__ void wide_advance_post(const WAdvanceArgs &a, WideLds
                 a.partrace[niter + (size_t)(prm.maxiter + 1) * lane] = L.x[lane];
         }
     }
-    if (done)
+    if (done && a.done_seq)
     {
         __threadfence_system(); // every lane: its own stores to the host's copy are out before the completion word
         wide_lds_sync();

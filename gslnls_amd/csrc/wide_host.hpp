@@ -155,6 +155,10 @@ inline std::string rtc_wide_step_expr(int jacmode, int PW)
 {
     return "&gslnls::wide_step_kernel<gslnls::ModelJit, " + std::to_string(jacmode) + ", " + std::to_string(PW) + ">";
 }
+inline std::string rtc_wide_fit_expr(int jacmode, int PW)
+{
+    return "&gslnls::wide_fit_kernel<gslnls::ModelJit, " + std::to_string(jacmode) + ", " + std::to_string(PW) + ">";
+}
 inline std::string rtc_wide_finalize_expr(int jacmode)
 {
     return "&gslnls::wide_finalize_kernel<gslnls::ModelJit, " + std::to_string(jacmode) + ">";
@@ -246,6 +250,14 @@ struct WideFit : DenseBase
     hipFunction_t fn_step[3] = {nullptr, nullptr, nullptr};
     bool step_failed[3] = {false, false, false};
     int lowering = GSLNLS_LOWER_AUTO;
+    // one workgroup = one complete fit (wide_fit_kernel): the batch form of the multi-start evaluator; built when a
+    // multi-start first asks for it (GSLNLS_WIDE_MS_BATCH=0: the points are fitted one after the other instead)
+    std::shared_ptr<RtcEntry> rtc_fit[3];
+    hipFunction_t fn_fit[3] = {nullptr, nullptr, nullptr};
+    bool fit_failed[3] = {false, false, false};
+    WState *d_ms_states = nullptr;
+    double *d_ms_starts = nullptr, *d_ms_records = nullptr, *d_ms_lupars = nullptr;
+    int ms_cap = 0;
     double ev_ms_total = 0.0;
     long long ev_launches_total = 0;
     float last_ms = 0.f;
@@ -276,6 +288,10 @@ struct WideFit : DenseBase
         hipFree(d_gsums);
         hipFree(d_fb);
         hipFree(d_stamps);
+        hipFree(d_ms_states);
+        hipFree(d_ms_starts);
+        hipFree(d_ms_records);
+        hipFree(d_ms_lupars);
         hipFree(d_ssrtrace);
         hipFree(d_partrace);
         hipFree(d_resid);
@@ -388,6 +404,69 @@ struct WideFit : DenseBase
         }
         bind_step(jm, lowering == GSLNLS_LOWER_JIT);
         return 0;
+    }
+
+    // the batch kernel of the multi-start evaluator: built (or found in the cache) now; false = not available
+    bool bind_fit(int jm)
+    {
+        // (read per call: the benchmark times both forms in one process)
+        const char *e = getenv("GSLNLS_WIDE_MS_BATCH");
+        if ((e && atoi(e) == 0) || fit_failed[jm])
+            return false;
+        if (fn_fit[jm])
+            return true;
+        const std::string ef = rtc_wide_fit_expr(jm, PW);
+        rtc_fit[jm] = rtc_request(rtc_src, {ef}, true);
+        std::string msg;
+        if (rtc_fit[jm]->state.load() == RTC_READY)
+            fn_fit[jm] = rtc_function(*rtc_fit[jm], ef, msg);
+        if (!fn_fit[jm])
+            fit_failed[jm] = true;
+        return fn_fit[jm] != nullptr;
+    }
+
+    // `count` complete short fits at once, one workgroup each: starts [count][p] (host) -> records [count][3 p + 8] (host)
+    int fit_batch(int jm, const LmParams &q, const double *starts, int count, const double *lupars, bool always_fit, double dtol,
+                  double *records)
+    {
+        const int K = 3 * p + 8;
+        if (ms_cap < count)
+        {
+            hipFree(d_ms_states);
+            hipFree(d_ms_starts);
+            hipFree(d_ms_records);
+            d_ms_states = nullptr;
+            d_ms_starts = d_ms_records = nullptr;
+            ms_cap = 0;
+            GSLNLS_HIP_OK(hipMalloc(&d_ms_states, sizeof(WState) * (size_t)count));
+            GSLNLS_HIP_OK(hipMalloc(&d_ms_starts, sizeof(double) * (size_t)count * p));
+            GSLNLS_HIP_OK(hipMalloc(&d_ms_records, sizeof(double) * (size_t)count * K));
+            ms_cap = count;
+        }
+        if (lupars && !d_ms_lupars)
+            GSLNLS_HIP_OK(hipMalloc(&d_ms_lupars, sizeof(double) * 2 * WP));
+        GSLNLS_HIP_OK(hipMemcpyAsync(d_ms_starts, starts, sizeof(double) * (size_t)count * p, hipMemcpyHostToDevice, stream));
+        if (lupars)
+            GSLNLS_HIP_OK(hipMemcpyAsync(d_ms_lupars, lupars, sizeof(double) * 2 * p, hipMemcpyHostToDevice, stream));
+        WFitArgs fa;
+        memset(&fa, 0, sizeof fa);
+        fa.pass = pass_args(q);
+        fa.prm = q;
+        fa.pivoted = pivoted;
+        fa.nfit = count;
+        fa.always_fit = always_fit ? 1 : 0;
+        fa.has_bounds = lupars != nullptr;
+        fa.dtol = dtol;
+        fa.starts = d_ms_starts;
+        fa.lupars = lupars ? d_ms_lupars : nullptr;
+        fa.states = d_ms_states;
+        fa.records = d_ms_records;
+        void *args[] = {(void *)&fa};
+        if (hipModuleLaunchKernel(fn_fit[jm], count, 1, 1, WIDE_T, 1, 1, 0, stream, args, nullptr) != hipSuccess)
+            return GSLNLS_E_NODEVICE;
+        GSLNLS_HIP_OK(hipMemcpyAsync(records, d_ms_records, sizeof(double) * (size_t)count * K, hipMemcpyDeviceToHost, stream));
+        GSLNLS_HIP_OK(hipStreamSynchronize(stream));
+        return hipGetLastError() == hipSuccess ? GSLNLS_SUCCESS : GSLNLS_E_NODEVICE;
     }
 
     // ask for / pick up the fused kernel; a failed build leaves the three-launch chain in place (it is complete by itself)
@@ -1422,6 +1501,21 @@ inline int WideMsEvaluator::run_host(MsBatch &b, int lo, int hi, double *out)
 {
     const int p = fit.p, K = 3 * p + 8, NA = p * (p + 1) / 2;
     std::vector<double> st(p), tot((size_t)fit.NV);
+    if (hi > lo && fit.bind_fit(jm))
+    {
+        // every point of the block at once, one workgroup per point (wide_fit_kernel)
+        std::vector<double> starts((size_t)(hi - lo) * p);
+        for (int idx = lo; idx < hi; ++idx)
+            for (int k = 0; k < p; ++k)
+                starts[(size_t)(idx - lo) * p + k] =
+                    b.draw[idx] >= 0 ? sobol_to_range(sobol_coord(tab, (unsigned int)b.draw[idx], k), b.range[2 * k], b.range[2 * k + 1], b.kd[k])
+                                     : b.start[(size_t)idx * p + k];
+        LmParams q = prm;
+        q.maxiter = b.maxiter;
+        q.gtol = 1e-3; // src/nls_mstart.c:91, :254
+        q.chisq_in = NAN;
+        return fit.fit_batch(jm, q, starts.data(), hi - lo, lupars, b.always_fit, b.dtol, out);
+    }
     for (int idx = lo; idx < hi; ++idx)
     {
         for (int k = 0; k < p; ++k)

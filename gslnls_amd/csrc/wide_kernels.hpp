@@ -156,124 +156,19 @@ __device__ __forceinline__ bool wide_arrive_last(unsigned int *ctr, unsigned int
     return *flag_s != 0;
 }
 
-// FUSED = false: rows -> one partial set per workgroup, nothing else is compiled (about a second in the in-process
-// compiler: what the first fit of a formula waits for).  FUSED = true: the same pass + the in-launch reduction + the LM
-// step + the speculative solve (several seconds: built in the background, bound when ready -- wide_host.hpp).
-template <class M, int JAC, int PW, bool FUSED>
-__device__ __forceinline__ void wide_pass_body(const WPassArgs &a)
+// One pass of one workgroup over the row tiles t, t + tstride, ... (64 rows per wavefront and tile): the row phase, the
+// MFMA contraction, then the four wavefronts' sums added in wave order into `full` (= tile[0]: PW x PW doubles, row-major)
+// and `gfull` (= ftile[0]: J^T f), ssr / non-finite flag per wavefront in red_s.  The first tile's rows arrive prefetched
+// in xr_n / yy_n / sw_n; `load_rows(tt)` refills them for tile tt.  Ends behind a workgroup barrier.
+template <class M, int JAC, int PW, class LOAD>
+__device__ __forceinline__ void wide_rows_to_sums(const WPassArgs &a, int phase, long long t, long long tstride, long long ntile,
+                                                  double (&xr_n)[M::NX], double &yy_n, double &sw_n, LOAD &&load_rows,
+                                                  double (*tile)[PW * WIDE_LD], double (*ftile)[64], const double *th_s,
+                                                  const double *vel_s, const double *delta_s, double (*red_s)[2])
 {
     constexpr int P = M::P, NX = M::NX, NB = PW / 16, NW = WIDE_T / 64, NQ = NB * (NB + 1) / 2;
-    constexpr int NA = P * (P + 1) / 2, NV = 2 + NA + P, NVP = (NV + 1) & ~1; // NVP: doubles from one set to the next
-    static_assert(P <= PW && PW <= 64 && PW % 16 == 0, "PW = 16 ceil(p / 16)");
-    // one LDS region, two tenants: the tiles of the pass, then (in the one workgroup that runs the LM step, and in the
-    // speculator) the working set of wide_advance followed by the totals of the pass
-    constexpr int TILE_D = NW * PW * WIDE_LD, ADV_D = (int)(sizeof(WideLds) / sizeof(double)) + ((NV + 1) & ~1);
-    constexpr int LDS_D = (!FUSED || TILE_D > ADV_D) ? TILE_D : ADV_D;
-    __shared__ __attribute__((aligned(16))) double lds_raw[LDS_D];
-    __shared__ double ftile[NW][64];
-    __shared__ double th_s[P], vel_s[P], delta_s[P];
-    __shared__ double red_s[NW][2];
-    __shared__ int flag_s;
-    double(*const tile)[PW * WIDE_LD] = reinterpret_cast<double(*)[PW * WIDE_LD]>(lds_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const WState *S = a.state;
-    // everything this workgroup needs from the previous launch is asked for at once (the state was written on another
-    // XCD: a load is most of two microseconds, and phase -> theta -> rows one after the other was six)
-    double st_x = 0.0, st_xt = 0.0, st_vel = 0.0;
-    if (tid < P)
-    {
-        st_x = S->x[tid];
-        st_xt = S->xt[tid];
-        st_vel = S->vel[tid];
-    }
-    const int phase = S->phase;
-    const int rb = FUSED ? (int)blockIdx.x - a.spec : (int)blockIdx.x; // row-block index; -1: the speculator
-    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto stamp = [&](int k) {
-        if (FUSED && a.stamps)
-            st[k] = __builtin_amdgcn_s_memrealtime();
-    };
-    stamp(0);
-    // ---- roles that end in the damped solve: the speculator now, the workgroup that completes the totals later ----
-    bool solver = false;       // this wavefront runs the solve below
-    const bool is_spec = FUSED && rb < 0;
-    WideLds &L = *reinterpret_cast<WideLds *>(lds_raw);
-    double *const totals_s = lds_raw + sizeof(WideLds) / sizeof(double);
-    WideCtx ctx;
-    double mu_solve = 0.0;
-    double *sol_dst = nullptr;
-    WAdvanceArgs adv = a.adv;
-    if (is_spec)
-    {
-        // A rejected trial leaves x, J^T J, D, g as they are and multiplies mu by nu (src/trust.c:530-545): the damped
-        // system of the step after a rejection is known before the pass has run.  This workgroup solves it while the
-        // others stream the rows; the LM step takes the solution if it rejects (bit for bit what it would compute).
-        if (wave != 0 || phase != PH_TRIAL) // (PH_DONE included: a launch past the end of the fit)
-            return;
-        const int p = P;
-        const bool mine = lane < p;
-        {
-            constexpr int IT = (NA + 63) / 64;
-            double ba[IT];
-#pragma unroll
-            for (int i = 0; i < IT; ++i)
-                ba[i] = lane + 64 * i < NA ? S->A[lane + 64 * i] : 0.0;
-            const double dg = mine ? S->diag[lane] : 0.0, gg = mine ? S->g[lane] : 0.0;
-            mu_solve = S->mu * S->nu;
-#pragma unroll
-            for (int i = 0; i < IT; ++i)
-                if (lane + 64 * i < NA)
-                    L.A[lane + 64 * i] = ba[i];
-            if (mine)
-            {
-                L.diag[lane] = dg;
-                L.rhs[lane] = -gg;
-            }
-        }
-        wide_lds_sync();
-        solver = true;
-        sol_dst = L.sol;
-    }
-    else
-    {
-    // the rows of this wavefront's first tile: requested before the state is waited for
-    const long long ntile = (a.n + 63) / 64;
-    const int nrb = FUSED ? (int)gridDim.x - a.spec : (int)gridDim.x;
-    const long long tstride = (long long)nrb * NW;
-    long long t = (long long)rb * NW + wave;
-    double xr_n[NX], yy_n = 0.0, sw_n = 0.0;
-    auto load_rows = [&](long long tt) {
-        const long long i = tt * 64 + lane;
-        const bool live = i < a.n;
-        const long long ic = live ? i : a.n - 1;
-#pragma unroll
-        for (int c = 0; c < NX; ++c)
-            xr_n[c] = a.x[(size_t)c * a.n + ic];
-        yy_n = a.y[ic];
-        sw_n = live ? (a.sw ? a.sw[ic] : 1.0) : 0.0;
-    };
-#pragma unroll
-    for (int c = 0; c < NX; ++c)
-        xr_n[c] = 0.0;
-    if (t < ntile)
-        load_rows(t);
-    if (phase == PH_DONE)
-        return;
-    if (tid < P)
-    {
-        const double t0 = (phase == PH_FVV) ? st_x : st_xt;
-        th_s[tid] = t0;
-        vel_s[tid] = st_vel;
-        double d = a.h_df * fabs(t0); // src/fdjac.c:36-38
-        if (d == 0.0)
-            d = a.h_df;
-        delta_s[tid] = d;
-    }
-    // the padding columns of the tiles (P .. PW - 1) are zeroed once; the row phase writes every other entry
-    if constexpr (P < PW)
-        for (int e = lane; e < (PW - P) * WIDE_LD; e += 64)
-            tile[wave][P * WIDE_LD + e] = 0.0;
-    __syncthreads();
+    (void)tid;
     const WideTheta th{th_s};
     double *const mytile = tile[wave];
     const int kk = lane >> 4, ii = lane & 15;
@@ -422,6 +317,129 @@ __device__ __forceinline__ void wide_pass_body(const WPassArgs &a)
         }
         __syncthreads();
     }
+}
+
+// FUSED = false: rows -> one partial set per workgroup, nothing else is compiled (about a second in the in-process
+// compiler: what the first fit of a formula waits for).  FUSED = true: the same pass + the in-launch reduction + the LM
+// step + the speculative solve (several seconds: built in the background, bound when ready -- wide_host.hpp).
+template <class M, int JAC, int PW, bool FUSED>
+__device__ __forceinline__ void wide_pass_body(const WPassArgs &a)
+{
+    constexpr int P = M::P, NX = M::NX, NB = PW / 16, NW = WIDE_T / 64, NQ = NB * (NB + 1) / 2;
+    constexpr int NA = P * (P + 1) / 2, NV = 2 + NA + P, NVP = (NV + 1) & ~1; // NVP: doubles from one set to the next
+    static_assert(P <= PW && PW <= 64 && PW % 16 == 0, "PW = 16 ceil(p / 16)");
+    // one LDS region, two tenants: the tiles of the pass, then (in the one workgroup that runs the LM step, and in the
+    // speculator) the working set of wide_advance followed by the totals of the pass
+    constexpr int TILE_D = NW * PW * WIDE_LD, ADV_D = (int)(sizeof(WideLds) / sizeof(double)) + ((NV + 1) & ~1);
+    constexpr int LDS_D = (!FUSED || TILE_D > ADV_D) ? TILE_D : ADV_D;
+    __shared__ __attribute__((aligned(16))) double lds_raw[LDS_D];
+    __shared__ double ftile[NW][64];
+    __shared__ double th_s[P], vel_s[P], delta_s[P];
+    __shared__ double red_s[NW][2];
+    __shared__ int flag_s;
+    double(*const tile)[PW * WIDE_LD] = reinterpret_cast<double(*)[PW * WIDE_LD]>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const WState *S = a.state;
+    // everything this workgroup needs from the previous launch is asked for at once (the state was written on another
+    // XCD: a load is most of two microseconds, and phase -> theta -> rows one after the other was six)
+    double st_x = 0.0, st_xt = 0.0, st_vel = 0.0;
+    if (tid < P)
+    {
+        st_x = S->x[tid];
+        st_xt = S->xt[tid];
+        st_vel = S->vel[tid];
+    }
+    const int phase = S->phase;
+    const int rb = FUSED ? (int)blockIdx.x - a.spec : (int)blockIdx.x; // row-block index; -1: the speculator
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int k) {
+        if (FUSED && a.stamps)
+            st[k] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
+    // ---- roles that end in the damped solve: the speculator now, the workgroup that completes the totals later ----
+    bool solver = false;       // this wavefront runs the solve below
+    const bool is_spec = FUSED && rb < 0;
+    WideLds &L = *reinterpret_cast<WideLds *>(lds_raw);
+    double *const totals_s = lds_raw + sizeof(WideLds) / sizeof(double);
+    WideCtx ctx;
+    double mu_solve = 0.0;
+    double *sol_dst = nullptr;
+    WAdvanceArgs adv = a.adv;
+    if (is_spec)
+    {
+        // A rejected trial leaves x, J^T J, D, g as they are and multiplies mu by nu (src/trust.c:530-545): the damped
+        // system of the step after a rejection is known before the pass has run.  This workgroup solves it while the
+        // others stream the rows; the LM step takes the solution if it rejects (bit for bit what it would compute).
+        if (wave != 0 || phase != PH_TRIAL) // (PH_DONE included: a launch past the end of the fit)
+            return;
+        const int p = P;
+        const bool mine = lane < p;
+        {
+            constexpr int IT = (NA + 63) / 64;
+            double ba[IT];
+#pragma unroll
+            for (int i = 0; i < IT; ++i)
+                ba[i] = lane + 64 * i < NA ? S->A[lane + 64 * i] : 0.0;
+            const double dg = mine ? S->diag[lane] : 0.0, gg = mine ? S->g[lane] : 0.0;
+            mu_solve = S->mu * S->nu;
+#pragma unroll
+            for (int i = 0; i < IT; ++i)
+                if (lane + 64 * i < NA)
+                    L.A[lane + 64 * i] = ba[i];
+            if (mine)
+            {
+                L.diag[lane] = dg;
+                L.rhs[lane] = -gg;
+            }
+        }
+        wide_lds_sync();
+        solver = true;
+        sol_dst = L.sol;
+    }
+    else
+    {
+    // the rows of this wavefront's first tile: requested before the state is waited for
+    const long long ntile = (a.n + 63) / 64;
+    const int nrb = FUSED ? (int)gridDim.x - a.spec : (int)gridDim.x;
+    const long long tstride = (long long)nrb * NW;
+    long long t = (long long)rb * NW + wave;
+    double xr_n[NX], yy_n = 0.0, sw_n = 0.0;
+    auto load_rows = [&](long long tt) {
+        const long long i = tt * 64 + lane;
+        const bool live = i < a.n;
+        const long long ic = live ? i : a.n - 1;
+#pragma unroll
+        for (int c = 0; c < NX; ++c)
+            xr_n[c] = a.x[(size_t)c * a.n + ic];
+        yy_n = a.y[ic];
+        sw_n = live ? (a.sw ? a.sw[ic] : 1.0) : 0.0;
+    };
+#pragma unroll
+    for (int c = 0; c < NX; ++c)
+        xr_n[c] = 0.0;
+    if (t < ntile)
+        load_rows(t);
+    if (phase == PH_DONE)
+        return;
+    if (tid < P)
+    {
+        const double t0 = (phase == PH_FVV) ? st_x : st_xt;
+        th_s[tid] = t0;
+        vel_s[tid] = st_vel;
+        double d = a.h_df * fabs(t0); // src/fdjac.c:36-38
+        if (d == 0.0)
+            d = a.h_df;
+        delta_s[tid] = d;
+    }
+    // the padding columns of the tiles (P .. PW - 1) are zeroed once; the row phase writes every other entry
+    if constexpr (P < PW)
+        for (int e = lane; e < (PW - P) * WIDE_LD; e += 64)
+            tile[wave][P * WIDE_LD + e] = 0.0;
+    __syncthreads();
+    wide_rows_to_sums<M, JAC, PW>(a, phase, t, tstride, ntile, xr_n, yy_n, sw_n, load_rows, tile, ftile, th_s, vel_s, delta_s, red_s);
+    double *const full = &tile[0][0];   // PW x PW doubles, row-major: (i, j) -> i * PW + j
+    double *const gfull = &ftile[0][0]; // PW doubles
     stamp(1); // rows done, workgroup sums staged
     double *out = a.partials + (size_t)rb * NVP;
     const bool fuse = FUSED && a.fuse != WIDE_FUSE_NONE;
@@ -669,6 +687,246 @@ template <class M, int JAC, int PW>
 __global__ __launch_bounds__(WIDE_T, GSLNLS_WIDE_WAVES(PW)) void wide_step_kernel(WPassArgs a)
 {
     wide_pass_body<M, JAC, PW, true>(a);
+}
+
+// ---- one workgroup = one complete fit -----------------------------------------------------------------------------------
+// The per-point work of gsl_multistart_driver for 10 <= p <= 64 (src/nls_mstart.c:42-128, :245-255): det filter at the
+// sampled point (det_eval_jtj, src/nls_utils.c:23-73), a short LM fit, det where it ended -- every sample point of a
+// batch at once instead of one after the other: workgroup f owns point f for its whole fit.  A trial step is the pass
+// over the n rows by the four wavefronts (wide_rows_to_sums: the workgroup's own sums ARE the totals), then the LM step by
+// the first wavefront (wide_advance_pre / solve / post, its state in HBM, touched by that wavefront only), a workgroup
+// barrier instead of a launch boundary.  Records are written position-addressed, (3 p + 8) doubles per point, as
+// ms_fit_kernel writes them (batch_kernels.hpp): x, diag, x0, chisq0, chisq1, det0, det1, ssr at the start, niter,
+// status, nevalf.
+struct WFitArgs
+{
+    WPassArgs pass;        // x, y, sw, n, h_df, h_fvv, fvv_analytic, wf_only (the other fields are not read)
+    LmParams prm;          // of the short fits (maxiter = mstart_p, gtol = 1e-3: src/nls_mstart.c:91, :254)
+    int pivoted, nfit, always_fit, has_bounds;
+    double dtol;
+    const double *starts;  // [nfit][p]
+    const double *lupars;  // [2 p] lower / upper pairs, or nullptr
+    WState *states;        // [nfit]: one state per workgroup
+    double *records;       // [nfit][3 p + 8]
+};
+
+template <class M, int JAC, int PW>
+__global__ __launch_bounds__(WIDE_T, GSLNLS_WIDE_WAVES(PW)) void wide_fit_kernel(WFitArgs fa)
+{
+    constexpr int P = M::P, NX = M::NX, NW = WIDE_T / 64;
+    constexpr int NA = P * (P + 1) / 2, NV = 2 + NA + P;
+    constexpr int TILE_D = NW * PW * WIDE_LD, ADV_D = (int)(sizeof(WideLds) / sizeof(double)) + ((NV + 1) & ~1);
+    constexpr int LDS_D = TILE_D > ADV_D ? TILE_D : ADV_D;
+    __shared__ __attribute__((aligned(16))) double lds_raw[LDS_D];
+    __shared__ double ftile[NW][64];
+    __shared__ double th_s[P], vel_s[P], delta_s[P];
+    __shared__ double red_s[NW][2];
+    __shared__ int phase_s;
+    double(*const tile)[PW * WIDE_LD] = reinterpret_cast<double(*)[PW * WIDE_LD]>(lds_raw);
+    WideLds &L = *reinterpret_cast<WideLds *>(lds_raw);
+    double *const totals_s = lds_raw + sizeof(WideLds) / sizeof(double);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f = blockIdx.x;
+    if (f >= fa.nfit)
+        return;
+    const WPassArgs &a = fa.pass;
+    WState *S = fa.states + f;
+    double *rec = fa.records + (size_t)f * (3 * P + 8);
+    const double *st0 = fa.starts + (size_t)f * P;
+    // ---- lm_state_reset: the start state of the fit (by the wavefront that will run its steps) ----
+    if (wave == 0)
+    {
+        if (lane < P)
+        {
+            const double v = st0[lane];
+            S->x[lane] = S->xt[lane] = v;
+            S->dx[lane] = S->vel[lane] = S->acc[lane] = S->g[lane] = 0.0;
+            S->diag[lane] = 1.0;
+            const double lo = fa.lupars ? fa.lupars[2 * lane] : -INFINITY, up = fa.lupars ? fa.lupars[2 * lane + 1] : INFINITY;
+            S->lo[lane] = isfinite(lo) ? lo : -INFINITY;
+            S->up[lane] = isfinite(up) ? up : INFINITY;
+            rec[2 * P + lane] = v; // x0
+        }
+        for (int k = lane; k < NA; k += 64)
+            S->A[k] = 0.0;
+        if (lane == 0)
+        {
+            S->fnorm2 = INFINITY;
+            S->mu = 0.0;
+            S->nu = 2.0;
+            S->delta = 0.0;
+            S->avratio = 0.0;
+            S->chisq0 = S->chisq1 = S->chisq_init = INFINITY;
+            S->bad_steps = S->niter = 0;
+            S->phase = PH_INIT;
+            S->status = S->info = ST_CONTINUE;
+            S->nevalf = S->nevaldf = S->nevalfvv = 0;
+            S->p = P;
+            S->end_launch = 0;
+        }
+    }
+    if (tid < P)
+    {
+        const double v = st0[tid];
+        th_s[tid] = v;
+        vel_s[tid] = 0.0;
+        double d = a.h_df * fabs(v);
+        if (d == 0.0)
+            d = a.h_df;
+        delta_s[tid] = d;
+    }
+    if (tid == 0)
+        phase_s = PH_INIT;
+    __syncthreads();
+    WAdvanceArgs adv;
+    adv.state = S;
+    adv.totals = totals_s;
+    adv.prm = fa.prm;
+    adv.ssrtrace = nullptr;
+    adv.partrace = nullptr;
+    adv.host_mirror = nullptr; // (no host copy, no completion word: the record is cut from the state below)
+    adv.done_seq = nullptr;
+    adv.seq = 0;
+    adv.launch_idx = 0;
+    adv.p = P;
+    adv.pivoted = fa.pivoted;
+    const long long ntile = (a.n + 63) / 64;
+    bool first = true;
+    for (int step = 0; step < (1 << 20); ++step)
+    {
+        const int phase = phase_s;
+        // the padding columns of the tiles (the LM step used the region: zero them again)
+        if constexpr (P < PW)
+            for (int e = lane; e < (PW - P) * WIDE_LD; e += 64)
+                tile[wave][P * WIDE_LD + e] = 0.0;
+        double xr_n[NX], yy_n = 0.0, sw_n = 0.0;
+        auto load_rows = [&](long long tt) {
+            const long long i = tt * 64 + lane;
+            const bool live = i < a.n;
+            const long long ic = live ? i : a.n - 1;
+#pragma unroll
+            for (int c = 0; c < NX; ++c)
+                xr_n[c] = a.x[(size_t)c * a.n + ic];
+            yy_n = a.y[ic];
+            sw_n = live ? (a.sw ? a.sw[ic] : 1.0) : 0.0;
+        };
+#pragma unroll
+        for (int c = 0; c < NX; ++c)
+            xr_n[c] = 0.0;
+        if (wave < ntile)
+            load_rows(wave);
+        __syncthreads();
+        wide_rows_to_sums<M, JAC, PW>(a, phase, (long long)wave, (long long)NW, ntile, xr_n, yy_n, sw_n, load_rows, tile, ftile, th_s,
+                                      vel_s, delta_s, red_s);
+        // the workgroup's sums are the totals of the pass: ssr, non-finite flag, packed lower J^T J, J^T f
+        {
+            const double *full = &tile[0][0], *gfull = &ftile[0][0];
+            if (tid == 0)
+            {
+                double s0 = red_s[0][0], s1 = red_s[0][1];
+                for (int w = 1; w < NW; ++w)
+                {
+                    s0 += red_s[w][0];
+                    s1 += red_s[w][1];
+                }
+                totals_s[0] = s0;
+                totals_s[1] = s1;
+            }
+            for (int e = tid; e < NA; e += WIDE_T)
+            {
+                int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+                while (i * (i + 1) / 2 > e)
+                    --i;
+                while ((i + 1) * (i + 2) / 2 <= e)
+                    ++i;
+                const int j = e - i * (i + 1) / 2;
+                totals_s[2 + e] = full[i * PW + j];
+            }
+            for (int k = tid; k < P; k += WIDE_T)
+                totals_s[2 + NA + k] = gfull[k];
+        }
+        __syncthreads();
+        if (wave == 0)
+        {
+            bool go = true;
+            if (first)
+            {
+                // det_eval_jtj at the sampled point; the fit is only run where the filter lets the point through
+                double det0 = wide_det_reg<PW>(totals_s + 2, P, lane);
+                if (JAC == JAC_ANALYTIC && !(totals_s[1] == 0.0))
+                    det0 = 0.0; // eval_df failed (src/nls_utils.c:47-48)
+                go = fa.always_fit || det0 > fa.dtol;
+                if (lane == 0)
+                {
+                    rec[3 * P + 2] = det0;
+                    rec[3 * P + 4] = totals_s[0];
+                }
+                if (!go)
+                {
+                    if (lane < P)
+                    {
+                        rec[lane] = st0[lane];
+                        rec[P + lane] = 1.0;
+                    }
+                    if (lane == 0)
+                    {
+                        rec[3 * P + 0] = INFINITY;
+                        rec[3 * P + 1] = totals_s[0];
+                        rec[3 * P + 3] = 0.0;
+                        rec[3 * P + 5] = 0.0;
+                        rec[3 * P + 6] = (double)ST_CONTINUE;
+                        rec[3 * P + 7] = 1.0;
+                        phase_s = -1;
+                    }
+                }
+            }
+            if (go)
+            {
+                WideCtx ctx;
+                wide_advance_pre<P>(adv, L, ctx);
+                if (ctx.active && ctx.want)
+                    wide_solve_pw<PW>(L, P, ctx.mu, L.rhs, ctx.want == 1 ? L.acc : L.vel, lane, adv.pivoted);
+                wide_advance_post<P>(adv, L, ctx);
+                // the next pass reads its point from LDS: the step's own copies of x, xt, vel are still there
+                const int nphase = S->phase;
+                if (lane < P)
+                {
+                    const double t0 = (nphase == PH_FVV) ? L.x[lane] : L.xt[lane];
+                    th_s[lane] = t0;
+                    vel_s[lane] = L.vel[lane];
+                    double d = a.h_df * fabs(t0);
+                    if (d == 0.0)
+                        d = a.h_df;
+                    delta_s[lane] = d;
+                }
+                if (lane == 0)
+                    phase_s = nphase;
+                if (nphase == PH_DONE)
+                {
+                    // the record of a fitted point
+                    const double det1 = wide_det_reg<PW>(L.A, P, lane);
+                    if (lane < P)
+                    {
+                        rec[lane] = L.x[lane];
+                        rec[P + lane] = L.diag[lane];
+                    }
+                    if (lane == 0)
+                    {
+                        rec[3 * P + 0] = S->chisq0;
+                        rec[3 * P + 1] = S->chisq1;
+                        rec[3 * P + 3] = det1;
+                        rec[3 * P + 5] = (double)S->niter;
+                        rec[3 * P + 6] = (double)S->status;
+                        rec[3 * P + 7] = (double)S->nevalf;
+                    }
+                }
+            }
+        }
+        first = false;
+        __syncthreads();
+        if (phase_s == PH_DONE || phase_s < 0)
+            return;
+    }
 }
 
 // After the fit: weighted residual and Jacobian at the final point in the layout C_nls returns them (resid n; grad

@@ -64,6 +64,13 @@ int wide_expr_build(const gslnls_model *fn, std::string &first_path)
             fprintf(stderr, "gslnls: native lowering (step kernel) failed: %s\n", step->log.c_str());
             return GSLNLS_E_UNSUPPORTED;
         }
+        // the one-workgroup-per-fit kernel of the multi-start evaluator
+        auto fitk = rtc_request(src, {rtc_wide_fit_expr(jm, PW)}, true);
+        if (fitk->state.load() != RTC_READY)
+        {
+            fprintf(stderr, "gslnls: native lowering (fit kernel) failed: %s\n", fitk->log.c_str());
+            return GSLNLS_E_UNSUPPORTED;
+        }
     }
     return GSLNLS_SUCCESS;
 }

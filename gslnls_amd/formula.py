@@ -18,8 +18,19 @@ import numpy as np
 
 _TOKEN = re.compile(r"\s*(?:(\d+\.?\d*(?:[eE][-+]?\d+)?|\.\d+(?:[eE][-+]?\d+)?)|([A-Za-z_.][A-Za-z_.0-9]*)|(\*\*|[-+*/^()~,]))")
 
+def _pnorm(x):
+    from scipy.special import erfc
+    return 0.5 * erfc(-np.asarray(x, dtype=np.float64) * 0.70710678118654752440)
+
+
+# the functions stats::deriv differentiates (R/nls.R:588-599 builds the Jacobian of a formula with it); csrc/expr_compile.hpp
+# lowers the same list
 FUNCS = {"exp": np.exp, "log": np.log, "sin": np.sin, "cos": np.cos, "tan": np.tan, "atan": np.arctan,
-         "sqrt": np.sqrt, "abs": np.abs, "tanh": np.tanh}
+         "sqrt": np.sqrt, "abs": np.abs, "tanh": np.tanh, "sinh": np.sinh, "cosh": np.cosh, "asin": np.arcsin,
+         "acos": np.arccos, "log1p": np.log1p, "expm1": np.expm1, "log2": np.log2, "log10": np.log10, "pnorm": _pnorm,
+         "dnorm": lambda x: np.exp(-0.5 * np.asarray(x, dtype=np.float64) ** 2) * 0.39894228040143267794,
+         "sinpi": lambda x: np.sin(np.pi * np.asarray(x)), "cospi": lambda x: np.cos(np.pi * np.asarray(x)),
+         "tanpi": lambda x: np.tan(np.pi * np.asarray(x))}
 CONSTS = {"pi": math.pi}
 
 

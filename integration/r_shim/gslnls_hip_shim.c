@@ -49,6 +49,122 @@ SEXP C_gslnls_shutdown(void)
     return R_NilValue;
 }
 
+/* ---- function models: gsl_nls(fn = <function>, y = ...) (R/nls.R:778) --------------------------------------------
+ * The closures are evaluated HERE, on the R thread, the way gsl_f / gsl_df / gsl_fvv evaluate them (src/nls.c:815-978:
+ * par as a named numeric vector, or a named list of scalars when start was a list -- control_int[13] == 0 --, then
+ * Rf_eval of the prepared call in `env`, then the type / length checks); the core (gslnls_nls_fn) calls back for every
+ * evaluation and does everything after it on the device.  An R error inside a closure must not long-jump through the
+ * core's C++ frames: R_tryEval catches it, the callback reports failure, C_nls_hip raises the error after the core
+ * has returned. */
+typedef struct
+{
+    SEXP fcall, dfcall, fvvcall, rho, names;
+    int n, p, startisnum, warn, r_error;
+} fn_route;
+
+static SEXP make_par(const fn_route *d, const double *theta)
+{
+    SEXP par;
+    if (d->startisnum)
+    {
+        par = PROTECT(Rf_allocVector(REALSXP, d->p));
+        for (int k = 0; k < d->p; k++)
+            REAL(par)[k] = theta[k];
+    }
+    else
+    {
+        par = PROTECT(Rf_allocVector(VECSXP, d->p));
+        for (int k = 0; k < d->p; k++)
+            SET_VECTOR_ELT(par, k, Rf_ScalarReal(theta[k]));
+    }
+    Rf_setAttrib(par, R_NamesSymbol, d->names);
+    UNPROTECT(1);
+    return par;
+}
+
+static int cb_f(const double *theta, int p, double *fval, int n, void *user)
+{
+    fn_route *d = (fn_route *)user;
+    (void)p;
+    SEXP par = PROTECT(make_par(d, theta));
+    SETCADR(d->fcall, par);
+    int err = 0;
+    SEXP v = PROTECT(R_tryEval(d->fcall, d->rho, &err));
+    if (err)
+    {
+        d->r_error = 1;
+        UNPROTECT(2);
+        return 1;
+    }
+    if (TYPEOF(v) != REALSXP || Rf_length(v) != n)
+    {
+        if (d->warn)
+            Rf_warning("Evaluating fn does not return numeric vector of expected length n");
+        UNPROTECT(2);
+        return 1; /* GSL_EBADFUNC, src/nls.c:843-844 */
+    }
+    memcpy(fval, REAL(v), sizeof(double) * (size_t)n); /* model values: the core subtracts y and applies :846-849 */
+    UNPROTECT(2);
+    return 0;
+}
+
+static int cb_jac(const double *theta, int p, double *J, int n, void *user)
+{
+    fn_route *d = (fn_route *)user;
+    SEXP par = PROTECT(make_par(d, theta));
+    SETCADR(d->dfcall, par);
+    int err = 0;
+    SEXP v = PROTECT(R_tryEval(d->dfcall, d->rho, &err));
+    if (err)
+    {
+        d->r_error = 1;
+        UNPROTECT(2);
+        return 1;
+    }
+    if (TYPEOF(v) != REALSXP || !Rf_isMatrix(v) || Rf_ncols(v) != p || Rf_nrows(v) != n)
+    {
+        if (d->warn)
+            Rf_warning("Evaluating jac does not return numeric matrix of dimensions n x p");
+        UNPROTECT(2);
+        return 1;
+    }
+    /* column-major n x p as R holds it (src/nls.c:905-912 transposes it into GSL's rows; the core keeps R's layout);
+     * non-finite entries are found by the device's pass over the matrix (:894-903) */
+    memcpy(J, REAL(v), sizeof(double) * (size_t)n * p);
+    UNPROTECT(2);
+    return 0;
+}
+
+static int cb_fvv(const double *theta, const double *vdir, int p, double *out, int n, void *user)
+{
+    fn_route *d = (fn_route *)user;
+    SEXP par = PROTECT(make_par(d, theta));
+    SEXP vpar = PROTECT(Rf_allocVector(REALSXP, p));
+    for (int k = 0; k < p; k++)
+        REAL(vpar)[k] = vdir[k];
+    Rf_setAttrib(vpar, R_NamesSymbol, d->names);
+    SETCADR(d->fvvcall, par);
+    SETCADDR(d->fvvcall, vpar);
+    int err = 0;
+    SEXP v = PROTECT(R_tryEval(d->fvvcall, d->rho, &err));
+    if (err)
+    {
+        d->r_error = 1;
+        UNPROTECT(3);
+        return 1;
+    }
+    if (TYPEOF(v) != REALSXP || Rf_length(v) != n)
+    {
+        if (d->warn)
+            Rf_warning("Evaluating fvv does not return numeric vector of expected length n");
+        UNPROTECT(3);
+        return 1;
+    }
+    memcpy(out, REAL(v), sizeof(double) * (size_t)n);
+    UNPROTECT(3);
+    return 0;
+}
+
 /* NA-filled REALSXP of length n (src/nls.c:774-780) */
 static SEXP na_vector(int n)
 {
@@ -72,10 +188,12 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
     /* ---- model lowering: formula RHS -> registry id, parameter order, data columns ---- */
     SEXP formula = closure_formula(fn);
     SEXP rhs = PROTECT(formula == R_NilValue ? R_NilValue : deparse_rhs(formula));
-    const char *pn[64];
-    int order[64];
+    const char **pn = (const char **)R_alloc((size_t)(p > 0 ? p : 1), sizeof(char *));
+    int *order = (int *)R_alloc((size_t)(p > 0 ? p : 1), sizeof(int));
     char cols[256];
     int model_id = 0;
+    for (int k = 0; k < p; k++)
+        order[k] = k;
     if (rhs != R_NilValue && p <= 64 && !Rf_isNull(parnames))
     {
         for (int k = 0; k < p; k++)
@@ -84,8 +202,9 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
     }
     const char *xn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     /* (up to 9 parameters and 3 data columns: interpreted or natively compiled row models; up to 64 parameters and 8
-     * columns: the wide path, J^T J on the matrix cores -- the core decides, include/gslnls_core.h) */
-    if (model_id <= 0 && rhs != R_NilValue && p <= 64 && !Rf_isNull(parnames))
+     * columns: the wide path, J^T J on the matrix cores; up to 512 parameters, single start and default loss: the Jacobian
+     * as a matrix in HBM -- the core decides, include/gslnls_core.h) */
+    if (model_id <= 0 && rhs != R_NilValue && p <= 512 && !Rf_isNull(parnames))
     {
         /* not a hand-written device model: hand the expression itself to the core (GSLNLS_MODEL_EXPR), which
          * compiles it with its symbolic gradient -- the analogue of R/nls.R:565,588-599.  Data columns are the
@@ -94,12 +213,16 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
         const int ok = formula_columns(formula, pn, p, cols, sizeof(cols), xn, &nxe);
         if (ok)
         {
-            model_id = GSLNLS_MODEL_EXPR;
             for (int k = 0; k < p; k++)
-                order[k] = k;
+                pn[k] = CHAR(STRING_ELT(parnames, k));
+            model_id = GSLNLS_MODEL_EXPR;
         }
     }
-    if (model_id <= 0 || Rf_isMatrix(swts) ||                    /* does not lower, or GLS weights */
+    /* a `function` model (no formula behind the closure): single start and default loss go to the core with the closures
+     * as callbacks (gslnls_nls_fn), any p up to 4096 */
+    const int fn_model = model_id <= 0 && formula == R_NilValue && TYPEOF(fn) == CLOSXP && !mstart && p <= 4096 &&
+                         INTEGER(VECTOR_ELT(loss_config, 0))[0] == 0;
+    if ((model_id <= 0 && !fn_model) || Rf_isMatrix(swts) ||     /* does not lower, or GLS weights */
         INTEGER(control_int)[2] > 1)                             /* dogleg / ddogleg / subspace2D */
     {
         UNPROTECT(1);
@@ -107,11 +230,12 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
     }
 
     /* data columns from the model frame, column-major n x nx in device regressor order */
-    SEXP mf = Rf_findVarInFrame(CLOENV(fn), Rf_install("mf"));
+    SEXP mf = fn_model ? R_UnboundValue : Rf_findVarInFrame(CLOENV(fn), Rf_install("mf"));
     int nx = 1;
-    for (const char *c = cols; *c; c++)
+    for (const char *c = cols; *c && !fn_model; c++)
         nx += (*c == ',');
-    double *X = (double *)R_alloc((size_t)n * nx, sizeof(double));
+    double *X = fn_model ? NULL : (double *)R_alloc((size_t)n * nx, sizeof(double));
+    if (!fn_model)
     {
         char buf[256];
         strncpy(buf, cols, sizeof(buf) - 1);
@@ -217,9 +341,34 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
         res.ssrtrace = REAL(strace);
     }
 
-    const int rc = gslnls_nls(&model, REAL(y), n, !Rf_isNull(jac), !Rf_isNull(fvv), st, mstart,
-                              Rf_isNull(swts) ? NULL : REAL(swts), 0, lu, INTEGER(control_int), REAL(control_dbl),
-                              hs, wgt_i, REAL(VECTOR_ELT(loss_config, 1)), &res);
+    int rc;
+    if (fn_model)
+    {
+        /* the calls the reference prepares once and re-aims at every evaluation (src/nls.c:155-216) */
+        fn_route d;
+        memset(&d, 0, sizeof(d));
+        d.fcall = PROTECT(Rf_lang2(fn, R_NilValue));
+        d.dfcall = PROTECT(Rf_isNull(jac) ? R_NilValue : Rf_lang2(jac, R_NilValue));
+        d.fvvcall = PROTECT(Rf_isNull(fvv) ? R_NilValue : Rf_lang3(fvv, R_NilValue, R_NilValue));
+        nprot += 3;
+        d.rho = env;
+        d.names = parnames;
+        d.n = n;
+        d.p = p;
+        d.startisnum = INTEGER(control_int)[13];
+        d.warn = 1; /* single start: params.warn = TRUE, src/nls.c:175-178 */
+        rc = gslnls_nls_fn(n, p, REAL(y), cb_f, Rf_isNull(jac) ? NULL : cb_jac, Rf_isNull(fvv) ? NULL : cb_fvv, &d, st,
+                           Rf_isNull(swts) ? NULL : REAL(swts), lu, INTEGER(control_int), REAL(control_dbl), &res);
+        if (d.r_error)
+        {
+            UNPROTECT(nprot);
+            Rf_error("error in the model function, its Jacobian or fvv (see the message above)");
+        }
+    }
+    else
+        rc = gslnls_nls(&model, REAL(y), n, !Rf_isNull(jac), !Rf_isNull(fvv), st, mstart,
+                        Rf_isNull(swts) ? NULL : REAL(swts), 0, lu, INTEGER(control_int), REAL(control_dbl),
+                        hs, wgt_i, REAL(VECTOR_ELT(loss_config, 1)), &res);
     if (rc == GSLNLS_E_INTERRUPTED)
         Rf_onintr(); /* does not return: the pending interrupt is re-raised now that the device loop is drained */
     /* no device / not lowered after all, or a qr / svd request on a problem too ill-conditioned for the normal

@@ -18,5 +18,5 @@ for p in (64, 100, 250, 500, 777, 1000, 1500, 2000):
         rc = L.gslnls_debug_mchol_solve(*args)
     dt = (time.perf_counter() - t0) / reps
     M = A + 1e-3 * np.diag(diag ** 2)
-    print("p = %4d: rc %d, %.3f ms per solve (incl. the %d KB upload), residual %.2e" % (
+    print(("pivoted" if os.environ.get("GSLNLS_LARGE_CHOL_PIVOTED") == "1" else "natural") + " p = %4d: rc %d, %.3f ms per solve (incl. the %d KB upload), residual %.2e" % (
         p, rc, 1e3 * dt, p * p * 8 // 1024, np.max(np.abs(M @ sol - rhs)) / np.max(np.abs(rhs))), flush=True)

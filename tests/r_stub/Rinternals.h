@@ -64,6 +64,9 @@ SEXP Rf_install(const char *);
 SEXP Rf_lang2(SEXP, SEXP);
 SEXP Rf_lang3(SEXP, SEXP, SEXP);
 SEXP Rf_eval(SEXP, SEXP);
+SEXP R_tryEval(SEXP, SEXP, int *);
+SEXP SETCADR(SEXP, SEXP);
+SEXP SETCADDR(SEXP, SEXP);
 SEXP Rf_findVar(SEXP, SEXP);
 SEXP Rf_findVarInFrame(SEXP, SEXP);
 SEXP Rf_getAttrib(SEXP, SEXP);

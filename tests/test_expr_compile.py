@@ -235,3 +235,47 @@ def test_second_directional_derivative(pb):
     num = (4 * d2(0.5e-2) - d2(1e-2)) / 3
     scale = np.max(np.abs(num)) + 1e-300
     assert np.max(np.abs(st["fvv"] - num)) / scale < 2e-5, pb["name"]
+
+
+VOCABULARY = [
+    ("a * sinh(b * x) + c", dict(a=1.3, b=0.7, c=0.2), (-2.0, 2.0)),
+    ("a * cosh(b * x) - c * x", dict(a=0.8, b=1.1, c=0.3), (-2.0, 2.0)),
+    ("a * asin(b * x) + c", dict(a=2.0, b=0.45, c=0.1), (-1.9, 1.9)),
+    ("a * acos(b * x) + c * x", dict(a=1.5, b=0.4, c=0.2), (-1.9, 1.9)),
+    ("a * log1p(b * x * x) + c", dict(a=1.2, b=0.9, c=-0.4), (-2.0, 2.0)),
+    ("a * expm1(-b * x) + c", dict(a=2.5, b=0.6, c=0.3), (0.0, 3.0)),
+    ("a * log2(b + x) + c * log10(b + x * x)", dict(a=1.1, b=2.5, c=0.7), (0.0, 4.0)),
+    ("a * pnorm((x - m) / s) + c", dict(a=3.0, m=0.4, s=1.3, c=0.5), (-3.0, 3.0)),
+    ("a * dnorm((x - m) / s) / s", dict(a=3.0, m=-0.3, s=0.8), (-3.0, 3.0)),
+    ("a * sinpi(b * x) + c * cospi(x)", dict(a=1.0, b=0.35, c=0.5), (-1.0, 1.0)),
+]
+
+
+@pytest.mark.parametrize("rhs_text,pars,xr", VOCABULARY, ids=[v[0].split("(")[0].split()[-1] for v in VOCABULARY])
+def test_the_rest_of_stats_derivs_table(rhs_text, pars, xr):
+    """The functions stats::deriv differentiates beyond the round-3 list (R/nls.R:588-599 builds the Jacobian with it):
+    sinh cosh asin acos log1p expm1 log2 log10 pnorm dnorm sinpi cospi tanpi.  Program value against numpy (1e-13),
+    symbolic gradient against Richardson-extrapolated differences, second directional derivative against differences of
+    the gradient."""
+    names = list(pars)
+    x = np.linspace(xr[0], xr[1], 41)
+    th = np.array([pars[k] for k in names])
+    val, grad, st = hs.expr_eval(rhs_text, names, ["x"], th, x)
+    rhs = F.parse_expr(rhs_text)
+
+    def ev(t):
+        env = {"x": x}
+        env.update({k: t[i] for i, k in enumerate(names)})
+        return np.asarray(F.evaluate(rhs, env), dtype=np.float64) * np.ones(len(x))
+
+    ref = ev(th)
+    np.testing.assert_allclose(val, ref, rtol=1e-13, atol=1e-13 * np.max(np.abs(ref)))
+    for k in range(len(names)):
+        h = 1e-4 * max(abs(th[k]), 1e-8)
+        e = np.zeros(len(names))
+        e[k] = h
+        d1 = (ev(th + e) - ev(th - e)) / (2 * h)
+        d2 = (ev(th + e / 2) - ev(th - e / 2)) / h
+        num = (4 * d2 - d1) / 3
+        scale = np.max(np.abs(num)) + 1e-300
+        assert np.max(np.abs(grad[:, k] - num)) / scale < 1e-6, (rhs_text, names[k])

@@ -431,3 +431,40 @@ def test_interpreter_slot_file_in_lds_equals_scratch_form(amd, nist, monkeypatch
             if k in a and a[k] is not None:
                 assert np.array_equal(np.asarray(a[k]), np.asarray(b[k]), equal_nan=True), (name, k)
         assert a["niter"] == b["niter"] and a["neval"] == b["neval"] and a["conv"] == b["conv"] == 0, name
+
+
+def _vocabulary():
+    from test_expr_compile import VOCABULARY
+    return VOCABULARY
+
+
+@pytest.mark.parametrize("case", range(10))
+@pytest.mark.parametrize("lowering", ["vm", "jit"])
+def test_one_fit_per_function_of_the_widened_vocabulary(amd, gslref, case, lowering):
+    """sinh cosh asin acos log1p expm1 log2 log10 pnorm dnorm sinpi cospi (the rest of stats::deriv's table, R/nls.R:588-599):
+    one fit per function through the interpreter and through native code, symbolic Jacobian, against the oracle with the
+    same model evaluated by numpy and a Richardson Jacobian; FD on both sides as a second check"""
+    rhs_text, pars, xr = _vocabulary()[case]
+    names = list(pars)
+    truth = np.array([pars[k] for k in names])
+    rng = np.random.Generator(np.random.PCG64(77 + case))
+    x = np.linspace(xr[0], xr[1], 200)
+    rhs = F.parse_expr(rhs_text)
+
+    def model(t):
+        env = {"x": x}
+        env.update({k: t[i] for i, k in enumerate(names)})
+        return np.asarray(F.evaluate(rhs, env), dtype=np.float64) * np.ones(len(x))
+
+    y = model(truth) + 0.01 * rng.standard_normal(len(x))
+    start = truth * (1.0 + 0.03 * np.where(np.arange(len(names)) % 2 == 0, 1.0, -1.0))
+    ctrl = dict(solver="cholesky")
+    fit = amd.gsl_nls("y ~ " + rhs_text, data=dict(x=x, y=y), start=dict(zip(names, start)), jac=True, control=ctrl,
+                      lowering=lowering)
+    ref = gslref.nls(len(x), len(names), start, fn=lambda t: model(t) - y, ctrl=gslref.control(**ctrl))
+    assert fit["conv"] == 0 and ref["conv"] == 0, (rhs_text, fit["conv"], ref["conv"])
+    rel = float(np.max(np.abs(fit["par"] - ref["par"]) / np.abs(ref["par"])))
+    assert rel < 1e-5 and abs(fit["ssr"] - ref["ssr"]) <= 1e-8 * ref["ssr"], (rhs_text, rel)
+    fd = amd.gsl_nls("y ~ " + rhs_text, data=dict(x=x, y=y), start=dict(zip(names, start)), control=ctrl, lowering=lowering)
+    relfd = float(np.max(np.abs(fd["par"] - ref["par"]) / np.abs(ref["par"])))
+    assert fd["conv"] == 0 and relfd < 1e-6 and abs(fd["ssr"] - ref["ssr"]) <= 1e-9 * ref["ssr"], (rhs_text, relfd)

@@ -169,13 +169,17 @@ def test_c3_full_size_properties(amd):
     assert 0.5e-4 < a["ssr"] / n < 2e-4
 
 
+@pytest.mark.parametrize("pivoted", ["0", "1"])
 @pytest.mark.parametrize("p", [3, 65, 130, 500, 777, 1100, 2050])
-def test_device_modified_cholesky_matches_the_oracle(amd, gslref, p):
+def test_device_modified_cholesky_matches_the_oracle(amd, gslref, p, pivoted, monkeypatch):
     """The damped normal equations of the gsl_nls_large lm step on the device (csrc/mchol_device.hip: panels of pivot
     steps by one workgroup, grid-wide trailing updates, implicit permutation) against gsl_linalg_mcholesky as restated
     by the oracle: well conditioned, badly scaled (pivoting matters), rank deficient (the modification kicks in; what the
-    system sees is compared), identical diagonal blocks (exact ties: the first position wins) and a zero column"""
+    system sees is compared), identical diagonal blocks (exact ties: the first position wins) and a zero column.
+    pivoted = 0 (default): the natural-order blocked Cholesky serves the numerically positive definite cases and hands the
+    rank-deficient and zero-column ones to the pivoted routine; pivoted = 1: the pivoted routine alone."""
     from gslnls_amd import _lib
+    monkeypatch.setenv("GSLNLS_LARGE_CHOL_PIVOTED", pivoted)
     L = _lib.lib()
     G = gslref.lib()
     rng = np.random.Generator(np.random.PCG64(4200 + p))

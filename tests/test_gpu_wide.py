@@ -5,8 +5,12 @@ formula compiled in process.  Bars: the oracle (same algorithm, model and Jacobi
 counts with the analytic Jacobian, coefficients to 1e-6 relative."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -622,3 +626,39 @@ print(json.dumps(dict(plain=plain, coll=coll, rc_init=rc_init, collectives=n1 - 
     assert r["plain"]["path"] == r["coll"]["path"] == 3 and r["plain"]["conv"] == r["coll"]["conv"] == 0
     assert r["plain"]["ms"] == r["coll"]["ms"] and r["plain"]["niter"] == r["coll"]["niter"]
     assert r["plain"]["par"] == r["coll"]["par"]
+
+
+def test_batch_fit_kernel_gives_the_records_of_the_point_by_point_evaluator(amd):
+    """The multi-start evaluator of the wide path fits every point of a batch at once, one workgroup per point
+    (wide_fit_kernel), where round 3 fitted them one after the other through the launch-per-step chain
+    (GSLNLS_WIDE_MS_BATCH=0): same state machine, same sums per workgroup -- but the one-after-the-other form adds the
+    partial sets of up to 512 workgroups where the batch form has one workgroup's sums, so the records agree to rounding,
+    not bit for bit; the det filter's decisions, iteration counts and status codes are identical.  Two child processes
+    (the switch is read once per process)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import json, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import gslnls_amd as A
+from test_gpu_wide import gaussians_problem
+pb = gaussians_problem(4, 0, 300, 11)
+x, y, names, truth = pb["x"], pb["y"], pb["names"], pb["truth"]
+lo, hi = truth * 0.8, truth * 1.2
+fit = A.gsl_nls(pb["formula"], data=dict(x=x, y=y), start={k: [float(a), float(b)] for k, a, b in zip(names, np.minimum(lo, hi), np.maximum(lo, hi))},
+                jac=True, control=dict(solver="cholesky", mstart_n=24, mstart_p=4, mstart_maxiter=3), lowering="jit")
+print(json.dumps(dict(par=[float(v) for v in fit["par"]], ssr=float(fit["ssr"]), conv=int(fit["conv"]), niter=int(fit["niter"]),
+                      ms=fit["mstart"])))
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    outs = []
+    for batch in ("1", "0"):
+        env = dict(os.environ, GSLNLS_WIDE_MS_BATCH=batch)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    a, b = outs
+    assert a["conv"] == b["conv"] == 0 and a["ms"]["nsp"] == b["ms"]["nsp"] and a["ms"]["nwsp"] == b["ms"]["nwsp"]
+    assert a["ms"]["iters"] == b["ms"]["iters"] and a["ms"]["stop"] == b["ms"]["stop"]
+    assert np.allclose(a["par"], b["par"], rtol=1e-8) and abs(a["ssr"] - b["ssr"]) <= 1e-10 * b["ssr"]
