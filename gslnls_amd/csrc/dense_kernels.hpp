@@ -438,7 +438,9 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
     // into vector lanes by the hundred, and 44 more that are live from here to the end made the compiler hand
     // lm_scale a wrong `scale` -- seen on Roszman1 with forward differences.  Those launches are bound by the
     // interpreter's slot file, not by this.)
-    constexpr bool PIN = (M::ID != 100);
+    // (... and not for natively compiled expression models with four parameters: see OUTLINE_ADVANCE below.)
+    constexpr bool OUTLINE_ADVANCE = (M::ID == 100) || (M::ID > 100 && P == 4);
+    constexpr bool PIN = !OUTLINE_ADVANCE;
     LmParams prm = ctx.prm;
     LmState<P> *state_out = ctx.state[parity];
     double *partials_out = ctx.partials[parity];
@@ -548,8 +550,12 @@ __global__ __launch_bounds__(T) void lm_step_kernel(const LmState<M::P> *prev, c
             phase_before = s.phase;
             advanced = true;
             GSLNLS_STAMP(2);
-            if constexpr (M::ID == 100)
+            if constexpr (OUTLINE_ADVANCE)
             {
+                // Natively compiled formulas with p = 4 (round 4: scripts/dev_dbg_native_p.py -- of p = 2 .. 9 exactly p = 4
+                // took other steps than the interpreter, the first one with a wrong damping parameter: the same
+                // miscompilation as below, now by the in-process compiler; every other p is bit-identical to the
+                // interpreter, and so is p = 4 with the state machine compiled on its own).
                 // Interpreted expression model: the kernel around this call spills registers by the kilobyte, and with
                 // lm_advance inlined into it the forward-difference instance for p = 4 took its first step with the
                 // damping parameter of the reset state (mu = 0) instead of the one just computed -- seen on Roszman1,

@@ -316,6 +316,16 @@ inline bool rtc_compile(const std::string &source, const std::vector<std::string
         log = "process is exiting";
         return false;
     }
+    if (const char *dump = getenv("GSLNLS_RTC_DUMP")) // developer aid: the generated translation unit as text
+    {
+        char name[512];
+        snprintf(name, sizeof name, "%s/gslnls_rtc_%016llx.hip", dump, rtc_hash(source));
+        if (FILE *fh = fopen(name, "w"))
+        {
+            fputs(source.c_str(), fh);
+            fclose(fh);
+        }
+    }
     RtcApi &api = rtc_api();
     if (!api.load())
     {

@@ -18,6 +18,37 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# ---- parity evidence: what each oracle comparison actually measured ------------------------------------------------------
+# Tests call record_parity(label, value); the table is printed at the end of the session (always, not only under -rA), so a
+# reader sees how much of each tolerance is used instead of only "passed".
+PARITY = []
+
+
+def record_parity(label, value, bar=None):
+    PARITY.append((str(label), float(value), bar))
+
+
+def rel_err(a, b):
+    """max relative difference of two coefficient vectors; recorded under the running test's name"""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    v = float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
+    label = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0].replace("tests/", "")
+    record_parity(label, v)
+    return v
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if not PARITY:
+        return
+    tr = terminalreporter
+    tr.section("measured relative error vs the oracle (record_parity)")
+    width = max(len(k) for k, _, _ in PARITY)
+    for k, v, bar in PARITY:
+        tr.write_line("%s  %.3e%s" % (k.ljust(width), v, "" if bar is None else "   (bar %.0e)" % bar))
+    worst = max(PARITY, key=lambda t: t[1])
+    tr.write_line("worst: %s %.3e over %d comparisons" % (worst[0], worst[1], len(PARITY)))
+
+
 def load_golden(name):
     with open(os.path.join(GOLDEN, name)) as fh:
         return json.load(fh)

@@ -9,7 +9,7 @@ bit-identical results, agreement between analytic and FD Jacobians.
 import numpy as np
 import pytest
 
-from conftest import c2_data
+from conftest import c2_data, record_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -25,7 +25,8 @@ def amd():
 
 
 def _rel(a, b):
-    return float(np.max(np.abs(np.asarray(a) - np.asarray(b)) / np.maximum(np.abs(np.asarray(b)), 1e-300)))
+    from conftest import rel_err
+    return rel_err(a, b)  # (recorded: the session summary prints what every comparison measured)
 
 
 @pytest.mark.parametrize("n", [1000, 65537, 300000])
@@ -44,6 +45,8 @@ def test_c2_matches_oracle(amd, gslref, n, jac):
     # default stopping rule |dx| < xtol(1 + |x|), xtol = 1.5e-8: both stop within ~xtol of the optimum,
     # so two correct implementations may differ by that much; the tight run below removes the slack
     assert _rel(fit["par"], ref["par"]) < 1e-6
+    record_parity("dense C2 n=%d jac=%s par" % (n, jac), _rel(fit["par"], ref["par"]), 1e-6)
+    record_parity("dense C2 n=%d jac=%s ssr" % (n, jac), abs(fit["ssr"] - ref["ssr"]) / ref["ssr"], 1e-10)
     assert abs(fit["ssr"] - ref["ssr"]) <= 1e-10 * ref["ssr"]
     # the last iteration sits at round-off level (ssrtol ~1e-15): whether its trials are accepted or it ends
     # in "no progress" + xtol convergence depends on the last bits, so the counters may differ there
@@ -384,7 +387,7 @@ def test_resident_kernel_equals_launch_per_step_kernel(amd):
     code = r"""
 import json, os, sys, numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
-from conftest import c2_data
+from conftest import c2_data, record_parity
 import gslnls_amd as A
 out = []
 ctrl = A.gsl_nls_control(solver="cholesky", xtol=1.49e-8, gtol=1.49e-8)

@@ -28,7 +28,8 @@ def amd():
 
 
 def _rel(a, b):
-    return float(np.max(np.abs(np.asarray(a) - np.asarray(b)) / np.maximum(np.abs(np.asarray(b)), 1e-300)))
+    from conftest import rel_err
+    return rel_err(a, b)  # (recorded: the session summary prints what every comparison measured)
 
 
 def linear_full_rank(n, p):
@@ -81,6 +82,7 @@ def test_linear_full_rank_as_a_function_2_2_and_2_3(amd, gslref, mgh):
     fit = amd.gsl_nls(fn, y=y, start=start, jac=jac, lower=target / 2, upper=start, control=dict(solver="cholesky"))
     ref = gslref.nls(5, 5, start, fn=fn, jac=jac, lower=target / 2, upper=start, ctrl=gslref.control(solver="cholesky"))
     assert fit["conv"] == ref["conv"] and fit["niter"] == ref["niter"]
+    __import__("conftest").rel_err(fit["par"], ref["par"])  # (recorded for the session summary)
     assert np.allclose(fit["par"], ref["par"], rtol=1e-8, atol=1e-10)
 
 
