@@ -1008,7 +1008,7 @@ def main():
     streamed = 16.0 * n / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else None
     traffic = None
     traffic_source = None
-    tpath = next((os.path.join(ROOT, "profiles", f) for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+    tpath = next((os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
                   if os.path.exists(os.path.join(ROOT, "profiles", f))), "")
     if os.path.exists(tpath):
         traffic_source = "committed profile %s (separate rocprofv3 --pmc passes), NOT measured in this run" % os.path.relpath(tpath, ROOT)

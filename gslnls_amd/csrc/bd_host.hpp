@@ -259,7 +259,7 @@ struct BdFit
             }
         }
         hipLaunchKernelGGL(bd_syrk_kernel, dim3(npair, nslice), dim3(BD_T), 0, st, d_J, (long long)n, p, nslice, d_cpart);
-        hipLaunchKernelGGL(bd_syrk_reduce_kernel, dim3(npair), dim3(BD_T), 0, st, d_cpart, p, npair, nslice, d_C);
+        hipLaunchKernelGGL(bd_syrk_reduce_kernel, dim3(npair, 16), dim3(BD_T), 0, st, d_cpart, p, npair, nslice, d_C);
         hipLaunchKernelGGL(bd_gemv_t_kernel, dim3(p), dim3(BD_T), 0, st, d_J, d_fbase, (long long)n, p, d_pv);
         GSLNLS_HIP_OK(hipMemcpyAsync(g_out, d_pv, sizeof(double) * p, hipMemcpyDeviceToHost, st));
         if (jtj_host)

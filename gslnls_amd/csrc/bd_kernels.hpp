@@ -232,7 +232,8 @@ __global__ __launch_bounds__(BD_T) void bd_syrk_reduce_kernel(const double *cpar
     while ((I + 1) * (I + 2) / 2 <= pair)
         ++I;
     const int Jb = pair - I * (I + 1) / 2;
-    for (int e = threadIdx.x; e < 4096; e += BD_T)
+    // (grid.y = 16: 256 elements of the 64 x 64 block per workgroup, one per thread)
+    for (int e = blockIdx.y * BD_T + threadIdx.x; e < 4096; e += gridDim.y * BD_T)
     {
         const int r = e >> 6, c = e & 63;
         const int gi = I * 64 + r, gj = Jb * 64 + c;

@@ -181,6 +181,71 @@ struct ExprCompiler
                 {"atan", VM_ATAN}, {"sqrt", VM_SQRT}, {"abs", VM_ABS}, {"tanh", VM_TANH}, {"sinh", VM_SINH},
                 {"cosh", VM_COSH}, {"asin", VM_ASIN}, {"acos", VM_ACOS}, {"log1p", VM_LOG1P}, {"expm1", VM_EXPM1},
                 {"pnorm", VM_PNORM}};
+            // the standard selfStart models by their closed forms (stats::SSasymp & co.: the reference's unit tests 6.x fit
+            // y ~ SSasymp(x, Asym, R0, lrc), inst/unit_tests/unit_tests_gslnls.R:267-293; R evaluates the model's own
+            // compiled gradient attribute, here the closed form is differentiated like any other expression)
+            {
+                const size_t na = t->args.size();
+                auto arg_n = [&](size_t k) { return build(t->args[k], parnames, varnames); };
+                auto add = [&](int a, int b) { return op2(VM_ADD, a, b); };
+                auto sub = [&](int a, int b) { return op2(VM_SUB, a, b); };
+                auto mul = [&](int a, int b) { return op2(VM_MUL, a, b); };
+                auto dvd = [&](int a, int b) { return op2(VM_DIV, a, b); };
+                auto ex = [&](int a) { return op1(VM_EXP, a); };
+                auto neg = [&](int a) { return op1(VM_NEG, a); };
+                const std::string &f = t->name;
+                if (f == "SSasymp" && na == 4) // Asym + (R0 - Asym) exp(-exp(lrc) input)
+                {
+                    const int in = arg_n(0), As = arg_n(1), R0 = arg_n(2), lrc = arg_n(3);
+                    return add(As, mul(sub(R0, As), ex(neg(mul(ex(lrc), in)))));
+                }
+                if (f == "SSasympOff" && na == 4) // Asym (1 - exp(-exp(lrc) (input - c0)))
+                {
+                    const int in = arg_n(0), As = arg_n(1), lrc = arg_n(2), c0 = arg_n(3);
+                    return mul(As, sub(cst(1.0), ex(neg(mul(ex(lrc), sub(in, c0))))));
+                }
+                if (f == "SSasympOrig" && na == 3) // Asym (1 - exp(-exp(lrc) input))
+                {
+                    const int in = arg_n(0), As = arg_n(1), lrc = arg_n(2);
+                    return mul(As, sub(cst(1.0), ex(neg(mul(ex(lrc), in)))));
+                }
+                if (f == "SSbiexp" && na == 5) // A1 exp(-exp(lrc1) input) + A2 exp(-exp(lrc2) input)
+                {
+                    const int in = arg_n(0), A1 = arg_n(1), l1 = arg_n(2), A2 = arg_n(3), l2 = arg_n(4);
+                    return add(mul(A1, ex(neg(mul(ex(l1), in)))), mul(A2, ex(neg(mul(ex(l2), in)))));
+                }
+                if (f == "SSfol" && na == 5) // Dose exp(lKe + lKa - lCl) (exp(-exp(lKe) t) - exp(-exp(lKa) t)) / (exp(lKa) - exp(lKe))
+                {
+                    const int D = arg_n(0), in = arg_n(1), lKe = arg_n(2), lKa = arg_n(3), lCl = arg_n(4);
+                    return dvd(mul(mul(D, ex(sub(add(lKe, lKa), lCl))), sub(ex(neg(mul(ex(lKe), in))), ex(neg(mul(ex(lKa), in))))),
+                               sub(ex(lKa), ex(lKe)));
+                }
+                if (f == "SSfpl" && na == 5) // A + (B - A) / (1 + exp((xmid - input) / scal))
+                {
+                    const int in = arg_n(0), A = arg_n(1), B = arg_n(2), xm = arg_n(3), sc = arg_n(4);
+                    return add(A, dvd(sub(B, A), add(cst(1.0), ex(dvd(sub(xm, in), sc)))));
+                }
+                if (f == "SSgompertz" && na == 4) // Asym exp(-b2 b3^x)
+                {
+                    const int in = arg_n(0), As = arg_n(1), b2 = arg_n(2), b3 = arg_n(3);
+                    return mul(As, ex(neg(mul(b2, op2(VM_POW, b3, in)))));
+                }
+                if (f == "SSlogis" && na == 4) // Asym / (1 + exp((xmid - input) / scal))
+                {
+                    const int in = arg_n(0), As = arg_n(1), xm = arg_n(2), sc = arg_n(3);
+                    return dvd(As, add(cst(1.0), ex(dvd(sub(xm, in), sc))));
+                }
+                if (f == "SSmicmen" && na == 3) // Vm input / (K + input)
+                {
+                    const int in = arg_n(0), Vm = arg_n(1), K = arg_n(2);
+                    return dvd(mul(Vm, in), add(K, in));
+                }
+                if (f == "SSweibull" && na == 5) // Asym - Drop exp(-exp(lrc) x^pwr)
+                {
+                    const int in = arg_n(0), As = arg_n(1), Dr = arg_n(2), lrc = arg_n(3), pw = arg_n(4);
+                    return sub(As, mul(Dr, ex(neg(mul(ex(lrc), op2(VM_POW, in, pw))))));
+                }
+            }
             if (t->args.size() != 1)
             {
                 error = "unsupported function " + t->name + " (one argument expected)";

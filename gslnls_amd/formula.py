@@ -30,7 +30,19 @@ FUNCS = {"exp": np.exp, "log": np.log, "sin": np.sin, "cos": np.cos, "tan": np.t
          "acos": np.arccos, "log1p": np.log1p, "expm1": np.expm1, "log2": np.log2, "log10": np.log10, "pnorm": _pnorm,
          "dnorm": lambda x: np.exp(-0.5 * np.asarray(x, dtype=np.float64) ** 2) * 0.39894228040143267794,
          "sinpi": lambda x: np.sin(np.pi * np.asarray(x)), "cospi": lambda x: np.cos(np.pi * np.asarray(x)),
-         "tanpi": lambda x: np.tan(np.pi * np.asarray(x))}
+         "tanpi": lambda x: np.tan(np.pi * np.asarray(x)),
+         # the standard selfStart models by their closed forms (stats::SSasymp & co.)
+         "SSasymp": lambda x, Asym, R0, lrc: Asym + (R0 - Asym) * np.exp(-np.exp(lrc) * x),
+         "SSasympOff": lambda x, Asym, lrc, c0: Asym * (1 - np.exp(-np.exp(lrc) * (x - c0))),
+         "SSasympOrig": lambda x, Asym, lrc: Asym * (1 - np.exp(-np.exp(lrc) * x)),
+         "SSbiexp": lambda x, A1, lrc1, A2, lrc2: A1 * np.exp(-np.exp(lrc1) * x) + A2 * np.exp(-np.exp(lrc2) * x),
+         "SSfol": lambda D, x, lKe, lKa, lCl: D * np.exp(lKe + lKa - lCl) * (np.exp(-np.exp(lKe) * x) - np.exp(-np.exp(lKa) * x))
+         / (np.exp(lKa) - np.exp(lKe)),
+         "SSfpl": lambda x, A, B, xmid, scal: A + (B - A) / (1 + np.exp((xmid - x) / scal)),
+         "SSgompertz": lambda x, Asym, b2, b3: Asym * np.exp(-b2 * b3 ** x),
+         "SSlogis": lambda x, Asym, xmid, scal: Asym / (1 + np.exp((xmid - x) / scal)),
+         "SSmicmen": lambda x, Vm, K: Vm * x / (K + x),
+         "SSweibull": lambda x, Asym, Drop, lrc, pwr: Asym - Drop * np.exp(-np.exp(lrc) * x ** pwr)}
 CONSTS = {"pi": math.pi}
 
 

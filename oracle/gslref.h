@@ -177,6 +177,10 @@ typedef struct
 #define GSLREF_MODEL_GAUSS1 4   /* Gauss1 family p=8          (R/nls_test.R:301) */
 #define GSLREF_MODEL_GLMEXP 5   /* exp(a_i^T theta), p = nx    */
 
+/* opt-in: the row models evaluate exp with the device's arithmetic (gslref_models.c), bit for bit */
+void gslref_set_device_exp(int on);
+double gslref_device_exp(double x);
+void gslref_device_exp_array(const double *x, double *out, int n);
 int gslref_model_f(const double *x, void *params, double *f);
 int gslref_model_df(const double *x, void *params, double *J);
 int gslref_model_fvv(const double *x, const double *v, void *params, double *fvv);

@@ -98,6 +98,10 @@ def lib():
         L.gslref_psip.restype = C.c_double
         L.gslref_hat_values.argtypes = [C.c_int, C.c_int, DP, DP]
         L.gslref_cooks_d.argtypes = [C.c_int, C.c_int, DP, DP, DP]
+        L.gslref_set_device_exp.argtypes = [C.c_int]
+        L.gslref_set_device_exp.restype = None
+        L.gslref_device_exp_array.argtypes = [DP, DP, C.c_int]
+        L.gslref_device_exp_array.restype = None
         _LIB = L
     return _LIB
 
@@ -338,6 +342,26 @@ def nls_large(n, p, start, fn=None, dfl=None, rowdata=None, algorithm="cgst", ct
                ssrtol=res.ssrtol, neval=dict(f=res.neval[0], dfu=res.neval[1], df2=res.neval[2], fvv=res.neval[3]),
                info=res.info, chisq_init=res.chisq_init, ret=status)
     del keep, st, w
+    return out
+
+
+class device_exp:
+    """with gslref.device_exp(): the oracle's row models evaluate exp with the device's arithmetic (gslref_models.c) --
+    finite-difference runs of oracle and device then walk the same trajectory bit for bit"""
+
+    def __enter__(self):
+        lib().gslref_set_device_exp(1)
+        return self
+
+    def __exit__(self, *a):
+        lib().gslref_set_device_exp(0)
+
+
+def gexp(x):
+    """the device's exp on a numpy array (for Python model closures handed to the oracle)"""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    lib().gslref_device_exp_array(_dp(x.reshape(-1)), _dp(out.reshape(-1)), x.size)
     return out
 
 

@@ -279,3 +279,44 @@ def test_the_rest_of_stats_derivs_table(rhs_text, pars, xr):
         num = (4 * d2 - d1) / 3
         scale = np.max(np.abs(num)) + 1e-300
         assert np.max(np.abs(grad[:, k] - num)) / scale < 1e-6, (rhs_text, names[k])
+
+
+SELFSTART = [
+    ("SSasymp(x, Asym, R0, lrc)", dict(Asym=1.2, R0=5.8, lrc=0.1), (0.0, 3.0)),
+    ("SSasympOff(x, Asym, lrc, c0)", dict(Asym=4.0, lrc=-0.3, c0=0.4), (0.5, 4.0)),
+    ("SSasympOrig(x, Asym, lrc)", dict(Asym=4.0, lrc=-0.3), (0.0, 4.0)),
+    ("SSbiexp(x, A1, lrc1, A2, lrc2)", dict(A1=3.0, lrc1=0.8, A2=1.0, lrc2=-1.2), (0.0, 4.0)),
+    ("SSfol(4.0, x, lKe, lKa, lCl)", dict(lKe=-2.5, lKa=0.4, lCl=-3.0), (0.2, 10.0)),
+    ("SSfpl(x, A, B, xmid, scal)", dict(A=0.5, B=4.0, xmid=2.0, scal=0.6), (0.0, 4.0)),
+    ("SSgompertz(x, Asym, b2, b3)", dict(Asym=5.0, b2=2.2, b3=0.6), (0.0, 4.0)),
+    ("SSlogis(x, Asym, xmid, scal)", dict(Asym=4.0, xmid=2.0, scal=0.5), (0.0, 4.0)),
+    ("SSmicmen(x, Vm, K)", dict(Vm=200.0, K=0.06), (0.02, 1.1)),
+    ("SSweibull(x, Asym, Drop, lrc, pwr)", dict(Asym=160.0, Drop=110.0, lrc=-1.5, pwr=2.2), (0.5, 4.0)),
+]
+
+
+@pytest.mark.parametrize("rhs_text,pars,xr", SELFSTART, ids=[v[0].split("(")[0] for v in SELFSTART])
+def test_selfstart_models_by_their_closed_forms(rhs_text, pars, xr):
+    """y ~ SSasymp(x, Asym, R0, lrc) and the other standard selfStart models (the reference's unit tests 6.x,
+    inst/unit_tests/unit_tests_gslnls.R:267-293) are lowered by their closed forms: value against the documented formula
+    evaluated by numpy, symbolic gradient against Richardson-extrapolated differences"""
+    names = list(pars)
+    x = np.linspace(xr[0], xr[1], 33)
+    th = np.array([pars[k] for k in names])
+    val, grad, st = hs.expr_eval(rhs_text, names, ["x"], th, x)
+    rhs = F.parse_expr(rhs_text)
+
+    def ev(t):
+        env = {"x": x}
+        env.update({k: t[i] for i, k in enumerate(names)})
+        return np.asarray(F.evaluate(rhs, env), dtype=np.float64) * np.ones(len(x))
+
+    ref = ev(th)
+    np.testing.assert_allclose(val, ref, rtol=1e-12, atol=1e-13 * np.max(np.abs(ref)))
+    for k in range(len(names)):
+        h = 1e-4 * max(abs(th[k]), 1e-8)
+        e = np.zeros(len(names))
+        e[k] = h
+        num = (4 * (ev(th + e / 2) - ev(th - e / 2)) / h - (ev(th + e) - ev(th - e)) / (2 * h)) / 3
+        scale = np.max(np.abs(num)) + 1e-300
+        assert np.max(np.abs(grad[:, k] - num)) / scale < 1e-6, (rhs_text, names[k])

@@ -506,3 +506,26 @@ def test_native_code_equals_the_interpreter_for_every_parameter_count(amd, p):
         assert fits[0]["niter"] == fits[1]["niter"] and fits[0]["neval"] == fits[1]["neval"]
         assert np.array_equal(fits[0]["ssrtrace"], fits[1]["ssrtrace"]), (p, jac)
         assert np.array_equal(fits[0]["partrace"], fits[1]["partrace"]), (p, jac)
+
+
+def test_selfstart_model_6_1(amd, gslref, readme):
+    """unit tests 6.1.x (inst/unit_tests/unit_tests_gslnls.R:254-297): y ~ SSasymp(x, Asym, R0, lrc) on the README's
+    example-1 data, started at ss_fit2's values (Asym = 1, R0 = 6, lrc = 0.25), LM and lmaccel.  The standard selfStart
+    models are lowered by their closed forms: the fit must equal the one of the written-out formula bit for bit, the
+    oracle's (same model as a numpy closure) to 1e-6, and reparametrise README example 1: A = R0 - Asym, lam = exp(lrc),
+    b = Asym."""
+    ex = readme["ex1"]
+    x, y = np.asarray(ex["x"], dtype=float), np.asarray(ex["y"], dtype=float)
+    start = dict(Asym=1.0, R0=6.0, lrc=0.25)
+    model = lambda t: t[0] + (t[1] - t[0]) * np.exp(-np.exp(t[2]) * x)  # noqa: E731
+    for alg in ("lm", "lmaccel"):
+        ss = amd.gsl_nls("y ~ SSasymp(x, Asym, R0, lrc)", data=dict(x=x, y=y), start=start, algorithm=alg, jac=True,
+                         fvv=(alg == "lmaccel"), control=dict(solver="cholesky"))
+        ex2 = amd.gsl_nls("y ~ Asym+(R0-Asym)*exp(-exp(lrc)*x)", data=dict(x=x, y=y), start=start, algorithm=alg, jac=True,
+                          fvv=(alg == "lmaccel"), control=dict(solver="cholesky"))
+        assert ss["conv"] == 0 and np.array_equal(ss["par"], ex2["par"]) and ss["niter"] == ex2["niter"]
+        o = gslref.nls(len(y), 3, list(start.values()), fn=lambda t: model(t) - y, algorithm=alg, ctrl=gslref.control(solver="cholesky"))
+        assert o["conv"] == 0 and _close(ss["par"], o["par"], rel=1e-6)
+        coef = np.asarray(list(ex["coef"].values()) if isinstance(ex["coef"], dict) else ex["coef"], dtype=float)  # A, lam, b
+        got = np.array([ss["par"][1] - ss["par"][0], np.exp(ss["par"][2]), ss["par"][0]])
+        assert np.all(np.abs(got - coef) <= 2e-4 * np.maximum(1.0, np.abs(coef)))
