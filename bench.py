@@ -501,9 +501,6 @@ def function_model_bench():
     return out
 
 
-def _unused():
-    return None
-
 
 def sparse_readme_bench():
     """The reference's own sparse example (README.md:1040-1146: penalty function I, p = 500, Jacobian a dgCMatrix)

@@ -486,7 +486,6 @@ struct BdFit
                 done = true;
             }
         }
-        bool step = false;
         if (!done)
         {
             scale(true);
@@ -505,7 +504,6 @@ struct BdFit
             niter = 0;
             bad_steps = 0;
             trace_row(0, chisq_init);
-            step = true;
         }
         // ---- driver2 / trust_iterate_lu_LD: one pass of the loop = one trial step ----
         long steps = 0;
@@ -664,7 +662,6 @@ struct BdFit
             if (itstatus != ST_CONTINUE)
                 (void)end_iteration(itstatus);
         }
-        (void)step;
         const double loop_ms = 1e3 * (now_s() - t_begin);
         // ---- result (src/nls.c:648-753) ----
         const bool ok = (status == ST_SUCCESS || status == ST_EMAXITER);
@@ -673,8 +670,8 @@ struct BdFit
                 out->par[k] = ok ? x[k] : start[k];
         // NOTE: after a failed last Jacobian (EBADFUNC at an accepted point) d_J / d_C hold that point's matrices; the
         // result is NaN-filled then, as the reference's is
-        std::vector<double> Afin;
-        if (ok && (out->covar || true))
+        std::vector<double> Afin; // J^T J at the final point: covariance and the solver-routing diagnostic
+        if (ok)
         {
             Afin.resize((size_t)p * p);
             if (dev_solve)

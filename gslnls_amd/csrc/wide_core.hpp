@@ -56,6 +56,17 @@ struct WAdvanceArgs
 
 #if defined(__HIPCC__) || defined(__HIPCC_RTC__)
 
+// the lane of this thread, as a value the compiler cannot trace: kernels that run the step in a loop (wide_fit_kernel,
+// wide_loop_kernel) otherwise have every lane-dependent LDS address of the loop body -- hundreds: tri(lane, k) for each
+// literal k of each sum -- computed once before the loop, spilled, and fetched back from scratch memory one use at a time
+// (an advance_pre of 11 us instead of 4).  Costs nothing where there is no loop.
+__device__ __forceinline__ int wide_lane()
+{
+    int l = (int)(threadIdx.x & 63u);
+    asm volatile("" : "+v"(l));
+    return l;
+}
+
 __device__ __forceinline__ void wide_lds_sync()
 {
     // LDS traffic between the lanes of ONE wavefront: make the stores visible before the loads that follow
@@ -759,17 +770,43 @@ struct WideCtx
 // solve of wide_kernels.hpp) put ONE call site of it between the two.
 // PFIX > 0: p is known when the kernel is compiled (the formula's kernels, wide_kernels.hpp): the staging loops and the
 // sums are cut to size and the other sizes are not compiled at all.
-template <int PFIX = 0>
-__device__ __forceinline__ void wide_advance_pre(const WAdvanceArgs &a, WideLds &L, WideCtx &c)
+// The part of the state that wide_advance_pre reads from memory, as registers of the calling wavefront: a kernel that
+// knows the LM step may be its to run (the group reducers of wide_step_kernel) asks for it BEFORE it finds out -- the
+// state was written by the previous launch, on another XCD, and the loads are most of two microseconds.
+template <int IT>
+struct WideStateRegs
 {
-    const int lane = threadIdx.x & 63;
+    double sv[9], d[8], ba[IT];
+    int i[8];
+};
+template <int P>
+__device__ __forceinline__ void wide_state_load(const WState *S, int lane, WideStateRegs<(P * (P + 1) / 2 + 63) / 64> &r)
+{
+    constexpr int NA = P * (P + 1) / 2, IT = (NA + 63) / 64;
+    const bool mine = lane < P;
+    const double *vec[9] = {S->x, S->xt, S->dx, S->vel, S->acc, S->g, S->diag, S->lo, S->up};
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        r.sv[k] = mine ? vec[k][lane] : 0.0;
+    r.d[0] = S->fnorm2, r.d[1] = S->mu, r.d[2] = S->nu, r.d[3] = S->delta, r.d[4] = S->avratio, r.d[5] = S->chisq0;
+    r.d[6] = S->chisq1, r.d[7] = S->chisq_init;
+    r.i[0] = S->bad_steps, r.i[1] = S->niter, r.i[2] = S->phase, r.i[3] = S->status, r.i[4] = S->info, r.i[5] = S->nevalf;
+    r.i[6] = S->nevaldf, r.i[7] = S->nevalfvv;
+#pragma unroll
+    for (int i = 0; i < IT; ++i)
+        r.ba[i] = lane + 64 * i < NA ? S->A[lane + 64 * i] : 0.0;
+}
+
+template <int PFIX = 0, class REGS = void>
+__device__ __forceinline__ void wide_advance_pre(const WAdvanceArgs &a, WideLds &L, WideCtx &c, const REGS *regs = nullptr)
+{
+    const int lane = wide_lane();
     WState *S = a.state;
     const int p = PFIX > 0 ? PFIX : a.p, NA = p * (p + 1) / 2;
     const LmParams prm = a.prm;
     c.want = 0;
     c.rejected = false;
     c.active = true;
-    const int phase_in = S->phase; // (checked below, after every load of the call is in flight)
     const double *tot = a.totals;
     const double *rA = tot + 2;
     const bool mine = lane < p;
@@ -777,20 +814,34 @@ __device__ __forceinline__ void wide_advance_pre(const WAdvanceArgs &a, WideLds 
     // Every global load of the call is issued here, before the first of them is waited for: a load is most of a
     // microsecond for this lone wavefront (the data was written by other XCDs), and a copy loop of NA / 64 trips that
     // waits for each trip's load in turn cost 5 us at p = 32.  J^T J of the pass that just ran is parked in L.M (free
-    // until the solve) for lm_take_point.
+    // until the solve) for lm_take_point.  (regs: the caller has them already.)
     const double r_ssr = tot[0], r_badj = tot[1];
     const double r_g = mine ? tot[2 + NA + lane] : 0.0;
     double sv[9];
+    double fnorm2, mu, nu, delta, avratio, chisq0, chisq1, chisq_init;
+    int bad_steps, niter, phase, status, info, nevalf, nevaldf, nevalfvv;
+    if constexpr (!__is_same(REGS, void))
+    {
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            sv[k] = regs->sv[k];
+        fnorm2 = regs->d[0], mu = regs->d[1], nu = regs->d[2], delta = regs->d[3], avratio = regs->d[4], chisq0 = regs->d[5];
+        chisq1 = regs->d[6], chisq_init = regs->d[7];
+        bad_steps = regs->i[0], niter = regs->i[1], phase = regs->i[2], status = regs->i[3], info = regs->i[4];
+        nevalf = regs->i[5], nevaldf = regs->i[6], nevalfvv = regs->i[7];
+    }
+    else
     {
         const double *vec[9] = {S->x, S->xt, S->dx, S->vel, S->acc, S->g, S->diag, S->lo, S->up};
 #pragma unroll
         for (int k = 0; k < 9; ++k)
             sv[k] = mine ? vec[k][lane] : 0.0;
+        fnorm2 = S->fnorm2, mu = S->mu, nu = S->nu, delta = S->delta, avratio = S->avratio, chisq0 = S->chisq0;
+        chisq1 = S->chisq1, chisq_init = S->chisq_init;
+        bad_steps = S->bad_steps, niter = S->niter, phase = S->phase, status = S->status, info = S->info;
+        nevalf = S->nevalf, nevaldf = S->nevaldf, nevalfvv = S->nevalfvv;
     }
-    double fnorm2 = S->fnorm2, mu = S->mu, nu = S->nu, delta = S->delta, avratio = S->avratio, chisq0 = S->chisq0,
-           chisq1 = S->chisq1, chisq_init = S->chisq_init;
-    int bad_steps = S->bad_steps, niter = S->niter, phase = S->phase, status = S->status, info = S->info, nevalf = S->nevalf,
-        nevaldf = S->nevaldf, nevalfvv = S->nevalfvv;
+    const int phase_in = phase; // (checked below, after every load of the call is in flight)
     auto stage_matrices = [&](auto trips) {
         constexpr int IT = decltype(trips)::value;
         double ba[IT], br[IT];
@@ -798,7 +849,10 @@ __device__ __forceinline__ void wide_advance_pre(const WAdvanceArgs &a, WideLds 
         for (int i = 0; i < IT; ++i)
         {
             const int k = lane + 64 * i;
-            ba[i] = k < NA ? S->A[k] : 0.0;
+            if constexpr (!__is_same(REGS, void))
+                ba[i] = regs->ba[i];
+            else
+                ba[i] = k < NA ? S->A[k] : 0.0;
             br[i] = k < NA ? rA[k] : 0.0;
         }
 #pragma unroll
@@ -1059,11 +1113,11 @@ __device__ __forceinline__ void wide_advance_pre(const WAdvanceArgs &a, WideLds 
 }
 
 template <int PFIX = 0>
-__device__ __forceinline__ void wide_advance_post(const WAdvanceArgs &a, WideLds &L, const WideCtx &c)
+__device__ __forceinline__ int wide_advance_post(const WAdvanceArgs &a, WideLds &L, const WideCtx &c) // -> the phase it leaves
 {
     if (!c.active)
-        return;
-    const int lane = threadIdx.x & 63;
+        return PH_DONE;
+    const int lane = wide_lane();
     WState *S = a.state;
     const int p = PFIX > 0 ? PFIX : a.p, NA = p * (p + 1) / 2;
     const LmParams prm = a.prm;
@@ -1130,20 +1184,31 @@ __device__ __forceinline__ void wide_advance_post(const WAdvanceArgs &a, WideLds
     for (int rep = 0; rep < (done && a.host_mirror ? 2 : 1); ++rep)
     {
         WState *D = rep == 0 ? S : a.host_mirror;
+        // (the state in memory: what this call cannot have changed is not written again -- the bounds never, and x, g, D,
+        // J^T J not by a rejected trial, the most common step of a fit near its end: 4.5 KB at p = 32 that the end of the
+        // launch would wait for)
+        const bool all = rep != 0, moved = all || !c.rejected;
         if (mine)
         {
-            D->x[lane] = L.x[lane];
             D->xt[lane] = L.xt[lane];
             D->dx[lane] = L.dx[lane];
             D->vel[lane] = L.vel[lane];
             D->acc[lane] = L.acc[lane];
-            D->g[lane] = L.g[lane];
-            D->diag[lane] = L.diag[lane];
-            D->lo[lane] = L.lo[lane];
-            D->up[lane] = L.up[lane];
+            if (moved)
+            {
+                D->x[lane] = L.x[lane];
+                D->g[lane] = L.g[lane];
+                D->diag[lane] = L.diag[lane];
+            }
+            if (all)
+            {
+                D->lo[lane] = L.lo[lane];
+                D->up[lane] = L.up[lane];
+            }
         }
-        for (int k = lane; k < NA; k += 64)
-            D->A[k] = L.A[k];
+        if (moved)
+            for (int k = lane; k < NA; k += 64)
+                D->A[k] = L.A[k];
         if (lane == 0)
         {
             D->fnorm2 = fnorm2;
@@ -1191,6 +1256,7 @@ __device__ __forceinline__ void wide_advance_post(const WAdvanceArgs &a, WideLds
         if (lane == 0)
             __hip_atomic_store(a.done_seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    return phase;
 }
 
 __device__ __forceinline__ void wide_advance(const WAdvanceArgs &a, WideLds &L)
@@ -1198,7 +1264,7 @@ __device__ __forceinline__ void wide_advance(const WAdvanceArgs &a, WideLds &L)
     WideCtx c;
     wide_advance_pre(a, L, c);
     if (c.active && c.want)
-        wide_solve(L, a.p, c.mu, L.rhs, c.want == 1 ? L.acc : L.vel, threadIdx.x & 63, a.pivoted);
+        wide_solve(L, a.p, c.mu, L.rhs, c.want == 1 ? L.acc : L.vel, wide_lane(), a.pivoted);
     wide_advance_post(a, L, c);
 }
 

@@ -249,6 +249,7 @@ struct WideFit : DenseBase
     // same sums in the same order, same LM step: the switch changes no bit of any result
     hipFunction_t fn_step[3] = {nullptr, nullptr, nullptr};
     bool step_failed[3] = {false, false, false};
+    int n_cu = 0;
     int lowering = GSLNLS_LOWER_AUTO;
     // one workgroup = one complete fit (wide_fit_kernel): the batch form of the multi-start evaluator; built when a
     // multi-start first asks for it (GSLNLS_WIDE_MS_BATCH=0: the points are fitted one after the other instead)
@@ -316,7 +317,18 @@ struct WideFit : DenseBase
         const long long tiles = ((long long)n + 63) / 64;
         long long g = (tiles + (WIDE_T / 64) - 1) / (WIDE_T / 64);
         // one workgroup per CU for the wide tiles (PW >= 48: LDS), two below
-        const int gmax = PW <= 32 ? WIDE_MAX_G : WIDE_MAX_G / 2;
+        // (one less than the device holds: the grid of a step has one more workgroup, the solver / the LM state machine)
+        {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1)
+                n_cu = 256;
+        }
+        int gmax = (PW <= 32 ? 2 : 1) * n_cu - 1;
+        if (gmax > WIDE_MAX_G)
+            gmax = WIDE_MAX_G;
+        if (gmax < 1)
+            gmax = 1;
         G = (int)(g < 1 ? 1 : (g > gmax ? gmax : g));
         GSLNLS_HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         GSLNLS_HIP_OK(hipEventCreate(&ev0));
@@ -369,8 +381,8 @@ struct WideFit : DenseBase
             pivoted = atoi(e) != 0;
         if (getenv("GSLNLS_WIDE_STAMPS"))
         {
-            GSLNLS_HIP_OK(hipMalloc(&d_stamps, sizeof(unsigned long long) * 10 * 1024));
-            GSLNLS_HIP_OK(hipMemset(d_stamps, 0, sizeof(unsigned long long) * 10 * 1024));
+            GSLNLS_HIP_OK(hipMalloc(&d_stamps, sizeof(unsigned long long) * (10 * 1024 + 16)));
+            GSLNLS_HIP_OK(hipMemset(d_stamps, 0, sizeof(unsigned long long) * (10 * 1024 + 16)));
         }
         lowering = fn->lowering;
         rtc_src = rtc_wide_source(*prog, nx);
@@ -425,12 +437,15 @@ struct WideFit : DenseBase
         return fn_fit[jm] != nullptr;
     }
 
-    // `count` complete short fits at once, one workgroup each: starts [count][p] (host) -> records [count][3 p + 8] (host)
+    // `count` complete short fits, one workgroup each, at most MS_CHUNK per launch (a workgroup keeps a 21 KB state in HBM):
+    // starts [count][p] (host) -> records [count][3 p + 8] (host)
+    static constexpr int MS_CHUNK = 16384;
     int fit_batch(int jm, const LmParams &q, const double *starts, int count, const double *lupars, bool always_fit, double dtol,
                   double *records)
     {
         const int K = 3 * p + 8;
-        if (ms_cap < count)
+        const int cap = count < MS_CHUNK ? count : MS_CHUNK;
+        if (ms_cap < cap)
         {
             hipFree(d_ms_states);
             hipFree(d_ms_starts);
@@ -438,34 +453,40 @@ struct WideFit : DenseBase
             d_ms_states = nullptr;
             d_ms_starts = d_ms_records = nullptr;
             ms_cap = 0;
-            GSLNLS_HIP_OK(hipMalloc(&d_ms_states, sizeof(WState) * (size_t)count));
-            GSLNLS_HIP_OK(hipMalloc(&d_ms_starts, sizeof(double) * (size_t)count * p));
-            GSLNLS_HIP_OK(hipMalloc(&d_ms_records, sizeof(double) * (size_t)count * K));
-            ms_cap = count;
+            GSLNLS_HIP_OK(hipMalloc(&d_ms_states, sizeof(WState) * (size_t)cap));
+            GSLNLS_HIP_OK(hipMalloc(&d_ms_starts, sizeof(double) * (size_t)cap * p));
+            GSLNLS_HIP_OK(hipMalloc(&d_ms_records, sizeof(double) * (size_t)cap * K));
+            ms_cap = cap;
         }
         if (lupars && !d_ms_lupars)
             GSLNLS_HIP_OK(hipMalloc(&d_ms_lupars, sizeof(double) * 2 * WP));
-        GSLNLS_HIP_OK(hipMemcpyAsync(d_ms_starts, starts, sizeof(double) * (size_t)count * p, hipMemcpyHostToDevice, stream));
         if (lupars)
             GSLNLS_HIP_OK(hipMemcpyAsync(d_ms_lupars, lupars, sizeof(double) * 2 * p, hipMemcpyHostToDevice, stream));
-        WFitArgs fa;
-        memset(&fa, 0, sizeof fa);
-        fa.pass = pass_args(q);
-        fa.prm = q;
-        fa.pivoted = pivoted;
-        fa.nfit = count;
-        fa.always_fit = always_fit ? 1 : 0;
-        fa.has_bounds = lupars != nullptr;
-        fa.dtol = dtol;
-        fa.starts = d_ms_starts;
-        fa.lupars = lupars ? d_ms_lupars : nullptr;
-        fa.states = d_ms_states;
-        fa.records = d_ms_records;
-        void *args[] = {(void *)&fa};
-        if (hipModuleLaunchKernel(fn_fit[jm], count, 1, 1, WIDE_T, 1, 1, 0, stream, args, nullptr) != hipSuccess)
-            return GSLNLS_E_NODEVICE;
-        GSLNLS_HIP_OK(hipMemcpyAsync(records, d_ms_records, sizeof(double) * (size_t)count * K, hipMemcpyDeviceToHost, stream));
-        GSLNLS_HIP_OK(hipStreamSynchronize(stream));
+        for (int lo = 0; lo < count; lo += MS_CHUNK)
+        {
+            const int m = count - lo < MS_CHUNK ? count - lo : MS_CHUNK;
+            GSLNLS_HIP_OK(hipMemcpyAsync(d_ms_starts, starts + (size_t)lo * p, sizeof(double) * (size_t)m * p, hipMemcpyHostToDevice, stream));
+            WFitArgs fa;
+            memset(&fa, 0, sizeof fa);
+            fa.pass = pass_args(q);
+            fa.prm = q;
+            fa.pivoted = pivoted;
+            fa.nfit = m;
+            fa.always_fit = always_fit ? 1 : 0;
+            fa.has_bounds = lupars != nullptr;
+            fa.dtol = dtol;
+            fa.starts = d_ms_starts;
+            fa.lupars = lupars ? d_ms_lupars : nullptr;
+            fa.states = d_ms_states;
+            fa.records = d_ms_records;
+            void *args[] = {(void *)&fa};
+            if (hipModuleLaunchKernel(fn_fit[jm], m, 1, 1, WIDE_T, 1, 1, 0, stream, args, nullptr) != hipSuccess)
+                return GSLNLS_E_NODEVICE;
+            GSLNLS_HIP_OK(hipMemcpyAsync(records + (size_t)lo * K, d_ms_records, sizeof(double) * (size_t)m * K, hipMemcpyDeviceToHost, stream));
+            GSLNLS_HIP_OK(hipStreamSynchronize(stream)); // (the next chunk reuses the buffers)
+            if (g_interrupt_hook && g_interrupt_hook())
+                return GSLNLS_E_INTERRUPTED;
+        }
         return hipGetLastError() == hipSuccess ? GSLNLS_SUCCESS : GSLNLS_E_NODEVICE;
     }
 
@@ -661,8 +682,13 @@ struct WideFit : DenseBase
         if (d_stamps && fuse && fn_step[jm])
         {
             const int ns = pred_steps > 0 && pred_steps < 1024 ? pred_steps : 0;
-            std::vector<unsigned long long> hs((size_t)10 * 1024);
+            std::vector<unsigned long long> hs((size_t)10 * 1024 + 16);
             (void)hipMemcpy(hs.data(), d_stamps, sizeof(unsigned long long) * hs.size(), hipMemcpyDeviceToHost);
+            {
+                const unsigned long long *r = &hs[(size_t)10 * 1024];
+                fprintf(stderr, "[wide stamps] first row block, last pass: start -> rows evaluated %.2f us | contraction %.2f | the four wavefronts' sums side by side %.2f\n",
+                        (double)(r[1] - r[0]) * 0.01, (double)(r[2] - r[1]) * 0.01, (double)(r[4] - r[2]) * 0.01);
+            }
             static const char *nm[8] = {"rows", "partial+arrive1", "reduce1", "arrive2", "reduce2", "advance_pre", "solve/spec", "post"};
             for (int kind = 0; kind < 2; ++kind)
             {

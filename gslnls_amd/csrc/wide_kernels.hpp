@@ -156,9 +156,79 @@ __device__ __forceinline__ bool wide_arrive_last(unsigned int *ctr, unsigned int
     return *flag_s != 0;
 }
 
+// ---- the two levels of the in-launch reduction -------------------------------------------------------------------------
+// The summation order of wide_reduce_kernel: group q adds the sets q, q + 16, ... in index order (level 1), then the group
+// sums are added in group order (level 2).  Fixed order => bit-identical totals whichever workgroups do the adding.
+// Sets and group sums are NVP = NV rounded up to even doubles apart: every load moves two values, 16 bytes, and the loads
+// of a round are all in flight before the first is added.
+typedef double wide_v2f64 __attribute__((ext_vector_type(2)));
+template <int NVP>
+__device__ __forceinline__ void wide_reduce_group(const double *partials, double *gsums, int G, int q, int tid)
+{
+    // one value pair per thread per trip, the 32 loads of a trip in flight together (two pairs per trip were 256 registers
+    // of loads in flight: more than there are, and the loads that came back from scratch memory waited for each other)
+    for (int va = tid; va < NVP / 2; va += WIDE_T)
+    {
+        constexpr int PER = WIDE_MAX_G / WIDE_NGRP;
+        wide_v2f64 ta[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+        {
+            const int g = q + WIDE_NGRP * k;
+            ta[k] = g < G ? *reinterpret_cast<const wide_v2f64 *>(partials + (size_t)g * NVP + 2 * va) : (wide_v2f64){0.0, 0.0};
+        }
+        wide_v2f64 sa = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            sa += ta[k];
+        wide_store_wt(gsums + (size_t)q * NVP + 2 * va, sa[0]);
+        wide_store_wt(gsums + (size_t)q * NVP + 2 * va + 1, sa[1]);
+    }
+}
+// put(v, r0, r1): values 2 v and 2 v + 1 of the totals
+template <int NVP, class PUT>
+__device__ __forceinline__ void wide_reduce_final(const double *gsums, int ngrp, int tid, PUT put)
+{
+    for (int v0 = 0; v0 < NVP / 2; v0 += 2 * WIDE_T)
+    {
+        const int va = v0 + tid, vb = va + WIDE_T;
+        wide_v2f64 ta[WIDE_NGRP], tb[WIDE_NGRP];
+#pragma unroll
+        for (int k = 0; k < WIDE_NGRP; ++k)
+            ta[k] = (va < NVP / 2 && k < ngrp) ? *reinterpret_cast<const wide_v2f64 *>(gsums + (size_t)k * NVP + 2 * va)
+                                               : (wide_v2f64){0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < WIDE_NGRP; ++k)
+            tb[k] = (vb < NVP / 2 && k < ngrp) ? *reinterpret_cast<const wide_v2f64 *>(gsums + (size_t)k * NVP + 2 * vb)
+                                               : (wide_v2f64){0.0, 0.0};
+        wide_v2f64 ra = ta[0], rb2 = tb[0];
+#pragma unroll
+        for (int k = 1; k < WIDE_NGRP; ++k)
+            ra += ta[k];
+#pragma unroll
+        for (int k = 1; k < WIDE_NGRP; ++k)
+            rb2 += tb[k];
+        if (va < NVP / 2)
+            put(va, ra[0], ra[1]);
+        if (vb < NVP / 2)
+            put(vb, rb2[0], rb2[1]);
+    }
+}
+
+// entry e of the four wavefronts' copies, added in wave order
+template <int PW>
+__device__ __forceinline__ double wide_sum4(double (*tile)[PW * WIDE_LD], int e)
+{
+    return ((tile[0][e] + tile[1][e]) + tile[2][e]) + tile[3][e];
+}
+__device__ __forceinline__ double wide_sum4g(double (*ftile)[64], int k)
+{
+    return ((ftile[0][k] + ftile[1][k]) + ftile[2][k]) + ftile[3][k];
+}
+
 // One pass of one workgroup over the row tiles t, t + tstride, ... (64 rows per wavefront and tile): the row phase, the
-// MFMA contraction, then the four wavefronts' sums added in wave order into `full` (= tile[0]: PW x PW doubles, row-major)
-// and `gfull` (= ftile[0]: J^T f), ssr / non-finite flag per wavefront in red_s.  The first tile's rows arrive prefetched
+// MFMA contraction, then each wavefront's sums in its own tile (PW x PW doubles, row-major) and its own row of ftile
+// (J^T f) -- wide_sum4 / wide_sum4g add the four --, ssr / non-finite flag per wavefront in red_s.  The first tile's rows arrive prefetched
 // in xr_n / yy_n / sw_n; `load_rows(tt)` refills them for tile tt.  Ends behind a workgroup barrier.
 template <class M, int JAC, int PW, class LOAD>
 __device__ __forceinline__ void wide_rows_to_sums(const WPassArgs &a, int phase, long long t, long long tstride, long long ntile,
@@ -169,6 +239,10 @@ __device__ __forceinline__ void wide_rows_to_sums(const WPassArgs &a, int phase,
     constexpr int P = M::P, NX = M::NX, NB = PW / 16, NW = WIDE_T / 64, NQ = NB * (NB + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     (void)tid;
+    // developer diagnostic (GSLNLS_WIDE_STAMPS=1): where the row phase of the first row block's first wavefront goes
+    unsigned long long *const rst = (a.stamps && blockIdx.x == (unsigned)a.spec && tid == 0) ? a.stamps + 10 * 1024 : nullptr;
+    if (rst)
+        rst[0] = __builtin_amdgcn_s_memrealtime();
     const WideTheta th{th_s};
     double *const mytile = tile[wave];
     const int kk = lane >> 4, ii = lane & 15;
@@ -252,6 +326,8 @@ __device__ __forceinline__ void wide_rows_to_sums(const WPassArgs &a, int phase,
         ftile[wave][lane] = f;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        if (rst)
+            rst[1] = __builtin_amdgcn_s_memrealtime(); // (last tile's) rows evaluated, gradient entries in the tile
         // ---------------- contraction phase: 16 chunks of 4 rows ----------------
 #pragma unroll 4
         for (int c = 0; c < 16; ++c)
@@ -278,10 +354,13 @@ __device__ __forceinline__ void wide_rows_to_sums(const WPassArgs &a, int phase,
         __builtin_amdgcn_wave_barrier();
     }
 
-    // ---------------- workgroup reduction -> one partial set (fixed order: wave 0, 1, 2, 3) ----------------
-    __syncthreads(); // every wave is done with its tile: the tiles become the staging area
-    double *const full = &tile[0][0]; // PW x PW doubles, row-major: (i, j) -> i * PW + j   (PW * PW <= NW * PW * 68)
-    double *const gfull = &ftile[0][0]; // PW doubles (<= NW * 64)
+    if (rst)
+        rst[2] = __builtin_amdgcn_s_memrealtime(); // contraction done
+    // ---------------- the four wavefronts' sums, side by side ----------------
+    // Every wavefront parks its blocks in ITS OWN tile (PW x PW doubles, row-major: (i, j) -> i * PW + j; PW * PW <=
+    // PW * 68) and its J^T f in its own row of ftile: no wavefront waits for another before the one barrier below.  The
+    // reader adds the four copies as ((w0 + w1) + w2) + w3 (wide_sum4): the association of the wave-after-wave form this
+    // replaces (three more barriers, 2.7 us at p = 32), so not a bit changes.
     ssr = wave_sum_wide(ssr);
     bad = wave_sum_wide(bad);
     if (lane == 0)
@@ -289,34 +368,30 @@ __device__ __forceinline__ void wide_rows_to_sums(const WPassArgs &a, int phase,
         red_s[wave][0] = ssr;
         red_s[wave][1] = bad;
     }
-    for (int w = 0; w < NW; ++w)
     {
-        if (wave == w)
+        double *const mine_full = tile[wave];
+        int q = 0;
+#pragma unroll
+        for (int ba = 0; ba < NB; ++ba)
+#pragma unroll
+            for (int bb = 0; bb <= ba; ++bb, ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    mine_full[(ba * 16 + 4 * r + kk) * PW + bb * 16 + ii] = acc[q][r];
+        // J^T f: entry 16 b + i is the sum over the four row groups kk of a lane column, kk ascending
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
         {
-            int q = 0;
-#pragma unroll
-            for (int ba = 0; ba < NB; ++ba)
-#pragma unroll
-                for (int bb = 0; bb <= ba; ++bb, ++q)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                    {
-                        const int e = (ba * 16 + 4 * r + kk) * PW + bb * 16 + ii;
-                        full[e] = (w == 0) ? acc[q][r] : full[e] + acc[q][r];
-                    }
-            // J^T f: entry 16 b + i is the sum over the four row groups kk of a lane column, kk ascending
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-            {
-                double s = gacc[b];
-                const double s1 = wide_shfl(s, ii + 16), s2 = wide_shfl(s, ii + 32), s3 = wide_shfl(s, ii + 48);
-                s = ((wide_shfl(s, ii) + s1) + s2) + s3;
-                if (kk == 0)
-                    gfull[b * 16 + ii] = (w == 0) ? s : gfull[b * 16 + ii] + s;
-            }
+            double s = gacc[b];
+            const double s1 = wide_shfl(s, ii + 16), s2 = wide_shfl(s, ii + 32), s3 = wide_shfl(s, ii + 48);
+            s = ((wide_shfl(s, ii) + s1) + s2) + s3;
+            if (kk == 0)
+                ftile[wave][b * 16 + ii] = s;
         }
-        __syncthreads();
     }
+    __syncthreads();
+    if (rst)
+        rst[4] = __builtin_amdgcn_s_memrealtime(); // the four wavefronts' sums added
 }
 
 // FUSED = false: rows -> one partial set per workgroup, nothing else is compiled (about a second in the in-process
@@ -438,8 +513,7 @@ __device__ __forceinline__ void wide_pass_body(const WPassArgs &a)
             tile[wave][P * WIDE_LD + e] = 0.0;
     __syncthreads();
     wide_rows_to_sums<M, JAC, PW>(a, phase, t, tstride, ntile, xr_n, yy_n, sw_n, load_rows, tile, ftile, th_s, vel_s, delta_s, red_s);
-    double *const full = &tile[0][0];   // PW x PW doubles, row-major: (i, j) -> i * PW + j
-    double *const gfull = &ftile[0][0]; // PW doubles
+    static_assert(NW == 4, "wide_sum4 adds four wavefronts");
     stamp(1); // rows done, workgroup sums staged
     double *out = a.partials + (size_t)rb * NVP;
     const bool fuse = FUSED && a.fuse != WIDE_FUSE_NONE;
@@ -471,17 +545,19 @@ __device__ __forceinline__ void wide_pass_body(const WPassArgs &a)
         while ((i + 1) * (i + 2) / 2 <= e)
             ++i;
         const int j = e - i * (i + 1) / 2;
+        const double v = wide_sum4<PW>(tile, i * PW + j);
         if (fuse)
-            wide_store_wt(out + 2 + e, full[i * PW + j]);
+            wide_store_wt(out + 2 + e, v);
         else
-            out[2 + e] = full[i * PW + j];
+            out[2 + e] = v;
     }
     for (int k = tid; k < P; k += WIDE_T)
     {
+        const double v = wide_sum4g(ftile, k);
         if (fuse)
-            wide_store_wt(out + 2 + NA + k, gfull[k]);
+            wide_store_wt(out + 2 + NA + k, v);
         else
-            out[2 + NA + k] = gfull[k];
+            out[2 + NA + k] = v;
     }
     if (fuse && NVP != NV && tid == 0)
         wide_store_wt(out + NV, 0.0); // (the pad of an odd set: read, never used)
@@ -498,88 +574,29 @@ __device__ __forceinline__ void wide_pass_body(const WPassArgs &a)
     if (!wide_arrive_last(&a.fb->tickets[q], members, &flag_s))
         return;
     stamp(2); // last of its group: acquired
-    // (sets and group sums are NVP = NV rounded up to even doubles apart: every load below moves two values, 16 bytes,
-    // and the loads of a round are all in flight before the first is added)
-    typedef double wide_v2f64 __attribute__((ext_vector_type(2)));
-    for (int v0 = 0; v0 < NVP / 2; v0 += 2 * WIDE_T)
-    {
-        // two value pairs per thread per trip: 2 x 32 loads of 16 bytes in flight
-        const int va = v0 + tid, vb = va + WIDE_T;
-        constexpr int PER = WIDE_MAX_G / WIDE_NGRP;
-        wide_v2f64 ta[PER], tb[PER];
-#pragma unroll
-        for (int k = 0; k < PER; ++k)
-        {
-            const int g = q + WIDE_NGRP * k;
-            ta[k] = (va < NVP / 2 && g < G) ? *reinterpret_cast<const wide_v2f64 *>(a.partials + (size_t)g * NVP + 2 * va)
-                                            : (wide_v2f64){0.0, 0.0};
-        }
-#pragma unroll
-        for (int k = 0; k < PER; ++k)
-        {
-            const int g = q + WIDE_NGRP * k;
-            tb[k] = (vb < NVP / 2 && g < G) ? *reinterpret_cast<const wide_v2f64 *>(a.partials + (size_t)g * NVP + 2 * vb)
-                                            : (wide_v2f64){0.0, 0.0};
-        }
-        wide_v2f64 sa = {0.0, 0.0}, sb = {0.0, 0.0};
-#pragma unroll
-        for (int k = 0; k < PER; ++k)
-            sa += ta[k];
-#pragma unroll
-        for (int k = 0; k < PER; ++k)
-            sb += tb[k];
-        if (va < NVP / 2)
-        {
-            wide_store_wt(a.gsums + (size_t)q * NVP + 2 * va, sa[0]);
-            wide_store_wt(a.gsums + (size_t)q * NVP + 2 * va + 1, sa[1]);
-        }
-        if (vb < NVP / 2)
-        {
-            wide_store_wt(a.gsums + (size_t)q * NVP + 2 * vb, sb[0]);
-            wide_store_wt(a.gsums + (size_t)q * NVP + 2 * vb + 1, sb[1]);
-        }
-    }
+    wide_reduce_group<NVP>(a.partials, a.gsums, G, q, tid);
     stamp(3); // group sums stored
+    // one of the (up to) 16 group reducers will run the LM step: each asks for the state now, so that the loads (written by
+    // the previous launch on another XCD: most of two microseconds) are under way while the arrival is counted
+    WideStateRegs<(NA + 63) / 64> sregs;
+    if (a.fuse == WIDE_FUSE_STEP && wave == 0)
+        wide_state_load<P>(adv.state, lane, sregs);
     if (!wide_arrive_last(&a.fb->ticket2, (unsigned int)ngrp, &flag_s))
         return;
     stamp(4); // last group reducer: acquired
-    for (int v0 = 0; v0 < NVP / 2; v0 += 2 * WIDE_T)
-    {
-        const int va = v0 + tid, vb = va + WIDE_T;
-        wide_v2f64 ta[WIDE_NGRP], tb[WIDE_NGRP];
-#pragma unroll
-        for (int k = 0; k < WIDE_NGRP; ++k)
-            ta[k] = (va < NVP / 2 && k < ngrp) ? *reinterpret_cast<const wide_v2f64 *>(a.gsums + (size_t)k * NVP + 2 * va)
-                                               : (wide_v2f64){0.0, 0.0};
-#pragma unroll
-        for (int k = 0; k < WIDE_NGRP; ++k)
-            tb[k] = (vb < NVP / 2 && k < ngrp) ? *reinterpret_cast<const wide_v2f64 *>(a.gsums + (size_t)k * NVP + 2 * vb)
-                                               : (wide_v2f64){0.0, 0.0};
-        wide_v2f64 ra = ta[0], rb2 = tb[0];
-#pragma unroll
-        for (int k = 1; k < WIDE_NGRP; ++k)
-            ra += ta[k];
-#pragma unroll
-        for (int k = 1; k < WIDE_NGRP; ++k)
-            rb2 += tb[k];
-        auto put = [&](int v, wide_v2f64 r) {
-            if (v >= NVP / 2)
-                return;
-            if (a.fuse == WIDE_FUSE_STEP)
-            {
-                totals_s[2 * v] = r[0]; // (behind the working set of the step: the tiles are dead)
-                totals_s[2 * v + 1] = r[1];
-            }
-            else
-            {
-                a.totals[2 * v] = r[0];
-                if (2 * v + 1 < NV)
-                    a.totals[2 * v + 1] = r[1];
-            }
-        };
-        put(va, ra);
-        put(vb, rb2);
-    }
+    wide_reduce_final<NVP>(a.gsums, ngrp, tid, [&](int v, double r0, double r1) {
+        if (a.fuse == WIDE_FUSE_STEP)
+        {
+            totals_s[2 * v] = r0; // (behind the working set of the step: the tiles are dead)
+            totals_s[2 * v + 1] = r1;
+        }
+        else
+        {
+            a.totals[2 * v] = r0;
+            if (2 * v + 1 < NV)
+                a.totals[2 * v + 1] = r1;
+        }
+    });
     // the counters go back to zero for the next launch (which starts after this one has ended)
     if (tid <= WIDE_NGRP)
         __hip_atomic_store(tid < WIDE_NGRP ? &a.fb->tickets[tid] : &a.fb->ticket2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -589,7 +606,7 @@ __device__ __forceinline__ void wide_pass_body(const WPassArgs &a)
     // ---------------- the LM step, by the first wavefront of this workgroup ----------------
     stamp(5); // totals in LDS
     adv.totals = totals_s;
-    wide_advance_pre<P>(adv, L, ctx);
+    wide_advance_pre<P, WideStateRegs<(NA + 63) / 64>>(adv, L, ctx, &sregs);
     if (!ctx.active)
         return;
     stamp(6); // decision taken, right-hand side ready
@@ -820,7 +837,6 @@ __global__ __launch_bounds__(WIDE_T, GSLNLS_WIDE_WAVES(PW)) void wide_fit_kernel
                                       vel_s, delta_s, red_s);
         // the workgroup's sums are the totals of the pass: ssr, non-finite flag, packed lower J^T J, J^T f
         {
-            const double *full = &tile[0][0], *gfull = &ftile[0][0];
             if (tid == 0)
             {
                 double s0 = red_s[0][0], s1 = red_s[0][1];
@@ -840,14 +856,15 @@ __global__ __launch_bounds__(WIDE_T, GSLNLS_WIDE_WAVES(PW)) void wide_fit_kernel
                 while ((i + 1) * (i + 2) / 2 <= e)
                     ++i;
                 const int j = e - i * (i + 1) / 2;
-                totals_s[2 + e] = full[i * PW + j];
+                totals_s[2 + e] = wide_sum4<PW>(tile, i * PW + j);
             }
             for (int k = tid; k < P; k += WIDE_T)
-                totals_s[2 + NA + k] = gfull[k];
+                totals_s[2 + NA + k] = wide_sum4g(ftile, k);
         }
         __syncthreads();
         if (wave == 0)
         {
+            const int lane = wide_lane(); // (the LDS addresses of this step are formed in this step: wide_core.hpp)
             bool go = true;
             if (first)
             {

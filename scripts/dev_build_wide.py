@@ -27,7 +27,7 @@ for ng in (int(a) for a in (sys.argv[1:] or ["4", "10", "20"])):
             name = None
             for line in out.splitlines():
                 line = line.strip()
-                if line.startswith(".name:") and "wide_pass" in line:
+                if line.startswith(".name:") and "wide_" in line:
                     name = line.split()[-1][:60]
                 if name and (line.startswith(".vgpr_count") or line.startswith(".sgpr_count") or line.startswith(".group_segment_fixed_size") or line.startswith(".private_segment_fixed_size") or line.startswith(".agpr_count")):
                     print("     ", os.path.basename(f)[:12], name, line)
