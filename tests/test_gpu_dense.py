@@ -359,11 +359,10 @@ def test_scaling_rules_and_central_differences_against_the_oracle(amd, gslref, r
         # ... and with the oracle's row models evaluating exp with the device's arithmetic (oracle/gslref_models.c:
         # gslref_device_exp, a transcription of csrc/devmath.hpp::gexp) the exp is out of the comparison: what is left is
         # the rounding of the residual itself (the device contracts a * e + b into one fma, gcc does not; sums over the
-        # rows in another order), again amplified by 1 / h.  The two lowerings of the formula round the residual
-        # differently (the interpreter evaluates the program operation by operation, the native kernel is contracted by
-        # the compiler) and "auto" takes whichever is ready, so both are run by name and both are recorded in the session
-        # summary, over the WHOLE trace: 1e-9 ... 9e-8 for the one, up to 1.6e-5 for the other, against 2e-7 ... 1e-5
-        # with glibc's exp.
+        # rows in another order), again amplified by 1 / h and by the conditioning of the problem.  Both lowerings of the
+        # formula are run by name ("auto" takes whichever is ready) and recorded in the session summary, over the WHOLE
+        # trace; measured: the two agree to the last digit printed; 1e-9 ... 4e-6 over the expdecay runs and Misra1a with
+        # central differences, 1.6e-5 / 7.0e-5 for Misra1a with forward differences (b2 ~ 5e-4: J^T J of condition 1e9).
         with gslref.device_exp():
             od = gslref.nls(len(yy), p, list(start.values()), rowdata=dict(model=model, x=xx, y=yy), use_jac=False,
                             ctrl=gslref.control(solver="cholesky", scale=scale, fdtype=fdtype), trace=True)
