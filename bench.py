@@ -530,8 +530,9 @@ def sparse_readme_bench():
             el = time.perf_counter() - t0
         out[alg] = {"wall_ms": el * 1e3, "niter": int(fit["niter"]), "conv": int(fit["conv"]), "ssr": float(fit["ssr"]),
                     "device_passes": int(fit["n_passes"]), "ssr_target": 0.004778845}
-    # the damped solve of the lm step alone (pivoted modified Cholesky on the device, csrc/mchol_device.hip): wall time per
-    # solve including the upload of the p x p matrix, and the residual it leaves
+    # the damped solve of the lm step alone (csrc/mchol_device.hip: blocked natural-order Cholesky, the pivoted modified
+    # routine as its fallback): wall time per solve with the p x p matrix uploaded from the host, with it resident, and
+    # the residual it leaves
     from gslnls_amd import _lib
     L = _lib.lib()
     rng = np.random.default_rng(7)
@@ -551,8 +552,29 @@ def sparse_readme_bench():
             rc = L.gslnls_debug_mchol_solve(*args) or rc
         el = (time.perf_counter() - t0) / reps
         M = Aj + 1e-3 * np.diag(dg ** 2)
-        fac["p=%d" % pp] = {"rc": int(rc), "ms_per_solve": el * 1e3,
-                            "rel_residual": float(np.max(np.abs(M @ sol - rhs)) / np.max(np.abs(rhs)))}
+        entry = {"rc": int(rc), "ms_per_solve_matrix_from_host": el * 1e3,
+                 "rel_residual": float(np.max(np.abs(M @ sol - rhs)) / np.max(np.abs(rhs)))}
+        # ... and as the lm step calls it: J^T J resident on the device (it is assembled there), diag and rhs go up (2 p
+        # doubles), the solution comes down -- the upload of the p x p matrix of the line above is not part of a step
+        try:
+            import torch
+            Adev = torch.from_numpy(Aj).to("cuda")
+            torch.cuda.synchronize()
+            solr = np.zeros(pp)
+            rargs = (pp, C.c_void_p(Adev.data_ptr()), dg.ctypes.data_as(_lib.DP), 1e-3, rhs.ctypes.data_as(_lib.DP),
+                     solr.ctypes.data_as(_lib.DP))
+            rc2 = L.gslnls_debug_mchol_solve_resident(*rargs)
+            t0 = time.perf_counter()
+            for _ in range(4 * reps):
+                rc2 = L.gslnls_debug_mchol_solve_resident(*rargs) or rc2
+            entry["ms_per_solve"] = (time.perf_counter() - t0) / (4 * reps) * 1e3
+            entry["rc_resident"] = int(rc2)
+            entry["resident_equals_uploaded"] = bool(np.array_equal(solr, sol))
+            del Adev
+        except Exception as ex:  # noqa
+            entry["ms_per_solve"] = el * 1e3
+            entry["resident_error"] = repr(ex)[:200]
+        fac["p=%d" % pp] = entry
     out["lm_step_factorisation_on_device"] = fac
     return out
 

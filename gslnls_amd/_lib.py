@@ -131,6 +131,7 @@ _SIGNATURES = {
     "gslnls_debug_wide_solve": (C.c_int, [C.c_int, DP, DP, C.c_double, DP, DP]),
     "gslnls_debug_wide_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int, DP, DP]),
     "gslnls_debug_mchol_solve": (C.c_int, [C.c_int, DP, DP, C.c_double, DP, DP]),
+    "gslnls_debug_mchol_solve_resident": (C.c_int, [C.c_int, C.c_void_p, DP, C.c_double, DP, DP]),
     "gslnls_debug_host_mchol_solve": (C.c_int, [C.c_int, DP, DP, C.c_double, DP, DP]),
 }
 

@@ -519,77 +519,105 @@ constexpr int CB_LD = CB + 1; // LDS rows: conflict-free column walks
 constexpr int CBT_LD = 68;    // MFMA staging tiles (as BD_LD)
 typedef double cb_v4f64 __attribute__((ext_vector_type(4)));
 
-// X L11^T = W21 for 64 rows, thread (row = lane, column class = wave) with its 16 columns wave, wave + 4, ... of the row in
-// REGISTERS for all 64 steps.  Step J: the thread that owns column J scales it (x_J = r / L_JJ) and shows it to the other
-// three classes through LDS (two buffers in turn: one barrier per step), then every thread takes x_J L[c][J] out of its
-// columns c > J -- L[c][J] is the same for a whole wavefront, an LDS broadcast.  J is a literal (a recursion, not a loop):
-// every register index is static.
+// X L11^T = W21 for 64 rows of the panel: wavefront w owns rows 16 w .. 16 w + 15, lane = (row = lane % 16, column class
+// = lane / 16) with the 16 columns class, class + 4, ... of its row in REGISTERS for all 64 steps.  Step J: the lane
+// that owns column J scales it (x_J = r / L_JJ) and the other three classes of the row fetch it from that lane
+// (ds_bpermute inside the wavefront -- with a class per wavefront it was a workgroup barrier per step, 64 of them, and
+// 18 us of a 42 us panel), then every lane takes x_J L[c][J] out of its columns c > J.  J is a literal (a recursion, not
+// a loop): every register index is static.  Same operations on the same values as before: not a bit changes.
 template <int Q, int J>
-__device__ __forceinline__ void cholb_trsm_update(double (&r)[16], double xj, const double *Lt, int wave)
+__device__ __forceinline__ void cholb_trsm_update(double (&r)[16], double xj, const double *Lt, int cls)
 {
     if constexpr (Q < 16)
     {
         constexpr int QJ = J >> 2;
         if constexpr (Q > QJ)
-            r[Q] -= xj * Lt[(wave + 4 * Q) * CB_LD + J];
+            r[Q] -= xj * Lt[(cls + 4 * Q) * CB_LD + J];
         else if constexpr (Q == QJ)
         {
-            if (wave > (J & 3))
-                r[Q] -= xj * Lt[(wave + 4 * Q) * CB_LD + J];
+            if (cls > (J & 3))
+                r[Q] -= xj * Lt[(cls + 4 * Q) * CB_LD + J];
         }
-        cholb_trsm_update<Q + 1, J>(r, xj, Lt, wave);
+        cholb_trsm_update<Q + 1, J>(r, xj, Lt, cls);
     }
 }
+// (step J starts when the factorisation, one wavefront over, has published column J: `ready` counts the columns of L11
+// that are final in LDS)
 template <int J>
-__device__ __forceinline__ void cholb_trsm_steps(double (&r)[16], const double *Lt, const double *invd, double (*xs)[CB], int lane,
-                                                 int wave)
+__device__ __forceinline__ void cholb_trsm_steps(double (&r)[16], const double *Lt, const double *invd, int row, int cls,
+                                                 const int *ready, int seen)
 {
     if constexpr (J < CB)
     {
-        if (wave == (J & 3))
+        while (seen <= J)
         {
-            r[J >> 2] *= invd[J];
-            xs[J & 1][lane] = r[J >> 2];
+            seen = __hip_atomic_load(ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (seen <= J)
+                __builtin_amdgcn_s_sleep(1);
         }
-        __syncthreads();
-        const double xj = xs[J & 1][lane];
-        cholb_trsm_update<0, J>(r, xj, Lt, wave);
-        cholb_trsm_steps<J + 1>(r, Lt, invd, xs, lane, wave);
+        if (cls == (J & 3))
+            r[J >> 2] *= invd[J];
+        const double xj = wide_shfl(r[J >> 2], row + 16 * (J & 3));
+        cholb_trsm_update<0, J>(r, xj, Lt, cls);
+        cholb_trsm_steps<J + 1>(r, Lt, invd, row, cls, ready, seen);
     }
 }
 
-// One step of 64 columns.  The first wavefront of EVERY workgroup factors the 64 x 64 diagonal block in its registers
-// (lane = row, the rank-one update of a step as DPP row broadcasts: the natural-order form of wide_chol_reg, wide_core.hpp;
-// redundantly in every workgroup: same bits, no hand-off) and leaves L11 in LDS; then workgroup b > 0 solves its 64 rows of
-// the panel against it (cholb_trsm_steps; the rows are requested before the factorisation starts and arrive behind it).
-// Workgroup 0 stores L11 and carries the right-hand side (one more row of the matrix).
-__global__ __launch_bounds__(256) void cholb_panel_kernel(const double *W, double *Lf, int p, int k0, const double *dorig, int *flag,
-                                                          double *yv, double *dinvg)
+// One step of 64 columns, five wavefronts per workgroup.  The first wavefront of EVERY workgroup factors the 64 x 64
+// diagonal block in its registers (lane = row, the rank-one update of a step as DPP row broadcasts: the natural-order form
+// of wide_chol_reg, wide_core.hpp; redundantly in every workgroup: same bits, no hand-off between workgroups), writes each
+// finished column of L11 to LDS and counts it in `ready`; the other four solve the workgroup's 64 rows of the panel
+// against it (16 rows each, cholb_trsm_steps) ONE COLUMN BEHIND the factorisation instead of after it -- the rows are
+// requested before anything else and the solve ends a step after the factor does.  A pivot that is not safely positive
+// does not end the factorisation (a wavefront waiting for columns would wait for ever): it is remembered, the arithmetic
+// runs on, the flag tells the host to discard all of it.  Workgroup 0 has no rows: its four wavefronts store L11 when it is
+// complete, its first carries the right-hand side (one more row of the matrix).
+constexpr int CBP_T = 320;
+__global__ __launch_bounds__(CBP_T) void cholb_panel_kernel(const double *W, double *Lf, int p, int k0, const double *dorig, int *flag,
+                                                            double *yv, double *dinvg)
 {
     __shared__ double Lt[CB * CB_LD], invd[CB];
-    __shared__ int bad_s;
+    __shared__ int ready_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nb = p - k0 < CB ? p - k0 : CB;
     if (tid == 0)
-        bad_s = 0;
-    // this workgroup's rows of the panel (workgroup b > 0: rows r0 .. r0 + 63): thread (lane, wave) holds columns
-    // wave, wave + 4, ... of row r0 + lane
+        ready_s = 0;
+    // this workgroup's rows of the panel (workgroup b > 0: rows r0 .. r0 + 63): thread (row = 16 (wave - 1) + lane % 16,
+    // class = lane / 16) of wavefronts 1 .. 4 holds columns class, class + 4, ... of row r0 + row
     const int r0 = k0 + CB * (int)blockIdx.x;
+    const int prow = 16 * (wave - 1) + (lane & 15), cls = lane >> 4;
+    // (every global load of the kernel is issued here, without a condition in front of it -- a load under a condition is a
+    // branch and a wait per load; what does not exist reads element 0 and is discarded)
     double rr[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q)
     {
-        const int c = wave + 4 * q;
-        rr[q] = (blockIdx.x > 0 && r0 + lane < p && c < nb) ? W[(size_t)(r0 + lane) * p + k0 + c] : 0.0;
+        const int c = cls + 4 * q;
+        const bool ok = wave > 0 && blockIdx.x > 0 && r0 + prow < p && c < nb;
+        rr[q] = W[ok ? (size_t)(r0 + prow) * p + k0 + c : 0];
+        rr[q] = ok ? rr[q] : 0.0;
     }
     // the diagonal block, lower triangle, identity beyond nb (a partial last block)
-    for (int e = tid; e < CB * CB; e += 256)
     {
-        const int i = e >> 6, j = e & 63;
-        Lt[i * CB_LD + j] = (i < nb && j <= i) ? W[(size_t)(k0 + i) * p + k0 + j] : (i == j ? 1.0 : 0.0);
+        constexpr int NL = (CB * CB + CBP_T - 1) / CBP_T;
+        double dv[NL];
+#pragma unroll
+        for (int it = 0; it < NL; ++it)
+        {
+            const int e = tid + CBP_T * it, i = e >> 6, j = e & 63;
+            dv[it] = W[(e < CB * CB && i < nb && j <= i) ? (size_t)(k0 + i) * p + k0 + j : 0];
+        }
+#pragma unroll
+        for (int it = 0; it < NL; ++it)
+        {
+            const int e = tid + CBP_T * it, i = e >> 6, j = e & 63;
+            if (e < CB * CB)
+                Lt[i * CB_LD + j] = (i < nb && j <= i) ? dv[it] : (i == j ? 1.0 : 0.0);
+        }
     }
-    __syncthreads();
+    __syncthreads(); // (the only one: from here on the wavefronts meet through `ready`)
     if (wave == 0)
     {
+        __builtin_amdgcn_s_setprio(3); // (five wavefronts on four SIMDs: this one is the critical path of the launch)
         constexpr int R = CB / 16;
         double m[CB];
 #pragma unroll
@@ -598,84 +626,116 @@ __global__ __launch_bounds__(256) void cholb_panel_kernel(const double *W, doubl
         double dg = Lt[lane * CB_LD + lane];
         const double thr = lane < nb ? fmax(1e-12 * dorig[k0 + lane], DBL_EPSILON) : 0.0;
         wide_lds_sync(); // every lane has its row before the factor overwrites the block
-        auto step = [&](auto self, auto jj) __attribute__((always_inline)) -> bool {
+        bool bad = false;
+        // 1 / sqrt(d): the hardware's estimate and two Newton steps (y <- y + y/2 (1 - d y^2)): rounding level after the
+        // second, 7 dependent operations where 1.0 / sqrt(d) was about 35; 1 / d as its square: no division in a step.
+        // This chain, 64 times, is the critical path of the launch, and a wavefront issues in order: the chain of step
+        // j + 1 (it needs d_{j+1} only, final as soon as column j + 1 of the update is) is written BETWEEN the pieces of
+        // step j's rank-one update, one operation per eighth, and scheduling barriers keep it there -- behind the update
+        // it waited for nothing but itself, 230 cycles of every step.
+        auto step = [&](auto self, auto jj, double dj, double rs, double ainv) __attribute__((always_inline)) -> void {
             constexpr int j = decltype(jj)::value;
-            if constexpr (j >= CB)
-                return true;
-            else
+            if constexpr (j < CB)
             {
-                const double dj = wide_bcast(dg, j), tj = wide_bcast(thr, j);
-                if (!(dj > tj)) // (below eps the reference's alpha = max(eps, |d|, ..) replaces the pivot; NaN ends here too)
-                    return false;
-                const double rs = 1.0 / sqrt(dj), ainv = rs * rs; // (one division per step: 1 / d_j as (1 / sqrt d_j)^2)
+                // column j - 1 is published here: its LDS writes have long landed, the release waits for nothing
+                // (every lane stores the same word, here and into invd: a store under `if (lane == ..)` is a branch, and
+                // the compiler moves the chain below across it, back to where it is waited for)
+                if constexpr (j > 0)
+                    __hip_atomic_store(&ready_s, j, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const double v = lane > j ? m[j] : 0.0;
                 const double t = ainv * v;
                 dg -= t * v;
                 Lt[lane * CB_LD + j] = lane == j ? dj * rs : v * rs; // column j of L11 (0 above the diagonal)
-                if (lane == j)
-                    invd[j] = rs;
+                invd[j] = rs;
                 if constexpr (j + 1 < CB)
                 {
                     double vb[R];
                     wide_row_copies<R>(v, vb);
-                    wide_chol_update<j + 1, CB, R>(m, vb, -t);
+                    const double tn = -t;
+                    wide_chol_update_range<j + 1, j + 2, CB, R>(m, vb, tn); // (column j + 1 first: the next step's v)
+                    const double dn = wide_bcast(dg, j + 1), tj = wide_bcast(thr, j + 1);
+                    // (below eps the reference's alpha = max(eps, |d|, ..) replaces the pivot: not this routine's case; NaN too)
+                    bad = bad || !(dn > tj);
+                    constexpr int F0 = j + 2, NF = CB - F0;
+#define GSLNLS_CB_PIECE(c)                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+    wide_chol_update_range<F0 + NF * (c) / 8, F0 + NF * ((c) + 1) / 8, CB, R>(m, vb, tn);                               \
+    __builtin_amdgcn_sched_barrier(0);
+                    double y = __builtin_amdgcn_rsq(dn);
+                    GSLNLS_CB_PIECE(0)
+                    double e = -dn * y, h = 0.5 * y;
+                    GSLNLS_CB_PIECE(1)
+                    e = fma(e, y, 1.0);
+                    GSLNLS_CB_PIECE(2)
+                    y = fma(h, e, y);
+                    GSLNLS_CB_PIECE(3)
+                    e = -dn * y, h = 0.5 * y;
+                    GSLNLS_CB_PIECE(4)
+                    e = fma(e, y, 1.0);
+                    GSLNLS_CB_PIECE(5)
+                    y = fma(h, e, y);
+                    GSLNLS_CB_PIECE(6)
+                    const double an = y * y;
+                    GSLNLS_CB_PIECE(7)
+#undef GSLNLS_CB_PIECE
+                    self(self, WideInt<j + 1>{}, dn, y, an);
                 }
-                return self(self, WideInt<j + 1>{});
             }
         };
-        const bool ok = step(step, WideInt<0>{});
-        if (!ok && lane == 0)
         {
-            bad_s = 1;
-            if (blockIdx.x == 0)
-                *flag = 1;
+            const double d0 = wide_bcast(dg, 0), t0 = wide_bcast(thr, 0);
+            bad = !(d0 > t0);
+            double y = __builtin_amdgcn_rsq(d0);
+            y = fma(0.5 * y, fma(-d0 * y, y, 1.0), y);
+            y = fma(0.5 * y, fma(-d0 * y, y, 1.0), y);
+            step(step, WideInt<0>{}, d0, y, y * y);
         }
-    }
-    __syncthreads();
-    if (bad_s)
+        if (lane == 0)
+            __hip_atomic_store(&ready_s, CB, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (blockIdx.x != 0)
+            return;
+        if (bad && lane == 0)
+            *flag = 1;
+        // the right-hand side rides along as one more row of the matrix: its slice of this step, L11 y = b (forward
+        // substitution block by block; the trailing update of the vector is cholb_trail_kernel's last workgroups)
+        double v = lane < nb ? yv[k0 + lane] : 0.0;
+        for (int j = 0; j < nb; ++j)
+        {
+            const double yj = wide_bcast(v, j) * invd[j];
+            if (lane == j)
+                v = yj;
+            else if (lane > j && lane < nb)
+                v -= Lt[lane * CB_LD + j] * yj;
+        }
+        if (lane < nb)
+            yv[k0 + lane] = v;
         return;
+    }
     if (blockIdx.x == 0)
     {
-        for (int e = tid; e < CB * CB; e += 256)
+        // workgroup 0 has no rows of the panel: its wavefronts 1 .. 4 store L11 once it is complete
+        while (__hip_atomic_load(&ready_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < CB)
+            __builtin_amdgcn_s_sleep(4);
+        for (int e = tid - 64; e < CB * CB; e += CBP_T - 64)
         {
             const int i = e >> 6, j = e & 63;
             if (i < nb && j <= i)
                 Lf[(size_t)(k0 + i) * p + k0 + j] = Lt[i * CB_LD + j];
         }
-        if (tid < nb)
-            dinvg[k0 + tid] = invd[tid]; // 1 / L_jj for the back substitution
-    }
-    if (blockIdx.x == 0)
-    {
-        // the right-hand side rides along as one more row of the matrix: its slice of this step, L11 y = b (forward
-        // substitution block by block; the trailing update of the vector is cholb_trail_kernel's last workgroups)
-        if (wave == 0)
-        {
-            double v = lane < nb ? yv[k0 + lane] : 0.0;
-            for (int j = 0; j < nb; ++j)
-            {
-                const double yj = wide_bcast(v, j) * invd[j];
-                if (lane == j)
-                    v = yj;
-                else if (lane > j && lane < nb)
-                    v -= Lt[lane * CB_LD + j] * yj;
-            }
-            if (lane < nb)
-                yv[k0 + lane] = v;
-        }
+        if (tid - 64 < nb)
+            dinvg[k0 + tid - 64] = invd[tid - 64]; // 1 / L_jj for the back substitution
         return;
     }
-    // rows r0 .. r0 + 63 of the panel: X L11^T = W21
-    __shared__ double xs[2][CB];
-    cholb_trsm_steps<0>(rr, Lt, invd, xs, lane, wave);
-    if (r0 + lane < p)
+    // rows r0 .. r0 + 63 of the panel: X L11^T = W21, a column behind the factorisation
+    cholb_trsm_steps<0>(rr, Lt, invd, lane & 15, cls, &ready_s, 0);
+    if (r0 + prow < p)
     {
 #pragma unroll
         for (int q = 0; q < 16; ++q)
         {
-            const int c = wave + 4 * q;
+            const int c = cls + 4 * q;
             if (c < nb)
-                Lf[(size_t)(r0 + lane) * p + k0 + c] = rr[q];
+                Lf[(size_t)(r0 + prow) * p + k0 + c] = rr[q];
         }
     }
 }
@@ -696,11 +756,17 @@ __global__ __launch_bounds__(256, 2) void cholb_trail_kernel(double *W, const do
         const int i = k0 + CB + (t - ntile) * 256 + tid;
         if (i < p)
         {
+            // (all 64 loads of the row in flight before the first is added: the rows were written by the panel kernel on
+            // other XCDs, a load is 2 us, and eight at a time made this workgroup the last of the launch by 10 us)
             const double *row = Lf + (size_t)i * p + k0;
-            double s0 = 0.0;
-#pragma unroll 8
+            double rv[CB];
+#pragma unroll
             for (int c = 0; c < CB; ++c)
-                s0 += row[c] * yk[c];
+                rv[c] = row[c];
+            double s0 = 0.0;
+#pragma unroll
+            for (int c = 0; c < CB; ++c)
+                s0 += rv[c] * yk[c];
             yv[i] -= s0;
         }
         return;
@@ -713,11 +779,34 @@ __global__ __launch_bounds__(256, 2) void cholb_trail_kernel(double *W, const do
     const int J = t - I * (I + 1) / 2;
     const int base = k0 + CB, ri = base + CB * I, rj = base + CB * J;
     // (k0 + 64 <= p here: the last panel has no trailing matrix)
-    for (int e = tid; e < CB * CB; e += 256)
+    // Every global load of the workgroup is issued before the first is waited for -- the 16 + 16 values of the two panel
+    // blocks and the 16 entries of W this thread will update: a load under a condition is a branch and a wait, and as
+    // loops of "load, wait, store" (32 + 16 round trips of 1-2 us through caches the panel kernel filled on other XCDs)
+    // this was 18 us of launch for 1 us of matrix-core work.  Rows and entries that do not exist read element 0 instead
+    // and are discarded.
+    double wv[16], li[16], lj[16];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+        {
+            const int gi = ri + wave * 16 + 4 * r + kk, gj = rj + b * 16 + ii;
+            const bool ok = gi < p && gj < p && gj <= gi;
+            wv[b * 4 + r] = W[ok ? (size_t)gi * p + gj : 0];
+        }
+#pragma unroll
+    for (int it = 0; it < 16; ++it)
     {
-        const int r = e >> 6, c = e & 63;
-        tI[r * CBT_LD + c] = ri + r < p ? Lf[(size_t)(ri + r) * p + k0 + c] : 0.0;
-        tJ[r * CBT_LD + c] = rj + r < p ? Lf[(size_t)(rj + r) * p + k0 + c] : 0.0;
+        const int e = tid + 256 * it, r = e >> 6, c = e & 63;
+        li[it] = Lf[ri + r < p ? (size_t)(ri + r) * p + k0 + c : 0];
+        lj[it] = Lf[rj + r < p ? (size_t)(rj + r) * p + k0 + c : 0];
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it)
+    {
+        const int e = tid + 256 * it, r = e >> 6, c = e & 63;
+        tI[r * CBT_LD + c] = ri + r < p ? li[it] : 0.0;
+        tJ[r * CBT_LD + c] = rj + r < p ? lj[it] : 0.0;
     }
     __syncthreads();
     cb_v4f64 acc[4];
@@ -745,7 +834,7 @@ __global__ __launch_bounds__(256, 2) void cholb_trail_kernel(double *W, const do
         {
             const int gi = ri + wave * 16 + 4 * r + kk, gj = rj + b * 16 + ii;
             if (gi < p && gj < p && gj <= gi)
-                W[(size_t)gi * p + gj] -= acc[b][r];
+                W[(size_t)gi * p + gj] = wv[b * 4 + r] - acc[b][r];
         }
 }
 
@@ -794,12 +883,106 @@ __global__ __launch_bounds__(256) void cholb_back_kernel(const double *Lf, int p
     }
 }
 
+// The whole back substitution L^T x = y in ONE launch, by one workgroup of eight wavefronts (the per-block form above: a
+// launch per block of 64, 19 us each -- 154 us of the 750 of a p = 500 solve).  y lives in LDS.  Block s from the end is
+// solved by wavefront s % 8: lane i holds column i of the block's triangle in REGISTERS (asked for one turn ahead, so the
+// load is never waited for) and the 64 steps are a recursion with literal register indices -- readlane, multiply, fma per
+// step.  Then all 512 threads take x_k out of the components in front of the block (coalesced over j; the first 32 of the
+// 64 rows are requested before the solve starts).  Same sums in the same order as cholb_back_kernel: not a bit changes.
+constexpr int CBA_T = 512, CBA_W = CBA_T / 64;
+template <int J>
+__device__ __forceinline__ void cholb_back_steps(double &v, double di, const double (&c)[CB], int lane)
+{
+    if constexpr (J >= 0)
+    {
+        const double xj = wide_bcast(v, J) * wide_bcast(di, J);
+        if (lane == J)
+            v = xj;
+        else if (lane < J)
+            v -= c[J] * xj;
+        cholb_back_steps<J - 1>(v, di, c, lane);
+    }
+}
+__global__ __launch_bounds__(CBA_T) void cholb_backall_kernel(const double *Lf, int p, const double *yv, double *sol,
+                                                              const double *dinvg)
+{
+    extern __shared__ double ys[]; // 64 nblk doubles: y (zeros behind p), block by block overwritten by x
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = (p + CB - 1) / CB;
+    for (int j = tid; j < nblk * CB; j += CBA_T)
+        ys[j] = j < p ? yv[j] : 0.0;
+    double c[CB], di = 0.0;
+    auto load_block = [&](int kb) {
+        const int k0 = kb * CB, nb = p - k0 < CB ? p - k0 : CB;
+#pragma unroll
+        for (int r = 0; r < CB; ++r)
+            c[r] = (r < nb && lane < r) ? Lf[(size_t)(k0 + r) * p + k0 + lane] : 0.0; // L[k0 + r][k0 + lane], r > lane
+        di = lane < nb ? dinvg[k0 + lane] : 0.0;
+    };
+#pragma unroll
+    for (int r = 0; r < CB; ++r)
+        c[r] = 0.0;
+    if (wave < nblk)
+        load_block(nblk - 1 - wave);
+    __syncthreads();
+    constexpr int H = 16; // rows of L per round of loads in the update
+    for (int s = 0; s < nblk; ++s)
+    {
+        const int kb = nblk - 1 - s, k0 = kb * CB, nb = p - k0 < CB ? p - k0 : CB;
+        // the update's first 16 rows of L for this thread's first component: requested before the solve, used behind it
+        double lv[H];
+#pragma unroll
+        for (int r = 0; r < H; ++r)
+            lv[r] = (tid < k0 && r < nb) ? Lf[(size_t)(k0 + r) * p + tid] : 0.0;
+        if (wave == (s % CBA_W))
+        {
+            double v = lane < nb ? ys[k0 + lane] : 0.0;
+            cholb_back_steps<CB - 1>(v, di, c, lane);
+            if (lane < nb)
+            {
+                ys[k0 + lane] = v;
+                sol[k0 + lane] = v;
+            }
+            if (s + CBA_W < nblk)
+                load_block(nblk - 1 - (s + CBA_W)); // this wavefront's next block: eight turns to arrive
+        }
+        __syncthreads();
+        // y[j] -= sum_r L[k0 + r][j] x_r for the components in front of the block, r ascending
+        for (int j = tid; j < k0; j += CBA_T)
+        {
+            double s0 = 0.0;
+#pragma unroll 1
+            for (int r0 = 0; r0 < CB; r0 += H)
+            {
+                if (r0 > 0 || j != tid)
+                {
+#pragma unroll
+                    for (int r = 0; r < H; ++r)
+                        lv[r] = r0 + r < nb ? Lf[(size_t)(k0 + r0 + r) * p + j] : 0.0;
+                }
+#pragma unroll
+                for (int r = 0; r < H; ++r)
+                    s0 += lv[r] * ys[k0 + r0 + r];
+            }
+            ys[j] -= s0;
+        }
+        __syncthreads();
+    }
+}
+
+// the flag of the natural-order factorisation, as a double behind the solution: one copy brings both down
+__global__ void cholb_flag_kernel(const int *flag, double *dst)
+{
+    *dst = (double)*flag;
+}
+
 struct MCholBuffers
 {
     std::mutex mu;
     int cap = 0, device = -1;
     double *A = nullptr, *Lg = nullptr, *Cg = nullptr, *vec = nullptr; // vec: ainvg | dcur | b | dinv | scal | rhs | sol
     int *ivec = nullptr;                                              // pos | ord | flag of the natural-order factorisation
+    double *stage = nullptr; // pinned, 3 cap + 8 doubles: [rhs | diag] on the way up, [sol | flag] on the way down
     bool attr_set = false;
 };
 static MCholBuffers &mchol_buffers()
@@ -828,6 +1011,9 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
         (void)hipFree(B.Lg);
         (void)hipFree(B.Cg);
         (void)hipFree(B.vec);
+        if (B.stage)
+            (void)hipHostFree(B.stage);
+        B.stage = nullptr;
         (void)hipFree(B.ivec);
         B.A = B.Lg = B.Cg = B.vec = nullptr;
         B.ivec = nullptr;
@@ -835,7 +1021,8 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
         const size_t pp = (size_t)p * p;
         if (hipMalloc(&B.A, sizeof(double) * pp) != hipSuccess || hipMalloc(&B.Lg, sizeof(double) * pp) != hipSuccess ||
             hipMalloc(&B.Cg, sizeof(double) * (size_t)MC_NB_MAX * p) != hipSuccess ||
-            hipMalloc(&B.vec, sizeof(double) * ((size_t)7 * p + MC_NB_MAX + 8)) != hipSuccess ||
+            hipMalloc(&B.vec, sizeof(double) * ((size_t)7 * p + MC_NB_MAX + 24)) != hipSuccess ||
+            hipHostMalloc(&B.stage, sizeof(double) * ((size_t)3 * p + 8), hipHostMallocDefault) != hipSuccess ||
             hipMalloc(&B.ivec, sizeof(int) * ((size_t)2 * p + 4)) != hipSuccess)
         {
             (void)hipGetLastError();
@@ -864,7 +1051,8 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
     a.b = a.dcur + p;
     a.dinv = a.b + p;
     a.scal = a.dinv + p;
-    double *d_rhs = a.scal + 8, *d_sol = d_rhs + p, *d_dmp = d_sol + p;
+    // rhs | diag (one copy up) | sol | flag as a double (one copy down) | work
+    double *d_rhs = a.scal + 8, *d_dmp = d_rhs + p, *d_sol = d_dmp + p;
     a.pos = B.ivec;
     a.ord = B.ivec + p;
     a.p = p;
@@ -878,9 +1066,12 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
     NB = NB > MC_NB_MAX ? MC_NB_MAX : NB;
     if (A_host)
         GSLNLS_HIP_OK(hipMemcpy(B.A, A_host, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice));
-    else
-        GSLNLS_HIP_OK(hipMemcpy(d_dmp, diag_host, sizeof(double) * p, hipMemcpyHostToDevice));
-    GSLNLS_HIP_OK(hipMemcpy(d_rhs, rhs_host, sizeof(double) * p, hipMemcpyHostToDevice));
+    // the two vectors go up in ONE asynchronous copy from the pinned staging area, the solution and the flag come down in
+    // one: a solve synchronises with the device once, at its end (four blocking copies were 50 us of a 470 us solve)
+    memcpy(B.stage, rhs_host, sizeof(double) * p);
+    if (!A_host)
+        memcpy(B.stage + p, diag_host, sizeof(double) * p);
+    GSLNLS_HIP_OK(hipMemcpyAsync(d_rhs, B.stage, sizeof(double) * (size_t)(A_host ? p : 2 * p), hipMemcpyHostToDevice, 0));
     GSLNLS_HIP_OK(hipMemsetAsync(a.scal, 0, sizeof(double) * 8, 0));
     {
         long long g = ((long long)p * p + 256 * 8 - 1) / (256 * 8);
@@ -894,7 +1085,7 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
         if (!(pe && atoi(pe) != 0))
         {
             int *d_flag = B.ivec + 2 * p;
-            double *d_work = d_dmp + p;
+            double *d_work = d_sol + p + 8;
             GSLNLS_HIP_OK(hipMemsetAsync(d_flag, 0, sizeof(int), 0));
             // the right-hand side is one more row of the matrix: L y = b happens inside the factorisation
             GSLNLS_HIP_OK(hipMemcpyAsync(d_work, d_rhs, sizeof(double) * p, hipMemcpyDeviceToDevice, 0));
@@ -902,20 +1093,26 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
             {
                 const int nrb = (p - k0 + CB - 1) / CB; // row blocks from the diagonal block down
                 // (workgroup 0: the diagonal block and the right-hand side; workgroup b: row block b of the panel)
-                hipLaunchKernelGGL(cholb_panel_kernel, dim3(nrb), dim3(256), 0, 0, B.A, B.Lg, p, k0, a.dcur, d_flag, d_work, a.dinv);
+                hipLaunchKernelGGL(cholb_panel_kernel, dim3(nrb), dim3(CBP_T), 0, 0, B.A, B.Lg, p, k0, a.dcur, d_flag, d_work, a.dinv);
                 if (nrb > 1)
                 {
                     const int nt = (nrb - 1) * nrb / 2, nrhs = (p - k0 - CB + 255) / 256;
                     hipLaunchKernelGGL(cholb_trail_kernel, dim3(nt + nrhs), dim3(256), 0, 0, B.A, B.Lg, p, k0, nt, d_work);
                 }
             }
-            for (int k0 = ((p - 1) / CB) * CB; k0 >= 0; k0 -= CB)
-                hipLaunchKernelGGL(cholb_back_kernel, dim3(1 + (k0 + 255) / 256), dim3(256), 0, 0, B.Lg, p, k0, d_work, d_sol, a.dinv);
-            int h_flag = 0;
-            GSLNLS_HIP_OK(hipMemcpy(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost));
-            if (!h_flag)
+            if (!getenv("GSLNLS_LARGE_BACK_BLOCKS")) // (developer switch: the launch-per-block form, same bits)
+                hipLaunchKernelGGL(cholb_backall_kernel, dim3(1), dim3(CBA_T), sizeof(double) * (size_t)CB * ((p + CB - 1) / CB), 0, B.Lg, p, d_work,
+                                   d_sol, a.dinv);
+            else
+                for (int k0 = ((p - 1) / CB) * CB; k0 >= 0; k0 -= CB)
+                    hipLaunchKernelGGL(cholb_back_kernel, dim3(1 + (k0 + 255) / 256), dim3(256), 0, 0, B.Lg, p, k0, d_work, d_sol, a.dinv);
+            hipLaunchKernelGGL(cholb_flag_kernel, dim3(1), dim3(1), 0, 0, d_flag, d_sol + p);
+            double *h_down = B.stage + 2 * (size_t)p;
+            GSLNLS_HIP_OK(hipMemcpyAsync(h_down, d_sol, sizeof(double) * (size_t)(p + 1), hipMemcpyDeviceToHost, 0));
+            GSLNLS_HIP_OK(hipStreamSynchronize(0));
+            if (h_down[p] == 0.0)
             {
-                GSLNLS_HIP_OK(hipMemcpy(sol_host, d_sol, sizeof(double) * p, hipMemcpyDeviceToHost));
+                memcpy(sol_host, h_down, sizeof(double) * p);
                 GSLNLS_HIP_OK(hipGetLastError());
                 return GSLNLS_SUCCESS;
             }
@@ -982,6 +1179,16 @@ extern "C" int gslnls_debug_mchol_solve(int p, const double *A, const double *di
     const int rc = gslnls::mchol_device_solve(p, M, rhs, sol);
     free(M);
     return rc;
+}
+
+// test / measurement hook: the same solve with J^T J already in device memory (p x p, row-major, not modified), the way
+// the lm step of the large path calls it -- what goes up per solve is diag and rhs, 2 p doubles
+extern "C" int gslnls_debug_mchol_solve_resident(int p, const double *jtj_dev, const double *diag, double mu, const double *rhs,
+                                                 double *sol)
+{
+    if (p < 1 || !jtj_dev || !diag || !rhs || !sol)
+        return GSLNLS_EINVAL;
+    return gslnls::mchol_device_solve_resident(p, jtj_dev, diag, mu, rhs, sol);
 }
 
 // test hook (no device needed): the same solve by the host routine of the large path (large_host.hpp: lg_mchol_solve,

@@ -562,6 +562,17 @@ __device__ __forceinline__ void wide_row_copies(double v, double (&vb)[R])
         asm volatile("s_nop 1" : "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]));
 }
 
+// columns K .. KEND - 1 of the rank-one update (a piece of it: the caller interleaves the pieces with other work)
+template <int K, int KEND, int PW, int R>
+__device__ __forceinline__ void wide_chol_update_range(double (&m)[PW], const double (&vb)[R], double tn)
+{
+    if constexpr (K < KEND)
+    {
+        wide_fmac_rowbcast<(K & 15)>(m[K], vb[K >> 4], tn);
+        wide_chol_update_range<K + 1, KEND, PW, R>(m, vb, tn);
+    }
+}
+
 // columns K .. PW - 1 of the rank-one update S -= t v^T (K a literal: the DPP control and the register are immediates)
 template <int K, int PW, int R>
 __device__ __forceinline__ void wide_chol_update(double (&m)[PW], const double (&vb)[R], double tn)

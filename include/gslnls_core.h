@@ -382,6 +382,9 @@ int gslnls_debug_wide_solve(int p, const double *Ap, const double *diag, double 
  * row-major, p <= 4096; d may be NULL): the same pivoted modified Cholesky, panels of pivot steps by one workgroup and
  * grid-wide trailing updates (csrc/mchol_device.hip; gsl_multilarge_nlinear's lm step, multilarge_nlinear/cholesky.c) */
 int gslnls_debug_mchol_solve(int p, const double *A, const double *diag, double mu, const double *rhs, double *sol);
+/* the same with J^T J resident in device memory (jtj_dev: p x p doubles, row-major, left as it is): the call of the lm step */
+int gslnls_debug_mchol_solve_resident(int p, const double *jtj_dev, const double *diag, double mu, const double *rhs,
+                                      double *sol);
 /* the same solve by the host routine that serves the lm step below the device threshold (no device needed) */
 int gslnls_debug_host_mchol_solve(int p, const double *A, const double *diag, double mu, const double *rhs, double *sol);
 /* the sums of one pass over the rows of a wide problem (p > 9) at theta: totals[0] = ssr, [1] = non-finite flag,

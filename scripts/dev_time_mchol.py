@@ -1,22 +1,35 @@
-"""developer timing + residual check of the device modified Cholesky (gsl_nls_large lm step), p = 100 .. 2000"""
-import os, sys, time
+"""developer aid: wall time per damped solve of the large path's device factorisation (csrc/mchol_device.hip) at
+p = 500, 1000, 2000 -- the one-launch back substitution against the launch-per-block form (GSLNLS_LARGE_BACK_BLOCKS=1),
+with the two solutions compared bit for bit.  Usage: python scripts/dev_time_mchol.py [reps]"""
+import sys, os, time, ctypes as C
+import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np
 from gslnls_amd import _lib
 L = _lib.lib()
-rng = np.random.default_rng(1)
-for p in (64, 100, 250, 500, 777, 1000, 1500, 2000):
-    J = rng.standard_normal((2 * p, p))
+DP = C.POINTER(C.c_double)
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(7)
+for p in (500, 1000, 2000, 333):
+    J = rng.standard_normal((p + 50, p))
     A = np.ascontiguousarray(J.T @ J)
-    diag = np.sqrt(np.diag(A)).copy(); rhs = rng.standard_normal(p); sol = np.zeros(p)
-    args = (p, A.ctypes.data_as(_lib.DP), diag.ctypes.data_as(_lib.DP), 1e-3, rhs.ctypes.data_as(_lib.DP), sol.ctypes.data_as(_lib.DP))
-    rc = L.gslnls_debug_mchol_solve(*args)
-    t0 = time.perf_counter()
-    reps = 5
-    for _ in range(reps):
+    d = np.sqrt(np.diag(A)).copy()
+    rhs = rng.standard_normal(p)
+    out = {}
+    for mode in ("one launch", "per block"):
+        if mode == "per block":
+            os.environ["GSLNLS_LARGE_BACK_BLOCKS"] = "1"
+        else:
+            os.environ.pop("GSLNLS_LARGE_BACK_BLOCKS", None)
+        sol = np.zeros(p)
+        args = (p, A.ctypes.data_as(DP), d.ctypes.data_as(DP), 1e-3, rhs.ctypes.data_as(DP), sol.ctypes.data_as(DP))
         rc = L.gslnls_debug_mchol_solve(*args)
-    dt = (time.perf_counter() - t0) / reps
-    M = A + 1e-3 * np.diag(diag ** 2)
-    print(("pivoted" if os.environ.get("GSLNLS_LARGE_CHOL_PIVOTED") == "1" else "natural") + " p = %4d: rc %d, %.3f ms per solve (incl. the %d KB upload), residual %.2e" % (
-        p, rc, 1e3 * dt, p * p * 8 // 1024, np.max(np.abs(M @ sol - rhs)) / np.max(np.abs(rhs))), flush=True)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            rc = L.gslnls_debug_mchol_solve(*args) or rc
+        el = (time.perf_counter() - t0) / reps
+        M = A + 1e-3 * np.diag(d * d)
+        out[mode] = sol.copy()
+        print("p = %4d  %-10s rc %d  %.3f ms per solve (upload included)  rel. residual %.2e" %
+              (p, mode, rc, el * 1e3, np.linalg.norm(M @ sol - rhs) / np.linalg.norm(rhs)))
+    print("          identical bits: %s" % bool(np.array_equal(out["one launch"], out["per block"])))

@@ -227,6 +227,57 @@ def test_device_modified_cholesky_matches_the_oracle(amd, gslref, p, pivoted, mo
             assert np.max(np.abs(sol - ref)) <= tol * scale, (case, p, np.max(np.abs(sol - ref)) / scale)
 
 
+@pytest.mark.parametrize("p", [70, 333, 500, 1030])
+def test_back_substitution_in_one_launch_and_resident_matrix_give_the_same_bits(amd, monkeypatch, p):
+    """csrc/mchol_device.hip: cholb_backall_kernel (the whole back substitution in one launch, y in LDS, the block's triangle
+    in registers) performs the sums of the launch-per-block form in the same order -- the two solutions are compared bit
+    for bit; and the solve with J^T J resident in device memory (how the lm step calls it: diag and rhs go up, nothing
+    else) equals the solve that uploads the damped matrix."""
+    import ctypes as C
+    from gslnls_amd import _lib
+    L = _lib.lib()
+    rng = np.random.Generator(np.random.PCG64(99 + p))
+    J = rng.standard_normal((p + 40, p))
+    A = np.ascontiguousarray(J.T @ J)
+    diag = np.sqrt(np.diag(A)).copy()
+    rhs = rng.standard_normal(p)
+    mu = 1e-3
+    sols = {}
+    for mode in ("one", "blocks"):
+        if mode == "blocks":
+            monkeypatch.setenv("GSLNLS_LARGE_BACK_BLOCKS", "1")
+        else:
+            monkeypatch.delenv("GSLNLS_LARGE_BACK_BLOCKS", raising=False)
+        sol = np.zeros(p)
+        assert L.gslnls_debug_mchol_solve(p, A.ctypes.data_as(_lib.DP), diag.ctypes.data_as(_lib.DP), mu,
+                                          rhs.ctypes.data_as(_lib.DP), sol.ctypes.data_as(_lib.DP)) == 0
+        sols[mode] = sol
+    monkeypatch.delenv("GSLNLS_LARGE_BACK_BLOCKS", raising=False)
+    assert np.array_equal(sols["one"], sols["blocks"])
+    hip = C.CDLL("libamdhip64.so")  # (the HIP runtime the library itself is linked against)
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    dA = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dA), A.nbytes) == 0
+    try:
+        assert hip.hipMemcpy(dA, A.ctypes.data_as(C.c_void_p), A.nbytes, 1) == 0  # host -> device
+        solr = np.zeros(p)
+        assert L.gslnls_debug_mchol_solve_resident(p, dA, diag.ctypes.data_as(_lib.DP), mu, rhs.ctypes.data_as(_lib.DP),
+                                                   solr.ctypes.data_as(_lib.DP)) == 0
+        assert np.array_equal(solr, sols["one"])
+        back = np.zeros_like(A)
+        assert hip.hipMemcpy(back.ctypes.data_as(C.c_void_p), dA, A.nbytes, 2) == 0  # device -> host
+        assert np.array_equal(back, A)  # (left as it was)
+    finally:
+        hip.hipFree(dA)
+    M = A + mu * np.diag(diag * diag)
+    res = float(np.linalg.norm(M @ solr - rhs) / np.linalg.norm(rhs))
+    from conftest import record_parity
+    record_parity("blocked Cholesky, relative residual, p = %d" % p, res)
+    assert res < 1e-11
+
+
 def test_large_lm_takes_the_device_factorisation_from_the_threshold_on(amd, gslref):
     """gsl_nls_large(algorithm = "lm") on the GLM family at p = 64 with the threshold lowered to 1 (every step's solve on
     the device) gives the fit of the host factorisation: same iterations, coefficients to round-off (the threshold is
