@@ -1181,6 +1181,36 @@ extern "C" int gslnls_debug_mchol_solve(int p, const double *A, const double *di
     return rc;
 }
 
+// test / measurement hooks: device memory through the runtime this library is linked against (a process may hold a second
+// copy of the HIP runtime -- PyTorch ships one -- whose allocations belong to another context)
+extern "C" int gslnls_debug_device_alloc(void **p, size_t bytes)
+{
+    if (!p)
+        return GSLNLS_EINVAL;
+    *p = nullptr;
+    if (hipMalloc(p, bytes ? bytes : 8) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return GSLNLS_E_NODEVICE;
+    }
+    return GSLNLS_SUCCESS;
+}
+extern "C" int gslnls_debug_device_free(void *p)
+{
+    return (!p || hipFree(p) == hipSuccess) ? GSLNLS_SUCCESS : GSLNLS_E_NODEVICE;
+}
+extern "C" int gslnls_debug_device_copy(void *dst, const void *src, size_t bytes, int to_device)
+{
+    if (!dst || !src)
+        return GSLNLS_EINVAL;
+    if (hipMemcpy(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return GSLNLS_E_NODEVICE;
+    }
+    return GSLNLS_SUCCESS;
+}
+
 // test / measurement hook: the same solve with J^T J already in device memory (p x p, row-major, not modified), the way
 // the lm step of the large path calls it -- what goes up per solve is diag and rhs, 2 p doubles
 extern "C" int gslnls_debug_mchol_solve_resident(int p, const double *jtj_dev, const double *diag, double mu, const double *rhs,

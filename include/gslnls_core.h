@@ -382,6 +382,12 @@ int gslnls_debug_wide_solve(int p, const double *Ap, const double *diag, double 
  * row-major, p <= 4096; d may be NULL): the same pivoted modified Cholesky, panels of pivot steps by one workgroup and
  * grid-wide trailing updates (csrc/mchol_device.hip; gsl_multilarge_nlinear's lm step, multilarge_nlinear/cholesky.c) */
 int gslnls_debug_mchol_solve(int p, const double *A, const double *diag, double mu, const double *rhs, double *sol);
+/* device memory through the HIP runtime this library is linked against (test / measurement hooks: a process may hold a
+ * second copy of the runtime, e.g. PyTorch's, whose allocations belong to another context); to_device: 1 host -> device,
+ * 0 device -> host */
+int gslnls_debug_device_alloc(void **p, size_t bytes);
+int gslnls_debug_device_free(void *p);
+int gslnls_debug_device_copy(void *dst, const void *src, size_t bytes, int to_device);
 /* the same with J^T J resident in device memory (jtj_dev: p x p doubles, row-major, left as it is): the call of the lm step */
 int gslnls_debug_mchol_solve_resident(int p, const double *jtj_dev, const double *diag, double mu, const double *rhs,
                                       double *sol);

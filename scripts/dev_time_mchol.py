@@ -12,10 +12,6 @@ DP = C.POINTER(C.c_double)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 sizes = [int(a) for a in sys.argv[2:]] or [500, 1000, 2000, 333]
 rng = np.random.default_rng(7)
-hip = C.CDLL("libamdhip64.so")
-hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-hip.hipFree.argtypes = [C.c_void_p]
 for p in sizes:
     J = rng.standard_normal((p + 50, p))
     A = np.ascontiguousarray(J.T @ J)
@@ -41,8 +37,8 @@ for p in sizes:
     print("          identical bits: %s" % bool(np.array_equal(out["one launch"], out["per block"])))
     os.environ.pop("GSLNLS_LARGE_BACK_BLOCKS", None)
     dA = C.c_void_p()
-    hip.hipMalloc(C.byref(dA), A.nbytes)
-    hip.hipMemcpy(dA, A.ctypes.data_as(C.c_void_p), A.nbytes, 1)
+    L.gslnls_debug_device_alloc(C.byref(dA), A.nbytes)
+    L.gslnls_debug_device_copy(dA, A.ctypes.data_as(C.c_void_p), A.nbytes, 1)
     sol = np.zeros(p)
     rargs = (p, dA, d.ctypes.data_as(DP), 1e-3, rhs.ctypes.data_as(DP), sol.ctypes.data_as(DP))
     rc = L.gslnls_debug_mchol_solve_resident(*rargs)
@@ -52,4 +48,4 @@ for p in sizes:
     el = (time.perf_counter() - t0) / reps
     print("          J^T J resident (the lm step's call): rc %d  %.3f ms per solve, same bits %s" %
           (rc, el * 1e3, bool(np.array_equal(sol, out["one launch"]))))
-    hip.hipFree(dA)
+    L.gslnls_debug_device_free(dA)

@@ -254,23 +254,19 @@ def test_back_substitution_in_one_launch_and_resident_matrix_give_the_same_bits(
         sols[mode] = sol
     monkeypatch.delenv("GSLNLS_LARGE_BACK_BLOCKS", raising=False)
     assert np.array_equal(sols["one"], sols["blocks"])
-    hip = C.CDLL("libamdhip64.so")  # (the HIP runtime the library itself is linked against)
-    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    hip.hipFree.argtypes = [C.c_void_p]
     dA = C.c_void_p()
-    assert hip.hipMalloc(C.byref(dA), A.nbytes) == 0
+    assert L.gslnls_debug_device_alloc(C.byref(dA), A.nbytes) == 0
     try:
-        assert hip.hipMemcpy(dA, A.ctypes.data_as(C.c_void_p), A.nbytes, 1) == 0  # host -> device
+        assert L.gslnls_debug_device_copy(dA, A.ctypes.data_as(C.c_void_p), A.nbytes, 1) == 0
         solr = np.zeros(p)
         assert L.gslnls_debug_mchol_solve_resident(p, dA, diag.ctypes.data_as(_lib.DP), mu, rhs.ctypes.data_as(_lib.DP),
                                                    solr.ctypes.data_as(_lib.DP)) == 0
         assert np.array_equal(solr, sols["one"])
         back = np.zeros_like(A)
-        assert hip.hipMemcpy(back.ctypes.data_as(C.c_void_p), dA, A.nbytes, 2) == 0  # device -> host
+        assert L.gslnls_debug_device_copy(back.ctypes.data_as(C.c_void_p), dA, A.nbytes, 0) == 0
         assert np.array_equal(back, A)  # (left as it was)
     finally:
-        hip.hipFree(dA)
+        L.gslnls_debug_device_free(dA)
     M = A + mu * np.diag(diag * diag)
     res = float(np.linalg.norm(M @ solr - rhs) / np.linalg.norm(rhs))
     from conftest import record_parity
