@@ -579,8 +579,21 @@ __device__ __forceinline__ void wide_pass_body(const WPassArgs &a)
     // one of the (up to) 16 group reducers will run the LM step: each asks for the state now, so that the loads (written by
     // the previous launch on another XCD: most of two microseconds) are under way while the arrival is counted
     WideStateRegs<(NA + 63) / 64> sregs;
+    // (... and for the speculator's result, which by now has been there for a while: tag, then the payload.  Nothing orders
+    // these loads against each other -- the fold in the tag and the bitwise comparison of mu below are what make a
+    // half-new payload "not there")
+    unsigned long long pre_tag = 0;
+    double pre_sv = 0.0, pre_smu = 0.0;
     if (a.fuse == WIDE_FUSE_STEP && wave == 0)
+    {
         wide_state_load<P>(adv.state, lane, sregs);
+        if (a.spec)
+        {
+            pre_tag = __hip_atomic_load(&a.fb->spec_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pre_sv = lane < P ? __hip_atomic_load(&a.fb->spec_vel[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            pre_smu = __hip_atomic_load(&a.fb->spec_mu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (!wide_arrive_last(&a.fb->ticket2, (unsigned int)ngrp, &flag_s))
         return;
     stamp(4); // last group reducer: acquired
@@ -621,37 +634,51 @@ __device__ __forceinline__ void wide_pass_body(const WPassArgs &a)
             // started before this workgroup did), else solve here.  {epoch, fold} guards against a payload that is not this
             // launch's: a mismatch of either is treated as "not there".
             const unsigned int epoch = ((unsigned int)adv.seq << 16) ^ (unsigned int)(adv.launch_idx + 1);
-            const unsigned long long t0 = __builtin_readcyclecounter();
-            bool got = false;
-            unsigned long long tag = 0;
-            for (;;)
-            {
-                tag = __hip_atomic_load(&a.fb->spec_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned int)(tag >> 32) == epoch)
-                {
-                    got = true;
-                    break;
-                }
-                if (__builtin_readcyclecounter() - t0 > 200000ull) // ~100 us: the speculator is not coming
-                    break;
-                __builtin_amdgcn_s_sleep(8);
-            }
-            if (got)
-            {
-                const double sv = lane < P ? __hip_atomic_load(&a.fb->spec_vel[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-                const double smu = __hip_atomic_load(&a.fb->spec_mu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            auto fold_of = [&](double sv) {
                 unsigned long long h = lane < P ? (unsigned long long)__double_as_longlong(sv) : 0ull;
                 h = (h >> 32) ^ (h & 0xffffffffull);
                 unsigned int f = (unsigned int)h;
 #pragma unroll
                 for (int m = 32; m >= 1; m >>= 1)
                     f ^= (unsigned int)__shfl_xor((int)f, m, 64);
-                if (f == (unsigned int)(tag & 0xffffffffull) && __double_as_longlong(smu) == __double_as_longlong(ctx.mu))
+                return f;
+            };
+            auto take = [&](unsigned long long tag, double sv, double smu) {
+                if ((unsigned int)(tag >> 32) == epoch && fold_of(sv) == (unsigned int)(tag & 0xffffffffull) &&
+                    __double_as_longlong(smu) == __double_as_longlong(ctx.mu))
                 {
                     if (lane < P)
                         L.vel[lane] = sv;
                     wide_lds_sync();
                     solver = false;
+                    return true;
+                }
+                return false;
+            };
+            // what was asked for before the arrival (the common case: the speculator finished 10 us ago) ...
+            if (!take(pre_tag, pre_sv, pre_smu))
+            {
+                // ... else wait for the tag of this launch, then fetch the payload
+                const unsigned long long t0 = __builtin_readcyclecounter();
+                bool got = false;
+                unsigned long long tag = 0;
+                for (;;)
+                {
+                    tag = __hip_atomic_load(&a.fb->spec_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned int)(tag >> 32) == epoch)
+                    {
+                        got = true;
+                        break;
+                    }
+                    if (__builtin_readcyclecounter() - t0 > 200000ull) // ~100 us: the speculator is not coming
+                        break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                if (got)
+                {
+                    const double sv = lane < P ? __hip_atomic_load(&a.fb->spec_vel[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                    const double smu = __hip_atomic_load(&a.fb->spec_mu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    (void)take(tag, sv, smu);
                 }
             }
         }
