@@ -66,7 +66,7 @@ inline std::string rtc_fmt_double(double v)
 // C++ text of instructions [0, upto) of the program; `sink` (value + gradient form of the wide path): gradient k is
 // handed to out.set(k, value) as soon as it exists instead of living in an array of P registers
 template <class Prog>
-inline std::string rtc_emit_ops(const Prog &pr, int upto)
+inline std::string rtc_emit_ops(const Prog &pr, int upto, bool sink = false)
 {
     const int base = 2 * pr.p + pr.nx + pr.nconst;
     auto ref = [&](int slot) -> std::string {
@@ -100,7 +100,15 @@ inline std::string rtc_emit_ops(const Prog &pr, int upto)
         default: e = std::string(fn1[pr.op[i]]) + "(" + a + ")"; break;
         }
         s += "        const double v" + std::to_string(i) + " = " + e + ";\n";
+        if (sink)
+            for (int k = 0; k < pr.p; ++k)
+                if (pr.grad_slot[k] == base + i)
+                    s += "        out.set(" + std::to_string(k) + ", v" + std::to_string(i) + ");\n";
     }
+    if (sink) // (gradient entries that are not the result of an instruction: a parameter, a data column, a constant)
+        for (int k = 0; k < pr.p; ++k)
+            if (pr.grad_slot[k] < base || pr.grad_slot[k] >= base + upto)
+                s += "        out.set(" + std::to_string(k) + ", " + ref(pr.grad_slot[k]) + ");\n";
     return s;
 }
 
@@ -137,9 +145,7 @@ inline std::string rtc_emit_model(const Prog &pr, int nx_model)
     s += "        return " + ref(pr.value_slot) + ";\n    }\n";
     // gradient entries handed out one by one (wide path: straight into the LDS tile, no P-register array)
     s += "    template <class TH, class XR, class SINK> __device__ __forceinline__ static double value_grad_sink(const TH &th, const XR &xr, SINK &out) {\n" + off;
-    s += rtc_emit_ops(pr, pr.nops);
-    for (int k = 0; k < pr.p; ++k)
-        s += "        out.set(" + std::to_string(k) + ", " + ref(pr.grad_slot[k]) + ");\n";
+    s += rtc_emit_ops(pr, pr.nops, true);
     s += "        return " + ref(pr.value_slot) + ";\n    }\n";
     if (pr.nfvv > 0)
     {
