@@ -181,11 +181,12 @@ struct gslnls_batch
     hipEvent_t e0 = nullptr, e1 = nullptr;
 };
 
-template <class M, int T>
-static int batch_irls_run_t(gslnls_batch *h, int lo, int hi, int jac, int fvv, const double *start, const double *lupars,
-                            const int *ci, const double *cd, int loss_rho, const double *loss_cc, float *kernel_ms)
+template <class M>
+static int batch_irls_run(gslnls_batch *h, int lo, int hi, int jac, int fvv, const double *start, const double *lupars,
+                          const int *ci, const double *cd, int loss_rho, const double *loss_cc, float *kernel_ms)
 {
     constexpr int P = M::P;
+    constexpr int T = 256;
     if (fvv && !M::HAS_FVV)
         return GSLNLS_E_UNSUPPORTED;
     IrlsBatchArgs<P> a;
@@ -263,17 +264,6 @@ static int batch_irls_run_t(gslnls_batch *h, int lo, int hi, int jac, int fvv, c
                 tot[6] / nd / 1e3, tot[7] / nd / 1e3);
     }
     return GSLNLS_SUCCESS;
-}
-// threads per data set: 256 (two workgroups per CU).  GSLNLS_BATCH_T=128 (developer switch, read per call): four smaller
-// workgroups per CU -- the measured stand-in for "two data sets sharing one lm_advance" 
-template <class M>
-static int batch_irls_run(gslnls_batch *h, int lo, int hi, int jac, int fvv, const double *start, const double *lupars,
-                          const int *ci, const double *cd, int loss_rho, const double *loss_cc, float *kernel_ms)
-{
-    const char *e = getenv("GSLNLS_BATCH_T");
-    if (e && atoi(e) == 128)
-        return batch_irls_run_t<M, 128>(h, lo, hi, jac, fvv, start, lupars, ci, cd, loss_rho, loss_cc, kernel_ms);
-    return batch_irls_run_t<M, 256>(h, lo, hi, jac, fvv, start, lupars, ci, cd, loss_rho, loss_cc, kernel_ms);
 }
 
 extern "C" {

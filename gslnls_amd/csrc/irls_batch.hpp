@@ -48,7 +48,7 @@ struct IrlsBatchArgs
 };
 
 template <class M, int JAC, int T>
-__global__ __launch_bounds__(T, 512 / T) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
+__global__ __launch_bounds__(T, 2) void irls_batch_kernel(IrlsBatchArgs<M::P> a)
 {
     constexpr int P = M::P, NX = M::NX;
     using Sums = PassSums<P>;
