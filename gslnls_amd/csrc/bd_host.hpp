@@ -13,10 +13,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <algorithm>
 #include <vector>
 #include "../../include/gslnls_core.h"
 #include "bd_kernels.hpp"
 #include "dense_host.hpp"
+#include "irls_kernels.hpp"
 #include "large_host.hpp"
 
 namespace gslnls
@@ -94,6 +96,19 @@ inline double bd_scaled_cond(int p, const std::vector<double> &A)
 }
 
 // where the model comes from: host closures (R functions) or a kernel compiled for the formula
+// r_i = f_i / sqrt(w_i) (the unweighted residual as the reference's IRLS driver recovers it, src/nls_irls.c:455-459) and the
+// bit pattern of |r_i|: the key of the radix select that finds the median (irls_kernels.hpp)
+static __global__ __launch_bounds__(256) void bd_unweight_keys_kernel(const double *fw, const double *sw, long long n, double *r,
+                                                                       unsigned long long *keys)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    {
+        const double v = fw[i] / sw[i];
+        r[i] = v;
+        keys[i] = (unsigned long long)__double_as_longlong(fabs(v));
+    }
+}
+
 struct BdModel
 {
     virtual ~BdModel() {}
@@ -115,6 +130,10 @@ struct BdFit
            *d_J = nullptr, *d_C = nullptr, *d_cpart = nullptr, *d_part = nullptr, *d_pv = nullptr, *d_u = nullptr;
     std::vector<double> h_part;
     int cur = 0;        // d_f[cur]: residual at the current point, d_f[cur ^ 1]: at the trial point
+    std::vector<double> last_x;    // where the last solve ended (whatever its status)
+    const double *last_f = nullptr; // its weighted residual there, on the device
+    void *irls_arena = nullptr;
+    size_t irls_arena_bytes = 0;
     int npanel = 0, npair = 0, nslice = 1;
     long nevalf = 0, nevaldf = 0, nevalfvv = 0;
     int device_ordinal = -1;
@@ -122,6 +141,10 @@ struct BdFit
     ~BdFit() { release(); }
     void release()
     {
+        if (irls_arena)
+            (void)hipFree(irls_arena);
+        irls_arena = nullptr;
+        irls_arena_bytes = 0;
         double *bufs[] = {d_y, d_sw, d_fval, d_f[0], d_f[1], d_fp, d_fm, d_J, d_C, d_cpart, d_part, d_pv, d_u};
         for (double *b : bufs)
             if (b)
@@ -323,7 +346,10 @@ struct BdFit
     }
 
     // The fit.  Same decisions in the same order as lm_advance<P> / wide_advance (which cite the reference line by line).
-    int solve(int jac, int fvv, const double *start, const double *lupars, const int *ci, const double *cd, gslnls_result *out)
+    // chisq_in: the chi^2 the convergence test of the first iteration compares with, when this solve is a re-solve of the
+    // IRLS driver (NaN: the start's own, as a plain fit)
+    int solve(int jac, int fvv, const double *start, const double *lupars, const int *ci, const double *cd, gslnls_result *out,
+              double chisq_in = NAN)
     {
         if (ci[2] > 1)
             return GSLNLS_E_UNSUPPORTED; // dogleg family: not lowered
@@ -500,7 +526,8 @@ struct BdFit
             mu = 1.0e-3 * mx * mx;
             nu = 2.0;
             avratio = 0.0;
-            chisq_init = chisq0 = chisq1 = fnorm2;
+            chisq_init = fnorm2;
+            chisq0 = chisq1 = (chisq_in == chisq_in) ? chisq_in : fnorm2; // (lm_core.hpp: the same rule)
             niter = 0;
             bad_steps = 0;
             trace_row(0, chisq_init);
@@ -710,6 +737,8 @@ struct BdFit
                 for (size_t i = 0; i < (size_t)n * p; ++i)
                     out->grad[i] = NAN;
         }
+        last_x = x;
+        last_f = d_f[cur];
         out->niter = niter;
         out->conv = status;
         out->info = info;
@@ -724,6 +753,185 @@ struct BdFit
         out->n_steps = (int)steps;
         out->jtj_cond = ok ? bd_scaled_cond(p, Afin) : NAN;
         out->code_path = 4;
+        return status;
+    }
+
+    // gsl_multifit_nlinear_rho_driver (src/nls_irls.c:412-546) around the matrix-path solve: the driver of wide_host.hpp /
+    // irls_host.hpp (cold re-start from the ORIGINAL start with the current weights, radix-select median of |r| on the
+    // device, psi family, n / sum(w) scaling, user weights multiplied in, test_delta_irls).  The unweighted residual is
+    // the last solve's weighted one divided by its weights, as the reference takes it (no extra evaluation of the model).
+    int irls(int jac, int fvv, const double *start, const double *lupars, const int *ci, const double *cd, int loss_rho,
+             const double *loss_cc, gslnls_result *out)
+    {
+        if (ci[2] > 1)
+            return GSLNLS_E_UNSUPPORTED;
+        const int irls_maxiter = ci[14];
+        const double irls_xtol = cd[10];
+        LossCfg Lc;
+        Lc.rho = loss_rho;
+        {
+            static const int ncc[9] = {0, 1, 2, 1, 1, 1, 1, 3, 3};
+            for (int k = 0; k < 3; ++k)
+                Lc.cc[k] = (loss_rho >= 1 && loss_rho <= 8 && k < ncc[loss_rho]) ? loss_cc[k] : 0.0;
+        }
+        const size_t nb = sizeof(double) * (size_t)n;
+        constexpr int TW = 256;
+        int nblk = (int)(((long long)n + TW - 1) / TW);
+        if (nblk > 1024)
+            nblk = 1024;
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t need = 6 * up(nb) + up(sizeof(unsigned long long) * (size_t)n) + up(sizeof(double) * nblk) +
+                            up(sizeof(SelectState) * 2) + up(sizeof(IrlsScalars));
+        if (irls_arena_bytes < need)
+        {
+            (void)hipFree(irls_arena);
+            irls_arena = nullptr;
+            irls_arena_bytes = 0;
+            GSLNLS_HIP_OK(hipMalloc(&irls_arena, need));
+            irls_arena_bytes = need;
+        }
+        char *q = static_cast<char *>(irls_arena);
+        auto take = [&](size_t b) {
+            char *r = q;
+            q += up(b);
+            return r;
+        };
+        double *d_r = reinterpret_cast<double *>(take(nb)), *d_wt = reinterpret_cast<double *>(take(nb)),
+               *d_psi = reinterpret_cast<double *>(take(nb)), *d_psip = reinterpret_cast<double *>(take(nb)),
+               *d_swA = reinterpret_cast<double *>(take(nb)), *d_swB = reinterpret_cast<double *>(take(nb));
+        unsigned long long *d_keys = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * (size_t)n));
+        double *d_pw = reinterpret_cast<double *>(take(sizeof(double) * nblk));
+        SelectState *d_sel = reinterpret_cast<SelectState *>(take(sizeof(SelectState) * 2));
+        IrlsScalars *d_sc = reinterpret_cast<IrlsScalars *>(take(sizeof(IrlsScalars)));
+        double *const user_sw = d_sw;
+        // the fit's own weights are put back however this function is left
+        struct RestoreSw
+        {
+            double *&ref;
+            double *val;
+            ~RestoreSw() { ref = val; }
+        } restore_sw{d_sw, user_sw};
+        double *sw_now = d_swA, *sw_next = d_swB;
+        if (user_sw)
+            GSLNLS_HIP_OK(hipMemcpyAsync(sw_now, user_sw, nb, hipMemcpyDeviceToDevice, st));
+        else
+        {
+            std::vector<double> ones((size_t)n, 1.0);
+            GSLNLS_HIP_OK(hipMemcpy(sw_now, ones.data(), nb, hipMemcpyHostToDevice));
+        }
+        std::vector<double> workp(p);
+        int irls_iter = 0, irls_status = ST_FAILURE, status = ST_CONTINUE;
+        double chisq_init = NAN, chisq_carry = NAN, sigma = 1.0;
+        long long nf = 0, ndf = 0, nfvv = 0;
+        double loop_ms = 0.0;
+        const int gf = (int)std::min<long long>(2048, ((long long)n + 255) / 256);
+        do
+        {
+            irls_iter += 1;
+            if (irls_iter > 1)
+            {
+                std::swap(sw_now, sw_next);
+                workp = last_x;
+            }
+            else
+                workp.assign(start, start + p);
+            d_sw = sw_now;
+            const int rc = solve(jac, fvv, start, lupars, ci, cd, out, irls_iter > 1 ? chisq_carry : NAN);
+            if (rc < 0 && rc != ST_EBADFUNC)
+                return rc; // (a library error, not a GSL status)
+            nf += out->neval[0];
+            ndf += out->neval[1];
+            nfvv += out->neval[2];
+            loop_ms += out->loop_ms;
+            status = out->conv;
+            if (irls_iter == 1)
+                chisq_init = out->chisq_init;
+            chisq_carry = out->ssr;
+            if (status == ST_EBADFUNC || (status == ST_ENOPROG && irls_iter == 1))
+                break;
+            // ---- re-weighting chain, all on the device ----
+            hipLaunchKernelGGL(bd_unweight_keys_kernel, dim3(gf), dim3(256), 0, st, last_f, sw_now, (long long)n, d_r, d_keys);
+            const unsigned long long k_lo = (unsigned long long)((n - 1) / 2), k_hi = (unsigned long long)(n / 2);
+            const int nsel = (k_lo == k_hi) ? 1 : 2;
+            for (int which = 0; which < nsel; ++which)
+            {
+                SelectState *ss = d_sel + which;
+                hipLaunchKernelGGL(select_init_kernel, dim3(1), dim3(1), 0, st, ss, which == 0 ? k_lo : k_hi);
+                for (int pass = 7; pass >= 0; --pass)
+                {
+                    hipLaunchKernelGGL(select_hist_kernel, dim3(std::min(1024, (int)((n + 255) / 256))), dim3(256), 0, st, d_keys,
+                                       (long long)n, pass, ss);
+                    hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(1), 0, st, pass, ss);
+                }
+            }
+            hipLaunchKernelGGL(irls_sigma_kernel, dim3(1), dim3(1), 0, st, d_sel, d_sel + (nsel - 1), d_sc);
+            hipLaunchKernelGGL((irls_weight_kernel<TW>), dim3(nblk), dim3(TW), 0, st, d_r, (long long)n, Lc, d_sc, d_wt, d_psi,
+                               d_psip, d_pw);
+            hipLaunchKernelGGL(irls_scale_kernel, dim3(1), dim3(1), 0, st, d_pw, nblk, (long long)n, d_sc);
+            hipLaunchKernelGGL((irls_apply_kernel<TW>), dim3(nblk), dim3(TW), 0, st, d_wt, (long long)n, d_sc, user_sw, sw_next);
+            IrlsScalars hsc;
+            GSLNLS_HIP_OK(hipMemcpyAsync(&hsc, d_sc, sizeof(hsc), hipMemcpyDeviceToHost, st));
+            GSLNLS_HIP_OK(hipStreamSynchronize(st));
+            sigma = hsc.sigma;
+            // test_delta_irls (src/nls_irls.c:343-362)
+            irls_status = ST_CONTINUE;
+            for (int k = 0; k < p; ++k)
+            {
+                const double xi = last_x[k], dxi = fabs(workp[k] - xi);
+                if (fmin(dxi / fabs(xi), dxi) < irls_xtol)
+                    irls_status = ST_SUCCESS;
+                else
+                {
+                    irls_status = ST_CONTINUE;
+                    break;
+                }
+            }
+            if (irls_status == ST_SUCCESS)
+                break;
+        } while (irls_status == ST_CONTINUE && irls_iter < irls_maxiter);
+        if (!(status == ST_EBADFUNC || (status == ST_ENOPROG && irls_iter == 1)))
+        {
+            if (irls_iter >= irls_maxiter && irls_status != ST_SUCCESS)
+            {
+                irls_status = ST_EMAXITER;
+                status = ST_EMAXITER;
+                out->conv = ST_EMAXITER;
+                out->info = ST_EMAXITER;
+            }
+        }
+        // (resid / grad / covar in `out` are the LAST solve's, with its weights: src/nls.c:695-737)
+        out->chisq_init = chisq_init;
+        out->neval[0] = (int)nf;
+        out->neval[1] = (int)ndf;
+        out->neval[2] = (int)nfvv;
+        out->loop_ms = (float)loop_ms;
+        const bool ok = (status == ST_SUCCESS || status == ST_EMAXITER);
+        double irls_delta = 0.0;
+        for (int k = 0; k < p; ++k)
+            irls_delta = fmax(irls_delta, fabs(workp[k] - last_x[k]));
+        out->irls_sigma = sigma;
+        out->irls_status = irls_status;
+        out->irls_niter = irls_iter;
+        out->irls_tol = irls_delta;
+        if (ok)
+        {
+            if (out->irls_weights)
+                GSLNLS_HIP_OK(hipMemcpy(out->irls_weights, d_wt, nb, hipMemcpyDeviceToHost));
+            if (out->irls_psi)
+                GSLNLS_HIP_OK(hipMemcpy(out->irls_psi, d_psi, nb, hipMemcpyDeviceToHost));
+            if (out->irls_dpsi)
+                GSLNLS_HIP_OK(hipMemcpy(out->irls_dpsi, d_psip, nb, hipMemcpyDeviceToHost));
+        }
+        else
+            for (int i = 0; i < n; ++i)
+            {
+                if (out->irls_weights)
+                    out->irls_weights[i] = NAN;
+                if (out->irls_psi)
+                    out->irls_psi[i] = NAN;
+                if (out->irls_dpsi)
+                    out->irls_dpsi[i] = NAN;
+            }
         return status;
     }
 };

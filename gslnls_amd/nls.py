@@ -213,8 +213,6 @@ def _gsl_nls_function(fn, y, start, algorithm, control, jac, fvv, trace, weights
     if algorithm not in ALGORITHMS:
         raise ValueError("'algorithm' should be one of %s" % ", ".join(ALGORITHMS))
     loss_cfg = gsl_nls_loss(loss) if isinstance(loss, str) else gsl_nls_loss(**loss)
-    if loss_cfg["rho"] != "default":
-        raise NotImplementedError("robust loss functions with a function model are not lowered to the device")
     ctrl = control if (control is not None and len(control) >= 23) else gsl_nls_control(**(control or {}))
     if isinstance(start, dict):
         names, vec = list(start.keys()), np.asarray([float(np.asarray(v).reshape(-1)[0]) for v in start.values()])
@@ -288,6 +286,11 @@ def _gsl_nls_function(fn, y, start, algorithm, control, jac, fvv, trace, weights
     out = dict(par=np.zeros(p), covar=np.zeros((p, p), order="F"), resid=np.zeros(n), grad=np.zeros((n, p), order="F"))
     res = _lib.Result()
     res.par, res.covar, res.resid, res.grad = _dp(out["par"]), _dp(out["covar"]), _dp(out["resid"]), _dp(out["grad"])
+    if loss_cfg["rho"] != "default":
+        for k in ("irls_weights", "irls_psi", "irls_dpsi"):
+            out[k] = np.zeros(n)
+            setattr(res, k, _dp(out[k]))
+    cc = np.asarray(list(loss_cfg["cc"].values()) or [0.0], dtype=np.float64)
     if trace:
         out["partrace"] = np.full((ctrl["maxiter"] + 1, p), np.nan, order="F")
         out["ssrtrace"] = np.full(ctrl["maxiter"] + 1, np.nan)
@@ -295,9 +298,9 @@ def _gsl_nls_function(fn, y, start, algorithm, control, jac, fvv, trace, weights
     # (a function-pointer type called without arguments is the NULL pointer)
     cbs = (_lib.FN_CB(f_cb), _lib.JAC_CB(jac_cb) if jac_fn else _lib.JAC_CB(), _lib.FVV_CB(fvv_cb) if fvv_fn else _lib.FVV_CB())
     st = np.ascontiguousarray(vec, dtype=np.float64)
-    rc = _lib.lib().gslnls_nls_fn(n, p, yv.ctypes.data_as(C.c_void_p), cbs[0], cbs[1], cbs[2], None, _dp(st),
-                                  None if sw is None else sw.ctypes.data_as(C.c_void_p), _dp(lu), ci.ctypes.data_as(IP), _dp(cd),
-                                  C.byref(res))
+    rc = _lib.lib().gslnls_nls_fn_loss(n, p, yv.ctypes.data_as(C.c_void_p), cbs[0], cbs[1], cbs[2], None, _dp(st),
+                                       None if sw is None else sw.ctypes.data_as(C.c_void_p), _dp(lu), ci.ctypes.data_as(IP),
+                                       _dp(cd), LOSSES.index(loss_cfg["rho"]), _dp(cc), C.byref(res))
     if errors:
         raise errors[0]
     _lib.check(rc)

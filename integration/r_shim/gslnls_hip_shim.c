@@ -202,7 +202,7 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
     }
     const char *xn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     /* (up to 9 parameters and 3 data columns: interpreted or natively compiled row models; up to 64 parameters and 8
-     * columns: the wide path, J^T J on the matrix cores; up to 512 parameters, single start and default loss: the Jacobian
+     * columns: the wide path, J^T J on the matrix cores; up to 512 parameters, single start: the Jacobian
      * as a matrix in HBM -- the core decides, include/gslnls_core.h) */
     if (model_id <= 0 && rhs != R_NilValue && p <= 512 && !Rf_isNull(parnames))
     {
@@ -218,10 +218,9 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
             model_id = GSLNLS_MODEL_EXPR;
         }
     }
-    /* a `function` model (no formula behind the closure): single start and default loss go to the core with the closures
-     * as callbacks (gslnls_nls_fn), any p up to 4096 */
-    const int fn_model = model_id <= 0 && formula == R_NilValue && TYPEOF(fn) == CLOSXP && !mstart && p <= 4096 &&
-                         INTEGER(VECTOR_ELT(loss_config, 0))[0] == 0;
+    /* a `function` model (no formula behind the closure): a single start goes to the core with the closures as callbacks
+     * (gslnls_nls_fn_loss: default or robust loss), any p up to 4096 */
+    const int fn_model = model_id <= 0 && formula == R_NilValue && TYPEOF(fn) == CLOSXP && !mstart && p <= 4096;
     if ((model_id <= 0 && !fn_model) || Rf_isMatrix(swts) ||     /* does not lower, or GLS weights */
         INTEGER(control_int)[2] > 1)                             /* dogleg / ddogleg / subspace2D */
     {
@@ -357,8 +356,9 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
         d.p = p;
         d.startisnum = INTEGER(control_int)[13];
         d.warn = 1; /* single start: params.warn = TRUE, src/nls.c:175-178 */
-        rc = gslnls_nls_fn(n, p, REAL(y), cb_f, Rf_isNull(jac) ? NULL : cb_jac, Rf_isNull(fvv) ? NULL : cb_fvv, &d, st,
-                           Rf_isNull(swts) ? NULL : REAL(swts), lu, INTEGER(control_int), REAL(control_dbl), &res);
+        rc = gslnls_nls_fn_loss(n, p, REAL(y), cb_f, Rf_isNull(jac) ? NULL : cb_jac, Rf_isNull(fvv) ? NULL : cb_fvv, &d, st,
+                                Rf_isNull(swts) ? NULL : REAL(swts), lu, INTEGER(control_int), REAL(control_dbl), wgt_i,
+                                REAL(VECTOR_ELT(loss_config, 1)), &res);
         if (d.r_error)
         {
             UNPROTECT(nprot);

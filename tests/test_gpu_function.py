@@ -236,3 +236,65 @@ def test_formula_with_100_parameters_matches_the_oracle(amd, gslref, jac):
     assert abs(fit["ssr"] - ref["ssr"]) <= 1e-9 * ref["ssr"]
     assert np.allclose(fit["resid"], ref["resid"], rtol=0, atol=1e-7)
     REPORT.append("formula p=100 jac=%s %.1e" % (jac, _rel(fit["par"], ref["par"])))
+
+
+@pytest.mark.parametrize("loss", ["huber", "bisquare", "welsh", "hampel"])
+def test_robust_losses_on_a_function_model_match_the_oracle(amd, gslref, loss):
+    """gsl_nls(fn = <function>, loss = ...): the IRLS driver (src/nls_irls.c:412-546) around the matrix-path solve
+    (BdFit::irls, csrc/bd_host.hpp) -- median of |r| and the re-weighting on the device, the closures on the host -- against
+    the oracle's rho driver with the same closures: an exponential decay with 8 % gross outliers, weights, and a
+    Jacobian closure for one half of the cases, forward differences for the other."""
+    rng = np.random.Generator(np.random.PCG64(20240 + len(loss)))
+    n = 400
+    x = np.linspace(0.0, 4.0, n)
+    truth = np.array([5.0, 1.3, 0.7])
+    y = truth[0] * np.exp(-truth[1] * x) + truth[2] + 0.05 * rng.standard_normal(n)
+    bad = rng.choice(n, n // 12, replace=False)
+    y[bad] += rng.choice([-1.0, 1.0], bad.size) * rng.uniform(2.0, 6.0, bad.size)
+    fn = lambda th: th[0] * np.exp(-th[1] * x) + th[2]  # noqa: E731
+    jac = lambda th: np.stack([np.exp(-th[1] * x), -th[0] * x * np.exp(-th[1] * x), np.ones(n)], axis=1)  # noqa: E731
+    start = np.array([3.0, 1.0, 0.0])
+    w = 1.0 + 0.5 * np.cos(x)
+    for use_jac, weights in ((True, None), (False, w)):
+        fit = amd.gsl_nls(fn, y=y, start=start, jac=jac if use_jac else None, weights=weights, loss=loss,
+                          control=dict(solver="cholesky"))
+        ref = gslref.nls(n, 3, start, fn=lambda th: fn(th) - y, jac=jac if use_jac else None, use_jac=use_jac, weights=weights,
+                         loss=loss, ctrl=gslref.control(solver="cholesky"))
+        assert fit["conv"] == ref["conv"] == 0 and fit["code_path"] == 4
+        assert fit["irls"]["irls_status"] == ref["irls"]["irls_status"] == 0
+        assert fit["irls"]["irls_niter"] == ref["irls"]["irls_niter"], (loss, use_jac, fit["irls"], ref["irls"])
+        assert _rel(fit["par"], ref["par"]) < 1e-7
+        assert abs(fit["irls"]["irls_sigma"] / ref["irls"]["irls_sigma"] - 1.0) < 1e-8
+        assert np.allclose(fit["irls_weights"], ref["irls_weights"], rtol=1e-6, atol=1e-9)
+        # (psi = r / sigma for small residuals: a coefficient difference of 6e-10 on a model of size 5 is 4e-8 of r / sigma)
+        assert np.allclose(fit["irls_psi"], ref["irls_psi"], rtol=1e-6, atol=1e-6)
+        assert abs(fit["ssr"] / ref["ssr"] - 1.0) < 1e-7
+        # the outliers are what the loss is there for: the coefficients come back close to the truth
+        assert np.max(np.abs(fit["par"] / truth - 1.0)) < 0.05
+        REPORT.append("irls %s jac=%d %.1e" % (loss, use_jac, _rel(fit["par"], ref["par"])))
+
+
+def test_formula_with_100_parameters_and_a_robust_loss_matches_the_oracle(amd, gslref):
+    """the formula form of the matrix path (p = 100) with loss = "huber": gslnls_nls -> bd_formula_nls -> BdFit::irls;
+    5 % of the responses are pushed far off, the oracle runs the same IRLS with closures"""
+    ng, n = 33, 3000
+    x, y, model, jacf, start, truth = gaussians(ng, n, 4200 + ng)
+    rng = np.random.Generator(np.random.PCG64(77))
+    bad = rng.choice(n, n // 20, replace=False)
+    y = y.copy()
+    y[bad] += rng.choice([-1.0, 1.0], bad.size) * 5.0
+    names, terms = [], []
+    for k in range(1, ng + 1):
+        names += ["a%d" % k, "m%d" % k, "s%d" % k]
+        terms.append("a%d*exp(-((x-m%d)/s%d)^2)" % (k, k, k))
+    names += ["c0"]
+    fit = amd.gsl_nls("y ~ " + " + ".join(terms) + " + c0", data=dict(x=x, y=y), start=dict(zip(names, start)), jac=True,
+                      loss="huber", control=dict(solver="cholesky"), lowering="jit")
+    ref = gslref.nls(n, len(start), start, fn=lambda th: model(th) - y, jac=jacf, loss="huber",
+                     ctrl=gslref.control(solver="cholesky"))
+    assert fit["conv"] == ref["conv"] == 0 and fit["code_path"] == 4
+    assert fit["irls"]["irls_niter"] == ref["irls"]["irls_niter"] and fit["irls"]["irls_status"] == ref["irls"]["irls_status"]
+    assert _rel(fit["par"], ref["par"]) < 1e-6
+    assert abs(fit["irls"]["irls_sigma"] / ref["irls"]["irls_sigma"] - 1.0) < 1e-7
+    assert np.allclose(fit["irls_weights"], ref["irls_weights"], rtol=1e-5, atol=1e-8)
+    REPORT.append("formula p=100 huber %.1e" % _rel(fit["par"], ref["par"]))
