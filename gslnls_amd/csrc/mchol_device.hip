@@ -983,6 +983,9 @@ struct MCholBuffers
     double *A = nullptr, *Lg = nullptr, *Cg = nullptr, *vec = nullptr; // vec: ainvg | dcur | b | dinv | scal | rhs | sol
     int *ivec = nullptr;                                              // pos | ord | flag of the natural-order factorisation
     double *stage = nullptr; // pinned, 3 cap + 8 doubles: [rhs | diag] on the way up, [sol | flag] on the way down
+    hipStream_t sq = nullptr;                // the stream of every copy and kernel of a solve
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; // around the kernels of a solve: gslnls_debug_mchol_last_device_ms
+    float last_device_ms = -1.f;
     bool attr_set = false;
 };
 static MCholBuffers &mchol_buffers()
@@ -1042,6 +1045,15 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
         }
         B.attr_set = true;
     }
+    // a stream of the library's own (non-blocking): on the null stream every launch is ordered against every blocking
+    // stream of the process -- with another runtime user in it (PyTorch) the 70 launches of a p = 2000 solve took 5 ms
+    // of host time for 1.7 ms of device work
+    if (!B.sq && hipStreamCreateWithFlags(&B.sq, hipStreamNonBlocking) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return GSLNLS_E_NODEVICE;
+    }
+    hipStream_t sq = B.sq;
     MCholArgs a;
     a.A = B.A;
     a.Lg = B.Lg;
@@ -1065,18 +1077,23 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
     int NB = (int)(((size_t)MC_LDS_BYTES - fixed) / (sizeof(double) * (size_t)p));
     NB = NB > MC_NB_MAX ? MC_NB_MAX : NB;
     if (A_host)
-        GSLNLS_HIP_OK(hipMemcpy(B.A, A_host, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice));
+        GSLNLS_HIP_OK(hipMemcpyAsync(B.A, A_host, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice, sq));
     // the two vectors go up in ONE asynchronous copy from the pinned staging area, the solution and the flag come down in
     // one: a solve synchronises with the device once, at its end (four blocking copies were 50 us of a 470 us solve)
     memcpy(B.stage, rhs_host, sizeof(double) * p);
     if (!A_host)
         memcpy(B.stage + p, diag_host, sizeof(double) * p);
-    GSLNLS_HIP_OK(hipMemcpyAsync(d_rhs, B.stage, sizeof(double) * (size_t)(A_host ? p : 2 * p), hipMemcpyHostToDevice, 0));
-    GSLNLS_HIP_OK(hipMemsetAsync(a.scal, 0, sizeof(double) * 8, 0));
+    GSLNLS_HIP_OK(hipMemcpyAsync(d_rhs, B.stage, sizeof(double) * (size_t)(A_host ? p : 2 * p), hipMemcpyHostToDevice, sq));
+    if (!B.ev0 && (hipEventCreate(&B.ev0) != hipSuccess || hipEventCreate(&B.ev1) != hipSuccess))
+        B.ev0 = B.ev1 = nullptr;
+    B.last_device_ms = -1.f;
+    if (B.ev0)
+        (void)hipEventRecord(B.ev0, sq);
+    GSLNLS_HIP_OK(hipMemsetAsync(a.scal, 0, sizeof(double) * 8, sq));
     {
         long long g = ((long long)p * p + 256 * 8 - 1) / (256 * 8);
         g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
-        hipLaunchKernelGGL(mchol_init_kernel, dim3((unsigned)g), dim3(256), 0, 0, a, d_rhs, A_host ? nullptr : jtj_dev, d_dmp, mu);
+        hipLaunchKernelGGL(mchol_init_kernel, dim3((unsigned)g), dim3(256), 0, sq, a, d_rhs, A_host ? nullptr : jtj_dev, d_dmp, mu);
     }
     // natural order first (level 3, no pivot search); the pivoted, modified factorisation below when it reports a pivot
     // that is not safely positive, or always under GSLNLS_LARGE_CHOL_PIVOTED=1
@@ -1086,30 +1103,34 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
         {
             int *d_flag = B.ivec + 2 * p;
             double *d_work = d_sol + p + 8;
-            GSLNLS_HIP_OK(hipMemsetAsync(d_flag, 0, sizeof(int), 0));
+            GSLNLS_HIP_OK(hipMemsetAsync(d_flag, 0, sizeof(int), sq));
             // the right-hand side is one more row of the matrix: L y = b happens inside the factorisation
-            GSLNLS_HIP_OK(hipMemcpyAsync(d_work, d_rhs, sizeof(double) * p, hipMemcpyDeviceToDevice, 0));
+            GSLNLS_HIP_OK(hipMemcpyAsync(d_work, d_rhs, sizeof(double) * p, hipMemcpyDeviceToDevice, sq));
             for (int k0 = 0; k0 < p; k0 += CB)
             {
                 const int nrb = (p - k0 + CB - 1) / CB; // row blocks from the diagonal block down
                 // (workgroup 0: the diagonal block and the right-hand side; workgroup b: row block b of the panel)
-                hipLaunchKernelGGL(cholb_panel_kernel, dim3(nrb), dim3(CBP_T), 0, 0, B.A, B.Lg, p, k0, a.dcur, d_flag, d_work, a.dinv);
+                hipLaunchKernelGGL(cholb_panel_kernel, dim3(nrb), dim3(CBP_T), 0, sq, B.A, B.Lg, p, k0, a.dcur, d_flag, d_work, a.dinv);
                 if (nrb > 1)
                 {
                     const int nt = (nrb - 1) * nrb / 2, nrhs = (p - k0 - CB + 255) / 256;
-                    hipLaunchKernelGGL(cholb_trail_kernel, dim3(nt + nrhs), dim3(256), 0, 0, B.A, B.Lg, p, k0, nt, d_work);
+                    hipLaunchKernelGGL(cholb_trail_kernel, dim3(nt + nrhs), dim3(256), 0, sq, B.A, B.Lg, p, k0, nt, d_work);
                 }
             }
             if (!getenv("GSLNLS_LARGE_BACK_BLOCKS")) // (developer switch: the launch-per-block form, same bits)
-                hipLaunchKernelGGL(cholb_backall_kernel, dim3(1), dim3(CBA_T), sizeof(double) * (size_t)CB * ((p + CB - 1) / CB), 0, B.Lg, p, d_work,
+                hipLaunchKernelGGL(cholb_backall_kernel, dim3(1), dim3(CBA_T), sizeof(double) * (size_t)CB * ((p + CB - 1) / CB), sq, B.Lg, p, d_work,
                                    d_sol, a.dinv);
             else
                 for (int k0 = ((p - 1) / CB) * CB; k0 >= 0; k0 -= CB)
-                    hipLaunchKernelGGL(cholb_back_kernel, dim3(1 + (k0 + 255) / 256), dim3(256), 0, 0, B.Lg, p, k0, d_work, d_sol, a.dinv);
-            hipLaunchKernelGGL(cholb_flag_kernel, dim3(1), dim3(1), 0, 0, d_flag, d_sol + p);
+                    hipLaunchKernelGGL(cholb_back_kernel, dim3(1 + (k0 + 255) / 256), dim3(256), 0, sq, B.Lg, p, k0, d_work, d_sol, a.dinv);
+            hipLaunchKernelGGL(cholb_flag_kernel, dim3(1), dim3(1), 0, sq, d_flag, d_sol + p);
+            if (B.ev0)
+                (void)hipEventRecord(B.ev1, sq);
             double *h_down = B.stage + 2 * (size_t)p;
-            GSLNLS_HIP_OK(hipMemcpyAsync(h_down, d_sol, sizeof(double) * (size_t)(p + 1), hipMemcpyDeviceToHost, 0));
-            GSLNLS_HIP_OK(hipStreamSynchronize(0));
+            GSLNLS_HIP_OK(hipMemcpyAsync(h_down, d_sol, sizeof(double) * (size_t)(p + 1), hipMemcpyDeviceToHost, sq));
+            GSLNLS_HIP_OK(hipStreamSynchronize(sq));
+            if (B.ev0 && hipEventElapsedTime(&B.last_device_ms, B.ev0, B.ev1) != hipSuccess)
+                B.last_device_ms = -1.f;
             if (h_down[p] == 0.0)
             {
                 memcpy(sol_host, h_down, sizeof(double) * p);
@@ -1120,11 +1141,11 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
                 fprintf(stderr, "[mchol] p = %d: the natural-order factorisation met a pivot that is not safely positive; the pivoted routine runs\n", p);
             // not numerically positive definite: the matrix (overwritten by the trailing updates) is formed again
             if (A_host)
-                GSLNLS_HIP_OK(hipMemcpy(B.A, A_host, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice));
-            GSLNLS_HIP_OK(hipMemsetAsync(a.scal, 0, sizeof(double) * 8, 0));
+                GSLNLS_HIP_OK(hipMemcpyAsync(B.A, A_host, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice, sq));
+            GSLNLS_HIP_OK(hipMemsetAsync(a.scal, 0, sizeof(double) * 8, sq));
             long long g = ((long long)p * p + 256 * 8 - 1) / (256 * 8);
             g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
-            hipLaunchKernelGGL(mchol_init_kernel, dim3((unsigned)g), dim3(256), 0, 0, a, d_rhs, A_host ? nullptr : jtj_dev, d_dmp, mu);
+            hipLaunchKernelGGL(mchol_init_kernel, dim3((unsigned)g), dim3(256), 0, sq, a, d_rhs, A_host ? nullptr : jtj_dev, d_dmp, mu);
         }
     }
     // the panel workgroup is sized to p (a wavefront without rows still pays for every barrier and reduction)
@@ -1136,15 +1157,16 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
         a.kb = kb;
         a.nb = p - kb < NB ? p - kb : NB;
         const size_t lds = fixed + sizeof(double) * (size_t)a.nb * p;
-        hipLaunchKernelGGL(mchol_panel_kernel, dim3(1), dim3(T), lds, 0, a);
+        hipLaunchKernelGGL(mchol_panel_kernel, dim3(1), dim3(T), lds, sq, a);
         if (kb + a.nb < p)
-            hipLaunchKernelGGL(mchol_trail_kernel, dim3(tiles, tiles), dim3(256), 0, 0, a);
+            hipLaunchKernelGGL(mchol_trail_kernel, dim3(tiles, tiles), dim3(256), 0, sq, a);
     }
     {
         const size_t bl = sizeof(double) * ((size_t)p + MC_BS * (MC_BS + 1) + MC_BS) + sizeof(int) * ((size_t)p + MC_BS) + 64;
-        hipLaunchKernelGGL(mchol_backsub_kernel, dim3(1), dim3(T), bl, 0, a, d_sol);
+        hipLaunchKernelGGL(mchol_backsub_kernel, dim3(1), dim3(T), bl, sq, a, d_sol);
     }
-    GSLNLS_HIP_OK(hipMemcpy(sol_host, d_sol, sizeof(double) * p, hipMemcpyDeviceToHost));
+    GSLNLS_HIP_OK(hipMemcpyAsync(sol_host, d_sol, sizeof(double) * p, hipMemcpyDeviceToHost, sq));
+    GSLNLS_HIP_OK(hipStreamSynchronize(sq));
     GSLNLS_HIP_OK(hipGetLastError());
     return GSLNLS_SUCCESS;
 }
@@ -1209,6 +1231,13 @@ extern "C" int gslnls_debug_device_copy(void *dst, const void *src, size_t bytes
         return GSLNLS_E_NODEVICE;
     }
     return GSLNLS_SUCCESS;
+}
+
+// milliseconds between the upload of the vectors and the download of the solution of the LAST natural-order solve of this
+// process (HIP events around its kernels: what the device did, whatever the host was busy with); < 0: not available
+extern "C" double gslnls_debug_mchol_last_device_ms(void)
+{
+    return (double)gslnls::mchol_buffers().last_device_ms;
 }
 
 // test / measurement hook: the same solve with J^T J already in device memory (p x p, row-major, not modified), the way

@@ -392,6 +392,8 @@ int gslnls_debug_mchol_solve(int p, const double *A, const double *diag, double 
 int gslnls_debug_device_alloc(void **p, size_t bytes);
 int gslnls_debug_device_free(void *p);
 int gslnls_debug_device_copy(void *dst, const void *src, size_t bytes, int to_device);
+/* device milliseconds of the last natural-order solve (HIP events around its kernels), < 0 when not available */
+double gslnls_debug_mchol_last_device_ms(void);
 /* the same with J^T J resident in device memory (jtj_dev: p x p doubles, row-major, left as it is): the call of the lm step */
 int gslnls_debug_mchol_solve_resident(int p, const double *jtj_dev, const double *diag, double mu, const double *rhs,
                                       double *sol);
