@@ -1077,7 +1077,7 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
     int NB = (int)(((size_t)MC_LDS_BYTES - fixed) / (sizeof(double) * (size_t)p));
     NB = NB > MC_NB_MAX ? MC_NB_MAX : NB;
     if (A_host)
-        GSLNLS_HIP_OK(hipMemcpyAsync(B.A, A_host, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice, sq));
+        GSLNLS_HIP_OK(hipMemcpy(B.A, A_host, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice)); // (pageable: the blocking form)
     // the two vectors go up in ONE asynchronous copy from the pinned staging area, the solution and the flag come down in
     // one: a solve synchronises with the device once, at its end (four blocking copies were 50 us of a 470 us solve)
     memcpy(B.stage, rhs_host, sizeof(double) * p);
@@ -1141,7 +1141,7 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
                 fprintf(stderr, "[mchol] p = %d: the natural-order factorisation met a pivot that is not safely positive; the pivoted routine runs\n", p);
             // not numerically positive definite: the matrix (overwritten by the trailing updates) is formed again
             if (A_host)
-                GSLNLS_HIP_OK(hipMemcpyAsync(B.A, A_host, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice, sq));
+                GSLNLS_HIP_OK(hipMemcpy(B.A, A_host, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice)); // (pageable: the blocking form)
             GSLNLS_HIP_OK(hipMemsetAsync(a.scal, 0, sizeof(double) * 8, sq));
             long long g = ((long long)p * p + 256 * 8 - 1) / (256 * 8);
             g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
