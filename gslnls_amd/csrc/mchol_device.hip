@@ -1002,6 +1002,7 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
 {
     if (p < 1 || p > MC_PMAX)
         return GSLNLS_E_UNSUPPORTED;
+    const double t_entry = now_s();
     MCholBuffers &B = mchol_buffers();
     std::lock_guard<std::mutex> lock(B.mu);
     int dev = 0;
@@ -1128,7 +1129,10 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
                 (void)hipEventRecord(B.ev1, sq);
             double *h_down = B.stage + 2 * (size_t)p;
             GSLNLS_HIP_OK(hipMemcpyAsync(h_down, d_sol, sizeof(double) * (size_t)(p + 1), hipMemcpyDeviceToHost, sq));
+            const double t_enq = now_s();
             GSLNLS_HIP_OK(hipStreamSynchronize(sq));
+            if (getenv("GSLNLS_LARGE_PROF"))
+                fprintf(stderr, "[mchol] p = %d: enqueue %.3f ms, wait %.3f ms\n", p, 1e3 * (t_enq - t_entry), 1e3 * (now_s() - t_enq));
             if (B.ev0 && hipEventElapsedTime(&B.last_device_ms, B.ev0, B.ev1) != hipSuccess)
                 B.last_device_ms = -1.f;
             if (h_down[p] == 0.0)
