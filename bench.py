@@ -530,6 +530,22 @@ def sparse_readme_bench():
             el = time.perf_counter() - t0
         out[alg] = {"wall_ms": el * 1e3, "niter": int(fit["niter"]), "conv": int(fit["conv"]), "ssr": float(fit["ssr"]),
                     "device_passes": int(fit["n_passes"]), "ssr_target": 0.004778845}
+    # ... and the two DENSE rows of the same table (README.md:1143-1144: the Jacobian closure returns a plain matrix)
+    Jd = np.zeros((p + 1, p))
+    Jd[np.arange(p), np.arange(p)] = a
+
+    def jac_dense(th):
+        Jd[p, :] = 2.0 * th
+        return Jd
+    out["reference_readme_quotes_ms"].update({"dense_cgst": 1320.0, "dense_lm": 7800.0})
+    for alg in ("cgst", "lm"):
+        for _ in range(2):
+            t0 = time.perf_counter()
+            fit = A.gsl_nls_large(fn, y=np.zeros(p + 1), start=np.arange(1.0, p + 1), algorithm=alg, jac=jac_dense,
+                                  control=dict(maxiter=500))
+            el = time.perf_counter() - t0
+        out["dense_" + alg] = {"wall_ms": el * 1e3, "niter": int(fit["niter"]), "conv": int(fit["conv"]),
+                               "ssr": float(fit["ssr"]), "device_passes": int(fit["n_passes"]), "ssr_target": 0.004778845}
     # the damped solve of the lm step alone (csrc/mchol_device.hip: blocked natural-order Cholesky, the pivoted modified
     # routine as its fallback): wall time per solve with the p x p matrix uploaded from the host, with it resident, and
     # the residual it leaves
