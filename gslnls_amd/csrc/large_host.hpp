@@ -46,6 +46,12 @@ struct LargeOps
     virtual int full_jtj(const double *xcur, double *jtj) = 0;          // p x p row-major (symmetric)
     // J^T J of the CURRENT point as it sits on the device (complete: no work pending on it), or nullptr
     virtual const double *jtj_device() { return nullptr; }
+    // Operators that can form J^T J on the device and leave it there: with jtj_device_only set, eval_jac / full_jtj compute
+    // it but do not copy the p x p matrix to the host (2 MB per accepted point at p = 500); jtj_download fetches the
+    // current one when the host needs it after all (the host factorisation as a fallback)
+    virtual bool can_keep_jtj_on_device() const { return false; }
+    bool jtj_device_only = false;
+    virtual int jtj_download(double *) { return GSLNLS_E_UNSUPPORTED; }
     virtual int residual(const double *xcur, double *resid_host) = 0;  // weighted residual at the current point
 };
 
@@ -227,6 +233,9 @@ int mchol_device_solve(int p, const double *A_host, const double *rhs_host, doub
 // ... with J^T J where the operators left it on the device (A = J^T J + mu D^2 is formed there)
 int mchol_device_solve_resident(int p, const double *jtj_dev, const double *diag_host, double mu, const double *rhs_host,
                                 double *sol_host);
+// s = (J^T J) v with J^T J where it sits on the device (p doubles up, p doubles down): the row sums of the predicted
+// reduction v^T J^T J v, each in the order of the host loop (j ascending, product and sum rounded separately)
+int mchol_device_symv(int p, const double *jtj_dev, const double *v_host, double *s_host);
 
 struct LargeResult
 {
@@ -245,6 +254,22 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
     if (!(trs == 0 || trs == 5))
         return GSLNLS_E_UNSUPPORTED; // lmaccel / dogleg / ddogleg / subspace2D of multilarge are not lowered
     const bool need_jtj = (trs == 0);
+    // from a few hundred parameters on the factorisation runs on the device (mchol_device.hip); GSLNLS_LARGE_CHOL_DEVICE_MIN
+    // moves the threshold, 0 = host always.  Operators that form J^T J on the device then keep it there: the damped solve
+    // and the row sums of the predicted reduction read it in place, the host copy is fetched only if the device refuses.
+    static const int dev_min = [] {
+        const char *e = getenv("GSLNLS_LARGE_CHOL_DEVICE_MIN");
+        return e ? atoi(e) : 400;
+    }();
+    const bool jtj_stays = need_jtj && dev_min > 0 && p >= dev_min && p <= 4096 && ops.can_keep_jtj_on_device() &&
+                           !getenv("GSLNLS_LARGE_JTJ_HOST");
+    ops.jtj_device_only = jtj_stays;
+    struct ClearMode
+    {
+        LargeOps &o;
+        ~ClearMode() { o.jtj_device_only = false; }
+    } clear_mode{ops};
+    bool host_jtj_valid = !jtj_stays;
     std::vector<double> x(start, start + p), g(p), dJ(p), JTJ(need_jtj ? (size_t)p * p : 0), diag(p, 1.0), dx(p, 0.0),
         xt(p), gt(p), dJt(p), JTJt(need_jtj ? (size_t)p * p : 0), vel(p, 0.0), z(p), r(p), d(p), wp(p), Bd(p);
     double fnorm2 = 0.0, bad = 0.0, delta, mu, nu = 2.0;
@@ -389,16 +414,12 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
         for (int i = 0; i < p; ++i)
             rhs[i] = -g[i];
         auto damped = [&]() { // A = J^T J + mu D^2 on the host (not needed when J^T J is taken where it sits on the device)
+            if (!host_jtj_valid && ops.jtj_download(JTJ.data()) == GSLNLS_SUCCESS)
+                host_jtj_valid = true;
             A = JTJ;
             for (int i = 0; i < p; ++i)
                 A[(size_t)i * p + i] += mu * diag[i] * diag[i];
         };
-        // from a few hundred parameters on the factorisation runs on the device (mchol_device.hip: p = 500 1.5 ms against
-        // 2.5 on the host, p = 1000 4.2 against ~ 30); GSLNLS_LARGE_CHOL_DEVICE_MIN moves the threshold, 0 = host always
-        static const int dev_min = [] {
-            const char *e = getenv("GSLNLS_LARGE_CHOL_DEVICE_MIN");
-            return e ? atoi(e) : 400;
-        }();
         vel.assign(p, 0.0);
         int drc = GSLNLS_E_UNSUPPORTED; // (below the threshold, or a size the device routine does not take: p > 4096)
         if (dev_min > 0 && p >= dev_min)
@@ -473,11 +494,24 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
                     else
                     {
                         double vJv = 0.0, Dv2 = 0.0;
+                        // the row sums s_i = sum_j (J^T J)_ij v_j where J^T J sits (same products, same order, rounded the same
+                        // way as the loop below), or on the host
+                        bool rows_done = false;
+                        if (jtj_stays)
+                        {
+                            if (const double *jd = ops.jtj_device())
+                                rows_done = mchol_device_symv(p, jd, vel.data(), wp.data()) == GSLNLS_SUCCESS;
+                            if (!rows_done && !host_jtj_valid && ops.jtj_download(JTJ.data()) == GSLNLS_SUCCESS)
+                                host_jtj_valid = true;
+                        }
                         for (int i = 0; i < p; ++i)
                         {
                             double s = 0.0;
-                            for (int j = 0; j < p; ++j)
-                                s += JTJ[i * p + j] * vel[j];
+                            if (rows_done)
+                                s = wp[i];
+                            else
+                                for (int j = 0; j < p; ++j)
+                                    s += JTJ[i * p + j] * vel[j];
                             vJv += s * vel[i];
                             Dv2 += (diag[i] * vel[i]) * (diag[i] * vel[i]);
                         }
@@ -510,6 +544,7 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
                 dJ = dJt;
                 if (need_jtj)
                     JTJ.swap(JTJt); // (the trial buffer is rewritten by the next evaluation: no 8 p^2-byte copy per iteration)
+                host_jtj_valid = !jtj_stays;
                 fnorm2 = ssr_t;
                 do_scale(false);
                 double b = 2.0 * rho - 1.0;

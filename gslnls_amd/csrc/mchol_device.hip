@@ -1175,6 +1175,42 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
     return GSLNLS_SUCCESS;
 }
 
+// s_i = sum_j A[j][i] v_j, j ascending, product and sum rounded separately: for the symmetric J^T J (sp_jtj_kernel forms
+// both triangles by the same sums) this is the host's row walk sum_j A[i][j] v_j bit for bit, read coalesced
+__global__ __launch_bounds__(256) void mchol_symv_kernel(const double *A, const double *v, int p, double *s)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p)
+        return;
+    double acc = 0.0;
+#pragma unroll 8
+    for (int j = 0; j < p; ++j)
+        acc = __dadd_rn(acc, __dmul_rn(A[(size_t)j * p + i], v[j]));
+    s[i] = acc;
+}
+
+int mchol_device_symv(int p, const double *jtj_dev, const double *v_host, double *s_host)
+{
+    if (p < 1 || !jtj_dev || !v_host || !s_host)
+        return GSLNLS_EINVAL;
+    MCholBuffers &B = mchol_buffers();
+    std::lock_guard<std::mutex> lock(B.mu);
+    int dev = 0;
+    GSLNLS_HIP_OK(hipGetDevice(&dev));
+    if (B.cap < p || B.device != dev || !B.sq || !B.stage)
+        return GSLNLS_E_UNSUPPORTED; // (the buffers are the solve's: it runs first)
+    // the solve's vectors are free between solves: v where its rhs goes, s where its solution goes
+    double *d_v = B.vec + MC_NB_MAX + 3 * (size_t)B.cap + 8, *d_s = d_v + 2 * (size_t)B.cap;
+    memcpy(B.stage, v_host, sizeof(double) * p);
+    GSLNLS_HIP_OK(hipMemcpyAsync(d_v, B.stage, sizeof(double) * p, hipMemcpyHostToDevice, B.sq));
+    hipLaunchKernelGGL(mchol_symv_kernel, dim3((p + 255) / 256), dim3(256), 0, B.sq, jtj_dev, d_v, p, d_s);
+    double *h_down = B.stage + 2 * (size_t)B.cap;
+    GSLNLS_HIP_OK(hipMemcpyAsync(h_down, d_s, sizeof(double) * p, hipMemcpyDeviceToHost, B.sq));
+    GSLNLS_HIP_OK(hipStreamSynchronize(B.sq));
+    memcpy(s_host, h_down, sizeof(double) * p);
+    return GSLNLS_SUCCESS;
+}
+
 int mchol_device_solve(int p, const double *A_host, const double *rhs_host, double *sol_host)
 {
     return mchol_device_solve_impl(p, A_host, nullptr, nullptr, 0.0, rhs_host, sol_host);

@@ -697,11 +697,20 @@ struct SparseCbOps : LargeOps
         hipLaunchKernelGGL(sp_jtj_kernel, dim3((unsigned)((threads + SP_T - 1) / SP_T)), dim3(SP_T), 0, st, d_colptr, d_rowidx,
                            d_perm, d_rowptr, d_colidx, d_val[b], p, d_jtj);
         jtj_current = false;
-        GSLNLS_HIP_OK(hipMemcpyAsync(jtj, d_jtj, bytes, hipMemcpyDeviceToHost, st));
+        if (!jtj_device_only)
+            GSLNLS_HIP_OK(hipMemcpyAsync(jtj, d_jtj, bytes, hipMemcpyDeviceToHost, st));
         GSLNLS_HIP_OK(hipStreamSynchronize(st));
         jtj_current = true;
         ++npass;
         return 0;
+    }
+    bool can_keep_jtj_on_device() const override { return true; }
+    int jtj_download(double *jtj) override
+    {
+        if (!jtj_current || !d_jtj)
+            return GSLNLS_FAILURE;
+        GSLNLS_HIP_OK(hipMemcpy(jtj, d_jtj, sizeof(double) * (size_t)p * p, hipMemcpyDeviceToHost));
+        return GSLNLS_SUCCESS;
     }
     int full_jtj(const double *, double *jtj) override { return jtj_of(cur, jtj); }
     // (eval_jac runs at accepted points only and ends in a stream synchronisation: what d_jtj holds is the current point's)

@@ -243,3 +243,25 @@ def test_weighted_lm_at_p_450_through_the_device_factorisation(amd, gslref):
     assert abs(fit["niter"] - ref["niter"]) <= 0.08 * ref["niter"] + 1
     __import__("conftest").rel_err(fit["par"], ref["par"])  # (recorded for the session summary)
     assert np.allclose(fit["par"], ref["par"], rtol=5e-3)
+
+
+def test_lm_with_jtj_kept_on_the_device_is_the_fit_with_the_host_copy(amd, monkeypatch):
+    """From the device-factorisation threshold on, J^T J of the sparse operators stays where sp_jtj_kernel formed it: the
+    damped solve reads it in place and the row sums of the predicted reduction v^T J^T J v are taken there
+    (mchol_symv_kernel: the host loop's products in the host loop's order, rounded separately).  GSLNLS_LARGE_JTJ_HOST=1
+    brings the 2 MB back to the host at every accepted point as before: same iterations, same coefficients, bit for bit."""
+    p = 500
+    fn, jac = penalty(p, "csc")
+    fits = {}
+    for mode in ("device", "host"):
+        if mode == "host":
+            monkeypatch.setenv("GSLNLS_LARGE_JTJ_HOST", "1")
+        else:
+            monkeypatch.delenv("GSLNLS_LARGE_JTJ_HOST", raising=False)
+        fits[mode] = amd.gsl_nls_large(fn, y=np.zeros(p + 1), start=np.arange(1.0, p + 1), algorithm="lm", jac=jac,
+                                       control=dict(maxiter=500))
+    monkeypatch.delenv("GSLNLS_LARGE_JTJ_HOST", raising=False)
+    a, b = fits["device"], fits["host"]
+    assert a["conv"] == b["conv"] == 0 and a["niter"] == b["niter"]
+    assert np.array_equal(np.asarray(a["par"]), np.asarray(b["par"])) and a["ssr"] == b["ssr"]
+    assert abs(a["ssr"] - 0.004778845) < 5e-10
