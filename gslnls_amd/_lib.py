@@ -81,6 +81,8 @@ _SIGNATURES = {
                                 C.POINTER(Result)]),
     "gslnls_nls_fn_loss": (C.c_int, [C.c_int, C.c_int, C.c_void_p, FN_CB, JAC_CB, FVV_CB, C.c_void_p, DP, C.c_void_p, DP, IP, DP,
                                      C.c_int, DP, C.POINTER(Result)]),
+    "gslnls_nls_fn_mstart": (C.c_int, [C.c_int, C.c_int, C.c_void_p, FN_CB, JAC_CB, FVV_CB, C.c_void_p, DP, IP, C.c_void_p, DP,
+                                       IP, DP, C.c_int, DP, C.POINTER(Result)]),
     "gslnls_dense_create": (C.c_void_p, [C.POINTER(Model), C.c_void_p, C.c_int, C.c_void_p, IP]),
     "gslnls_dense_destroy": (None, [C.c_void_p]),
     "gslnls_dense_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, DP, DP, IP, DP, C.c_int, C.POINTER(Result)]),

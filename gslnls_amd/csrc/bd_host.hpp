@@ -20,6 +20,8 @@
 #include "dense_host.hpp"
 #include "irls_kernels.hpp"
 #include "large_host.hpp"
+#include "mstart_driver.hpp"
+#include "robust_host.hpp"
 
 namespace gslnls
 {
@@ -131,6 +133,12 @@ struct BdFit
     std::vector<double> h_part;
     int cur = 0;        // d_f[cur]: residual at the current point, d_f[cur ^ 1]: at the trial point
     std::vector<double> last_x;    // where the last solve ended (whatever its status)
+    // more of the state the last solve ended in -- what gsl_multistart_driver reads out of the solver workspace after a
+    // concentration / local-search fit (src/nls_mstart.c:91-95, :254-258, :324-326): trust_state->diag, chisq0 / chisq1 of
+    // driver2, and det(J^T J) of the workspace Jacobian (filled only when the solve was asked for it: `want_det`)
+    std::vector<double> end_diag;
+    double end_chisq0 = INFINITY, end_chisq1 = INFINITY, end_det = 0.0;
+    int end_niter = 0, end_status = ST_CONTINUE;
     const double *last_f = nullptr; // its weighted residual there, on the device
     void *irls_arena = nullptr;
     size_t irls_arena_bytes = 0;
@@ -345,19 +353,61 @@ struct BdFit
         return GSLNLS_SUCCESS;
     }
 
+    // det_cholesky_jtj (src/nls_utils.c:55-73): (prod L_ii)^2 of the plain Cholesky factor, 0 when it does not exist
+    static double det_chol(std::vector<double> &M)
+    {
+        const int q = (int)llround(sqrt((double)M.size()));
+        if (!lg_chol(q, M))
+            return 0.0;
+        double det = 1.0;
+        for (int i = 0; i < q; ++i)
+            det *= M[(size_t)i * q + i];
+        return det * det;
+    }
+    // det_eval_jtj (src/nls_utils.c:23-53): f and J at x, det(J^T J); 0 when either evaluation fails.  *ssr = ||f||^2.
+    int det_at(const double *x, int jac, const int *ci, const double *cd, double *det, double *ssr)
+    {
+        const LmParams prm = make_params(ci, cd, jac, 0, false, d_sw != nullptr);
+        *det = 0.0;
+        *ssr = INFINITY;
+        int rc = resid_at(x, d_f[cur], ssr);
+        if (rc == GSLNLS_EBADFUNC)
+            return GSLNLS_SUCCESS;
+        if (rc)
+            return rc;
+        std::vector<double> gtmp(p), dtmp(p), M((size_t)p * p);
+        double badj = 0.0;
+        rc = jac_at(x, d_f[cur], prm, gtmp.data(), dtmp.data(), &badj, M.data());
+        if (rc == GSLNLS_EBADFUNC || badj != 0.0)
+            return GSLNLS_SUCCESS;
+        if (rc)
+            return rc;
+        *det = det_chol(M);
+        return GSLNLS_SUCCESS;
+    }
+
     // The fit.  Same decisions in the same order as lm_advance<P> / wide_advance (which cite the reference line by line).
     // chisq_in: the chi^2 the convergence test of the first iteration compares with, when this solve is a re-solve of the
     // IRLS driver (NaN: the start's own, as a plain fit)
+    // point_fit_maxiter >= 0: one of the multi-start driver's short fits (src/nls_mstart.c:91, :254): that many iterations at
+    // most, gtol = 1e-3, no result vectors -- only the end state above, with det(J^T J) where the fit ended
     int solve(int jac, int fvv, const double *start, const double *lupars, const int *ci, const double *cd, gslnls_result *out,
-              double chisq_in = NAN)
+              double chisq_in = NAN, int point_fit_maxiter = -1)
     {
         if (ci[2] > 1)
             return GSLNLS_E_UNSUPPORTED; // dogleg family: not lowered
         if ((jac && !model->has_jac) || (fvv && !model->has_fvv))
             return GSLNLS_EINVAL;
-        const LmParams prm = make_params(ci, cd, jac, fvv, lupars != nullptr, d_sw != nullptr);
+        LmParams prm_ = make_params(ci, cd, jac, fvv, lupars != nullptr, d_sw != nullptr);
+        const bool point_fit = point_fit_maxiter >= 0;
+        if (point_fit)
+        {
+            prm_.maxiter = point_fit_maxiter;
+            prm_.gtol = 1e-3;
+        }
+        const LmParams prm = prm_;
         const int maxiter = prm.maxiter;
-        const bool trace = ci[1] != 0 && out->ssrtrace && out->partrace;
+        const bool trace = !point_fit && ci[1] != 0 && out->ssrtrace && out->partrace;
         // (read per fit: the tests run one problem through both factorisations)
         const char *dev_env = getenv("GSLNLS_LARGE_CHOL_DEVICE_MIN");
         const int dev_min = dev_env ? atoi(dev_env) : 400;
@@ -512,6 +562,7 @@ struct BdFit
                 done = true;
             }
         }
+        const bool have_jtj = !done; // J^T J of the start point exists (the fit's matrices are valid from here on)
         if (!done)
         {
             scale(true);
@@ -657,13 +708,14 @@ struct BdFit
                 else if (rc)
                     return rc;
                 if (prm.jac_analytic)
-                {
                     nevaldf += 1;
-                    if (badj != 0.0)
-                        itstatus = ST_EBADFUNC;
-                }
                 else
                     nevalf += lm_fd_cost(prm, p);
+                // a failed eval_df -- a non-finite analytic entry, or the closure failing at one of the difference points
+                // (forward_jac_LD / center_jac_LD return eval_f's status, src/fdjac.c:46-48, :104-112) -- ends the iteration with
+                // that status (src/trust.c:496-510), whatever the Jacobian's kind
+                if (badj != 0.0)
+                    itstatus = ST_EBADFUNC;
                 if (itstatus == ST_SUCCESS)
                 {
                     x = xt;
@@ -690,6 +742,44 @@ struct BdFit
                 (void)end_iteration(itstatus);
         }
         const double loop_ms = 1e3 * (now_s() - t_begin);
+        end_diag = diag;
+        end_chisq0 = chisq0;
+        end_chisq1 = chisq1;
+        end_niter = niter;
+        end_status = status;
+        if (point_fit)
+        {
+            // what the multi-start driver takes from the workspace (src/nls_mstart.c:91-95): nothing n-sized, and
+            // det_cholesky_jtj of the Jacobian the solver holds -- the one of the last accepted point
+            end_det = 0.0;
+            if (have_jtj)
+            {
+                std::vector<double> M;
+                if (dev_solve)
+                {
+                    M.resize((size_t)p * p);
+                    GSLNLS_HIP_OK(hipMemcpy(M.data(), d_C, sizeof(double) * (size_t)p * p, hipMemcpyDeviceToHost));
+                }
+                else
+                    M = A;
+                end_det = det_chol(M);
+            }
+            last_x = x;
+            last_f = d_f[cur];
+            out->niter = niter;
+            out->conv = status;
+            out->info = info;
+            out->ssr = chisq1;
+            out->ssrtol = chisq0 - chisq1;
+            out->neval[0] = (int)nevalf;
+            out->neval[1] = (int)nevaldf;
+            out->neval[2] = (int)nevalfvv;
+            out->chisq_init = chisq_init;
+            out->loop_ms = (float)loop_ms;
+            out->n_steps = (int)steps;
+            out->code_path = 4;
+            return status;
+        }
         // ---- result (src/nls.c:648-753) ----
         const bool ok = (status == ST_SUCCESS || status == ST_EMAXITER);
         for (int k = 0; k < p; ++k)
@@ -935,6 +1025,278 @@ struct BdFit
         return status;
     }
 };
+
+// ---- multi-start on the matrix path (round 5) ------------------------------------------------------------------------
+// The per-point work of gsl_multistart_driver (src/nls_mstart.c:42-128, :236-349) for function models and for formulas
+// beyond 64 parameters: quasi-random point -> sampling range, det_eval_jtj, the short fit, det_cholesky_jtj again -- one
+// point after the other (a closure is evaluated on the calling thread, one parameter vector at a time, exactly as the
+// reference's loop does), every n x p and p x p operation of each of them on the device.  The record layout is the one of
+// batch_core.hpp (MsRecord), so the commit of mstart_driver.hpp replays the reference's loop from these records as it
+// does for the lane kernel and the wide path.
+struct BdMsEvaluator : MsEvaluator
+{
+    BdFit &fit;
+    SobolTable tab;
+    int jac = 0, fvv = 0;
+    const int *ci = nullptr;
+    const double *cd = nullptr;
+    const double *lupars = nullptr;
+    std::vector<double> staged;
+    explicit BdMsEvaluator(BdFit &f) : fit(f) { sobol_build(tab, f.p); }
+
+    int run_host(MsBatch &b, int lo, int hi, double *out)
+    {
+        const int p = fit.p, K = 3 * p + 8;
+        if (b.p != p || b.K != K)
+            return GSLNLS_EINVAL;
+        std::vector<double> st(p);
+        gslnls_result scratch;
+        for (int idx = lo; idx < hi; ++idx)
+        {
+            if (g_interrupt_hook && g_interrupt_hook())
+                return GSLNLS_E_INTERRUPTED;
+            for (int k = 0; k < p; ++k)
+                st[k] = b.draw[idx] >= 0 ? sobol_to_range(sobol_coord(tab, (unsigned int)b.draw[idx], k), b.range[2 * k],
+                                                           b.range[2 * k + 1], b.kd[k])
+                                         : b.start[(size_t)idx * p + k];
+            double *rec = out + (size_t)(idx - lo) * K;
+            double *rx = rec, *rdiag = rec + p, *rx0 = rec + 2 * p, *sc = rec + 3 * p;
+            double det0 = 0.0, ssr0 = INFINITY;
+            int rc = fit.det_at(st.data(), jac, ci, cd, &det0, &ssr0);
+            if (rc)
+                return rc;
+            for (int k = 0; k < p; ++k)
+                rx0[k] = st[k];
+            sc[2] = det0;
+            sc[4] = ssr0;
+            if (b.always_fit || det0 > b.dtol)
+            {
+                memset(&scratch, 0, sizeof(scratch));
+                rc = fit.solve(jac, fvv, st.data(), lupars, ci, cd, &scratch, NAN, b.maxiter);
+                if (rc < 0)
+                    return rc; // (a library error or the step guard, not a GSL status: the end state was not written)
+                for (int k = 0; k < p; ++k)
+                {
+                    rx[k] = fit.last_x[k];
+                    rdiag[k] = fit.end_diag[k];
+                }
+                sc[0] = fit.end_chisq0;
+                sc[1] = fit.end_chisq1;
+                sc[3] = fit.end_det;
+                sc[5] = (double)fit.end_niter;
+                sc[6] = (double)fit.end_status;
+                sc[7] = (double)fit.nevalf;
+            }
+            else
+            {
+                for (int k = 0; k < p; ++k)
+                {
+                    rx[k] = st[k];
+                    rdiag[k] = 1.0;
+                }
+                sc[0] = INFINITY;
+                sc[1] = ssr0;
+                sc[3] = 0.0;
+                sc[5] = 0.0;
+                sc[6] = (double)ST_CONTINUE;
+                sc[7] = 1.0;
+            }
+        }
+        return 0;
+    }
+    int run_async(MsBatch &b, int lo, int hi, double *dev_out) override
+    {
+        const size_t nd = (size_t)(hi - lo) * (3 * fit.p + 8);
+        staged.assign(nd, 0.0);
+        const int rc = run_host(b, lo, hi, staged.data());
+        if (rc)
+            return rc;
+        // (`staged` lives as long as the evaluator: the copy is complete before the collective that follows it on the stream)
+        GSLNLS_HIP_OK(hipMemcpyAsync(dev_out, staged.data(), sizeof(double) * nd, hipMemcpyHostToDevice, fit.st));
+        return 0;
+    }
+    int run(MsBatch &b, int lo, int hi, double *out, bool out_on_device) override
+    {
+        if (!out)
+            return GSLNLS_E_UNSUPPORTED; // (records are produced on the host: somebody has to take them)
+        if (!out_on_device)
+            return run_host(b, lo, hi, out);
+        const int rc = run_async(b, lo, hi, out);
+        if (rc)
+            return rc;
+        GSLNLS_HIP_OK(hipStreamSynchronize(fit.st));
+        return 0;
+    }
+    void *stream() override { return (void *)fit.st; }
+    int fetch(const double *src, bool src_on_device, double *dst, size_t nd) override
+    {
+        if (src_on_device)
+            GSLNLS_HIP_OK(hipMemcpy(dst, src, sizeof(double) * nd, hipMemcpyDeviceToHost));
+        else
+            memcpy(dst, src, sizeof(double) * nd);
+        return 0;
+    }
+    int fetch_stream(const double *dev_src, double *dst, size_t nd) override
+    {
+        if (nd)
+            GSLNLS_HIP_OK(hipMemcpyAsync(dst, dev_src, sizeof(double) * nd, hipMemcpyDeviceToHost, fit.st));
+        GSLNLS_HIP_OK(hipStreamSynchronize(fit.st));
+        return 0;
+    }
+    int poke(double *dev_dst, double value) override
+    {
+        GSLNLS_HIP_OK(hipMemcpyAsync(dev_dst, &value, sizeof(double), hipMemcpyHostToDevice, fit.st));
+        GSLNLS_HIP_OK(hipStreamSynchronize(fit.st));
+        return 0;
+    }
+};
+
+// robust second pass (src/nls.c:401-443): Cook's distances at the first pass's optimum from the resident residual and
+// Jacobian; observations with D_i > min(4 / n, 5 MAD(D)) get weight zero.  1: a second pass has to run (d_sw_robust
+// filled), 0: not (also when hat_values fails: J^T J singular), < 0: error
+inline int bd_robust_weights(BdFit &fit, int jac, const double *mpopt, const int *ci, const double *cd, double *d_sw_robust)
+{
+    const int n = fit.n, p = fit.p;
+    const LmParams prm = make_params(ci, cd, jac, 0, false, fit.d_sw != nullptr);
+    double ssr = INFINITY, badj = 0.0;
+    int rc = fit.resid_at(mpopt, fit.d_f[fit.cur], &ssr);
+    if (rc == GSLNLS_EBADFUNC)
+        return 0;
+    if (rc)
+        return rc < 0 ? rc : -1;
+    std::vector<double> gtmp(p), dtmp(p), A((size_t)p * p);
+    rc = fit.jac_at(mpopt, fit.d_f[fit.cur], prm, gtmp.data(), dtmp.data(), &badj, A.data());
+    if (rc == GSLNLS_EBADFUNC || badj != 0.0)
+        return 0;
+    if (rc)
+        return rc < 0 ? rc : -1;
+    if (!lg_chol(p, A)) // cooks_d -> hat_values fails: no second pass (src/nls.c:419-421)
+        return 0;
+    lg_chol_invert(p, A);
+    const double s2 = ssr / (n - p);
+    hipStream_t st = fit.st;
+    // (J^T J)^-1 takes the place of J^T J on the device: the next evaluation of a Jacobian rewrites it
+    GSLNLS_HIP_OK(hipMemcpyAsync(fit.d_C, A.data(), sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice, st));
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t nb8 = up(sizeof(double) * (size_t)n);
+    char *arena = nullptr;
+    GSLNLS_HIP_OK(hipMalloc(&arena, 2 * nb8 + up(sizeof(SelectState) * 2) + 256));
+    double *d_d = reinterpret_cast<double *>(arena);
+    unsigned long long *d_keys = reinterpret_cast<unsigned long long *>(arena + nb8);
+    SelectState *d_sel = reinterpret_cast<SelectState *>(arena + 2 * nb8);
+    int *d_cnt = reinterpret_cast<int *>(arena + 2 * nb8 + up(sizeof(SelectState) * 2));
+    if (hipMemsetAsync(d_cnt, 0, sizeof(int), st) != hipSuccess)
+    {
+        (void)hipFree(arena);
+        return GSLNLS_E_NODEVICE;
+    }
+    int gf = (int)(((long long)n + 255) / 256);
+    gf = gf > 2048 ? 2048 : (gf < 1 ? 1 : gf);
+    hipLaunchKernelGGL(bd_cooks_kernel, dim3(gf), dim3(BD_T), 0, st, fit.d_f[fit.cur], fit.d_J, (long long)n, p, fit.d_C, s2, d_d,
+                       d_keys, (double *)nullptr);
+    double med = 0.0, med2 = 0.0;
+    rc = device_median(st, d_keys, n, d_sel, &med);
+    if (!rc)
+    {
+        hipLaunchKernelGGL(absdev_keys_kernel, dim3(gf), dim3(256), 0, st, d_d, (long long)n, med, d_keys);
+        rc = device_median(st, d_keys, n, d_sel, &med2);
+    }
+    int noutlier = 0;
+    if (!rc)
+    {
+        const double mad = 1.482602218505602 * med2;
+        const double thresh = fmin(4.0 / n, 5 * mad);
+        hipLaunchKernelGGL(outlier_weights_kernel, dim3(gf), dim3(256), 0, st, d_d, (long long)n, thresh, fit.d_sw, d_sw_robust, d_cnt);
+        (void)hipMemcpyAsync(&noutlier, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+    }
+    (void)hipFree(arena);
+    if (rc)
+        return rc < 0 ? rc : -1;
+    return (noutlier > 0 && noutlier < (n - p)) ? 1 : 0;
+}
+
+// multi-start branch of C_nls (src/nls.c:274-532) on the matrix path: the host driver of mstart_driver.hpp (the
+// reference's commit order) around BdMsEvaluator, the robust second pass when a loss function is set, the final solve
+inline int bd_mstart(BdFit &fit, int jac, int fvv, const double *start2p, const double *lupars, const int *ci, const double *cd,
+                     const int *has_start, const MsComm &comm, int loss_rho, const double *loss_cc, gslnls_result *out)
+{
+    if (ci[2] > 1)
+        return GSLNLS_E_UNSUPPORTED;
+    if ((jac && !fit.model->has_jac) || (fvv && !fit.model->has_fvv))
+        return GSLNLS_EINVAL;
+    if (ci[6] < 1 || ci[8] < 0 || ci[8] > ci[6])
+        return GSLNLS_EINVAL;
+    const int p = fit.p;
+    MsState m;
+    ms_init(m, p, ci, cd, start2p, has_start, lupars);
+    BdMsEvaluator ev(fit);
+    ev.jac = jac;
+    ev.fvv = fvv;
+    ev.ci = ci;
+    ev.cd = cd;
+    ev.lupars = lupars;
+    int rc = ms_major_loop(m, ev, comm, start2p);
+    if (rc)
+        return rc < 0 && rc > -100 ? GSLNLS_FAILURE : rc;
+    if (loss_rho != 0)
+    {
+        if (m.mssropt[1] < m.mssropt[0])
+            m.mpopt = m.mpopt1;
+        double *d_sw_robust = nullptr;
+        GSLNLS_HIP_OK(hipMalloc(&d_sw_robust, sizeof(double) * (size_t)fit.n));
+        const int second = bd_robust_weights(fit, jac, m.mpopt.data(), ci, cd, d_sw_robust);
+        if (second < 0)
+        {
+            (void)hipFree(d_sw_robust);
+            return second;
+        }
+        if (second == 1)
+        {
+            double *keep_sw = fit.d_sw;
+            fit.d_sw = d_sw_robust;
+            m.next_draw = 0; // gsl_qrng_init
+            m.mstop = ST_CONTINUE;
+            m.mstarts = m.nsp = m.nwsp = 0;
+            m.dtol = 1.0e-6;
+            m.rejectscl = 1.25;
+            m.mssropt[0] = m.mssropt[1] = INFINITY;
+            m.ssrconv[0] = m.ssrconv[1] = 1.0;
+            std::fill(m.ntix.begin(), m.ntix.end(), 0);
+            std::fill(m.luchange.begin(), m.luchange.end(), 0);
+            rc = ms_major_loop(m, ev, comm, start2p);
+            fit.d_sw = keep_sw; // "reset original weights" (src/nls.c:490-507)
+        }
+        (void)hipFree(d_sw_robust);
+        if (rc)
+            return rc < 0 && rc > -100 ? GSLNLS_FAILURE : rc;
+    }
+    // src/nls.c:518-531
+    if (m.mssropt[1] < m.mssropt[0])
+    {
+        m.mssropt[0] = m.mssropt[1];
+        m.ssrconv[0] = m.ssrconv[1];
+        m.mpopt = m.mpopt1;
+    }
+    const double ftol = cd[6];
+    if (m.mssropt[0] < ftol || m.ssrconv[0] < ftol)
+    {
+        if (lupars)
+            m.mpopt[0] = fmin(m.mpopt[0] + 1.0e-4, std::isfinite(lupars[1]) ? lupars[1] : INFINITY);
+        else
+            m.mpopt[0] = m.mpopt[0] + 1.0e-4;
+    }
+    if (loss_rho != 0)
+        rc = fit.irls(jac, fvv, m.mpopt.data(), lupars, ci, cd, loss_rho, loss_cc, out);
+    else
+        rc = fit.solve(jac, fvv, m.mpopt.data(), lupars, ci, cd, out);
+    out->mstart_nsp = m.nsp;
+    out->mstart_nwsp = m.nwsp;
+    out->mstart_iters = m.mstarts;
+    out->mstart_stop = m.mstop;
+    out->mstart_ssropt = m.mssropt[0];
+    return rc;
+}
 
 // host closures as the model: gslnls_nls_fn (capi.hip)
 struct BdCallbackModel : BdModel

@@ -13,7 +13,8 @@
 //   bd_resid_kernel    f = sqrt(w) (m - y) with the reference's non-finite rule (src/nls.c:843-849) + sum of squares;
 //   bd_weight_kernel   rows of an analytic Jacobian scaled by sqrt(w) (src/fdf.c:135-177) + non-finite check;
 //   bd_fdcol_kernel    one column of a forward / central difference Jacobian (src/fdjac.c:81-128, :147-168);
-//   bd_quad_kernel     rows of v^T (J^T J) v for the predicted reduction (GSL lm_preduction).
+//   bd_quad_kernel     rows of v^T (J^T J) v for the predicted reduction (GSL lm_preduction);
+//   bd_cooks_kernel    hat values and Cook's distances of the robust multi-start second pass (src/nls_utils.c:88-150).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "lm_core.hpp"
@@ -156,6 +157,33 @@ __global__ __launch_bounds__(BD_T) void bd_quad_kernel(const double *C, const do
     s = bd_block_sum(s, red_s);
     if (threadIdx.x == 0)
         out[i] = s * v[i];
+}
+
+// hat values h_i = J_i (J^T J)^-1 J_i^T and Cook's distances D_i = e_i^2 / (p s^2) h_i / (1 - h_i)^2 from the resident
+// residual and Jacobian (hat_values / cooks_d, src/nls_utils.c:88-150), any p: lane = row, (J^T J)^-1 read as broadcasts
+// (every lane the same address) in the order of the reference's row sum
+__global__ __launch_bounds__(BD_T) void bd_cooks_kernel(const double *resid, const double *J, long long n, int p, const double *Cinv,
+                                                        double s2, double *d, unsigned long long *keys, double *hat)
+{
+    for (long long i = (long long)blockIdx.x * BD_T + threadIdx.x; i < n; i += (long long)gridDim.x * BD_T)
+    {
+        double h = 0.0;
+        for (int j = 0; j < p; ++j)
+        {
+            double t = 0.0;
+            for (int k = 0; k < p; ++k)
+                t += J[i + (size_t)n * k] * Cinv[(size_t)k * p + j];
+            h += t * J[i + (size_t)n * j];
+        }
+        const double e = resid[i];
+        const double di = (e * e) / (p * s2) * (h / ((1 - h) * (1 - h)));
+        if (d)
+            d[i] = di;
+        if (keys)
+            keys[i] = (unsigned long long)__double_as_longlong(fabs(di));
+        if (hat)
+            hat[i] = h;
+    }
 }
 
 // ---- J^T J ------------------------------------------------------------------------------------------------------------

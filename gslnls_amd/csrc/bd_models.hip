@@ -13,9 +13,10 @@ namespace gslnls
 {
 
 // gslnls_nls_fn (capi.hip): the closures of a function model
+// start_is_matrix: 2 x p ranges + has_start -> the multi-start procedure (bd_mstart), through `comm` when one is bound
 int bd_callback_nls(int n, int p, const double *y, gslnls_fn_cb f, gslnls_jac_cb jac, gslnls_fvv_cb fvv, void *user,
-                    const double *start, const double *swts, const double *lupars, const int *ci, const double *cd,
-                    int loss_rho, const double *loss_cc, gslnls_result *out)
+                    const double *start, int start_is_matrix, const int *has_start, const MsComm &comm, const double *swts,
+                    const double *lupars, const int *ci, const double *cd, int loss_rho, const double *loss_cc, gslnls_result *out)
 {
     BdCallbackModel m;
     m.n = n;
@@ -30,6 +31,8 @@ int bd_callback_nls(int n, int p, const double *y, gslnls_fn_cb f, gslnls_jac_cb
     int rc = fit.init(n, p, y, swts, &m);
     if (rc)
         return rc;
+    if (start_is_matrix)
+        return bd_mstart(fit, jac != nullptr, fvv != nullptr, start, lupars, ci, cd, has_start, comm, loss_rho, loss_cc, out);
     if (loss_rho != 0)
         return fit.irls(jac != nullptr, fvv != nullptr, start, lupars, ci, cd, loss_rho, loss_cc, out);
     return fit.solve(jac != nullptr, fvv != nullptr, start, lupars, ci, cd, out);
@@ -77,9 +80,10 @@ struct BdFormulaModel : BdModel
     double *d_scratch = nullptr;
 };
 
-// gsl_nls() on a formula with 64 < p <= 512 parameters: single start; robust losses through BdFit::irls
-int bd_formula_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv, const double *start, const double *swts,
-                   const double *lupars, const int *ci, const double *cd, int loss_rho, const double *loss_cc, gslnls_result *out)
+// gsl_nls() on a formula with 64 < p <= 512 parameters; robust losses through BdFit::irls, start ranges through bd_mstart
+int bd_formula_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv, const double *start, int start_is_matrix,
+                   const int *has_start, const MsComm &comm, const double *swts, const double *lupars, const int *ci,
+                   const double *cd, int loss_rho, const double *loss_cc, gslnls_result *out)
 {
     if (!fn->expr || !fn->parnames || (fn->nx > 0 && !fn->xnames) || fn->nx > WIDE_NX || fn->p > BIG_MAX_P || fn->x_on_device)
         return fn->p > BIG_MAX_P || fn->nx > WIDE_NX || fn->x_on_device ? GSLNLS_E_UNSUPPORTED : GSLNLS_EINVAL;
@@ -129,6 +133,8 @@ int bd_formula_nls(const gslnls_model *fn, const double *y, int n, int jac, int 
     int rc = fit.init(n, fn->p, y, swts, &m);
     if (rc)
         return rc;
+    if (start_is_matrix)
+        return bd_mstart(fit, jac, fvv, start, lupars, ci, cd, has_start, comm, loss_rho, loss_cc, out);
     if (loss_rho != 0)
         return fit.irls(jac, fvv, start, lupars, ci, cd, loss_rho, loss_cc, out);
     return fit.solve(jac, fvv, start, lupars, ci, cd, out);

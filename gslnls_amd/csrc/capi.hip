@@ -84,11 +84,13 @@ int ms_rccl_run_batch(MsEvaluator &ev, const MsComm &comm, MsBatch &b, int per, 
 namespace gslnls
 {
 DenseBase *make_dense_expr(const gslnls_model *fn, const double *y, int n, const double *swts, int *err); // vm_models.hip
-int bd_formula_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv, const double *start, const double *swts,
-                   const double *lupars, const int *ci, const double *cd, int loss_rho, const double *loss_cc, gslnls_result *out);
+int bd_formula_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv, const double *start, int start_is_matrix,
+                   const int *has_start, const MsComm &comm, const double *swts, const double *lupars, const int *ci,
+                   const double *cd, int loss_rho, const double *loss_cc, gslnls_result *out);
 int bd_callback_nls(int n, int p, const double *y, gslnls_fn_cb f, gslnls_jac_cb jac, gslnls_fvv_cb fvv, void *user,
-                    const double *start, const double *swts, const double *lupars, const int *ci, const double *cd,
-                    int loss_rho, const double *loss_cc, gslnls_result *out); // bd_models.hip
+                    const double *start, int start_is_matrix, const int *has_start, const MsComm &comm, const double *swts,
+                    const double *lupars, const int *ci, const double *cd, int loss_rho, const double *loss_cc,
+                    gslnls_result *out); // bd_models.hip
 void trim_dense_expr();                                                                                         // vm_models.hip
 }
 
@@ -1014,10 +1016,11 @@ int gslnls_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv,
 #ifndef GSLNLS_NO_EXPR
     if (fn && fn->id == GSLNLS_MODEL_EXPR && fn->p > 64) // (WIDE_MAX_P, vm_program.hpp)
     {
-        // more than 64 parameters: the Jacobian is a matrix in HBM (csrc/bd_host.hpp); single start
-        if (start_is_matrix || loss_rho < 0 || loss_rho > 8 || (loss_rho != 0 && !loss_cc))
-            return start_is_matrix ? GSLNLS_E_UNSUPPORTED : GSLNLS_EINVAL;
-        const int rcb = bd_formula_nls(fn, y, n, jac, fvv, start, swts, lupars, control_int, control_dbl, loss_rho, loss_cc, out);
+        // more than 64 parameters: the Jacobian is a matrix in HBM (csrc/bd_host.hpp)
+        if (loss_rho < 0 || loss_rho > 8 || (loss_rho != 0 && !loss_cc) || (start_is_matrix && !has_start))
+            return GSLNLS_EINVAL;
+        const int rcb = bd_formula_nls(fn, y, n, jac, fvv, start, start_is_matrix, has_start, g_comm, swts, lupars, control_int,
+                                       control_dbl, loss_rho, loss_cc, out);
         g_call_prof.total_ms = 1e3 * (now_s() - t0);
         return rcb;
     }
@@ -1060,7 +1063,8 @@ int gslnls_nls_fn(int n, int p, const double *y, gslnls_fn_cb f, gslnls_jac_cb j
         return GSLNLS_EINVAL;
     if (p > 4096)
         return GSLNLS_E_UNSUPPORTED;
-    return bd_callback_nls(n, p, y, f, jac, fvv, user, start, swts, lupars, control_int, control_dbl, 0, nullptr, out);
+    return bd_callback_nls(n, p, y, f, jac, fvv, user, start, 0, nullptr, g_comm, swts, lupars, control_int, control_dbl, 0, nullptr,
+                           out);
 }
 
 int gslnls_nls_fn_loss(int n, int p, const double *y, gslnls_fn_cb f, gslnls_jac_cb jac, gslnls_fvv_cb fvv, void *user,
@@ -1072,7 +1076,22 @@ int gslnls_nls_fn_loss(int n, int p, const double *y, gslnls_fn_cb f, gslnls_jac
         return GSLNLS_EINVAL;
     if (p > 4096)
         return GSLNLS_E_UNSUPPORTED;
-    return bd_callback_nls(n, p, y, f, jac, fvv, user, start, swts, lupars, control_int, control_dbl, loss_rho, loss_cc, out);
+    return bd_callback_nls(n, p, y, f, jac, fvv, user, start, 0, nullptr, g_comm, swts, lupars, control_int, control_dbl, loss_rho,
+                           loss_cc, out);
+}
+
+int gslnls_nls_fn_mstart(int n, int p, const double *y, gslnls_fn_cb f, gslnls_jac_cb jac, gslnls_fvv_cb fvv, void *user,
+                         const double *start2p, const int *has_start, const double *swts, const double *lupars,
+                         const int *control_int, const double *control_dbl, int loss_rho, const double *loss_cc,
+                         gslnls_result *out)
+{
+    if (!f || !y || !start2p || !has_start || !control_int || !control_dbl || !out || n < 1 || p < 1 || loss_rho < 0 ||
+        loss_rho > 8 || (loss_rho != 0 && !loss_cc))
+        return GSLNLS_EINVAL;
+    if (p > 4096)
+        return GSLNLS_E_UNSUPPORTED;
+    return bd_callback_nls(n, p, y, f, jac, fvv, user, start2p, 1, has_start, g_comm, swts, lupars, control_int, control_dbl,
+                           loss_rho, loss_cc, out);
 }
 
 int gslnls_last_call_profile(double *ms, int cap)

@@ -107,7 +107,23 @@ def _bounds(lower, upper, names):
         b = np.atleast_1d(np.asarray(b, dtype=np.float64))
         return np.full(p, b[0]) if b.size == 1 else b
     lo, up = expand(lower, -np.inf), expand(upper, np.inf)
+    if np.all(np.isinf(lo) & (lo < 0)) and np.all(np.isinf(up) & (up > 0)):
+        return None  # if(all(is.infinite(.lupars))) .lupars <- NULL (R/nls.R:558-560)
     return np.ascontiguousarray(np.stack([lo, up], axis=1).reshape(-1))
+
+
+def _ranges_inside_bounds(mat, has_start, lo_b, up_b):
+    """R/nls.R:545-557: missing range ends are moved inside the bounds first, then every range has to lie within them"""
+    if has_start is not None:
+        m0, m1 = ~has_start[0], ~has_start[1]
+        if m0.any():
+            old = mat[0, m0].copy()
+            mat[0, m0] = np.maximum(old, lo_b[m0])
+            mat[1, m0] = mat[1, m0] + (mat[0, m0] - old)
+        if m1.any():
+            mat[1, m1] = np.minimum(mat[1, m1], up_b[m1])
+    if np.any(mat[0] < lo_b) or np.any(mat[1] > up_b):
+        raise ValueError("Starting parameter ranges must be contained within 'lower' and 'upper' bounds")
 
 
 class DenseProblem:
@@ -203,7 +219,7 @@ def _finish(out, res, trace, algorithm, n):
     return GslNlsFit(out)
 
 
-def _gsl_nls_function(fn, y, start, algorithm, control, jac, fvv, trace, weights, lower, upper, loss):
+def _gsl_nls_function(fn, y, start, algorithm, control, jac, fvv, trace, weights, lower, upper, loss, parnames=None):
     """gsl_nls.function (R/nls.R:778-1060): `fn(par)` returns the n model values -- or (values, gradient), the analogue of
     the "gradient" attribute README example 4 uses --, `y` the response, `jac` / `fvv` optional functions jac(par) -> n x p,
     fvv(par, v) -> n.  The closures run on this thread, where the reference runs them (src/nls.c:815-978); every n x p and
@@ -214,17 +230,12 @@ def _gsl_nls_function(fn, y, start, algorithm, control, jac, fvv, trace, weights
         raise ValueError("'algorithm' should be one of %s" % ", ".join(ALGORITHMS))
     loss_cfg = gsl_nls_loss(loss) if isinstance(loss, str) else gsl_nls_loss(**loss)
     ctrl = control if (control is not None and len(control) >= 23) else gsl_nls_control(**(control or {}))
-    if isinstance(start, dict):
-        names, vec = list(start.keys()), np.asarray([float(np.asarray(v).reshape(-1)[0]) for v in start.values()])
-        if any(np.asarray(v).size != 1 for v in start.values()):
-            raise NotImplementedError("multi-start with a function model is not lowered to the device")
-    else:
-        vec = np.asarray(start, dtype=np.float64).reshape(-1)
-        names = ["par%d" % (k + 1) for k in range(len(vec))]
-    p = len(vec)
+    # start values, ranges or missing values (NaN): R/nls.R:399-437 for functions as for formulas (R/nls.R:842-880)
+    names, vec, mat, has_start = _normalise_start(start, parnames)
+    p = len(names)
     yv = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
     n = len(yv)
-    first = fn(vec.copy())
+    first = fn((vec if mat is None else 0.5 * (mat[0] + mat[1])).copy())
     grad_in_fn = isinstance(first, tuple)
     if jac is True and not grad_in_fn:
         raise ValueError("jac = True needs a model function that returns (values, gradient)")
@@ -282,9 +293,12 @@ def _gsl_nls_function(fn, y, start, algorithm, control, jac, fvv, trace, weights
         lo_b, up_b = lu.reshape(p, 2)[:, 0], lu.reshape(p, 2)[:, 1]
         if np.any(lo_b > up_b):
             raise ValueError("Parameter lower bounds cannot be larger than upper bounds")
-        if np.any(vec < lo_b) or np.any(vec > up_b):
+        if mat is not None:
+            _ranges_inside_bounds(mat, has_start, lo_b, up_b)
+        elif np.any(vec < lo_b) or np.any(vec > up_b):
             raise ValueError("Starting parameters must be contained within 'lower' and/or 'upper' bounds")
-    ci, cd = pack_control(ctrl, algorithm, trace, True, False)
+    any_missing = bool(has_start is not None and not np.all(has_start))
+    ci, cd = pack_control(ctrl, algorithm, trace, True, any_missing)
     out = dict(par=np.zeros(p), covar=np.zeros((p, p), order="F"), resid=np.zeros(n), grad=np.zeros((n, p), order="F"))
     res = _lib.Result()
     res.par, res.covar, res.resid, res.grad = _dp(out["par"]), _dp(out["covar"]), _dp(out["resid"]), _dp(out["grad"])
@@ -299,10 +313,19 @@ def _gsl_nls_function(fn, y, start, algorithm, control, jac, fvv, trace, weights
         res.partrace, res.ssrtrace = _dp(out["partrace"]), _dp(out["ssrtrace"])
     # (a function-pointer type called without arguments is the NULL pointer)
     cbs = (_lib.FN_CB(f_cb), _lib.JAC_CB(jac_cb) if jac_fn else _lib.JAC_CB(), _lib.FVV_CB(fvv_cb) if fvv_fn else _lib.FVV_CB())
-    st = np.ascontiguousarray(vec, dtype=np.float64)
-    rc = _lib.lib().gslnls_nls_fn_loss(n, p, yv.ctypes.data_as(C.c_void_p), cbs[0], cbs[1], cbs[2], None, _dp(st),
-                                       None if sw is None else sw.ctypes.data_as(C.c_void_p), _dp(lu), ci.ctypes.data_as(IP),
-                                       _dp(cd), LOSSES.index(loss_cfg["rho"]), _dp(cc), C.byref(res))
+    if mat is not None:
+        # start ranges: the multi-start procedure with the closures as the model (src/nls.c:274-532)
+        st = np.ascontiguousarray(mat.T.reshape(-1))
+        hs = np.ascontiguousarray(has_start.T.reshape(-1).astype(np.int32))
+        rc = _lib.lib().gslnls_nls_fn_mstart(n, p, yv.ctypes.data_as(C.c_void_p), cbs[0], cbs[1], cbs[2], None, _dp(st),
+                                             hs.ctypes.data_as(IP), None if sw is None else sw.ctypes.data_as(C.c_void_p),
+                                             _dp(lu), ci.ctypes.data_as(IP), _dp(cd), LOSSES.index(loss_cfg["rho"]), _dp(cc),
+                                             C.byref(res))
+    else:
+        st = np.ascontiguousarray(vec, dtype=np.float64)
+        rc = _lib.lib().gslnls_nls_fn_loss(n, p, yv.ctypes.data_as(C.c_void_p), cbs[0], cbs[1], cbs[2], None, _dp(st),
+                                           None if sw is None else sw.ctypes.data_as(C.c_void_p), _dp(lu), ci.ctypes.data_as(IP),
+                                           _dp(cd), LOSSES.index(loss_cfg["rho"]), _dp(cc), C.byref(res))
     if errors:
         raise errors[0]
     _lib.check(rc)
@@ -388,17 +411,7 @@ def gsl_nls(fn, data=None, start=None, algorithm="lm", control=None, jac=None, f
         if np.any(lo_b > up_b):
             raise ValueError("Parameter lower bounds cannot be larger than upper bounds")
         if mat is not None:
-            if has_start is not None:
-                # missing range ends are moved inside the bounds first (R/nls.R:545-552)
-                m0, m1 = ~has_start[0], ~has_start[1]
-                if m0.any():
-                    old = mat[0, m0].copy()
-                    mat[0, m0] = np.maximum(old, lo_b[m0])
-                    mat[1, m0] = mat[1, m0] + (mat[0, m0] - old)
-                if m1.any():
-                    mat[1, m1] = np.minimum(mat[1, m1], up_b[m1])
-            if np.any(mat[0] < lo_b) or np.any(mat[1] > up_b):
-                raise ValueError("Starting parameter ranges must be contained within 'lower' and 'upper' bounds")
+            _ranges_inside_bounds(mat, has_start, lo_b, up_b)
         elif np.any(vec < lo_b) or np.any(vec > up_b):
             raise ValueError("Starting parameters must be contained within 'lower' and/or 'upper' bounds")
         lu = np.ascontiguousarray(lu.reshape(p, 2)[order].reshape(-1))

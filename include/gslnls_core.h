@@ -35,8 +35,8 @@ extern "C" {
 #define GSLNLS_MODEL_GAUSS1 4   /* NIST Gauss1 family        p=8  R/nls_test.R:301 */
 #define GSLNLS_MODEL_EXPR 100  /* any formula right-hand side: compiled to a device program with symbolic
                                    gradient (csrc/expr_compile.hpp); p <= 512, at most 8 regressor columns (beyond 9
-                                   parameters or 3 columns: the wide path; beyond 64 parameters, single start only: the
-                                   Jacobian as a matrix in HBM, csrc/bd_host.hpp) */
+                                   parameters or 3 columns: the wide path; beyond 64 parameters: the Jacobian as a
+                                   matrix in HBM, csrc/bd_host.hpp) */
 #define GSLNLS_MODEL_GLMEXP 5   /* exp(a_i . theta), dense A n x p ROW-major in `x`, nx = p in {16,32,64};
                                    gsl_nls_large only */
 
@@ -170,9 +170,14 @@ int gslnls_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv,
  *   jac  : n x p column-major dm/dtheta as an R matrix is laid out, or NULL for finite differences (control_int[5])
  *   fvv  : D^2 m[v, v] into out[n], or NULL (lmaccel then differences f, src/fdfvv.c)
  *   start p values; swts sqrt(weights) [n] or NULL; lupars 2 x p or NULL; control_int / control_dbl as gslnls_nls.
- * Single start (multi-start of function models keeps the GSL path: GSLNLS_E_UNSUPPORTED).  gslnls_nls_fn_loss: the same
- * with a robust loss (loss_rho, loss_cc as gslnls_nls; 0 = default): the IRLS driver of src/nls_irls.c:412-546 around the
- * solve, residual median and re-weighting on the device.  out->code_path = 4.
+ * gslnls_nls_fn_loss: the same with a robust loss (loss_rho, loss_cc as gslnls_nls; 0 = default): the IRLS driver of
+ * src/nls_irls.c:412-546 around the solve, residual median and re-weighting on the device.  out->code_path = 4.
+ * gslnls_nls_fn_mstart: `start` of C_nls is a 2 x p matrix of ranges (Rf_isMatrix(start), src/nls.c:274-532; the
+ * reference's unit tests 4.2.x / 4.3.x): the whole multi-start procedure -- quasi-random points, det filter,
+ * concentration fits of mstart_p iterations, local searches, stopping rule, robust second pass, final solve / IRLS -- with
+ * the closures as the model (gsl_multistart_driver, src/nls_mstart.c:24-350).  start2p / has_start: 2 x p column-major as
+ * gslnls_nls takes them.  The points are fitted one after the other, as the closures can only be evaluated one parameter
+ * vector at a time on the calling thread; each fit's n x p and p x p work runs on the device.
  */
 typedef int (*gslnls_fn_cb)(const double *theta, int p, double *fval, int n, void *user);
 typedef int (*gslnls_jac_cb)(const double *theta, int p, double *J, int n, void *user);
@@ -183,6 +188,10 @@ int gslnls_nls_fn(int n, int p, const double *y, gslnls_fn_cb f, gslnls_jac_cb j
 int gslnls_nls_fn_loss(int n, int p, const double *y, gslnls_fn_cb f, gslnls_jac_cb jac, gslnls_fvv_cb fvv, void *user,
                        const double *start, const double *swts, const double *lupars, const int *control_int,
                        const double *control_dbl, int loss_rho, const double *loss_cc, gslnls_result *out);
+int gslnls_nls_fn_mstart(int n, int p, const double *y, gslnls_fn_cb f, gslnls_jac_cb jac, gslnls_fvv_cb fvv, void *user,
+                         const double *start2p, const int *has_start, const double *swts, const double *lupars,
+                         const int *control_int, const double *control_dbl, int loss_rho, const double *loss_cc,
+                         gslnls_result *out);
 
 /* Where the wall time of the last gslnls_nls() call of this process went, milliseconds:
  *   ms[0] create (allocation / re-binding of a parked problem), [1] H2D of x, y, swts, [2] the solve loop (plus
