@@ -77,6 +77,9 @@ _SIGNATURES = {
                              C.c_int, DP, IP, DP, IP, C.c_int, DP, C.POINTER(Result)]),
     "gslnls_solver_served": (C.c_int, [IP, C.POINTER(Result)]),
     "gslnls_last_call_profile": (C.c_int, [DP, C.c_int]),
+    "gslnls_trace_text": (C.c_size_t, [C.c_char_p, C.c_size_t]),
+    "gslnls_trace_set_order": (C.c_int, [IP, C.c_int]),
+    "gslnls_format_trace": (C.c_size_t, [C.POINTER(Result), C.c_int, C.c_int, IP, C.c_int, C.c_char_p, C.c_size_t]),
     "gslnls_nls_fn": (C.c_int, [C.c_int, C.c_int, C.c_void_p, FN_CB, JAC_CB, FVV_CB, C.c_void_p, DP, C.c_void_p, DP, IP, DP,
                                 C.POINTER(Result)]),
     "gslnls_nls_fn_loss": (C.c_int, [C.c_int, C.c_int, C.c_void_p, FN_CB, JAC_CB, FVV_CB, C.c_void_p, DP, C.c_void_p, DP, IP, DP,
@@ -168,6 +171,15 @@ def lib():
 
 def symbols():
     return sorted(_SIGNATURES)
+
+
+def trace_text():
+    """the text a verbose call of the reference prints (include/gslnls_core.h, gslnls_trace_text), of the last call"""
+    L = lib()
+    need = L.gslnls_trace_text(None, 0)
+    buf = C.create_string_buffer(need + 1)
+    L.gslnls_trace_text(buf, need + 1)
+    return buf.value.decode()
 
 
 def strerror(code):

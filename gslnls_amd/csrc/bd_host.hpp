@@ -937,6 +937,8 @@ struct BdFit
             if (irls_iter == 1)
                 chisq_init = out->chisq_init;
             chisq_carry = out->ssr;
+            trace_printf("IRLS iter: %3d, weighted ssr: %g, par: (", irls_iter, out->ssr); // (src/nls_irls.c:466-472)
+            trace_vector(last_x.data(), p);
             if (status == ST_EBADFUNC || (status == ST_ENOPROG && irls_iter == 1))
                 break;
             // ---- re-weighting chain, all on the device ----
@@ -1256,6 +1258,7 @@ inline int bd_mstart(BdFit &fit, int jac, int fvv, const double *start2p, const 
             double *keep_sw = fit.d_sw;
             fit.d_sw = d_sw_robust;
             m.next_draw = 0; // gsl_qrng_init
+            m.second_pass = true;
             m.mstop = ST_CONTINUE;
             m.mstarts = m.nsp = m.nwsp = 0;
             m.dtol = 1.0e-6;
@@ -1271,6 +1274,7 @@ inline int bd_mstart(BdFit &fit, int jac, int fvv, const double *start2p, const 
         if (rc)
             return rc < 0 && rc > -100 ? GSLNLS_FAILURE : rc;
     }
+    ms_trace_finished(m);
     // src/nls.c:518-531
     if (m.mssropt[1] < m.mssropt[0])
     {

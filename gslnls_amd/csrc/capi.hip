@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "../../include/gslnls_core.h"
+#include "trace_log.hpp"
 #include "dense_host.hpp"
 #include "mstart_host.hpp"
 #include "formula.hpp"
@@ -431,6 +432,11 @@ int gslnls_large_solve(gslnls_large *h, const double *start, const int *control_
     ops.nevalf = ops.nevaldfu = ops.nevaldf2 = 0;
     ops.npass = 0;
     LargeResult R;
+    trace_begin(control_int[1] != 0);
+    struct TraceOff
+    {
+        ~TraceOff() { g_trace_on = false; }
+    } trace_off;
     const bool trace = control_int[1] != 0 && out->ssrtrace && out->partrace;
     if (trace)
     {
@@ -488,6 +494,20 @@ int gslnls_large_solve(gslnls_large *h, const double *start, const int *control_
     out->neval[3] = 0;
     out->n_passes = (int)ops.npass;
     out->last_pass_ms = ops.pass_ms;
+    // the summary block of a verbose call (src/nls_large.c:259-273)
+    trace_printf("*******************\nsummary from method 'multilarge/%s'\n", gslnls_algorithm_name(control_int[2]));
+    trace_printf("number of iterations: %d\n", out->niter);
+    // (gsl_strerror of the convergence test's info = 1 / 2, i.e. of GSL_EDOM / GSL_ERANGE: what the reference prints)
+    trace_printf("reason for stopping: %s\n", gslnls_strerror(out->info));
+    trace_printf("initial ssr = %g\n", out->chisq_init);
+    trace_printf("final ssr = %g\n", out->ssr);
+    trace_printf("ssr/dof = %g\n", out->ssr / (n - p));
+    trace_printf("ssr achieved tolerance = %g\n", out->ssrtol);
+    trace_printf("function evaluations: %d\n", out->neval[0]);
+    trace_printf("jacobian-vector product evaluations: %d\n", out->neval[1]);
+    trace_printf("jacobian-jacobian product evaluations: %d\n", out->neval[2]);
+    trace_printf("fvv evaluations: %d\n", out->neval[3]);
+    trace_printf("status = %s\n*******************\n", gslnls_strerror(out->conv));
     return R.status;
 }
 
@@ -1004,6 +1024,91 @@ int gslnls_dense_diagnostics(gslnls_dense *h, int jac, const double *par, const 
     return h->impl->diagnostics(jac, par, control_int, control_dbl, hat, cooks);
 }
 
+// ---- trace = TRUE: the text of a verbose call (trace_log.hpp) ------------------------------------------------------------
+// iteration lines of the final solve (callback, src/nls.c:980-995; none under a robust loss: callback_irls only records,
+// src/nls_irls.c:364-374) + the summary block (src/nls.c:610-630), appended to `log`
+static void format_nls_trace(const gslnls_result *res, int n, int p, const int *ci, int loss_rho, std::string &log)
+{
+    char buf[512];
+    auto put = [&](const char *fmt, auto... a) {
+        snprintf(buf, sizeof(buf), fmt, a...);
+        log += buf;
+    };
+    const int maxiter = ci[0];
+    if (!loss_rho && res->ssrtrace && res->partrace)
+        for (int it = 1; it <= res->niter && it <= maxiter; ++it)
+        {
+            put("iter %3d: ssr = %g, par = (", it, res->ssrtrace[it]);
+            for (int k = 0; k < p; ++k)
+                put((k < p - 1) ? "%g, " : "%g)\n", res->partrace[it + (size_t)(maxiter + 1) * trace_index(k, p)]);
+        }
+    put("*******************\nsummary from method 'multifit/%s'\n", gslnls_algorithm_name(ci[2]));
+    if (loss_rho)
+    {
+        put("IRLS number of iterations: %d\n", res->irls_niter);
+        put("IRLS achieved tolerance: %g\n", res->irls_tol);
+        put("IRLS convergence status: %s\n", gslnls_strerror(res->irls_status));
+    }
+    put("number of iterations: %d\n", res->niter);
+    put("initial ssr: %g\n", res->chisq_init);
+    put("final ssr: %g\n", res->ssr);
+    put("ssr/dof: %g\n", res->ssr / (n - p));
+    put("ssr achieved tolerance: %g\n", res->ssrtol);
+    put("function evaluations: %d\n", res->neval[0]);
+    put("jacobian evaluations: %d\n", res->neval[1]);
+    put("fvv evaluations: %d\n", res->neval[2]);
+    put("status: %s\n*******************\n", gslnls_strerror(res->conv));
+}
+
+static size_t copy_text(const std::string &t, char *buf, size_t cap)
+{
+    if (buf && cap)
+    {
+        const size_t k = t.size() < cap - 1 ? t.size() : cap - 1;
+        memcpy(buf, t.data(), k);
+        buf[k] = 0;
+    }
+    return t.size();
+}
+
+size_t gslnls_trace_text(char *buf, size_t cap) { return copy_text(g_trace_log, buf, cap); }
+
+size_t gslnls_format_trace(const gslnls_result *res, int n, int p, const int *control_int, int loss_rho, char *buf, size_t cap)
+{
+    if (!res || !control_int || p < 1)
+        return 0;
+    std::string t;
+    format_nls_trace(res, n, p, control_int, loss_rho, t);
+    return copy_text(t, buf, cap);
+}
+
+int gslnls_trace_set_order(const int *par_order, int p)
+{
+    g_trace_inv.clear();
+    if (!par_order || p < 1)
+        return GSLNLS_SUCCESS;
+    g_trace_inv.assign(p, -1);
+    for (int j = 0; j < p; ++j)
+        if (par_order[j] >= 0 && par_order[j] < p)
+            g_trace_inv[par_order[j]] = j;
+    for (int k = 0; k < p; ++k)
+        if (g_trace_inv[k] < 0)
+        {
+            g_trace_inv.clear();
+            return GSLNLS_EINVAL; // not a permutation
+        }
+    return GSLNLS_SUCCESS;
+}
+
+// closes the log of a verbose gslnls_nls* call: a fit that produced a result (any GSL status) gets its lines
+static void trace_finish_nls(int rc, const gslnls_result *out, int n, int p, const int *ci, int loss_rho)
+{
+    if (g_trace_on && rc > GSLNLS_E_NODEVICE)
+        format_nls_trace(out, n, p, ci, loss_rho, g_trace_log);
+    g_trace_on = false;
+    g_trace_inv.clear();
+}
+
 int gslnls_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv, const double *start,
                int start_is_matrix, const double *swts, int swts_is_matrix, const double *lupars,
                const int *control_int, const double *control_dbl, const int *has_start, int loss_rho,
@@ -1013,6 +1118,7 @@ int gslnls_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv,
         return GSLNLS_E_UNSUPPORTED; // GLS: n x n factor, not lowered
     g_call_prof = CallProfile();
     const double t0 = now_s();
+    trace_begin(control_int && control_int[1] != 0);
 #ifndef GSLNLS_NO_EXPR
     if (fn && fn->id == GSLNLS_MODEL_EXPR && fn->p > 64) // (WIDE_MAX_P, vm_program.hpp)
     {
@@ -1022,6 +1128,7 @@ int gslnls_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv,
         const int rcb = bd_formula_nls(fn, y, n, jac, fvv, start, start_is_matrix, has_start, g_comm, swts, lupars, control_int,
                                        control_dbl, loss_rho, loss_cc, out);
         g_call_prof.total_ms = 1e3 * (now_s() - t0);
+        trace_finish_nls(rcb, out, n, fn->p, control_int, loss_rho);
         return rcb;
     }
 #endif
@@ -1052,6 +1159,7 @@ int gslnls_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv,
     g_call_prof.loop_ms = 1e3 * (t2 - t1) - g_call_prof.finalize_ms - g_call_prof.d2h_ms;
     g_call_prof.destroy_ms = 1e3 * (t3 - t2);
     g_call_prof.total_ms = 1e3 * (t3 - t0);
+    trace_finish_nls(rc, out, n, fn->p, control_int, loss_rho);
     return rc;
 }
 
@@ -1063,8 +1171,11 @@ int gslnls_nls_fn(int n, int p, const double *y, gslnls_fn_cb f, gslnls_jac_cb j
         return GSLNLS_EINVAL;
     if (p > 4096)
         return GSLNLS_E_UNSUPPORTED;
-    return bd_callback_nls(n, p, y, f, jac, fvv, user, start, 0, nullptr, g_comm, swts, lupars, control_int, control_dbl, 0, nullptr,
-                           out);
+    trace_begin(control_int[1] != 0);
+    const int rc = bd_callback_nls(n, p, y, f, jac, fvv, user, start, 0, nullptr, g_comm, swts, lupars, control_int, control_dbl, 0,
+                                   nullptr, out);
+    trace_finish_nls(rc, out, n, p, control_int, 0);
+    return rc;
 }
 
 int gslnls_nls_fn_loss(int n, int p, const double *y, gslnls_fn_cb f, gslnls_jac_cb jac, gslnls_fvv_cb fvv, void *user,
@@ -1076,8 +1187,11 @@ int gslnls_nls_fn_loss(int n, int p, const double *y, gslnls_fn_cb f, gslnls_jac
         return GSLNLS_EINVAL;
     if (p > 4096)
         return GSLNLS_E_UNSUPPORTED;
-    return bd_callback_nls(n, p, y, f, jac, fvv, user, start, 0, nullptr, g_comm, swts, lupars, control_int, control_dbl, loss_rho,
-                           loss_cc, out);
+    trace_begin(control_int[1] != 0);
+    const int rc = bd_callback_nls(n, p, y, f, jac, fvv, user, start, 0, nullptr, g_comm, swts, lupars, control_int, control_dbl,
+                                   loss_rho, loss_cc, out);
+    trace_finish_nls(rc, out, n, p, control_int, loss_rho);
+    return rc;
 }
 
 int gslnls_nls_fn_mstart(int n, int p, const double *y, gslnls_fn_cb f, gslnls_jac_cb jac, gslnls_fvv_cb fvv, void *user,
@@ -1090,8 +1204,11 @@ int gslnls_nls_fn_mstart(int n, int p, const double *y, gslnls_fn_cb f, gslnls_j
         return GSLNLS_EINVAL;
     if (p > 4096)
         return GSLNLS_E_UNSUPPORTED;
-    return bd_callback_nls(n, p, y, f, jac, fvv, user, start2p, 1, has_start, g_comm, swts, lupars, control_int, control_dbl,
-                           loss_rho, loss_cc, out);
+    trace_begin(control_int[1] != 0);
+    const int rc = bd_callback_nls(n, p, y, f, jac, fvv, user, start2p, 1, has_start, g_comm, swts, lupars, control_int, control_dbl,
+                                   loss_rho, loss_cc, out);
+    trace_finish_nls(rc, out, n, p, control_int, loss_rho);
+    return rc;
 }
 
 int gslnls_last_call_profile(double *ms, int cap)
@@ -1124,6 +1241,10 @@ const char *gslnls_strerror(int code)
         return "failure";
     case GSLNLS_CONTINUE:
         return "the iteration has not converged yet";
+    case 1:
+        return "input domain error"; // GSL_EDOM (only ever printed as "reason for stopping" of the large path, info = 1)
+    case 2:
+        return "output range error"; // GSL_ERANGE (the same, info = 2)
     case GSLNLS_EINVAL:
         return "invalid argument supplied by user";
     case GSLNLS_EBADFUNC:

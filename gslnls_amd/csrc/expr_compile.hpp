@@ -180,7 +180,7 @@ struct ExprCompiler
                 {"exp", VM_EXP}, {"log", VM_LOG}, {"sin", VM_SIN}, {"cos", VM_COS}, {"tan", VM_TAN},
                 {"atan", VM_ATAN}, {"sqrt", VM_SQRT}, {"abs", VM_ABS}, {"tanh", VM_TANH}, {"sinh", VM_SINH},
                 {"cosh", VM_COSH}, {"asin", VM_ASIN}, {"acos", VM_ACOS}, {"log1p", VM_LOG1P}, {"expm1", VM_EXPM1},
-                {"pnorm", VM_PNORM}};
+                {"pnorm", VM_PNORM}, {"gamma", VM_GAMMA}, {"lgamma", VM_LGAMMA}, {"digamma", VM_PSI0}, {"trigamma", VM_PSI1}};
             // the standard selfStart models by their closed forms (stats::SSasymp & co.: the reference's unit tests 6.x fit
             // y ~ SSasymp(x, Asym, R0, lrc), inst/unit_tests/unit_tests_gslnls.R:267-293; R evaluates the model's own
             // compiled gradient attribute, here the closed form is differentiated like any other expression)
@@ -246,6 +246,23 @@ struct ExprCompiler
                     return sub(As, mul(Dr, ex(neg(mul(ex(lrc), op2(VM_POW, in, pw))))));
                 }
             }
+            if (t->name == "psigamma" && (t->args.size() == 1 || t->args.size() == 2))
+            {
+                // psigamma(x, deriv = 0L): the order has to be a literal 0..4 (stats::deriv's own rule: a constant order)
+                int order = 0;
+                if (t->args.size() == 2)
+                {
+                    const int on = build(t->args[1], parnames, varnames);
+                    const double ov = nodes[on].kind == K_CONST ? nodes[on].c : NAN;
+                    if (!(ov == 0.0 || ov == 1.0 || ov == 2.0 || ov == 3.0 || ov == 4.0))
+                    {
+                        error = "psigamma: the order has to be a constant 0..4";
+                        return cst(NAN);
+                    }
+                    order = (int)ov;
+                }
+                return op1((unsigned char)(VM_PSI0 + order), build(t->args[0], parnames, varnames));
+            }
             if (t->args.size() != 1)
             {
                 error = "unsupported function " + t->name + " (one argument expected)";
@@ -258,6 +275,10 @@ struct ExprCompiler
                 return op2(VM_DIV, op1(VM_LOG, arg), cst(2.30258509299404568402));
             if (t->name == "dnorm") // exp(-x^2 / 2) / sqrt(2 pi)
                 return op2(VM_MUL, op1(VM_EXP, op2(VM_MUL, cst(-0.5), op2(VM_MUL, arg, arg))), cst(0.39894228040143267794));
+            if (t->name == "factorial") // gamma(x + 1)
+                return op1(VM_GAMMA, op2(VM_ADD, arg, cst(1.0)));
+            if (t->name == "lfactorial") // lgamma(x + 1)
+                return op1(VM_LGAMMA, op2(VM_ADD, arg, cst(1.0)));
             if (t->name == "sinpi" || t->name == "cospi" || t->name == "tanpi")
                 return op1(t->name == "sinpi" ? VM_SIN : (t->name == "cospi" ? VM_COS : VM_TAN),
                            op2(VM_MUL, cst(3.14159265358979323846), arg));
@@ -379,6 +400,22 @@ struct ExprCompiler
                 break;
             case VM_EXPM1:
                 r = op2(VM_MUL, op1(VM_EXP, a), diff(a, k, dcache, dep));
+                break;
+            case VM_GAMMA: // gamma(a) digamma(a) a'
+                r = op2(VM_MUL, op2(VM_MUL, n, op1(VM_PSI0, a)), diff(a, k, dcache, dep));
+                break;
+            case VM_LGAMMA:
+                r = op2(VM_MUL, op1(VM_PSI0, a), diff(a, k, dcache, dep));
+                break;
+            case VM_PSI0:
+            case VM_PSI1:
+            case VM_PSI2:
+            case VM_PSI3: // psigamma(a, n)' = psigamma(a, n + 1) a'
+                r = op2(VM_MUL, op1((unsigned char)(nd.op + 1), a), diff(a, k, dcache, dep));
+                break;
+            case VM_PSI4:
+                error = "psigamma: derivative beyond order 4";
+                r = cst(NAN);
                 break;
             case VM_PNORM: // dnorm(a) a'
                 r = op2(VM_MUL, op2(VM_MUL, op1(VM_EXP, op2(VM_MUL, cst(-0.5), op2(VM_MUL, a, a))), cst(0.39894228040143267794)),

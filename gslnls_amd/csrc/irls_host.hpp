@@ -5,6 +5,7 @@
 // irls_kernels.hpp.  It reads back only the p-sized state to apply the stopping rule
 // test_delta_irls (src/nls_irls.c:343-362); residuals, weights, psi, psi' stay in HBM until the end.
 #pragma once
+#include "trace_log.hpp"
 #include "dense_host.hpp"
 #include "irls_kernels.hpp"
 
@@ -117,6 +118,8 @@ int DenseFit<M>::irls(int jac, int fvv, const double *start, const double *lupar
         if (irls_iter == 1)
             chisq_init = s.chisq_init;
         chisq_carry = s.chisq1;
+        trace_printf("IRLS iter: %3d, weighted ssr: %g, par: (", irls_iter, s.chisq1); // (src/nls_irls.c:466-472)
+        trace_vector(s.x, P);
         if (status == ST_EBADFUNC || (status == ST_ENOPROG && irls_iter == 1))
             break;
 

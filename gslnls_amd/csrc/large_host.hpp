@@ -9,6 +9,7 @@
 // two device passes of large_kernels.hpp.  Residual, m = exp(A x) and the row data never leave
 // HBM during the iteration.
 #pragma once
+#include "trace_log.hpp"
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <float.h>
@@ -413,12 +414,19 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
         std::vector<double> A, rhs(p);
         for (int i = 0; i < p; ++i)
             rhs[i] = -g[i];
-        auto damped = [&]() { // A = J^T J + mu D^2 on the host (not needed when J^T J is taken where it sits on the device)
-            if (!host_jtj_valid && ops.jtj_download(JTJ.data()) == GSLNLS_SUCCESS)
+        // A = J^T J + mu D^2 on the host (not needed when J^T J is taken where it sits on the device); a host copy that
+        // cannot be fetched is an error of the fit, never a reason to go on with a stale or empty matrix
+        auto damped = [&]() -> int {
+            if (!host_jtj_valid)
+            {
+                if (ops.jtj_download(JTJ.data()) != GSLNLS_SUCCESS)
+                    return GSLNLS_E_NODEVICE;
                 host_jtj_valid = true;
+            }
             A = JTJ;
             for (int i = 0; i < p; ++i)
                 A[(size_t)i * p + i] += mu * diag[i] * diag[i];
+            return GSLNLS_SUCCESS;
         };
         vel.assign(p, 0.0);
         int drc = GSLNLS_E_UNSUPPORTED; // (below the threshold, or a size the device routine does not take: p > 4096)
@@ -428,14 +436,16 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
                 drc = mchol_device_solve_resident(p, jd, diag.data(), mu, rhs.data(), vel.data());
             else
             {
-                damped();
+                if (const int e = damped())
+                    return e;
                 drc = mchol_device_solve(p, A.data(), rhs.data(), vel.data());
             }
         }
         if (drc == GSLNLS_E_UNSUPPORTED)
         {
             if (A.empty())
-                damped();
+                if (const int e = damped())
+                    return e;
             lg_mchol_solve(p, A, rhs, vel);
         }
         else if (drc != GSLNLS_SUCCESS)
@@ -501,8 +511,12 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
                         {
                             if (const double *jd = ops.jtj_device())
                                 rows_done = mchol_device_symv(p, jd, vel.data(), wp.data()) == GSLNLS_SUCCESS;
-                            if (!rows_done && !host_jtj_valid && ops.jtj_download(JTJ.data()) == GSLNLS_SUCCESS)
+                            if (!rows_done && !host_jtj_valid)
+                            {
+                                if (ops.jtj_download(JTJ.data()) != GSLNLS_SUCCESS)
+                                    return GSLNLS_E_NODEVICE;
                                 host_jtj_valid = true;
+                            }
                         }
                         for (int i = 0; i < p; ++i)
                         {
@@ -578,6 +592,47 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
         if (partrace)
             for (int k = 0; k < p; ++k)
                 partrace[iter + (size_t)(maxiter + 1) * k] = x[k];
+        if (g_trace_on)
+        {
+            // callback_large (src/nls_large.c:715-739): |x|^2 and cond(J) = 1 / gsl_multilarge_nlinear_rcond.  GSL's
+            // Steihaug-Toint solver reports rcond = 0 (cgst.c: not implemented) -> inf; its lm solver the square root of
+            // the 1-norm reciprocal condition of J^T J from the Cholesky factor (cholesky.c: gsl_linalg_cholesky_rcond, an
+            // estimator) -- here the 1-norm condition itself, from the explicit inverse (trace runs only)
+            double xsq = 0.0, cond = INFINITY;
+            for (int k = 0; k < p; ++k)
+                xsq += x[k] * x[k];
+            if (need_jtj)
+            {
+                if (!host_jtj_valid)
+                {
+                    if (ops.jtj_download(JTJ.data()) != GSLNLS_SUCCESS)
+                        return GSLNLS_E_NODEVICE;
+                    host_jtj_valid = true;
+                }
+                std::vector<double> Ai(JTJ);
+                double n1 = 0.0, n1i = 0.0;
+                for (int j = 0; j < p; ++j)
+                {
+                    double c = 0.0;
+                    for (int i = 0; i < p; ++i)
+                        c += fabs(JTJ[(size_t)i * p + j]);
+                    n1 = fmax(n1, c);
+                }
+                if (lg_chol(p, Ai))
+                {
+                    lg_chol_invert(p, Ai);
+                    for (int j = 0; j < p; ++j)
+                    {
+                        double c = 0.0;
+                        for (int i = 0; i < p; ++i)
+                            c += fabs(Ai[(size_t)i * p + j]);
+                        n1i = fmax(n1i, c);
+                    }
+                    cond = sqrt(n1 * n1i);
+                }
+            }
+            trace_printf("iter %3d: ssr = %g, |x|^2 = %g, cond(J) = %g\n", iter, fnorm2, xsq, cond);
+        }
         // gsl_multilarge_nlinear_test
         bool ok = true;
         for (int i = 0; i < p && ok; ++i)

@@ -27,6 +27,7 @@
 #include <vector>
 #include "lm_core.hpp"
 #include "sobol.hpp"
+#include "trace_log.hpp"
 
 namespace gslnls
 {
@@ -140,6 +141,7 @@ struct MsState
     long long next_draw = 0; // global Sobol draw counter (gsl_qrng state)
     double xtol = 0, ftol = 0;
     long long total_fits = 0; // concentration + local-search fits actually run (for the benchmark)
+    bool second_pass = false; // the robust second pass (use_weights of gsl_multistart_driver: only the trace line differs)
 };
 
 inline int ms_run_batch(MsEvaluator &ev, const MsComm &comm, MsBatch &b)
@@ -439,6 +441,10 @@ inline int ms_major_iteration(MsState &m, MsEvaluator &ev, const MsComm &comm)
                             for (int k = 0; k < p; ++k)
                                 m.diag[k] = pow(diagmin / rdiag[k], 0.25);
                         }
+                        // (src/nls_mstart.c:331-337)
+                        trace_printf("mstart%s ssr* = %g, det(JTJ) = %g, NSP = %d, NWSP = %d, par = (", m.second_pass ? " (second pass)" : "",
+                                     m.mssropt[0], det1, m.nsp, m.nwsp);
+                        trace_vector(rx, p);
                     }
                 }
                 else if (mchisq1 < 0.99 * fmin(m.mssropt[0], m.mssropt[1]))
@@ -481,6 +487,17 @@ inline int ms_major_loop(MsState &m, MsEvaluator &ev, const MsComm &comm, const 
         }
     } while (m.mstop == ST_CONTINUE);
     return 0;
+}
+
+// the two lines that close the multi-start stage of a verbose call (src/nls.c:510-517)
+inline void ms_trace_finished(const MsState &m)
+{
+    if (m.mstop == ST_SUCCESS)
+        trace_printf("multi-start algorithm finished successfully (NSP = %d, NWSP = %d, # iterations = %d)\n", m.nsp, m.nwsp, m.mstarts);
+    if (m.mstop == ST_EMAXITER)
+        trace_printf("multi-start algorithm reached max. number of global iterations (NSP = %d, NWSP = %d, # iterations = %d)\n", m.nsp,
+                     m.nwsp, m.mstarts);
+    trace_printf("*******************\n");
 }
 
 // state set-up of src/nls.c:297-369

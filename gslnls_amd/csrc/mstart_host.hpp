@@ -318,6 +318,7 @@ int DenseFit<M>::mstart(int jac, int fvv, const double *start2p, const double *l
             ctx.sw = d_sw_robust;
             ev.prm.has_weights = 1;
             m.next_draw = 0; // gsl_qrng_init
+            m.second_pass = true;
             m.mstop = ST_CONTINUE;
             m.mstarts = m.nsp = m.nwsp = 0;
             m.dtol = 1.0e-6;
@@ -333,6 +334,7 @@ int DenseFit<M>::mstart(int jac, int fvv, const double *start2p, const double *l
         if (rc)
             return rc < 0 && rc > -100 ? GSLNLS_FAILURE : rc;
     }
+    ms_trace_finished(m);
     // src/nls.c:518-531
     if (m.mssropt[1] < m.mssropt[0])
     {

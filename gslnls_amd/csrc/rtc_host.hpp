@@ -81,7 +81,7 @@ inline std::string rtc_emit_ops(const Prog &pr, int upto, bool sink = false)
         return "v" + std::to_string(slot - base);
     };
     static const char *fn1[] = {"", "", "", "", "", "", "", "gexp", "log", "sin", "cos", "tan", "atan", "sqrt", "fabs", "tanh", "",
-                                "sinh", "cosh", "asin", "acos", "log1p", "expm1", ""};
+                                "sinh", "cosh", "asin", "acos", "log1p", "expm1", "", "tgamma", "lgamma", "", "", "", "", ""};
     std::string s;
     for (int i = 0; i < upto; ++i)
     {
@@ -97,6 +97,9 @@ inline std::string rtc_emit_ops(const Prog &pr, int upto, bool sink = false)
         case VM_POW: e = "pow(" + a + ", " + b + ")"; break;
         case VM_SIGN: e = "(" + a + " > 0.0 ? 1.0 : (" + a + " < 0.0 ? -1.0 : 0.0))"; break;
         case VM_PNORM: e = "0.5 * erfc(-" + a + " * 0.70710678118654752440)"; break;
+        case VM_PSI0: case VM_PSI1: case VM_PSI2: case VM_PSI3: case VM_PSI4:
+            e = "gpsigamma(" + a + ", " + std::to_string((int)pr.op[i] - (int)VM_PSI0) + ")";
+            break;
         default: e = std::string(fn1[pr.op[i]]) + "(" + a + ")"; break;
         }
         s += "        const double v" + std::to_string(i) + " = " + e + ";\n";

@@ -52,7 +52,16 @@ enum VmOp : unsigned char
     VM_ACOS,
     VM_LOG1P,
     VM_EXPM1,
-    VM_PNORM // standard normal distribution function: 0.5 erfc(-x / sqrt(2))
+    VM_PNORM, // standard normal distribution function: 0.5 erfc(-x / sqrt(2))
+    // the gamma family of the same table (round 5): gamma, lgamma, and psigamma(x, n) for n = 0 (digamma), 1 (trigamma), 2, 3, 4
+    // -- each the derivative of the one before it (devmath.hpp: gpsigamma)
+    VM_GAMMA,
+    VM_LGAMMA,
+    VM_PSI0,
+    VM_PSI1,
+    VM_PSI2,
+    VM_PSI3,
+    VM_PSI4
 };
 
 template <int MAX_OPS, int MAX_CONST, int MAX_P, bool PACKED>
@@ -110,6 +119,13 @@ inline double vm_apply_long(unsigned int op, double x, double y)
     case VM_LOG1P: return log1p(x);
     case VM_EXPM1: return expm1(x);
     case VM_PNORM: return 0.5 * erfc(-x * 0.70710678118654752440);
+    case VM_GAMMA: return tgamma(x);
+    case VM_LGAMMA: return lgamma(x);
+    case VM_PSI0: return gpsigamma(x, 0);
+    case VM_PSI1: return gpsigamma(x, 1);
+    case VM_PSI2: return gpsigamma(x, 2);
+    case VM_PSI3: return gpsigamma(x, 3);
+    case VM_PSI4: return gpsigamma(x, 4);
     default: return NAN;
     }
 }

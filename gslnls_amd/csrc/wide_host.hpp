@@ -1037,6 +1037,8 @@ struct WideFit : DenseBase
             if (irls_iter == 1)
                 chisq_init = s.chisq_init;
             chisq_carry = s.chisq1;
+            trace_printf("IRLS iter: %3d, weighted ssr: %g, par: (", irls_iter, s.chisq1); // (src/nls_irls.c:466-472)
+            trace_vector(s.x, p);
             if (status == ST_EBADFUNC || (status == ST_ENOPROG && irls_iter == 1))
                 break;
             // ---- re-weighting chain, all on the device ----
@@ -1317,6 +1319,7 @@ struct WideFit : DenseBase
                 cur_sw = d_sw_robust;
                 ev.prm.has_weights = 1;
                 m.next_draw = 0; // gsl_qrng_init
+            m.second_pass = true;
                 m.mstop = ST_CONTINUE;
                 m.mstarts = m.nsp = m.nwsp = 0;
                 m.dtol = 1.0e-6;
@@ -1332,6 +1335,7 @@ struct WideFit : DenseBase
             if (rc)
                 return rc < 0 && rc > -100 ? GSLNLS_FAILURE : rc;
         }
+        ms_trace_finished(m);
         if (m.mssropt[1] < m.mssropt[0])
         {
             m.mssropt[0] = m.mssropt[1];

@@ -16,11 +16,24 @@ import re
 
 import numpy as np
 
-_TOKEN = re.compile(r"\s*(?:(\d+\.?\d*(?:[eE][-+]?\d+)?|\.\d+(?:[eE][-+]?\d+)?)|([A-Za-z_.][A-Za-z_.0-9]*)|(\*\*|[-+*/^()~,]))")
+_TOKEN = re.compile(r"\s*(?:(\d+\.?\d*(?:[eE][-+]?\d+)?|\.\d+(?:[eE][-+]?\d+)?)|([A-Za-z_.][A-Za-z_.0-9]*)|(\*\*|<=|>=|==|!=|[-+*/^()~,<>]))")
 
 def _pnorm(x):
     from scipy.special import erfc
     return 0.5 * erfc(-np.asarray(x, dtype=np.float64) * 0.70710678118654752440)
+
+
+def _polygamma(x, n=0):
+    from scipy.special import digamma, polygamma
+    n = int(n)
+    return digamma(x) if n == 0 else polygamma(n, x)
+
+
+def _gammafn(name):
+    def f(x):
+        import scipy.special as sp
+        return getattr(sp, name)(np.asarray(x, dtype=np.float64))
+    return f
 
 
 # the functions stats::deriv differentiates (R/nls.R:588-599 builds the Jacobian of a formula with it); csrc/expr_compile.hpp
@@ -31,6 +44,14 @@ FUNCS = {"exp": np.exp, "log": np.log, "sin": np.sin, "cos": np.cos, "tan": np.t
          "dnorm": lambda x: np.exp(-0.5 * np.asarray(x, dtype=np.float64) ** 2) * 0.39894228040143267794,
          "sinpi": lambda x: np.sin(np.pi * np.asarray(x)), "cospi": lambda x: np.cos(np.pi * np.asarray(x)),
          "tanpi": lambda x: np.tan(np.pi * np.asarray(x)),
+         "gamma": _gammafn("gamma"), "lgamma": _gammafn("gammaln"), "digamma": _gammafn("digamma"),
+         "trigamma": lambda x: _polygamma(x, 1), "psigamma": _polygamma,
+         "factorial": lambda x: _gammafn("gamma")(np.asarray(x, dtype=np.float64) + 1.0),
+         "lfactorial": lambda x: _gammafn("gammaln")(np.asarray(x, dtype=np.float64) + 1.0),
+         # R functions outside stats::deriv's table: a formula that uses them cannot be lowered to the device (nor
+         # differentiated by the reference); the mirror evaluates them in the closure route, as R evaluates .fn
+         "ifelse": lambda c, a, b: np.where(c, a, b), "pmax": lambda *a: np.maximum.reduce(np.broadcast_arrays(*a)),
+         "pmin": lambda *a: np.minimum.reduce(np.broadcast_arrays(*a)),
          # the standard selfStart models by their closed forms (stats::SSasymp & co.)
          "SSasymp": lambda x, Asym, R0, lrc: Asym + (R0 - Asym) * np.exp(-np.exp(lrc) * x),
          "SSasympOff": lambda x, Asym, lrc, c0: Asym * (1 - np.exp(-np.exp(lrc) * (x - c0))),
@@ -96,6 +117,14 @@ class _Parser:
         return tok
 
     def expr(self):
+        # comparisons bind weaker than + - (R's precedence); they only occur inside ifelse() and the like
+        node = self.sum()
+        while self.peek()[0] == "op" and self.peek()[1] in ("<", ">", "<=", ">=", "==", "!="):
+            op = self.take()[1]
+            node = Node(op, (node, self.sum()))
+        return node
+
+    def sum(self):
         node = self.term()
         while self.peek() in (("op", "+"), ("op", "-")):
             op = self.take()[1]
@@ -209,6 +238,9 @@ def evaluate(node, env):
         return a / b
     if op == "^":
         return np.power(a, b)
+    cmp = {"<": np.less, ">": np.greater, "<=": np.less_equal, ">=": np.greater_equal, "==": np.equal, "!=": np.not_equal}
+    if op in cmp:
+        return cmp[op](a, b)
     raise ValueError(op)
 
 

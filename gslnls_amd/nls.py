@@ -203,6 +203,15 @@ class DenseProblem:
         return float(_lib.lib().gslnls_dense_time_pass(self._h, int(bool(jac)), _dp(th), int(reps)))
 
 
+def _print_trace(trace):
+    """trace = TRUE: what the reference prints while it runs (iteration lines, multi-start / IRLS progress, the summary
+    block; src/nls.c:610-630, :980-995) -- collected by the core, printed here once the call is back, as the R shim
+    does with Rprintf"""
+    if trace:
+        import sys
+        sys.stdout.write(_lib.trace_text())
+
+
 def _finish(out, res, trace, algorithm, n):
     out.update(niter=res.niter, conv=res.conv, status=_lib.strerror(res.conv), ssr=res.ssr, ssrtol=res.ssrtol,
                algorithm=_lib.lib().gslnls_algorithm_name(ALGORITHMS.index(algorithm)).decode(),
@@ -329,6 +338,7 @@ def _gsl_nls_function(fn, y, start, algorithm, control, jac, fvv, trace, weights
     if errors:
         raise errors[0]
     _lib.check(rc)
+    _print_trace(trace)
     fit = _finish(out, res, trace, algorithm, n)
     fit["solver_served"] = bool(_lib.lib().gslnls_solver_served(ci.ctypes.data_as(IP), C.byref(res)))
     fit["parnames"] = names
@@ -445,11 +455,39 @@ def gsl_nls(fn, data=None, start=None, algorithm="lm", control=None, jac=None, f
         out["partrace"] = np.full((ctrl["maxiter"] + 1, p), np.nan, order="F")
         out["ssrtrace"] = np.full(ctrl["maxiter"] + 1, np.nan)
         res.partrace, res.ssrtrace = _dp(out["partrace"]), _dp(out["ssrtrace"])
+    if trace:
+        od = np.ascontiguousarray(order, dtype=np.int32)
+        _lib.lib().gslnls_trace_set_order(od.ctypes.data_as(IP), p)  # printed vectors in the caller's parameter order
     rc = _lib.lib().gslnls_nls(C.byref(m), yc.ctypes.data_as(C.c_void_p), n, int(bool(jac)), int(bool(fvv)),
                                _dp(st), int(mat is not None), None if sw is None else sw.ctypes.data_as(C.c_void_p),
                                sw_is_matrix, _dp(lu), ci.ctypes.data_as(IP), _dp(cd), hs.ctypes.data_as(IP),
                                LOSSES.index(loss_cfg["rho"]), _dp(cc), C.byref(res))
+    if rc == _lib.E_UNSUPPORTED and mid == _lib.MODEL_EXPR and not sw_is_matrix and ALGORITHMS.index(algorithm) <= 1:
+        # The core cannot lower this right-hand side (a function outside stats::deriv's table -- ifelse, pmax, ... --, a
+        # comparison, too long a program).  The reference never lowers anything: its .fn closure evaluates the expression
+        # (R/nls.R:565) and, where stats::deriv fails, jac stays NULL with a warning (R/nls.R:588-599).  The same here:
+        # the expression evaluated by this module's own evaluator becomes the model closure of the callback route
+        # (gslnls_nls_fn_loss / gslnls_nls_fn_mstart: every n x p and p x p operation still on the device).
+        import warnings
+        cols = {k: np.asarray(v, dtype=np.float64) for k, v in data.items()}
+
+        def closure(th, _rhs=rhs, _names=names):
+            env = dict(cols)
+            env.update(zip(_names, th))
+            v = np.asarray(F.evaluate(_rhs, env), dtype=np.float64)
+            return np.broadcast_to(v, (n,)).copy() if v.shape != (n,) else v
+        if jac:
+            warnings.warn("failed to symbolically derive 'jac': the model expression is not in the derivatives table; "
+                          "finite differences are used")
+        if fvv:
+            warnings.warn("failed to symbolically derive 'fvv': the model expression is not in the derivatives table; "
+                          "finite differences are used")
+        fit = _gsl_nls_function(closure, yv, start, algorithm, ctrl, None, None, trace, weights, lower, upper, loss,
+                                parnames=names)
+        fit["lowered"] = False
+        return fit
     _lib.check(rc)
+    _print_trace(trace)
     fit = _finish(out, res, trace, algorithm, n)
     # solver routing rule of the boundary (include/gslnls_core.h): a "qr" / "svd" request is served on the normal
     # equations only while the scaled condition number allows it; the R shim re-runs such a fit through GSL, this

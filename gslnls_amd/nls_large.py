@@ -79,6 +79,10 @@ class LargeProblem:
         rc = _lib.lib().gslnls_large_solve(self._h, st.ctypes.data_as(DP), ci.ctypes.data_as(IP),
                                            cd.ctypes.data_as(DP), C.byref(res))
         _lib.check(rc)
+        if trace:
+            # what callback_large and the summary block print (src/nls_large.c:259-273, :715-739), collected by the core
+            import sys
+            sys.stdout.write(_lib.trace_text())
         out.update(niter=res.niter, conv=res.conv, status=_lib.strerror(res.conv), ssr=res.ssr, ssrtol=res.ssrtol,
                    chisq_init=res.chisq_init, info=res.info, n=n,
                    algorithm=_lib.lib().gslnls_algorithm_name(LARGE_ALGORITHMS.index(algorithm)).decode(),

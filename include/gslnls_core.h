@@ -193,6 +193,22 @@ int gslnls_nls_fn_mstart(int n, int p, const double *y, gslnls_fn_cb f, gslnls_j
                          const int *control_int, const double *control_dbl, int loss_rho, const double *loss_cc,
                          gslnls_result *out);
 
+/* trace = TRUE (control_int[1] != 0).  The reference prints while it runs: one line per iteration of the final solve
+ * (src/nls.c:980-995), one per accepted stationary point of the multi-start stage and its closing lines
+ * (src/nls_mstart.c:331-337, src/nls.c:510-517), one per IRLS iteration (src/nls_irls.c:466-472), the summary block
+ * (src/nls.c:610-630); on the large path one line per iteration with |x|^2 and cond(J) and its own summary
+ * (src/nls_large.c:259-273, :715-739).  The core collects exactly that text, in that order, during gslnls_nls /
+ * gslnls_nls_fn* / gslnls_nls_large / gslnls_large_solve; the binding prints it after the call has returned (Rprintf may
+ * long-jump on a user interrupt and must not run below the core's C++ frames).  gslnls_trace_text copies the text of the
+ * last call (NUL-terminated, truncated to cap) and returns its full length; an empty text when trace was off.
+ * gslnls_format_trace: the iteration lines + summary block alone, from a result that carries partrace / ssrtrace (what
+ * the entry points append themselves; exposed so that the format can be checked without a device). */
+size_t gslnls_trace_text(char *buf, size_t cap);
+/* par_order[j] = the caller's index of the core's j-th parameter (what gslnls_lower_formula returned; NULL = identity):
+ * the parameter vectors of the NEXT verbose call are printed in the caller's order.  Consumed by that call. */
+int gslnls_trace_set_order(const int *par_order, int p);
+size_t gslnls_format_trace(const gslnls_result *res, int n, int p, const int *control_int, int loss_rho, char *buf, size_t cap);
+
 /* Where the wall time of the last gslnls_nls() call of this process went, milliseconds:
  *   ms[0] create (allocation / re-binding of a parked problem), [1] H2D of x, y, swts, [2] the solve loop (plus
  *   multi-start / IRLS driver work), [3] the finalize kernel (resid, grad, covar), [4] D2H of the result vectors,

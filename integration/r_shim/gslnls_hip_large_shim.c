@@ -237,6 +237,8 @@ SEXP C_nls_large_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, 
         return C_nls_large(fn, y, jac, fvv, env, start, weights, control_int, control_dbl);
     }
     const int ok = (out.conv == GSLNLS_SUCCESS || out.conv == GSLNLS_EMAXITER);
+    if (verbose)
+        print_trace_text(); /* callback_large's lines and the summary block (src/nls_large.c:259-273, :715-739) */
     if (lowered && ok)
     {
         /* `grad`: the Jacobian at the returned coefficients, from the closure the reference would have called last */

@@ -60,6 +60,9 @@ typedef struct
 {
     SEXP fcall, dfcall, fvvcall, rho, names;
     int n, p, startisnum, warn, r_error;
+    int bad_result; /* 1 fn, 2 jac, 3 fvv returned the wrong type / length: the warning of src/nls.c:843-844 (:891-892,
+                       :953-954) is raised by C_nls_hip once the core has returned -- Rf_warning long-jumps under
+                       options(warn = 2) and must not run below the core's C++ frames */
 } fn_route;
 
 static SEXP make_par(const fn_route *d, const double *theta)
@@ -98,8 +101,8 @@ static int cb_f(const double *theta, int p, double *fval, int n, void *user)
     }
     if (TYPEOF(v) != REALSXP || Rf_length(v) != n)
     {
-        if (d->warn)
-            Rf_warning("Evaluating fn does not return numeric vector of expected length n");
+        if (d->warn && !d->bad_result)
+            d->bad_result = 1;
         UNPROTECT(2);
         return 1; /* GSL_EBADFUNC, src/nls.c:843-844 */
     }
@@ -123,8 +126,8 @@ static int cb_jac(const double *theta, int p, double *J, int n, void *user)
     }
     if (TYPEOF(v) != REALSXP || !Rf_isMatrix(v) || Rf_ncols(v) != p || Rf_nrows(v) != n)
     {
-        if (d->warn)
-            Rf_warning("Evaluating jac does not return numeric matrix of dimensions n x p");
+        if (d->warn && !d->bad_result)
+            d->bad_result = 2;
         UNPROTECT(2);
         return 1;
     }
@@ -155,8 +158,8 @@ static int cb_fvv(const double *theta, const double *vdir, int p, double *out, i
     }
     if (TYPEOF(v) != REALSXP || Rf_length(v) != n)
     {
-        if (d->warn)
-            Rf_warning("Evaluating fvv does not return numeric vector of expected length n");
+        if (d->warn && !d->bad_result)
+            d->bad_result = 3;
         UNPROTECT(3);
         return 1;
     }
@@ -193,13 +196,13 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
     char cols[256];
     int model_id = 0;
     for (int k = 0; k < p; k++)
-        order[k] = k;
-    if (rhs != R_NilValue && p <= 64 && !Rf_isNull(parnames))
     {
-        for (int k = 0; k < p; k++)
-            pn[k] = CHAR(STRING_ELT(parnames, k));
-        model_id = gslnls_lower_formula(CHAR(STRING_ELT(rhs, 0)), p, pn, order, cols, sizeof(cols));
+        order[k] = k;
+        pn[k] = Rf_isNull(parnames) ? "" : CHAR(STRING_ELT(parnames, k)); /* (R_alloc does not zero: every entry, here) */
     }
+    cols[0] = 0;
+    if (rhs != R_NilValue && p <= 64 && !Rf_isNull(parnames))
+        model_id = gslnls_lower_formula(CHAR(STRING_ELT(rhs, 0)), p, pn, order, cols, sizeof(cols));
     const char *xn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     /* (up to 9 parameters and 3 data columns: interpreted or natively compiled row models; up to 64 parameters and 8
      * columns: the wide path, J^T J on the matrix cores; up to 512 parameters, single start: the Jacobian
@@ -210,23 +213,20 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
          * compiles it with its symbolic gradient -- the analogue of R/nls.R:565,588-599.  Data columns are the
          * variables of the RHS that are not parameters: all.vars(formula[[3]]) minus names(start). */
         int nxe = 0;
-        const int ok = formula_columns(formula, pn, p, cols, sizeof(cols), xn, &nxe);
-        if (ok)
-        {
-            for (int k = 0; k < p; k++)
-                pn[k] = CHAR(STRING_ELT(parnames, k));
+        if (formula_columns(formula, pn, p, cols, sizeof(cols), xn, &nxe))
             model_id = GSLNLS_MODEL_EXPR;
-        }
     }
-    /* a `function` model (no formula behind the closure): a single start goes to the core with the closures as callbacks
-     * (gslnls_nls_fn_loss: default or robust loss), any p up to 4096 */
-    const int fn_model = model_id <= 0 && formula == R_NilValue && TYPEOF(fn) == CLOSXP && !mstart && p <= 4096;
-    if ((model_id <= 0 && !fn_model) || Rf_isMatrix(swts) ||     /* does not lower, or GLS weights */
-        INTEGER(control_int)[2] > 1)                             /* dogleg / ddogleg / subspace2D */
+    /* What still leaves for GSL: GLS weights (an n x n factor), the dogleg family, more than 4096 parameters.  Everything
+     * else is served: a formula the core can lower has its rows evaluated on the device; ANY other closure -- a `function`
+     * model, or the .fn / .jac / .fvv closures gsl_nls.formula builds around a formula the compiler cannot lower (ifelse,
+     * pmax, user functions, symbols that are not columns of the model frame; R/nls.R:565-640) -- goes to the core as host
+     * callbacks (gslnls_nls_fn_loss / gslnls_nls_fn_mstart: single start or start ranges, default or robust loss). */
+    if (Rf_isMatrix(swts) || INTEGER(control_int)[2] > 1 || p > 4096 || TYPEOF(fn) != CLOSXP)
     {
         UNPROTECT(1);
         return C_nls(fn, y, jac, fvv, env, start, swts, lupars, control_int, control_dbl, has_start, loss_config);
     }
+    int fn_model = model_id <= 0; /* the closures as callbacks */
 
     /* data columns from the model frame, column-major n x nx in device regressor order */
     SEXP mf = fn_model ? R_UnboundValue : Rf_findVarInFrame(CLOENV(fn), Rf_install("mf"));
@@ -246,10 +246,9 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
             if (raw == R_NilValue)
             {
                 /* the symbol is not a column of the model frame (a global, a length-1 constant, ...): the closure
-                 * would still evaluate it through its enclosure, the device cannot -> the GSL path */
-                UNPROTECT(1);
-                return C_nls(fn, y, jac, fvv, env, start, swts, lupars, control_int, control_dbl, has_start,
-                             loss_config);
+                 * evaluates it through its enclosure, a device row model cannot -> the closures as callbacks */
+                fn_model = 1;
+                break;
             }
             SEXP col = PROTECT(Rf_coerceVector(raw, REALSXP));
             memcpy(X + (size_t)c * n, REAL(col), sizeof(double) * n);
@@ -271,10 +270,14 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
             model.lowering = GSLNLS_LOWER_VM;
     }
 
-    /* start / bounds / has_start permuted into device parameter order */
+    /* start / bounds / has_start permuted into device parameter order (the identity for the callback route: the closures
+     * take `par` in the caller's order) */
     double *st = (double *)R_alloc(2 * p, sizeof(double)), *lu = NULL;
     int *hs = (int *)R_alloc(2 * p, sizeof(int));
     SEXP startvec = PROTECT(Rf_coerceVector(start, REALSXP));
+    if (fn_model)
+        for (int k = 0; k < p; k++)
+            order[k] = k;
     for (int k = 0; k < p; k++)
     {
         if (mstart)
@@ -340,7 +343,22 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
         res.ssrtrace = REAL(strace);
     }
 
-    int rc;
+    int rc = GSLNLS_E_UNSUPPORTED;
+    if (verbose)
+        gslnls_trace_set_order(order, p); /* the printed parameter vectors in the caller's order */
+    if (!fn_model)
+    {
+        rc = gslnls_nls(&model, REAL(y), n, !Rf_isNull(jac), !Rf_isNull(fvv), st, mstart,
+                        Rf_isNull(swts) ? NULL : REAL(swts), 0, lu, INTEGER(control_int), REAL(control_dbl),
+                        hs, wgt_i, REAL(VECTOR_ELT(loss_config, 1)), &res);
+        if (rc == GSLNLS_E_UNSUPPORTED)
+        {
+            /* the core refused the expression after all (a function outside the lowering vocabulary, too many
+             * instructions, ...): the formula's own closures are still there.  Only GSLNLS_MODEL_EXPR can end up here,
+             * and it never permutes the parameters, so st / lu / hs are already in the caller's order. */
+            fn_model = 1;
+        }
+    }
     if (fn_model)
     {
         /* the calls the reference prepares once and re-aims at every evaluation (src/nls.c:155-216) */
@@ -355,20 +373,28 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
         d.n = n;
         d.p = p;
         d.startisnum = INTEGER(control_int)[13];
-        d.warn = 1; /* single start: params.warn = TRUE, src/nls.c:175-178 */
-        rc = gslnls_nls_fn_loss(n, p, REAL(y), cb_f, Rf_isNull(jac) ? NULL : cb_jac, Rf_isNull(fvv) ? NULL : cb_fvv, &d, st,
-                                Rf_isNull(swts) ? NULL : REAL(swts), lu, INTEGER(control_int), REAL(control_dbl), wgt_i,
-                                REAL(VECTOR_ELT(loss_config, 1)), &res);
+        d.warn = !mstart; /* params.warn: TRUE for a single start only, src/nls.c:175-178 */
+        if (mstart)
+            rc = gslnls_nls_fn_mstart(n, p, REAL(y), cb_f, Rf_isNull(jac) ? NULL : cb_jac, Rf_isNull(fvv) ? NULL : cb_fvv, &d, st,
+                                      hs, Rf_isNull(swts) ? NULL : REAL(swts), lu, INTEGER(control_int), REAL(control_dbl),
+                                      wgt_i, REAL(VECTOR_ELT(loss_config, 1)), &res);
+        else
+            rc = gslnls_nls_fn_loss(n, p, REAL(y), cb_f, Rf_isNull(jac) ? NULL : cb_jac, Rf_isNull(fvv) ? NULL : cb_fvv, &d, st,
+                                    Rf_isNull(swts) ? NULL : REAL(swts), lu, INTEGER(control_int), REAL(control_dbl), wgt_i,
+                                    REAL(VECTOR_ELT(loss_config, 1)), &res);
         if (d.r_error)
         {
             UNPROTECT(nprot);
             Rf_error("error in the model function, its Jacobian or fvv (see the message above)");
         }
+        /* the core's frames are gone: the warning the reference raises inside gsl_f / gsl_df / gsl_fvv */
+        if (d.bad_result == 1)
+            Rf_warning("Evaluating fn does not return numeric vector of expected length n");
+        else if (d.bad_result == 2)
+            Rf_warning("Evaluating jac does not return numeric matrix of dimensions n x p");
+        else if (d.bad_result == 3)
+            Rf_warning("Evaluating fvv does not return numeric vector of expected length n");
     }
-    else
-        rc = gslnls_nls(&model, REAL(y), n, !Rf_isNull(jac), !Rf_isNull(fvv), st, mstart,
-                        Rf_isNull(swts) ? NULL : REAL(swts), 0, lu, INTEGER(control_int), REAL(control_dbl),
-                        hs, wgt_i, REAL(VECTOR_ELT(loss_config, 1)), &res);
     if (rc == GSLNLS_E_INTERRUPTED)
         Rf_onintr(); /* does not return: the pending interrupt is re-raised now that the device loop is drained */
     /* no device / not lowered after all, or a qr / svd request on a problem too ill-conditioned for the normal
@@ -379,6 +405,8 @@ SEXP C_nls_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP s
         return C_nls(fn, y, jac, fvv, env, start, swts, lupars, control_int, control_dbl, has_start, loss_config);
     }
     const int ok = (res.conv == GSLNLS_SUCCESS || res.conv == GSLNLS_EMAXITER);
+    if (verbose)
+        print_trace_text(); /* iteration lines, multi-start / IRLS progress, summary block (src/nls.c:610-630) */
 
     /* back to the caller's parameter order */
     for (int k = 0; k < p; k++)

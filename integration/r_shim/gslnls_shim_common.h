@@ -10,6 +10,7 @@
 #include <R.h>
 #include <Rinternals.h>
 #include <string.h>
+#include "gslnls_core.h"
 
 /* `formula` as the closure .fn sees it: .fn <- function(par, .data = mf) eval(formula[[3]], ...) is created inside
  * gsl_nls.formula (R/nls.R:565), so its enclosure is that call's frame, which binds `formula` and `mf`.  Only that
@@ -94,6 +95,27 @@ static int formula_columns(SEXP formula, const char **pn, int p, char *cols, siz
     UNPROTECT(1);
     *nxe_out = nxe;
     return ok;
+}
+
+/* trace = TRUE: the text the reference prints while it runs, collected by the core during the call that has just
+ * returned (include/gslnls_core.h, gslnls_trace_text), handed to Rprintf piece by piece (Rprintf's own buffer is
+ * bounded) */
+static void print_trace_text(void)
+{
+    const size_t len = gslnls_trace_text(NULL, 0);
+    if (!len)
+        return;
+    char *txt = (char *)R_alloc(len + 1, 1);
+    gslnls_trace_text(txt, len + 1);
+    for (size_t off = 0; off < len;)
+    {
+        char piece[1025];
+        size_t k = len - off < 1024 ? len - off : 1024;
+        memcpy(piece, txt + off, k);
+        piece[k] = 0;
+        Rprintf("%s", piece);
+        off += k;
+    }
 }
 
 #endif

@@ -288,6 +288,13 @@ def readme_traces():
     ex2_accel_fvv = _parse_trace(block(772, 783))
     assert len(ex2_lm) == 26 and len(ex2_accel) == 12 and len(ex2_accel_fvv) == 12, (
         len(ex2_lm), len(ex2_accel), len(ex2_accel_fvv))
+
+    def printed(first, last):
+        """the console output of a verbose call as the README shows it (iteration lines + summary block), without the
+        "#> " prefix: expected OUTPUT of the path, the text the trace = TRUE tests compare with line by line"""
+        out = [ln[3:] for ln in block(first, last)]
+        assert all(ln.startswith("#> ") for ln in block(first, last)) and out[-1] == "*" * 19, out[-1]
+        return out
     return dict(
         rng_check_max_abs_err=err,
         ex1=dict(cite="README.md:157-195, :246-268, :405-409; data literal unit_tests_gslnls.R:254-265",
@@ -299,9 +306,10 @@ def readme_traces():
         ex2=dict(cite="README.md:540-604, :636-658, :772-794",
                  model="a*exp(-(x-b)^2/(2*c^2))", x=x2.tolist(), y=y2.tolist(), start=[1.0, 0.0, 1.0],
                  lm=dict(trace=ex2_lm, niter=26, initial_ssr=210.146, final_ssr=2.7583,
-                         neval_f=124, neval_J=0, ssrtol=1.33227e-15),
-                 lmaccel=dict(trace=ex2_accel, niter=12, final_ssr=2.7583, neval_f=76, neval_J=0, neval_fvv=0),
-                 lmaccel_fvv=dict(trace=ex2_accel_fvv, niter=12, neval_f=58, neval_fvv=18)),
+                         neval_f=124, neval_J=0, ssrtol=1.33227e-15, printed=printed(568, 605)),
+                 lmaccel=dict(trace=ex2_accel, niter=12, final_ssr=2.7583, neval_f=76, neval_J=0, neval_fvv=0,
+                              printed=printed(636, 659)),
+                 lmaccel_fvv=dict(trace=ex2_accel_fvv, niter=12, neval_f=58, neval_fvv=18, printed=printed(772, 795))),
     )
 
 

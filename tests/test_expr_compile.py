@@ -320,3 +320,70 @@ def test_selfstart_models_by_their_closed_forms(rhs_text, pars, xr):
         num = (4 * (ev(th + e / 2) - ev(th - e / 2)) / h - (ev(th + e) - ev(th - e)) / (2 * h)) / 3
         scale = np.max(np.abs(num)) + 1e-300
         assert np.max(np.abs(grad[:, k] - num)) / scale < 1e-6, (rhs_text, names[k])
+
+
+# ---- the gamma family of stats::deriv's table (round 5): gamma, lgamma, digamma, trigamma, psigamma, factorial, lfactorial ----
+GAMMA_CASES = [
+    ("a * gamma(b * x)", ["a", "b"], [1.3, 0.7]),
+    ("a * lgamma(x + b)", ["a", "b"], [2.0, 0.4]),
+    ("a * digamma(b + x) + trigamma(x * b)", ["a", "b"], [0.5, 1.1]),
+    ("psigamma(a * x, 2) + b * psigamma(x, 1)", ["a", "b"], [0.9, 2.0]),
+    ("a * factorial(x / b) - lfactorial(x * b)", ["a", "b"], [1.0, 1.7]),
+    ("exp(lgamma(a + x) - lgamma(a) - lgamma(x + 1)) * b^x", ["a", "b"], [2.5, 0.3]),  # negative-binomial kernel
+]
+
+
+@pytest.mark.parametrize("rhs_text,names,theta", GAMMA_CASES, ids=[c[0] for c in GAMMA_CASES])
+def test_gamma_family_value_gradient_and_second_directional_derivative(rhs_text, names, theta):
+    """device arithmetic of the family (devmath.hpp: gpsigamma by recurrence + asymptotic series) against scipy.special through
+    the mirror's evaluator; the symbolic gradient (gamma' = gamma digamma, lgamma' = digamma, psigamma(., n)' = psigamma(., n + 1))
+    and D^2 f[v, v] against Richardson-extrapolated differences of the scipy evaluation"""
+    rhs = F.parse_expr(rhs_text)
+    x = np.linspace(0.6, 6.0, 23)
+    th = np.array(theta)
+    v = np.array([0.7, -0.4])
+    val, grad, st = hs.expr_eval(rhs_text, names, ["x"], th, x[:, None], direction=v)
+
+    def ev(t):
+        env = {"x": x}
+        env.update(dict(zip(names, t)))
+        return np.asarray(F.evaluate(rhs, env), dtype=np.float64) * np.ones(len(x))
+    ref = ev(th)
+    np.testing.assert_allclose(val, ref, rtol=2e-13, atol=1e-14)
+    for k in range(len(names)):
+        h = 1e-3 * max(abs(th[k]), 1e-8)
+        e = np.zeros(len(names))
+        e[k] = h
+        num = (4 * (ev(th + e / 2) - ev(th - e / 2)) / h - (ev(th + e) - ev(th - e)) / (2 * h)) / 3
+        assert np.max(np.abs(grad[:, k] - num)) / (np.max(np.abs(num)) + 1e-300) < 1e-7, (rhs_text, names[k])
+    if st.get("fvv") is not None:
+        h = 1e-3
+        num2 = (-ev(th + 2 * h * v) + 16 * ev(th + h * v) - 30 * ref + 16 * ev(th - h * v) - ev(th - 2 * h * v)) / (12 * h * h)
+        assert np.max(np.abs(st["fvv"] - num2)) / (np.max(np.abs(num2)) + 1e-300) < 1e-5, rhs_text
+
+
+def test_psigamma_reflection_and_limits_of_the_vocabulary():
+    # negative non-integer arguments go through the reflection formula
+    x = np.array([-0.5, -1.3, -2.7, 0.2, 0.45])
+    for n in range(5):
+        val, _, _ = hs.expr_eval("psigamma(x + a, %d)" % n, ["a"], ["x"], [0.0], x[:, None])
+        from scipy.special import digamma, polygamma
+        m = 4
+        ref = (digamma(x + m) if n == 0 else polygamma(n, x + m)) - sum(
+            (-1.0) ** n * [1, 1, 2, 6, 24][n] / (x + k) ** (n + 1) for k in range(m))
+        np.testing.assert_allclose(val, ref, rtol=1e-12)
+    # the order has to be a literal 0..4; the fifth derivative is outside the table
+    with pytest.raises(ValueError):
+        hs.expr_eval("psigamma(x, a)", ["a"], ["x"], [1.0], np.array([[1.0]]))
+    with pytest.raises(ValueError):
+        hs.expr_eval("psigamma(x * a, 5)", ["a"], ["x"], [1.0], np.array([[1.0]]))
+    # ... and a function outside the table is refused (the bindings then evaluate the formula's own closure instead)
+    with pytest.raises(ValueError):
+        hs.expr_eval("ifelse(x, a, 1)", ["a"], ["x"], [1.0], np.array([[1.0]]))
+
+
+def test_mirror_evaluator_knows_comparisons_ifelse_pmax():
+    rhs = F.parse_expr("ifelse(x < c0, a + b * x, a + b * c0) + pmax(0, x - 2) * d")
+    env = dict(x=np.array([0.0, 1.0, 2.0, 3.0]), c0=1.5, a=1.0, b=2.0, d=10.0)
+    np.testing.assert_allclose(F.evaluate(rhs, env), [1.0, 3.0, 4.0, 14.0])
+    assert F.symbols(rhs) == ["x", "c0", "a", "b", "d"]

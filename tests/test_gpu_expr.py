@@ -529,3 +529,88 @@ def test_selfstart_model_6_1(amd, gslref, readme):
         coef = np.asarray(list(ex["coef"].values()) if isinstance(ex["coef"], dict) else ex["coef"], dtype=float)  # A, lam, b
         got = np.array([ss["par"][1] - ss["par"][0], np.exp(ss["par"][2]), ss["par"][0]])
         assert np.all(np.abs(got - coef) <= 2e-4 * np.maximum(1.0, np.abs(coef)))
+
+
+# ---- round 5: the gamma family on the device, and formulas outside the lowering vocabulary through their closure ----------
+GAMMA_FITS = [
+    ("a * exp(lgamma(b + x) - lgamma(b) - lgamma(x + 1)) * c^x", dict(a=40.0, b=3.0, c=0.45), (0.0, 12.0)),  # neg.-binomial shape
+    ("a * gamma(b * x) / gamma(x + b)", dict(a=2.0, b=0.8), (0.5, 4.0)),
+    ("a * digamma(x + b) + c * trigamma(b * x)", dict(a=1.5, b=0.7, c=2.0), (0.3, 6.0)),
+    ("a * psigamma(x / b, 2) + factorial(c * x)", dict(a=0.5, b=1.2, c=0.4), (0.5, 5.0)),
+]
+
+
+@pytest.mark.parametrize("case", range(len(GAMMA_FITS)))
+@pytest.mark.parametrize("lowering", ["vm", "jit"])
+def test_gamma_family_formulas_fit_on_the_device(amd, gslref, case, lowering):
+    """gamma lgamma digamma trigamma psigamma factorial (stats::deriv's table, R/nls.R:588-599): value and symbolic gradient
+    on the device, interpreter and native code, against the oracle's driver on the scipy evaluation of the same formula"""
+    rhs_text, pars, xr = GAMMA_FITS[case]
+    names = list(pars)
+    truth = np.array([pars[k] for k in names])
+    rng = np.random.Generator(np.random.PCG64(500 + case))
+    x = np.linspace(xr[0], xr[1], 160)
+    rhs = F.parse_expr(rhs_text)
+
+    def model(t):
+        env = {"x": x}
+        env.update({k: t[i] for i, k in enumerate(names)})
+        return np.asarray(F.evaluate(rhs, env), dtype=np.float64) * np.ones(len(x))
+    y = model(truth) * (1.0 + 0.005 * rng.standard_normal(len(x)))
+    start = truth * (1.0 + 0.03 * np.where(np.arange(len(names)) % 2 == 0, 1.0, -1.0))
+    ctrl = dict(solver="cholesky")
+    fit = amd.gsl_nls("y ~ " + rhs_text, data=dict(x=x, y=y), start=dict(zip(names, start)), jac=True, control=ctrl, lowering=lowering)
+    ref = gslref.nls(len(x), len(names), start, fn=lambda t: model(t) - y, ctrl=gslref.control(**ctrl))
+    assert fit["conv"] == 0 and ref["conv"] == 0 and fit["code_path"] == (1 if lowering == "vm" else 2)
+    from conftest import rel_err
+    assert rel_err(fit["par"], ref["par"]) < 1e-5 and abs(fit["ssr"] - ref["ssr"]) <= 1e-8 * ref["ssr"], rhs_text
+    acc = amd.gsl_nls("y ~ " + rhs_text, data=dict(x=x, y=y), start=dict(zip(names, start)), jac=True, fvv=True, algorithm="lmaccel",
+                      control=ctrl, lowering=lowering)
+    assert acc["conv"] == 0 and acc["neval"]["fvv"] > 0 and rel_err(acc["par"], ref["par"]) < 1e-5
+
+
+def test_formula_outside_the_vocabulary_is_served_through_its_closure(amd, gslref):
+    """ifelse / pmax / a comparison are not in stats::deriv's table: the reference fits such a formula through its .fn closure
+    with a difference Jacobian (R/nls.R:565, :588-599 warn and leave jac NULL).  Here the core refuses the expression and the
+    binding hands the same closure to the callback route (gslnls_nls_fn_loss): code_path 4, every n x p operation on the
+    device, the same fit as the oracle's driver on the same closure -- single start, start ranges, and a robust loss"""
+    rng = np.random.Generator(np.random.PCG64(77))
+    n = 400
+    x = np.linspace(0.0, 10.0, n)
+    truth = dict(a=1.0, b=0.8, c0=4.0, d=1.5)
+    rhs_text = "ifelse(x < c0, a + b * x, a + b * c0) + d * pmax(0, x - 7)"
+    rhs = F.parse_expr(rhs_text)
+    names = list(truth)
+
+    def model(t):
+        env = {"x": x}
+        env.update(dict(zip(names, t)))
+        return np.asarray(F.evaluate(rhs, env), dtype=np.float64)
+    y = model(np.array(list(truth.values()))) + 0.05 * rng.standard_normal(n)
+    start = dict(a=0.5, b=1.0, c0=3.5, d=1.0)
+    ctrl = dict(solver="cholesky")
+    with pytest.warns(UserWarning, match="failed to symbolically derive 'jac'"):
+        fit = amd.gsl_nls("y ~ " + rhs_text, data=dict(x=x, y=y), start=start, jac=True, control=ctrl)
+    ref = gslref.nls(n, 4, list(start.values()), fn=lambda t: model(t) - y, ctrl=gslref.control(**ctrl))
+    assert fit["code_path"] == 4 and fit["lowered"] is False and fit["conv"] == ref["conv"] == 0
+    assert fit["neval"]["J"] == 0 and fit["parnames"] == names
+    from conftest import rel_err
+    # (a kink in the model: the difference Jacobian of the knot's column changes by whole rows with the last bits of c0; both
+    # sides stop within the default xtol of the optimum)
+    assert abs(fit["niter"] - ref["niter"]) <= 2 and rel_err(fit["par"], ref["par"]) < 1e-6
+    assert abs(fit["ssr"] - ref["ssr"]) <= 1e-9 * ref["ssr"]
+    # start ranges: the multi-start driver around the same closure
+    ms = dict(solver="cholesky", mstart_n=6, mstart_q=2, mstart_r=1.2)
+    fit = amd.gsl_nls("y ~ " + rhs_text, data=dict(x=x, y=y), start=dict(a=[0, 2], b=[0.2, 2], c0=[2, 6], d=[0.5, 3]), control=ms)
+    mat = np.array([[0, 0.2, 2, 0.5], [2, 2, 6, 3]], dtype=float)
+    ref = gslref.nls(n, 4, mat, fn=lambda t: model(t) - y, ctrl=gslref.control(**ms), has_start=np.ones((2, 4), bool))
+    assert fit["code_path"] == 4 and fit["conv"] == ref["conv"] == 0
+    assert (fit["mstart"]["nsp"], fit["mstart"]["nwsp"], fit["mstart"]["iters"]) == (ref["mstart"]["nsp"], ref["mstart"]["nwsp"], ref["mstart"]["iters"])
+    assert rel_err(fit["par"], ref["par"]) < 1e-6
+    # robust loss
+    yo = y.copy()
+    yo[[15, 120, 333]] += 4.0
+    fit = amd.gsl_nls("y ~ " + rhs_text, data=dict(x=x, y=yo), start=start, loss="huber", control=ctrl)
+    ref = gslref.nls(n, 4, list(start.values()), fn=lambda t: model(t) - yo, ctrl=gslref.control(**ctrl), loss="huber")
+    assert fit["conv"] == ref["conv"] == 0 and fit["irls"]["irls_niter"] == ref["irls"]["irls_niter"]
+    assert rel_err(fit["par"], ref["par"]) < 1e-6
