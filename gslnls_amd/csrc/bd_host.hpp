@@ -9,7 +9,7 @@
 // iteration is the one of lm_advance<P> (lm_core.hpp) and wide_advance (wide_core.hpp) -- the same state machine a third
 // time, with a run-time p up to 4096 and p-vectors on the host: a trial step has to come back to the host anyway when
 // the model is a closure, and for p > 64 the p x p factorisation (hundreds of microseconds) hides a round trip.
-// Every n x p and p x p operation is a device kernel (bd_kernels.hpp; mchol_device.hip from p = 400 on).
+// Every n x p and p x p operation is a device kernel (bd_kernels.hpp; the damped solve: mchol_device.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -409,8 +409,11 @@ struct BdFit
         const int maxiter = prm.maxiter;
         const bool trace = !point_fit && ci[1] != 0 && out->ssrtrace && out->partrace;
         // (read per fit: the tests run one problem through both factorisations)
+        // (round 5: the device from p = 65 on -- "the damped solve resident on the device", BASELINE north_star; measured with
+        // the round-5 kernels, profiles/r05_large_chol_solve_times.txt: device 0.063 / 0.066 / 0.123 / 0.196 ms at p = 100 / 128 /
+        // 200 / 333 against the host's 0.039 / 0.076 / 0.219 / 0.780)
         const char *dev_env = getenv("GSLNLS_LARGE_CHOL_DEVICE_MIN");
-        const int dev_min = dev_env ? atoi(dev_env) : 400;
+        const int dev_min = dev_env ? atoi(dev_env) : 65;
         const bool dev_solve = dev_min > 0 && p >= dev_min;
         std::vector<double> x(start, start + p), xt(p), dx(p, 0.0), vel(p, 0.0), acc(p, 0.0), g(p), gt(p), diag(p, 1.0), djj(p),
             djjt(p), lo(p, -INFINITY), up(p, INFINITY), rhs(p), gfvv(p);
@@ -451,7 +454,7 @@ struct BdFit
                     diag[j] = fmax(diag[j], norm);
             }
         };
-        // (J^T J + mu D^2) sol = b: gsl_linalg_mcholesky on the device from p = 400 on, the host routine below
+        // (J^T J + mu D^2) sol = b: gsl_linalg_mcholesky on the device (every p of this path unless the threshold is moved), else the host routine
         auto damped_solve = [&](const std::vector<double> &b, std::vector<double> &sol) -> int {
             sol.assign(p, 0.0);
             if (dev_solve)

@@ -255,12 +255,12 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
     if (!(trs == 0 || trs == 5))
         return GSLNLS_E_UNSUPPORTED; // lmaccel / dogleg / ddogleg / subspace2D of multilarge are not lowered
     const bool need_jtj = (trs == 0);
-    // from a few hundred parameters on the factorisation runs on the device (mchol_device.hip); GSLNLS_LARGE_CHOL_DEVICE_MIN
+    // beyond one wavefront's 64 parameters the factorisation runs on the device (mchol_device.hip); GSLNLS_LARGE_CHOL_DEVICE_MIN
     // moves the threshold, 0 = host always.  Operators that form J^T J on the device then keep it there: the damped solve
     // and the row sums of the predicted reduction read it in place, the host copy is fetched only if the device refuses.
     static const int dev_min = [] {
         const char *e = getenv("GSLNLS_LARGE_CHOL_DEVICE_MIN");
-        return e ? atoi(e) : 400;
+        return e ? atoi(e) : 65; // (round 5: was 400 -- measured against the round-3 kernels; see bd_host.hpp)
     }();
     const bool jtj_stays = need_jtj && dev_min > 0 && p >= dev_min && p <= 4096 && ops.can_keep_jtj_on_device() &&
                            !getenv("GSLNLS_LARGE_JTJ_HOST");

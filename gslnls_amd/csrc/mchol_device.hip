@@ -740,8 +740,292 @@ __global__ __launch_bounds__(CBP_T) void cholb_panel_kernel(const double *W, dou
     }
 }
 
+// ---- round 5: the diagonal block on FOUR wavefronts ------------------------------------------------------------------------
+// The kernel above spends its 25 us on one wavefront: a step issues the rank-one update of all 63 - j columns behind the
+// pivot plus ~45 instructions of pivot arithmetic, 64 times, in order.  Only the update of the columns up to the end of
+// the current 16-column sub-block is needed before the next pivot.  Here wavefront h of the first four owns columns
+// 16 h .. 16 h + 15 of the block (lane = row, 16 registers): it takes the pivots of its own sub-block (the step of the
+// kernel above, on 16 columns) and publishes, per step, the multiplier column t = v / d and the column v itself in LDS
+// (plus 1 / L_jj and L_jj); the wavefronts behind it apply the step to THEIR columns from there (3 LDS reads + 16 DPP
+// multiply-adds), a step or two behind the owner -- when the owner's sub-block is done the next wavefront has caught up
+// and takes over.  What the owner does NOT do any more, because it is not needed for the next pivot: form the column of
+// L (v / L_jj: whoever reads L multiplies -- same product, same rounding), make all four row-group copies of v for the
+// DPP broadcasts (one suffices for 16 columns), test every pivot against its threshold as it goes (a lane's diagonal
+// entry is final once its pivot is taken: the wavefront tests its 16 at the end).  The critical path is 64 x (16-column
+// step of ~45 instructions) instead of 64 x (64-column step of ~110); every multiply-add is the one the kernel above
+// issues, on the same operands in the same order (fma(-t_i, v_k, S_ik), steps ascending): the factor is bit-identical.
+// Wavefronts 4 .. 7 solve the workgroup's panel rows a column behind, as in the kernel above.
+constexpr int CBQ_T = 512;
+
+template <int K, int KEND>
+__device__ __forceinline__ void cholb_upd16(double (&m)[16], double vbh, double tn)
+{
+    if constexpr (K < KEND)
+    {
+        wide_fmac_rowbcast<K>(m[K], vbh, tn);
+        cholb_upd16<K + 1, KEND>(m, vbh, tn);
+    }
+}
+
+// v of row 16 H + l % 16 in lane l (the one row-group copy the DPP broadcasts of sub-block H need)
+template <int H>
+__device__ __forceinline__ double cholb_row_copy(double v)
+{
+    const long long bits = __double_as_longlong(v);
+    const unsigned int lo = (unsigned int)(bits & 0xffffffffll), hi = (unsigned int)(bits >> 32);
+    const auto l16 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false); // [0] = rows [0, 0, 2, 2], [1] = rows [1, 1, 3, 3]
+    const auto h16 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const unsigned int ls = l16[H & 1], hs = h16[H & 1];
+    const auto l32 = __builtin_amdgcn_permlane32_swap(ls, ls, false, false); // [0] = the lower row of the pair everywhere, [1] the upper
+    const auto h32 = __builtin_amdgcn_permlane32_swap(hs, hs, false, false);
+    double r = __longlong_as_double(((long long)h32[H >> 1] << 32) | l32[H >> 1]);
+    asm volatile("s_nop 1" : "+v"(r)); // (a DPP operand written by the instruction before: 2 wait states)
+    return r;
+}
+
+// what the diagonal-block wavefronts publish per column J: the multipliers t, the column v, 1 / L_JJ and L_JJ
+struct CholbPub
+{
+    double T[CB * CB], V[CB * CB], invd[CB], ldiag[CB];
+};
+
+// wavefront H of the diagonal block: columns 16 H .. 16 H + 15.  Returns true when a pivot of its sub-block was not safely positive.
+template <int H>
+__device__ __forceinline__ bool cholb_diag_wave(const double *Lt, CholbPub &P, int *ready, const double *dorig, int k0, int nb, int lane)
+{
+    constexpr int C0 = 16 * H;
+    double m[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+        m[c] = (C0 + c) < lane ? Lt[lane * CB_LD + C0 + c] : 0.0; // (entries on and above the diagonal never reach a result)
+    double dg = Lt[lane * CB_LD + lane];
+    const double thr = lane < nb ? fmax(1e-12 * dorig[k0 + lane], DBL_EPSILON) : 0.0;
+    // the steps of the sub-blocks in front: applied from what their owners published
+    int seen = 0;
+    for (int J = 0; J < C0; ++J)
+    {
+        while (seen <= J)
+        {
+            seen = __hip_atomic_load(ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (seen <= J)
+                __builtin_amdgcn_s_sleep(1);
+        }
+        const double t = P.T[J * CB + lane], v = P.V[J * CB + lane];
+        double vbh = P.V[J * CB + C0 + (lane & 15)];
+        dg -= t * v;
+        const double tn = -t;
+        asm volatile("s_nop 1" : "+v"(vbh)); // (a DPP operand written by the instruction before: 2 wait states)
+        cholb_upd16<0, 16>(m, vbh, tn);
+    }
+    auto step = [&](auto self, auto jj, double dj, double rs, double ainv) __attribute__((always_inline)) -> void {
+        constexpr int j = decltype(jj)::value; // local column; J = C0 + j
+        if constexpr (j < 16)
+        {
+            constexpr int J = C0 + j;
+            if constexpr (J > 0)
+                __hip_atomic_store(ready, J, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); // columns < J are final
+            const double v = lane > J ? m[j] : 0.0;
+            const double t = ainv * v;
+            dg -= t * v;
+            P.T[J * CB + lane] = t;
+            P.V[J * CB + lane] = v;
+            P.invd[J] = rs; // (every lane stores the same word: a store under `if (lane == ..)` is a branch)
+            P.ldiag[J] = dj * rs;
+            if constexpr (j + 1 < 16)
+            {
+                const double vbh = cholb_row_copy<H>(v);
+                const double tn = -t;
+                cholb_upd16<j + 1, j + 2>(m, vbh, tn); // (column j + 1 first: the next step's v)
+                const double dn = wide_bcast(dg, J + 1);
+                constexpr int F0 = j + 2, NF = 16 - F0;
+#define GSLNLS_CBQ_PIECE(c)                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+    cholb_upd16<F0 + NF * (c) / 8, F0 + NF * ((c) + 1) / 8>(m, vbh, tn);                                                \
+    __builtin_amdgcn_sched_barrier(0);
+                double y = __builtin_amdgcn_rsq(dn);
+                GSLNLS_CBQ_PIECE(0)
+                double e = -dn * y, h = 0.5 * y;
+                GSLNLS_CBQ_PIECE(1)
+                e = fma(e, y, 1.0);
+                GSLNLS_CBQ_PIECE(2)
+                y = fma(h, e, y);
+                GSLNLS_CBQ_PIECE(3)
+                e = -dn * y, h = 0.5 * y;
+                GSLNLS_CBQ_PIECE(4)
+                e = fma(e, y, 1.0);
+                GSLNLS_CBQ_PIECE(5)
+                y = fma(h, e, y);
+                GSLNLS_CBQ_PIECE(6)
+                const double an = y * y;
+                GSLNLS_CBQ_PIECE(7)
+#undef GSLNLS_CBQ_PIECE
+                self(self, WideInt<j + 1>{}, dn, y, an);
+            }
+        }
+    };
+    {
+        const double d0 = wide_bcast(dg, C0);
+        double y = __builtin_amdgcn_rsq(d0);
+        y = fma(0.5 * y, fma(-d0 * y, y, 1.0), y);
+        y = fma(0.5 * y, fma(-d0 * y, y, 1.0), y);
+        step(step, WideInt<0>{}, d0, y, y * y);
+    }
+    // the whole sub-block is final: the wavefront behind takes over, the solving wavefronts go on
+    __hip_atomic_store(ready, C0 + 16, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // a lane's diagonal entry has not changed since its pivot was taken (its v is 0 from then on): the 16 pivots of the
+    // sub-block against their thresholds, at once (below eps the reference's alpha = max(eps, |d|, ..) replaces the pivot:
+    // not this routine's case; NaN too)
+    const bool mine = lane >= C0 && lane < C0 + 16;
+    return __ballot(mine && !(dg > thr)) != 0ull;
+}
+
+// X L11^T = W21 for 64 rows of the panel as cholb_trsm_steps does it, with L11 read as the published v / L_JJ (the product
+// the one-wavefront kernel stores: same operands, same rounding)
+template <int Q, int J>
+__device__ __forceinline__ void cholb_trsm_update_v(double (&r)[16], double xj, const double *Vj, double rs, int cls)
+{
+    if constexpr (Q < 16)
+    {
+        constexpr int QJ = J >> 2;
+        if constexpr (Q > QJ)
+            r[Q] -= xj * __dmul_rn(Vj[cls + 4 * Q], rs);
+        else if constexpr (Q == QJ)
+        {
+            if (cls > (J & 3))
+                r[Q] -= xj * __dmul_rn(Vj[cls + 4 * Q], rs);
+        }
+        cholb_trsm_update_v<Q + 1, J>(r, xj, Vj, rs, cls);
+    }
+}
+template <int J>
+__device__ __forceinline__ void cholb_trsm_steps_v(double (&r)[16], const CholbPub &P, int row, int cls, const int *ready, int seen)
+{
+    if constexpr (J < CB)
+    {
+        while (seen <= J)
+        {
+            seen = __hip_atomic_load(ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (seen <= J)
+                __builtin_amdgcn_s_sleep(1);
+        }
+        const double rs = P.invd[J];
+        if (cls == (J & 3))
+            r[J >> 2] *= rs;
+        const double xj = wide_shfl(r[J >> 2], row + 16 * (J & 3));
+        cholb_trsm_update_v<0, J>(r, xj, P.V + J * CB, rs, cls);
+        cholb_trsm_steps_v<J + 1>(r, P, row, cls, ready, seen);
+    }
+}
+
+__global__ __launch_bounds__(CBQ_T) void cholb_panel4_kernel(const double *W, double *Lf, int p, int k0, const double *dorig, int *flag,
+                                                             double *yv, double *dinvg)
+{
+    __shared__ double Lt[CB * CB_LD];
+    __shared__ CholbPub P;
+    __shared__ int ready_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nb = p - k0 < CB ? p - k0 : CB;
+    if (tid == 0)
+        ready_s = 0;
+    // this workgroup's rows of the panel (workgroup b > 0: rows r0 .. r0 + 63): thread (row = 16 (wave - 4) + lane % 16,
+    // class = lane / 16) of wavefronts 4 .. 7 holds columns class, class + 4, ... of row r0 + row
+    const int r0 = k0 + CB * (int)blockIdx.x;
+    const int prow = 16 * (wave - 4) + (lane & 15), cls = lane >> 4;
+    double rr[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+    {
+        const int c = cls + 4 * q;
+        const bool ok = wave >= 4 && blockIdx.x > 0 && r0 + prow < p && c < nb;
+        rr[q] = W[ok ? (size_t)(r0 + prow) * p + k0 + c : 0];
+        rr[q] = ok ? rr[q] : 0.0;
+    }
+    // the diagonal block, lower triangle, identity beyond nb (a partial last block)
+    {
+        constexpr int NL = (CB * CB + CBQ_T - 1) / CBQ_T;
+        double dv[NL];
+#pragma unroll
+        for (int it = 0; it < NL; ++it)
+        {
+            const int e = tid + CBQ_T * it, i = e >> 6, j = e & 63;
+            dv[it] = W[(e < CB * CB && i < nb && j <= i) ? (size_t)(k0 + i) * p + k0 + j : 0];
+        }
+#pragma unroll
+        for (int it = 0; it < NL; ++it)
+        {
+            const int e = tid + CBQ_T * it, i = e >> 6, j = e & 63;
+            if (e < CB * CB)
+                Lt[i * CB_LD + j] = (i < nb && j <= i) ? dv[it] : (i == j ? 1.0 : 0.0);
+        }
+    }
+    __syncthreads(); // (the only one: from here on the wavefronts meet through `ready`; Lt is only read after it)
+    if (wave < 4)
+    {
+        __builtin_amdgcn_s_setprio(3); // (the chain of pivots is the critical path of the launch)
+        bool bad;
+        switch (wave)
+        {
+        case 0: bad = cholb_diag_wave<0>(Lt, P, &ready_s, dorig, k0, nb, lane); break;
+        case 1: bad = cholb_diag_wave<1>(Lt, P, &ready_s, dorig, k0, nb, lane); break;
+        case 2: bad = cholb_diag_wave<2>(Lt, P, &ready_s, dorig, k0, nb, lane); break;
+        default: bad = cholb_diag_wave<3>(Lt, P, &ready_s, dorig, k0, nb, lane); break;
+        }
+        if (blockIdx.x != 0)
+            return;
+        if (bad && lane == 0)
+            *flag = 1;
+        if (wave != 0)
+            return;
+        // the right-hand side rides along as one more row of the matrix: its slice of this step, L11 y = b
+        while (__hip_atomic_load(&ready_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < CB)
+            __builtin_amdgcn_s_sleep(2);
+        double v = lane < nb ? yv[k0 + lane] : 0.0;
+        for (int j = 0; j < nb; ++j)
+        {
+            const double rs = P.invd[j];
+            const double yj = wide_bcast(v, j) * rs;
+            if (lane == j)
+                v = yj;
+            else if (lane > j && lane < nb)
+                v -= __dmul_rn(P.V[j * CB + lane], rs) * yj;
+        }
+        if (lane < nb)
+            yv[k0 + lane] = v;
+        return;
+    }
+    if (blockIdx.x == 0)
+    {
+        // workgroup 0 has no rows of the panel: its wavefronts 4 .. 7 store L11 once it is complete
+        while (__hip_atomic_load(&ready_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < CB)
+            __builtin_amdgcn_s_sleep(4);
+        for (int e = tid - 256; e < CB * CB; e += CBQ_T - 256)
+        {
+            const int i = e >> 6, j = e & 63;
+            if (i < nb && j <= i)
+                Lf[(size_t)(k0 + i) * p + k0 + j] = i == j ? P.ldiag[j] : __dmul_rn(P.V[j * CB + i], P.invd[j]);
+        }
+        if (tid - 256 < nb)
+            dinvg[k0 + tid - 256] = P.invd[tid - 256]; // 1 / L_jj for the back substitution
+        return;
+    }
+    // rows r0 .. r0 + 63 of the panel: X L11^T = W21, a column behind the factorisation
+    cholb_trsm_steps_v<0>(rr, P, lane & 15, cls, &ready_s, 0);
+    if (r0 + prow < p)
+    {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+        {
+            const int c = cls + 4 * q;
+            if (c < nb)
+                Lf[(size_t)(r0 + prow) * p + k0 + c] = rr[q];
+        }
+    }
+}
+
 // W[I][J] -= L[I][kblk] L[J][kblk]^T for the tiles I >= J behind the panel (tile index from blockIdx.x, lower triangle)
-__global__ __launch_bounds__(256, 2) void cholb_trail_kernel(double *W, const double *Lf, int p, int k0, int ntile, double *yv)
+// part: 0 all tiles (+ the right-hand side), 1 the tiles of the NEXT panel's column block only, J = 0 (+ the right-hand
+// side), 2 the tiles behind it, J >= 1 -- round 5: part 1 is all the next panel kernel waits for, part 2 runs on a
+// second stream beside that panel (mchol_device_solve_impl).  A tile is computed the same way whichever launch it is in.
+__global__ __launch_bounds__(256, 2) void cholb_trail_kernel(double *W, const double *Lf, int p, int k0, int ntile, double *yv, int part)
 {
     __shared__ double tI[CB * CBT_LD], tJ[CB * CBT_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, ii = lane & 15;
@@ -771,12 +1055,27 @@ __global__ __launch_bounds__(256, 2) void cholb_trail_kernel(double *W, const do
         }
         return;
     }
-    int I = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-    while (I * (I + 1) / 2 > t)
-        --I;
-    while ((I + 1) * (I + 2) / 2 <= t)
-        ++I;
-    const int J = t - I * (I + 1) / 2;
+    int I, J;
+    if (part == 1)
+    {
+        I = t;
+        J = 0;
+    }
+    else
+    {
+        I = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while (I * (I + 1) / 2 > t)
+            --I;
+        while ((I + 1) * (I + 2) / 2 <= t)
+            ++I;
+        J = t - I * (I + 1) / 2;
+        if (part == 2)
+        {
+            // the lower triangle of the blocks behind the next panel's column: (I, J) -> (I + 1, J + 1)
+            I += 1;
+            J += 1;
+        }
+    }
     const int base = k0 + CB, ri = base + CB * I, rj = base + CB * J;
     // (k0 + 64 <= p here: the last panel has no trailing matrix)
     // Every global load of the workgroup is issued before the first is waited for -- the 16 + 16 values of the two panel
@@ -903,13 +1202,19 @@ __device__ __forceinline__ void cholb_back_steps(double &v, double di, const dou
         cholb_back_steps<J - 1>(v, di, c, lane);
     }
 }
-__global__ __launch_bounds__(CBA_T) void cholb_backall_kernel(const double *Lf, int p, const double *yv, double *sol,
-                                                              const double *dinvg)
+// Round 5: blocks kb_lo .. kb_hi - 1 only (from the last to the first), and only the components of that segment are
+// updated here (written back to yv for the segments in front); the components in front of the segment receive the
+// segment's contributions from cholb_backupd_kernel, spread over many workgroups -- as ONE workgroup the update of all
+// p^2 / 2 entries of L^T was 0.47 ms of a 1.55 ms solve at p = 2000.  Same sums in the same order whichever way it is cut.
+__global__ __launch_bounds__(CBA_T) void cholb_backall_kernel(const double *Lf, int p, double *yv, double *sol,
+                                                              const double *dinvg, int kb_lo, int kb_hi)
 {
-    extern __shared__ double ys[]; // 64 nblk doubles: y (zeros behind p), block by block overwritten by x
+    extern __shared__ double ys_seg[]; // 64 (kb_hi - kb_lo) doubles: y of the segment (zeros behind p), block by block overwritten by x
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nblk = (p + CB - 1) / CB;
-    for (int j = tid; j < nblk * CB; j += CBA_T)
+    const int jbase = kb_lo * CB;
+    double *ys = ys_seg - jbase; // indexed by the component's own number
+    const int nblk = kb_hi;      // (the blocks behind kb_hi are done: their x is in sol, their contributions are in yv)
+    for (int j = jbase + tid; j < nblk * CB; j += CBA_T)
         ys[j] = j < p ? yv[j] : 0.0;
     double c[CB], di = 0.0;
     auto load_block = [&](int kb) {
@@ -922,18 +1227,20 @@ __global__ __launch_bounds__(CBA_T) void cholb_backall_kernel(const double *Lf, 
 #pragma unroll
     for (int r = 0; r < CB; ++r)
         c[r] = 0.0;
-    if (wave < nblk)
+    const int nseg = kb_hi - kb_lo;
+    if (wave < nseg)
         load_block(nblk - 1 - wave);
     __syncthreads();
     constexpr int H = 16; // rows of L per round of loads in the update
-    for (int s = 0; s < nblk; ++s)
+    for (int s = 0; s < nseg; ++s)
     {
         const int kb = nblk - 1 - s, k0 = kb * CB, nb = p - k0 < CB ? p - k0 : CB;
         // the update's first 16 rows of L for this thread's first component: requested before the solve, used behind it
+        const int j0 = jbase + tid;
         double lv[H];
 #pragma unroll
         for (int r = 0; r < H; ++r)
-            lv[r] = (tid < k0 && r < nb) ? Lf[(size_t)(k0 + r) * p + tid] : 0.0;
+            lv[r] = (j0 < k0 && r < nb) ? Lf[(size_t)(k0 + r) * p + j0] : 0.0;
         if (wave == (s % CBA_W))
         {
             double v = lane < nb ? ys[k0 + lane] : 0.0;
@@ -943,18 +1250,18 @@ __global__ __launch_bounds__(CBA_T) void cholb_backall_kernel(const double *Lf, 
                 ys[k0 + lane] = v;
                 sol[k0 + lane] = v;
             }
-            if (s + CBA_W < nblk)
+            if (s + CBA_W < nseg)
                 load_block(nblk - 1 - (s + CBA_W)); // this wavefront's next block: eight turns to arrive
         }
         __syncthreads();
-        // y[j] -= sum_r L[k0 + r][j] x_r for the components in front of the block, r ascending
-        for (int j = tid; j < k0; j += CBA_T)
+        // y[j] -= sum_r L[k0 + r][j] x_r for the components of the segment in front of the block, r ascending
+        for (int j = j0; j < k0; j += CBA_T)
         {
             double s0 = 0.0;
 #pragma unroll 1
             for (int r0 = 0; r0 < CB; r0 += H)
             {
-                if (r0 > 0 || j != tid)
+                if (r0 > 0 || j != j0)
                 {
 #pragma unroll
                     for (int r = 0; r < H; ++r)
@@ -970,10 +1277,145 @@ __global__ __launch_bounds__(CBA_T) void cholb_backall_kernel(const double *Lf, 
     }
 }
 
+// y[j] -= sum_r L[k0 + r][j] x_r for the blocks kb_hi - 1 .. kb_lo (in that order: the order the one-workgroup kernel
+// subtracts them in) and the components j in front of the segment: one thread per component, coalesced over j
+__global__ __launch_bounds__(64) void cholb_backupd_kernel(const double *Lf, int p, double *yv, const double *sol, int kb_lo, int kb_hi)
+{
+    __shared__ double xs[CB];
+    const int j = blockIdx.x * 64 + threadIdx.x, jend = kb_lo * CB;
+    double yj = j < jend ? yv[j] : 0.0;
+    for (int kb = kb_hi - 1; kb >= kb_lo; --kb)
+    {
+        const int k0 = kb * CB, nb = p - k0 < CB ? p - k0 : CB;
+        __syncthreads();
+        xs[threadIdx.x] = (int)threadIdx.x < nb ? sol[k0 + threadIdx.x] : 0.0;
+        __syncthreads();
+        constexpr int H = 16;
+        double s0 = 0.0;
+#pragma unroll 1
+        for (int r0 = 0; r0 < CB; r0 += H)
+        {
+            double lv[H];
+#pragma unroll
+            for (int r = 0; r < H; ++r)
+                lv[r] = (j < jend && r0 + r < nb) ? Lf[(size_t)(k0 + r0 + r) * p + j] : 0.0;
+#pragma unroll
+            for (int r = 0; r < H; ++r)
+                s0 += lv[r] * xs[r0 + r];
+        }
+        yj -= s0;
+    }
+    if (j < jend)
+        yv[j] = yj;
+}
+
+// The same update with the blocks of the segment side by side: part[t - kb_lo][j] = sum_r L[64 t + r][j] x_r (r ascending,
+// as above) by workgroup (j chunk, t) -- the blocks' contributions do not depend on each other, only the ORDER in which
+// they are subtracted from y_j is fixed -- and cholb_backsum_kernel subtracts them, last block first.  Same bits as
+// cholb_backupd_kernel, (kb_hi - kb_lo) times the workgroups.
+__global__ __launch_bounds__(64) void cholb_backpart_kernel(const double *Lf, int p, const double *sol, int kb_lo, double *part)
+{
+    __shared__ double xs[CB];
+    const int j = blockIdx.x * 64 + threadIdx.x, jend = kb_lo * CB, kb = kb_lo + (int)blockIdx.y;
+    const int k0 = kb * CB, nb = p - k0 < CB ? p - k0 : CB;
+    xs[threadIdx.x] = (int)threadIdx.x < nb ? sol[k0 + threadIdx.x] : 0.0;
+    __syncthreads();
+    constexpr int H = 16;
+    double s0 = 0.0;
+#pragma unroll 1
+    for (int r0 = 0; r0 < CB; r0 += H)
+    {
+        double lv[H];
+#pragma unroll
+        for (int r = 0; r < H; ++r)
+            lv[r] = (j < jend && r0 + r < nb) ? Lf[(size_t)(k0 + r0 + r) * p + j] : 0.0;
+#pragma unroll
+        for (int r = 0; r < H; ++r)
+            s0 += lv[r] * xs[r0 + r];
+    }
+    if (j < jend)
+        part[(size_t)blockIdx.y * p + j] = s0;
+}
+__global__ __launch_bounds__(256) void cholb_backsum_kernel(int p, double *yv, int kb_lo, int kb_hi, const double *part)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= kb_lo * CB)
+        return;
+    double yj = yv[j];
+    for (int kb = kb_hi - 1; kb >= kb_lo; --kb)
+        yj -= part[(size_t)(kb - kb_lo) * p + j];
+    yv[j] = yj;
+}
+
 // the flag of the natural-order factorisation, as a double behind the solution: one copy brings both down
 __global__ void cholb_flag_kernel(const int *flag, double *dst)
 {
     *dst = (double)*flag;
+}
+
+// Round 5: the end of a solve as the host sees it.  The solution and the flag go to pinned host memory the device writes
+// through its mapping, then -- behind a system-scope fence -- the sequence number of the solve: the host polls that word
+// instead of waiting in hipStreamSynchronize (measured on the driver's box: 5.2 ms of wall time for 1.7 ms of device time
+// at p = 2000, most of it the wake-up of the waiting thread).
+__global__ __launch_bounds__(256) void cholb_publish_kernel(const double *sol, const int *flag, int p, double *h_out, unsigned long long seq)
+{
+    for (int j = threadIdx.x; j < p; j += 256)
+        h_out[j] = sol[j];
+    if (threadIdx.x == 0)
+        h_out[p] = (double)*flag;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(h_out + p + 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// Round 5: what the natural-order factorisation needs before its first panel, in ONE launch: the lower triangle of
+// A = J^T J + mu D^2 in 64 x 64 tiles (the kernels above never read above the diagonal; mchol_init_kernel copies the full
+// matrix with a 64-bit division per element and reads it twice -- 106 us of a 1.32 ms solve at p = 2000 -- and finds
+// gamma and xi, which only the pivoted routine wants), the diagonal as the thresholds' reference, the right-hand side as
+// the extra row, the flag cleared.  src == nullptr: the matrix was uploaded into W already (only the vectors).
+__global__ __launch_bounds__(256) void cholb_init_kernel(const double *src, double *W, int p, const double *dmp, double mu, const double *rhs,
+                                                         double *work, double *dorig, int *flag, int ntile)
+{
+    const int tid = threadIdx.x, t = blockIdx.x;
+    if (t >= ntile)
+    {
+        for (int r = tid; r < p; r += 256)
+        {
+            dorig[r] = src ? __dadd_rn(src[(size_t)r * p + r], __dmul_rn(__dmul_rn(mu, dmp[r]), dmp[r])) : W[(size_t)r * p + r];
+            work[r] = rhs[r];
+        }
+        if (tid == 0)
+            *flag = 0;
+        return;
+    }
+    int I = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while (I * (I + 1) / 2 > t)
+        --I;
+    while ((I + 1) * (I + 2) / 2 <= t)
+        ++I;
+    const int J = t - I * (I + 1) / 2;
+    double v[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it)
+    {
+        const int e = tid + 256 * it, i = I * CB + (e >> 6), k = J * CB + (e & 63);
+        v[it] = src[(i < p && k < p) ? (size_t)i * p + k : 0];
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it)
+    {
+        const int e = tid + 256 * it, i = I * CB + (e >> 6), k = J * CB + (e & 63);
+        if (i < p && k <= i)
+        {
+            double x = v[it];
+            if (i == k)
+                x = __dadd_rn(x, __dmul_rn(__dmul_rn(mu, dmp[i]), dmp[i])); // (rounded like the host's A[i][i] += mu d d)
+            W[(size_t)i * p + k] = x;
+        }
+    }
 }
 
 struct MCholBuffers
@@ -984,6 +1426,11 @@ struct MCholBuffers
     int *ivec = nullptr;                                              // pos | ord | flag of the natural-order factorisation
     double *stage = nullptr; // pinned, 3 cap + 8 doubles: [rhs | diag] on the way up, [sol | flag] on the way down
     hipStream_t sq = nullptr;                // the stream of every copy and kernel of a solve
+    hipStream_t sq2 = nullptr;               // round 5: the trailing updates behind the next panel's column run beside that panel
+    hipEvent_t evp[2] = {nullptr, nullptr}, evr[2] = {nullptr, nullptr}; // panel k done / rest of trailing update k done (ping-pong)
+    hipEvent_t evdone = nullptr;             // behind the last kernel of a solve: polled beside the sequence word
+    double *down = nullptr, *down_dev = nullptr; // pinned + mapped, cap + 2 doubles: solution | flag | sequence number
+    unsigned long long seq = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr; // around the kernels of a solve: gslnls_debug_mchol_last_device_ms
     float last_device_ms = -1.f;
     bool attr_set = false;
@@ -1018,6 +1465,9 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
         if (B.stage)
             (void)hipHostFree(B.stage);
         B.stage = nullptr;
+        if (B.down)
+            (void)hipHostFree(B.down);
+        B.down = B.down_dev = nullptr;
         (void)hipFree(B.ivec);
         B.A = B.Lg = B.Cg = B.vec = nullptr;
         B.ivec = nullptr;
@@ -1027,6 +1477,8 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
             hipMalloc(&B.Cg, sizeof(double) * (size_t)MC_NB_MAX * p) != hipSuccess ||
             hipMalloc(&B.vec, sizeof(double) * ((size_t)7 * p + MC_NB_MAX + 24)) != hipSuccess ||
             hipHostMalloc(&B.stage, sizeof(double) * ((size_t)3 * p + 8), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&B.down, sizeof(double) * ((size_t)p + 2), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void **)&B.down_dev, B.down, 0) != hipSuccess ||
             hipMalloc(&B.ivec, sizeof(int) * ((size_t)2 * p + 4)) != hipSuccess)
         {
             (void)hipGetLastError();
@@ -1055,6 +1507,26 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
         return GSLNLS_E_NODEVICE;
     }
     hipStream_t sq = B.sq;
+    if (!B.sq2)
+    {
+        if (hipStreamCreateWithFlags(&B.sq2, hipStreamNonBlocking) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            return GSLNLS_E_NODEVICE;
+        }
+        for (int k = 0; k < 2; ++k)
+            if (hipEventCreateWithFlags(&B.evp[k], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&B.evr[k], hipEventDisableTiming) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                return GSLNLS_E_NODEVICE;
+            }
+        if (hipEventCreateWithFlags(&B.evdone, hipEventDisableTiming) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            return GSLNLS_E_NODEVICE;
+        }
+    }
     MCholArgs a;
     a.A = B.A;
     a.Lg = B.Lg;
@@ -1090,51 +1562,138 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
     B.last_device_ms = -1.f;
     if (B.ev0)
         (void)hipEventRecord(B.ev0, sq);
-    GSLNLS_HIP_OK(hipMemsetAsync(a.scal, 0, sizeof(double) * 8, sq));
-    {
+    auto pivoted_init = [&]() -> int {
+        GSLNLS_HIP_OK(hipMemsetAsync(a.scal, 0, sizeof(double) * 8, sq));
         long long g = ((long long)p * p + 256 * 8 - 1) / (256 * 8);
         g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
         hipLaunchKernelGGL(mchol_init_kernel, dim3((unsigned)g), dim3(256), 0, sq, a, d_rhs, A_host ? nullptr : jtj_dev, d_dmp, mu);
-    }
+        return GSLNLS_SUCCESS;
+    };
     // natural order first (level 3, no pivot search); the pivoted, modified factorisation below when it reports a pivot
     // that is not safely positive, or always under GSLNLS_LARGE_CHOL_PIVOTED=1
     {
         const char *pe = getenv("GSLNLS_LARGE_CHOL_PIVOTED");
-        if (!(pe && atoi(pe) != 0))
+        if (pe && atoi(pe) != 0)
+        {
+            if (const int e = pivoted_init())
+                return e;
+        }
+        else
         {
             int *d_flag = B.ivec + 2 * p;
             double *d_work = d_sol + p + 8;
-            GSLNLS_HIP_OK(hipMemsetAsync(d_flag, 0, sizeof(int), sq));
-            // the right-hand side is one more row of the matrix: L y = b happens inside the factorisation
-            GSLNLS_HIP_OK(hipMemcpyAsync(d_work, d_rhs, sizeof(double) * p, hipMemcpyDeviceToDevice, sq));
-            for (int k0 = 0; k0 < p; k0 += CB)
+            // the lower triangle of A, the diagonal, the right-hand side as one more row of the matrix (L y = b happens
+            // inside the factorisation), the flag: one launch
+            {
+                const int nb64 = (p + CB - 1) / CB, ntile = A_host ? 0 : nb64 * (nb64 + 1) / 2;
+                hipLaunchKernelGGL(cholb_init_kernel, dim3(ntile + 1), dim3(256), 0, sq, A_host ? nullptr : jtj_dev, B.A, p, d_dmp, mu, d_rhs,
+                                   d_work, a.dcur, d_flag, ntile);
+            }
+            const bool panel_v1 = getenv("GSLNLS_LARGE_PANEL_V1") != nullptr; // (developer switch: the one-wavefront diagonal block, same bits)
+            // GSLNLS_LARGE_LOOKAHEAD=1: the trailing update behind the next panel's column on a second stream, beside that
+            // panel.  Built, bit-identical, and MEASURED SLOWER on this runtime (p = 500 / 1000 / 2000: 0.357 / 0.774 / 1.66 ms
+            // against 0.291 / 0.607 / 1.33 in stream order, gpurun_out mchol_r05_b.txt): every cross-stream dependency is
+            // a barrier packet whose latency exceeds the 7-10 us of trailing update it hides.  Off by default.
+            const bool lookahead = getenv("GSLNLS_LARGE_LOOKAHEAD") != nullptr;
+            const bool back_v1 = getenv("GSLNLS_LARGE_BACK_V1") != nullptr; // (developer switch: the one-workgroup back substitution, same bits)
+            int nrest = 0; // launches on the second stream so far
+            for (int k0 = 0, step = 0; k0 < p; k0 += CB, ++step)
             {
                 const int nrb = (p - k0 + CB - 1) / CB; // row blocks from the diagonal block down
                 // (workgroup 0: the diagonal block and the right-hand side; workgroup b: row block b of the panel)
-                hipLaunchKernelGGL(cholb_panel_kernel, dim3(nrb), dim3(CBP_T), 0, sq, B.A, B.Lg, p, k0, a.dcur, d_flag, d_work, a.dinv);
+                if (panel_v1)
+                    hipLaunchKernelGGL(cholb_panel_kernel, dim3(nrb), dim3(CBP_T), 0, sq, B.A, B.Lg, p, k0, a.dcur, d_flag, d_work, a.dinv);
+                else
+                    hipLaunchKernelGGL(cholb_panel4_kernel, dim3(nrb), dim3(CBQ_T), 0, sq, B.A, B.Lg, p, k0, a.dcur, d_flag, d_work, a.dinv);
                 if (nrb > 1)
                 {
                     const int nt = (nrb - 1) * nrb / 2, nrhs = (p - k0 - CB + 255) / 256;
-                    hipLaunchKernelGGL(cholb_trail_kernel, dim3(nt + nrhs), dim3(256), 0, sq, B.A, B.Lg, p, k0, nt, d_work);
+                    if (!lookahead || nrb == 2)
+                    {
+                        if (nrest > 0) // (the last of the second stream's updates reaches into this tile)
+                            GSLNLS_HIP_OK(hipStreamWaitEvent(sq, B.evr[(nrest - 1) & 1], 0));
+                        hipLaunchKernelGGL(cholb_trail_kernel, dim3(nt + nrhs), dim3(256), 0, sq, B.A, B.Lg, p, k0, nt, d_work, 0);
+                        nrest = 0;
+                    }
+                    else
+                    {
+                        // The next panel only needs its own column block (and the right-hand side) updated: those nrb - 1
+                        // tiles stay on this stream; the tiles behind them go to the second stream, which they share with
+                        // nothing but the same tiles of the steps before and after -- beside the next panel kernel, whose
+                        // 20 us are the latency of one wavefront while the other 250 CUs are idle.
+                        GSLNLS_HIP_OK(hipEventRecord(B.evp[step & 1], sq)); // panel `step` is complete
+                        GSLNLS_HIP_OK(hipStreamWaitEvent(B.sq2, B.evp[step & 1], 0));
+                        const int nt2 = (nrb - 2) * (nrb - 1) / 2;
+                        hipLaunchKernelGGL(cholb_trail_kernel, dim3(nt2), dim3(256), 0, B.sq2, B.A, B.Lg, p, k0, nt2, d_work, 2);
+                        GSLNLS_HIP_OK(hipEventRecord(B.evr[nrest & 1], B.sq2));
+                        // this step's tiles of the next column block come behind the previous step's update of them
+                        if (nrest > 0)
+                            GSLNLS_HIP_OK(hipStreamWaitEvent(sq, B.evr[(nrest - 1) & 1], 0));
+                        hipLaunchKernelGGL(cholb_trail_kernel, dim3(nrb - 1 + nrhs), dim3(256), 0, sq, B.A, B.Lg, p, k0, nrb - 1, d_work, 1);
+                        nrest += 1;
+                    }
                 }
             }
-            if (!getenv("GSLNLS_LARGE_BACK_BLOCKS")) // (developer switch: the launch-per-block form, same bits)
-                hipLaunchKernelGGL(cholb_backall_kernel, dim3(1), dim3(CBA_T), sizeof(double) * (size_t)CB * ((p + CB - 1) / CB), sq, B.Lg, p, d_work,
-                                   d_sol, a.dinv);
-            else
+            if (getenv("GSLNLS_LARGE_BACK_BLOCKS")) // (developer switch: the launch-per-block form, same bits)
                 for (int k0 = ((p - 1) / CB) * CB; k0 >= 0; k0 -= CB)
                     hipLaunchKernelGGL(cholb_back_kernel, dim3(1 + (k0 + 255) / 256), dim3(256), 0, sq, B.Lg, p, k0, d_work, d_sol, a.dinv);
-            hipLaunchKernelGGL(cholb_flag_kernel, dim3(1), dim3(1), 0, sq, d_flag, d_sol + p);
+            else
+            {
+                // segments of the blocks, from the last to the first: one workgroup walks a segment, then every workgroup
+                // the device has takes the segment's x out of the components in front of it
+                const int nblk = (p + CB - 1) / CB;
+                // (measured, gpurun_out mchol_r05_d.txt: up to 8 blocks one segment is fastest -- p = 500: 0.260 ms against 0.265
+                // cut in two --, from 16 blocks on the cut pays: p = 1000 0.536 against 0.577, p = 2000 1.16 against 1.39)
+                const int seg = back_v1 ? nblk : (nblk <= 8 ? nblk : (nblk <= 16 ? (nblk + 1) / 2 : (nblk + 3) / 4));
+                for (int hi = nblk; hi > 0; hi -= seg)
+                {
+                    const int lo = hi - seg > 0 ? hi - seg : 0;
+                    hipLaunchKernelGGL(cholb_backall_kernel, dim3(1), dim3(CBA_T), sizeof(double) * (size_t)CB * (hi - lo), sq, B.Lg, p, d_work,
+                                       d_sol, a.dinv, lo, hi);
+                    if (lo > 0 && getenv("GSLNLS_LARGE_BACKUPD_V1")) // (developer switch: the blocks of a segment one after the other, same bits)
+                        hipLaunchKernelGGL(cholb_backupd_kernel, dim3((lo * CB + 63) / 64), dim3(64), 0, sq, B.Lg, p, d_work, d_sol, lo, hi);
+                    else if (lo > 0)
+                    {
+                        // (B.Cg: MC_NB_MAX x p doubles of the pivoted routine, idle here; a segment has at most 16 blocks)
+                        hipLaunchKernelGGL(cholb_backpart_kernel, dim3((lo * CB + 63) / 64, hi - lo), dim3(64), 0, sq, B.Lg, p, d_sol, lo, B.Cg);
+                        hipLaunchKernelGGL(cholb_backsum_kernel, dim3((lo * CB + 255) / 256), dim3(256), 0, sq, p, d_work, lo, hi, B.Cg);
+                    }
+                }
+            }
             if (B.ev0)
                 (void)hipEventRecord(B.ev1, sq);
-            double *h_down = B.stage + 2 * (size_t)p;
-            GSLNLS_HIP_OK(hipMemcpyAsync(h_down, d_sol, sizeof(double) * (size_t)(p + 1), hipMemcpyDeviceToHost, sq));
+            B.seq += 1;
+            B.down[p + 1] = 0.0; // (the word the device is about to write; any value but the new sequence number)
+            hipLaunchKernelGGL(cholb_publish_kernel, dim3(1), dim3(256), 0, sq, d_sol, d_flag, p, B.down_dev, B.seq);
+            GSLNLS_HIP_OK(hipEventRecord(B.evdone, sq));
             const double t_enq = now_s();
-            GSLNLS_HIP_OK(hipStreamSynchronize(sq));
+            {
+                // the device writes the sequence number behind the solution: poll it (the event beside it only to notice a
+                // launch failure or a device fault, which would never write the word)
+                volatile unsigned long long *word = reinterpret_cast<volatile unsigned long long *>(B.down + p + 1);
+                for (;;)
+                {
+                    if (*word == B.seq)
+                        break;
+                    const hipError_t q = hipEventQuery(B.evdone);
+                    if (q == hipSuccess)
+                    {
+                        if (*word != B.seq)
+                            GSLNLS_HIP_OK(hipStreamSynchronize(sq)); // (the write is on its way: the stream's end covers it)
+                        break;
+                    }
+                    if (q != hipErrorNotReady)
+                    {
+                        (void)hipGetLastError();
+                        return GSLNLS_E_NODEVICE;
+                    }
+                }
+                __sync_synchronize();
+            }
+            double *h_down = B.down;
             if (getenv("GSLNLS_LARGE_PROF"))
                 fprintf(stderr, "[mchol] p = %d: enqueue %.3f ms, wait %.3f ms\n", p, 1e3 * (t_enq - t_entry), 1e3 * (now_s() - t_enq));
-            if (B.ev0 && hipEventElapsedTime(&B.last_device_ms, B.ev0, B.ev1) != hipSuccess)
-                B.last_device_ms = -1.f;
+            B.last_device_ms = -2.f; // (read on demand: gslnls_debug_mchol_last_device_ms -- no event wait inside a solve)
             if (h_down[p] == 0.0)
             {
                 memcpy(sol_host, h_down, sizeof(double) * p);
@@ -1146,10 +1705,8 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
             // not numerically positive definite: the matrix (overwritten by the trailing updates) is formed again
             if (A_host)
                 GSLNLS_HIP_OK(hipMemcpy(B.A, A_host, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice)); // (pageable: the blocking form)
-            GSLNLS_HIP_OK(hipMemsetAsync(a.scal, 0, sizeof(double) * 8, sq));
-            long long g = ((long long)p * p + 256 * 8 - 1) / (256 * 8);
-            g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
-            hipLaunchKernelGGL(mchol_init_kernel, dim3((unsigned)g), dim3(256), 0, sq, a, d_rhs, A_host ? nullptr : jtj_dev, d_dmp, mu);
+            if (const int e = pivoted_init())
+                return e;
         }
     }
     // the panel workgroup is sized to p (a wavefront without rows still pays for every barrier and reduction)
@@ -1277,7 +1834,14 @@ extern "C" int gslnls_debug_device_copy(void *dst, const void *src, size_t bytes
 // process (HIP events around its kernels: what the device did, whatever the host was busy with); < 0: not available
 extern "C" double gslnls_debug_mchol_last_device_ms(void)
 {
-    return (double)gslnls::mchol_buffers().last_device_ms;
+    gslnls::MCholBuffers &B = gslnls::mchol_buffers();
+    std::lock_guard<std::mutex> lock(B.mu);
+    if (B.last_device_ms == -2.f) // the last solve left its two events for whoever asks
+    {
+        if (!B.ev0 || hipEventSynchronize(B.ev1) != hipSuccess || hipEventElapsedTime(&B.last_device_ms, B.ev0, B.ev1) != hipSuccess)
+            B.last_device_ms = -1.f;
+    }
+    return (double)B.last_device_ms;
 }
 
 // test / measurement hook: the same solve with J^T J already in device memory (p x p, row-major, not modified), the way

@@ -266,9 +266,10 @@ def _gsl_nls_function(fn, y, start, algorithm, control, jac, fvv, trace, weights
 
     def jac_cb(theta, pp, out, nn, _user):
         try:
-            Jm = np.asarray(jac_fn(np.ctypeslib.as_array(theta, shape=(pp,)).copy()), dtype=np.float64)
-            if hasattr(Jm, "toarray"):
+            Jm = jac_fn(np.ctypeslib.as_array(theta, shape=(pp,)).copy())
+            if hasattr(Jm, "toarray"):  # (a scipy sparse matrix: asarray would wrap it in a 0-d object array)
                 Jm = Jm.toarray()
+            Jm = np.asarray(Jm, dtype=np.float64)
             if Jm.shape != (nn, pp):
                 return 1
             # (two sequential copies on purpose: the core's buffer is pinned host memory, and a transposing assignment
