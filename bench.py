@@ -502,6 +502,69 @@ def function_model_bench():
 
 
 
+def matrix_path_bench(_lib):
+    """gsl_nls() on FORMULAS beyond 64 parameters (the matrix path, csrc/bd_host.hpp: no closure, rows by a kernel compiled for
+    the formula, J^T J on the matrix cores, the damped solve on the device): sums of Gaussians with p = 99, 198, 501 -- wall
+    time per trial step from the library's own profile of the call (gslnls_last_matrix_path_profile), split into the damped
+    solve with the fused trial evaluation, the Jacobian + J^T J + J^T f of the accepted points and the rest; the device time
+    of one J^T J (HIP events) against the measured MFMA f64 rate 47.8 TFLOP/s; the device time of one damped solve."""
+    import gslnls_amd as A
+    L = _lib.lib()
+    out = {"workload": "formula models with p > 64: sums of ng Gaussians a*exp(-((x-m)/w)^2), p = 3 ng, analytic Jacobian, lm, "
+                       "solver = cholesky; one host synchronisation per trial step (the solve's), one more per accepted point",
+           "mfma_f64_measured_tflops": 47.8, "cases": []}
+    for ng, n in ((33, 3000), (66, 5000), (167, 20000)):
+        pp = 3 * ng
+        rng = np.random.Generator(np.random.PCG64(ng))
+        x = np.linspace(0.0, 10.0 * ng, n)
+        amp, mid, wid = rng.uniform(2.0, 6.0, ng), 10.0 * np.arange(ng) + rng.uniform(3.0, 7.0, ng), rng.uniform(1.2, 2.4, ng)
+        y = np.sum(amp * np.exp(-((x[:, None] - mid) / wid) ** 2), axis=1) + 0.01 * rng.standard_normal(n)
+        rhs = " + ".join("a%d * exp(-((x - m%d) / w%d)^2)" % (g, g, g) for g in range(ng))
+        start = {}
+        for g in range(ng):
+            start["a%d" % g], start["m%d" % g], start["w%d" % g] = 0.9 * amp[g], mid[g] + 0.15, 1.1 * wid[g]
+        best = None
+        for _ in range(4):  # (the first call compiles the formula's kernels or loads them from the cache)
+            t0 = time.perf_counter()
+            fit = A.gsl_nls("y ~ " + rhs, data=dict(x=x, y=y), start=start, jac=True, control=dict(solver="cholesky"))
+            el = 1e3 * (time.perf_counter() - t0)
+            prof = np.zeros(12)
+            L.gslnls_last_matrix_path_profile(prof.ctypes.data_as(_lib.DP), 12)
+            if best is None or prof[1] < best[1][1]:
+                best = (el, prof.copy())
+        el, prof = best
+        steps, njac = max(1.0, prof[8]), prof[9]
+        syrk_ms = float(L.gslnls_debug_bd_syrk_ms(n, pp, 20))
+        # the damped solve alone, J^T J resident (HIP events around its kernels)
+        J0 = rng.standard_normal((pp + 50, pp))
+        Am = np.ascontiguousarray(J0.T @ J0)
+        dA = C.c_void_p()
+        L.gslnls_debug_device_alloc(C.byref(dA), Am.nbytes)
+        L.gslnls_debug_device_copy(dA, Am.ctypes.data_as(C.c_void_p), Am.nbytes, 1)
+        d, r, sol = np.sqrt(np.diag(Am)).copy(), rng.standard_normal(pp), np.zeros(pp)
+        sm = []
+        for _ in range(12):
+            L.gslnls_debug_mchol_solve_resident(pp, dA, d.ctypes.data_as(_lib.DP), 1e-3, r.ctypes.data_as(_lib.DP), sol.ctypes.data_as(_lib.DP))
+            sm.append(L.gslnls_debug_mchol_last_device_ms())
+        L.gslnls_debug_device_free(dA)
+        out["cases"].append({
+            "p": pp, "n": n, "niter": int(fit["niter"]), "conv": int(fit["conv"]), "trial_steps": int(prof[8]), "jacobians": int(njac),
+            "host_syncs_per_trial_step": 1 if prof[10] else None,
+            "us_per_trial_step": 1e3 * prof[1] / steps,
+            "breakdown_us_per_trial_step": {"damped_solve_and_trial_evaluation": 1e3 * prof[2] / steps,
+                                            "jacobian_jtj_jtf_of_accepted_points": 1e3 * prof[3] / steps,
+                                            "residuals_outside_the_fused_step": 1e3 * prof[4] / steps,
+                                            "host_vectors_and_decisions": 1e3 * (prof[1] - prof[2] - prof[3] - prof[4]) / steps},
+            "per_call_ms": {"whole_call": el, "set_up": prof[0], "loop": prof[1], "covariance_host": prof[5],
+                            "resid_and_grad_to_host": prof[6], "condition_diagnostic_host": prof[7]},
+            "jtj_device_ms": syrk_ms, "jtj_tflops": 2.0 * n * pp * pp / (syrk_ms * 1e-3) / 1e12 / 2.0 if syrk_ms > 0 else None,
+            "jtj_frac_of_measured_mfma_rate": (n * pp * pp / (syrk_ms * 1e-3) / 1e12) / 47.8 if syrk_ms > 0 else None,
+            "damped_solve_device_ms": float(np.median(sm))})
+    out["note"] = ("J^T J flops counted as n p^2 (the lower triangle is computed: n p (p + 1) flops of the 2 n p^2 of the full product); "
+                   "trial steps include the first evaluation's share of the loop")
+    return out
+
+
 def sparse_readme_bench():
     """The reference's own sparse example (README.md:1040-1146: penalty function I, p = 500, Jacobian a dgCMatrix)
     through gsl_nls_large(fn, jac) -- host closures, every product with J on the device.  One call each for cgst and lm
@@ -1154,6 +1217,7 @@ def main():
             side("wide_dense", wide_dense_bench, _lib)
             side("wide_multistart", wide_multistart_bench, L, _lib)
             side("function_models", function_model_bench)
+            side("matrix_path", matrix_path_bench, _lib)
     if world > 1:
         L.gslnls_comm_destroy()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -77,6 +77,8 @@ _SIGNATURES = {
                              C.c_int, DP, IP, DP, IP, C.c_int, DP, C.POINTER(Result)]),
     "gslnls_solver_served": (C.c_int, [IP, C.POINTER(Result)]),
     "gslnls_last_call_profile": (C.c_int, [DP, C.c_int]),
+    "gslnls_last_matrix_path_profile": (C.c_int, [DP, C.c_int]),
+    "gslnls_debug_bd_syrk_ms": (C.c_double, [C.c_int, C.c_int, C.c_int]),
     "gslnls_trace_text": (C.c_size_t, [C.c_char_p, C.c_size_t]),
     "gslnls_trace_set_order": (C.c_int, [IP, C.c_int]),
     "gslnls_format_trace": (C.c_size_t, [C.POINTER(Result), C.c_int, C.c_int, IP, C.c_int, C.c_char_p, C.c_size_t]),

@@ -97,6 +97,15 @@ inline double bd_scaled_cond(int p, const std::vector<double> &A)
     return lmax * lmin_inv;
 }
 
+// where the wall time of the last fit on the matrix path went (gslnls_last_matrix_path_profile): milliseconds
+struct BdProfile
+{
+    double setup_ms = 0, loop_ms = 0, solve_ms = 0, jac_ms = 0, resid_ms = 0, covar_ms = 0, down_ms = 0, cond_ms = 0;
+    long trial_steps = 0, jacobians = 0;
+    int fused = 0, p = 0, n = 0;
+};
+inline BdProfile g_bd_prof;
+
 // where the model comes from: host closures (R functions) or a kernel compiled for the formula
 // r_i = f_i / sqrt(w_i) (the unweighted residual as the reference's IRLS driver recovers it, src/nls_irls.c:455-459) and the
 // bit pattern of |r_i|: the key of the radix select that finds the median (irls_kernels.hpp)
@@ -121,7 +130,38 @@ struct BdModel
     // analytic second directional derivative D^2 m[v, v] -> d_out[n], unweighted.  Only called when has_fvv.
     virtual int fvv(const double *theta, const double *v, double *d_out, hipStream_t st) = 0;
     bool has_jac = false, has_fvv = false;
+    // models whose rows are evaluated by a device kernel (a formula) can take theta from device memory: the trial step then
+    // evaluates m(x + dx) behind the damped solve without coming back to the host in between (BdFit::solve, round 5)
+    virtual bool theta_on_device() const { return false; }
+    virtual int values_dev(const double *d_theta, double *d_fval, hipStream_t st)
+    {
+        (void)d_theta;
+        (void)d_fval;
+        (void)st;
+        return 1;
+    }
 };
+
+// xt = x + dx, a component that would leave its bound moved to x + dx / max(|dx|, delta) |x - bound| (trust_trial_step_lu,
+// src/trust.c:9-32): the host loop of BdFit::solve, one thread per component
+static __global__ __launch_bounds__(256) void bd_trial_kernel(const double *x, const double *dx, const double *lo, const double *up, double delta,
+                                                               int has_bounds, int p, double *xt)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= p)
+        return;
+    const double xk = x[k], dk = dx[k];
+    double t = xk + dk;
+    if (has_bounds)
+    {
+        // (product and sum rounded separately, as the host's loop rounds them: no contraction into an fma)
+        if (t < lo[k])
+            t = __dadd_rn(xk, __dmul_rn(dk / fmax(fabs(dk), delta), fabs(xk - lo[k])));
+        else if (t > up[k])
+            t = __dadd_rn(xk, __dmul_rn(dk / fmax(fabs(dk), delta), fabs(xk - up[k])));
+    }
+    xt[k] = t;
+}
 
 struct BdFit
 {
@@ -131,6 +171,10 @@ struct BdFit
     double *d_y = nullptr, *d_sw = nullptr, *d_fval = nullptr, *d_f[2] = {nullptr, nullptr}, *d_fp = nullptr, *d_fm = nullptr,
            *d_J = nullptr, *d_C = nullptr, *d_cpart = nullptr, *d_part = nullptr, *d_pv = nullptr, *d_u = nullptr;
     std::vector<double> h_part;
+    // round 5: x, bounds and what a fused trial step sends home (x + dx | rows of dx^T J^T J dx | partial sums of ||f||^2) on
+    // the device; pinned staging for every small copy (a pageable destination makes an asynchronous copy a blocking one)
+    double *d_pub = nullptr, *h_pin = nullptr;
+    double *h_xmap = nullptr, *d_xmap = nullptr; // pinned + mapped, 3 p doubles: x | lower | upper bounds, read by bd_trial_kernel in place
     int cur = 0;        // d_f[cur]: residual at the current point, d_f[cur ^ 1]: at the trial point
     std::vector<double> last_x;    // where the last solve ended (whatever its status)
     // more of the state the last solve ended in -- what gsl_multistart_driver reads out of the solver workspace after a
@@ -153,11 +197,17 @@ struct BdFit
             (void)hipFree(irls_arena);
         irls_arena = nullptr;
         irls_arena_bytes = 0;
-        double *bufs[] = {d_y, d_sw, d_fval, d_f[0], d_f[1], d_fp, d_fm, d_J, d_C, d_cpart, d_part, d_pv, d_u};
+        double *bufs[] = {d_y, d_sw, d_fval, d_f[0], d_f[1], d_fp, d_fm, d_J, d_C, d_cpart, d_part, d_pv, d_u, d_pub};
         for (double *b : bufs)
             if (b)
                 (void)hipFree(b);
         d_y = d_sw = d_fval = d_f[0] = d_f[1] = d_fp = d_fm = d_J = d_C = d_cpart = d_part = d_pv = d_u = nullptr;
+        d_pub = nullptr;
+        if (h_pin)
+            (void)hipHostFree(h_pin);
+        if (h_xmap)
+            (void)hipHostFree(h_xmap);
+        h_pin = h_xmap = d_xmap = nullptr;
         if (st)
             (void)hipStreamDestroy(st);
         st = nullptr;
@@ -199,6 +249,10 @@ struct BdFit
         GSLNLS_HIP_OK(hipMalloc(&d_cpart, sizeof(double) * (size_t)nslice * npair * 4096));
         GSLNLS_HIP_OK(hipMalloc(&d_part, sizeof(double) * BD_MAXG));
         GSLNLS_HIP_OK(hipMalloc(&d_pv, sizeof(double) * (size_t)4 * p));
+        GSLNLS_HIP_OK(hipMalloc(&d_pub, sizeof(double) * ((size_t)2 * p + BD_MAXG)));
+        GSLNLS_HIP_OK(hipHostMalloc(&h_xmap, sizeof(double) * (size_t)3 * p, hipHostMallocMapped));
+        GSLNLS_HIP_OK(hipHostGetDevicePointer((void **)&d_xmap, h_xmap, 0));
+        GSLNLS_HIP_OK(hipHostMalloc(&h_pin, sizeof(double) * ((size_t)4 * p + 2 * BD_MAXG), hipHostMallocDefault));
         h_part.resize(BD_MAXG);
         GSLNLS_HIP_OK(hipMemcpyAsync(d_y, y, nb, hipMemcpyHostToDevice, st));
         if (swts)
@@ -244,6 +298,7 @@ struct BdFit
                double *jtj_host)
     {
         *badj = 0.0;
+        int nbadparts = 0;
         if (prm.jac_analytic)
         {
             if (model->jacobian(theta, d_J, st))
@@ -252,10 +307,9 @@ struct BdFit
             long long gl = (tot + BD_T - 1) / BD_T;
             const int g = (int)(gl > BD_MAXG ? BD_MAXG : gl);
             hipLaunchKernelGGL(bd_weight_kernel, dim3(g), dim3(BD_T), 0, st, d_J, d_sw, (long long)n, p, d_part);
-            double b = 0.0;
-            if (int rc = sum_parts(g, &b))
-                return rc;
-            *badj = (b == 0.0) ? 0.0 : 1.0;
+            // (its flags travel with g and the diagonal below: one synchronisation per Jacobian, not two)
+            nbadparts = g;
+            GSLNLS_HIP_OK(hipMemcpyAsync(h_pin + 4 * (size_t)p, d_part, sizeof(double) * g, hipMemcpyDeviceToHost, st));
         }
         else
         {
@@ -292,16 +346,27 @@ struct BdFit
         hipLaunchKernelGGL(bd_syrk_kernel, dim3(npair, nslice), dim3(BD_T), 0, st, d_J, (long long)n, p, nslice, d_cpart);
         hipLaunchKernelGGL(bd_syrk_reduce_kernel, dim3(npair, 16), dim3(BD_T), 0, st, d_cpart, p, npair, nslice, d_C);
         hipLaunchKernelGGL(bd_gemv_t_kernel, dim3(p), dim3(BD_T), 0, st, d_J, d_fbase, (long long)n, p, d_pv);
-        GSLNLS_HIP_OK(hipMemcpyAsync(g_out, d_pv, sizeof(double) * p, hipMemcpyDeviceToHost, st));
+        // g and diag(J^T J) through the pinned staging area (h_pin: g | diagonal | .. | the weight kernel's flags)
+        GSLNLS_HIP_OK(hipMemcpyAsync(h_pin, d_pv, sizeof(double) * p, hipMemcpyDeviceToHost, st));
         if (jtj_host)
             GSLNLS_HIP_OK(hipMemcpyAsync(jtj_host, d_C, sizeof(double) * (size_t)p * p, hipMemcpyDeviceToHost, st));
         else
-            GSLNLS_HIP_OK(hipMemcpy2DAsync(djj_out, sizeof(double), d_C, sizeof(double) * ((size_t)p + 1), sizeof(double), (size_t)p,
+            GSLNLS_HIP_OK(hipMemcpy2DAsync(h_pin + p, sizeof(double), d_C, sizeof(double) * ((size_t)p + 1), sizeof(double), (size_t)p,
                                            hipMemcpyDeviceToHost, st));
         GSLNLS_HIP_OK(hipStreamSynchronize(st));
+        memcpy(g_out, h_pin, sizeof(double) * p);
         if (jtj_host)
             for (int j = 0; j < p; ++j)
                 djj_out[j] = jtj_host[(size_t)j * p + j];
+        else
+            memcpy(djj_out, h_pin + p, sizeof(double) * p);
+        if (nbadparts)
+        {
+            double b = 0.0;
+            for (int k = 0; k < nbadparts; ++k)
+                b += h_pin[4 * (size_t)p + k];
+            *badj = (b == 0.0) ? 0.0 : 1.0;
+        }
         GSLNLS_HIP_OK(hipGetLastError());
         return GSLNLS_SUCCESS;
     }
@@ -586,6 +651,39 @@ struct BdFit
             bad_steps = 0;
             trace_row(0, chisq_init);
         }
+        // Round 5, models evaluated by a device kernel (formulas), algorithm lm, device solve: ONE host synchronisation per
+        // trial step.  Behind the back substitution, on the solve's stream: x + dx (bounds applied), the model there, its
+        // weighted residual with the partial sums of ||f||^2, the rows of dx^T (J^T J) dx -- published with the solution.
+        // The host adds the partial sums in the order sum_parts / quad_device add them: the same numbers as the stepwise path.
+        struct TrialTail
+        {
+            BdFit *fit;
+            double delta;
+            int has_bounds, g;
+        } tt{this, 0.0, prm.has_bounds ? 1 : 0, grid_n()};
+        const bool fused_trial = dev_solve && prm.trs == 0 && model->theta_on_device() && !getenv("GSLNLS_BD_STEPWISE");
+        if (fused_trial)
+            for (int k = 0; k < p; ++k)
+            {
+                h_xmap[k] = x[k];
+                h_xmap[p + k] = lo[k];
+                h_xmap[2 * (size_t)p + k] = up[k];
+            }
+        auto tail_enqueue = [](void *ctx, void *stream, const double *d_sol) {
+            TrialTail &t = *static_cast<TrialTail *>(ctx);
+            BdFit &f = *t.fit;
+            hipStream_t s2 = (hipStream_t)stream;
+            const int p = f.p;
+            double *d_xt = f.d_pub, *d_quad = f.d_pub + p, *d_parts = f.d_pub + 2 * (size_t)p;
+            hipLaunchKernelGGL(bd_trial_kernel, dim3((p + 255) / 256), dim3(256), 0, s2, f.d_xmap, d_sol, f.d_xmap + p, f.d_xmap + 2 * (size_t)p,
+                               t.delta, t.has_bounds, p, d_xt);
+            (void)f.model->values_dev(d_xt, f.d_fval, s2);
+            hipLaunchKernelGGL(bd_resid_kernel, dim3(t.g), dim3(BD_T), 0, s2, f.d_fval, f.d_y, f.d_sw, (long long)f.n, f.d_f[f.cur ^ 1], d_parts);
+            hipLaunchKernelGGL(bd_quad_kernel, dim3(p), dim3(BD_T), 0, s2, f.d_C, d_sol, p, d_quad);
+        };
+        std::vector<double> pub(fused_trial ? (size_t)2 * p + tt.g : 0);
+        double prof_solve = 0.0, prof_jac = 0.0, prof_resid = 0.0;
+        long prof_njac = 0;
         // ---- driver2 / trust_iterate_lu_LD: one pass of the loop = one trial step ----
         long steps = 0;
         const long max_steps = ((long)maxiter * 17 + 2) * (prm.trs ? 2 : 1) + 2;
@@ -598,8 +696,29 @@ struct BdFit
             // lm_begin_step: velocity of the damped system
             for (int k = 0; k < p; ++k)
                 rhs[k] = -g[k];
-            if ((rc = damped_solve(rhs, vel)))
+            bool trial_done = false; // the fused tail delivered x + dx, ||f(x + dx)||^2 and dx^T J^T J dx with the solution
+            const double t_s0 = now_s();
+            if (fused_trial)
+            {
+                tt.delta = delta;
+                MCholTail tail;
+                tail.enqueue = tail_enqueue;
+                tail.ctx = &tt;
+                tail.extra_dev = d_pub;
+                tail.extra_n = 2 * p + tt.g;
+                tail.extra_host = pub.data();
+                int valid = 0;
+                vel.assign(p, 0.0);
+                rc = mchol_device_solve_resident_tail(p, d_C, diag.data(), mu, rhs.data(), vel.data(), &tail, &valid);
+                if (rc == GSLNLS_E_UNSUPPORTED)
+                    rc = damped_solve(rhs, vel); // (a size the device routine does not take)
+                if (rc)
+                    return rc;
+                trial_done = valid != 0;
+            }
+            else if ((rc = damped_solve(rhs, vel)))
                 return rc;
+            prof_solve += now_s() - t_s0;
             if (prm.trs == 1)
             {
                 // geodesic acceleration (src/trust.c:252-286)
@@ -658,12 +777,29 @@ struct BdFit
                 xt[k] = t;
             }
             // trust_eval_step + radius / mu updates (src/trust.c:474-545)
-            double ssr_t = INFINITY;
-            rc = resid_at(xt.data(), d_f[cur ^ 1], &ssr_t);
-            if (rc == GSLNLS_EBADFUNC)
-                ssr_t = INFINITY;
-            else if (rc)
-                return rc;
+            double ssr_t = INFINITY, vAv_tail = 0.0;
+            if (trial_done)
+            {
+                // (x + dx as the device formed it: the same expression on the same values; the sums in sum_parts' order)
+                for (int k = 0; k < p; ++k)
+                    xt[k] = pub[k];
+                double s0 = 0.0;
+                for (int k = 0; k < tt.g; ++k)
+                    s0 += pub[2 * (size_t)p + k];
+                ssr_t = s0;
+                for (int i = 0; i < p; ++i)
+                    vAv_tail += pub[(size_t)p + i];
+            }
+            else
+            {
+                const double t_r0 = now_s();
+                rc = resid_at(xt.data(), d_f[cur ^ 1], &ssr_t);
+                prof_resid += now_s() - t_r0;
+                if (rc == GSLNLS_EBADFUNC)
+                    ssr_t = INFINITY;
+                else if (rc)
+                    return rc;
+            }
             nevalf += 1;
             double rho;
             if (!(ssr_t < fnorm2))
@@ -673,7 +809,9 @@ struct BdFit
                 const double finv = 1.0 / fnorm2;
                 const double ared = 1.0 - ssr_t * finv;
                 double vAv = 0.0, Dv2 = 0.0;
-                if (dev_solve)
+                if (trial_done)
+                    vAv = vAv_tail;
+                else if (dev_solve)
                 {
                     if ((rc = quad_device(vel.data(), &vAv)))
                         return rc;
@@ -705,7 +843,10 @@ struct BdFit
             if (found)
             {
                 itstatus = ST_SUCCESS;
+                const double t_j0 = now_s();
                 rc = jac_at(xt.data(), d_f[cur ^ 1], prm, gt.data(), djjt.data(), &badj, dev_solve ? nullptr : A.data());
+                prof_jac += now_s() - t_j0;
+                prof_njac += 1;
                 if (rc == GSLNLS_EBADFUNC)
                     badj = 1.0;
                 else if (rc)
@@ -722,6 +863,8 @@ struct BdFit
                 if (itstatus == ST_SUCCESS)
                 {
                     x = xt;
+                    if (fused_trial)
+                        memcpy(h_xmap, x.data(), sizeof(double) * p); // (read in place by the next trial step's kernel)
                     g = gt;
                     djj = djjt;
                     cur ^= 1;
@@ -785,6 +928,8 @@ struct BdFit
         }
         // ---- result (src/nls.c:648-753) ----
         const bool ok = (status == ST_SUCCESS || status == ST_EMAXITER);
+        const double t_res0 = now_s();
+        double t_res1 = t_res0, t_res2 = t_res0;
         for (int k = 0; k < p; ++k)
             if (out->par)
                 out->par[k] = ok ? x[k] : start[k];
@@ -814,6 +959,7 @@ struct BdFit
                 for (int j = 0; j < p; ++j)
                     out->covar[i + (size_t)p * j] = good ? Ci[(size_t)i * p + j] : NAN;
         }
+        t_res1 = now_s();
         if (out->resid)
         {
             if (ok)
@@ -830,6 +976,7 @@ struct BdFit
                 for (size_t i = 0; i < (size_t)n * p; ++i)
                     out->grad[i] = NAN;
         }
+        t_res2 = now_s();
         last_x = x;
         last_f = d_f[cur];
         out->niter = niter;
@@ -845,6 +992,24 @@ struct BdFit
         out->n_launches = 0;
         out->n_steps = (int)steps;
         out->jtj_cond = ok ? bd_scaled_cond(p, Afin) : NAN;
+        if (!point_fit)
+        {
+            g_bd_prof.loop_ms = loop_ms;
+            g_bd_prof.solve_ms = 1e3 * prof_solve;
+            g_bd_prof.jac_ms = 1e3 * prof_jac;
+            g_bd_prof.resid_ms = 1e3 * prof_resid;
+            g_bd_prof.covar_ms = 1e3 * (t_res1 - t_res0);
+            g_bd_prof.down_ms = 1e3 * (t_res2 - t_res1);
+            g_bd_prof.cond_ms = 1e3 * (now_s() - t_res2);
+            g_bd_prof.trial_steps = steps;
+            g_bd_prof.jacobians = prof_njac;
+            g_bd_prof.fused = fused_trial ? 1 : 0;
+            g_bd_prof.p = p;
+            g_bd_prof.n = n;
+        }
+        if (getenv("GSLNLS_LARGE_PROF"))
+            fprintf(stderr, "[bd] p = %d n = %d: loop %.2f ms (%ld trial steps), covariance %.2f ms, resid + grad down %.2f ms, condition %.2f ms\n", p, n,
+                    loop_ms, steps, 1e3 * (t_res1 - t_res0), 1e3 * (t_res2 - t_res1), 1e3 * (now_s() - t_res2));
         out->code_path = 4;
         return status;
     }
@@ -1303,6 +1468,61 @@ inline int bd_mstart(BdFit &fit, int jac, int fvv, const double *start2p, const 
     out->mstart_stop = m.mstop;
     out->mstart_ssropt = m.mssropt[0];
     return rc;
+}
+
+// measurement hook: device milliseconds of one J^T J (bd_syrk_kernel + bd_syrk_reduce_kernel) on an n x p matrix of noise,
+// by HIP events over `reps` repetitions; < 0 on error
+inline double bd_time_syrk(int n, int p, int reps)
+{
+    if (n < 1 || p < 1 || p > 4096 || reps < 1)
+        return -1.0;
+    const int npanel = (p + 63) / 64, npair = npanel * (npanel + 1) / 2;
+    const long long ntile = ((long long)n + 63) / 64;
+    long long sl = (512 + npair - 1) / npair;
+    sl = sl > ntile ? ntile : sl;
+    sl = sl > 32 ? 32 : (sl < 1 ? 1 : sl);
+    const int nslice = (int)sl;
+    double *dJ = nullptr, *dC = nullptr, *dpart = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t st = nullptr;
+    double ms = -1.0;
+    if (hipMalloc(&dJ, sizeof(double) * (size_t)n * p) == hipSuccess && hipMalloc(&dC, sizeof(double) * (size_t)p * p) == hipSuccess &&
+        hipMalloc(&dpart, sizeof(double) * (size_t)nslice * npair * 4096) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
+        hipEventCreate(&e1) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess)
+    {
+        std::vector<double> h((size_t)n * p);
+        unsigned long long sd = 88172645463325252ull;
+        for (double &v : h)
+        {
+            sd ^= sd << 13;
+            sd ^= sd >> 7;
+            sd ^= sd << 17;
+            v = (double)(sd >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+        }
+        (void)hipMemcpy(dJ, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
+        for (int r = 0; r < reps + 2; ++r)
+        {
+            if (r == 2)
+                (void)hipEventRecord(e0, st);
+            hipLaunchKernelGGL(bd_syrk_kernel, dim3(npair, nslice), dim3(BD_T), 0, st, dJ, (long long)n, p, nslice, dpart);
+            hipLaunchKernelGGL(bd_syrk_reduce_kernel, dim3(npair, 16), dim3(BD_T), 0, st, dpart, p, npair, nslice, dC);
+        }
+        (void)hipEventRecord(e1, st);
+        float f = 0.f;
+        if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&f, e0, e1) == hipSuccess)
+            ms = (double)f / reps;
+    }
+    (void)hipGetLastError();
+    if (st)
+        (void)hipStreamDestroy(st);
+    if (e0)
+        (void)hipEventDestroy(e0);
+    if (e1)
+        (void)hipEventDestroy(e1);
+    (void)hipFree(dJ);
+    (void)hipFree(dC);
+    (void)hipFree(dpart);
+    return ms;
 }
 
 // host closures as the model: gslnls_nls_fn (capi.hip)

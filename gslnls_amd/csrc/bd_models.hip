@@ -1,7 +1,9 @@
 // bd_models.hip -- the translation unit of the "Jacobian as a matrix in HBM" path (bd_host.hpp, bd_kernels.hpp): gsl_nls() on
 // R functions (host closures) and on formulas with more than 64 parameters (rows by a kernel compiled in process).
 #include <hip/hip_runtime.h>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/gslnls_core.h"
@@ -44,7 +46,7 @@ inline std::string rtc_bd_expr(int mode) { return "&gslnls::bd_model_kernel<gsln
 struct BdFormulaModel : BdModel
 {
     int n = 0, p = 0, nx = 1;
-    double *d_x = nullptr, *d_theta = nullptr;
+    double *d_x = nullptr, *d_theta = nullptr, *d_ring = nullptr;
     std::shared_ptr<RtcEntry> rtc;
     hipFunction_t fn_mode[3] = {nullptr, nullptr, nullptr};
     ~BdFormulaModel() override
@@ -53,23 +55,41 @@ struct BdFormulaModel : BdModel
             (void)hipFree(d_x);
         if (d_theta)
             (void)hipFree(d_theta);
+        if (d_ring)
+            (void)hipFree(d_ring);
+        if (h_ring)
+            (void)hipHostFree(h_ring);
     }
+    // theta / v are the caller's vectors and may change as soon as this returns: they go through a ring of pinned slots
+    // (one asynchronous copy each, no synchronisation -- round 5; the ring is longer than the evaluations a Jacobian by
+    // central differences enqueues between two synchronisations of the fit: 2 p + 2 <= 1026)
+    static constexpr int RING = 1100;
+    double *h_ring = nullptr;
+    int ring_at = 0;
     int launch(int mode, const double *theta, const double *v, double *d_fval, double *d_J, hipStream_t st)
     {
-        if (hipMemcpyAsync(d_theta, theta, sizeof(double) * p, hipMemcpyHostToDevice, st) != hipSuccess)
+        double *slot = h_ring + (size_t)ring_at * 2 * p;
+        ring_at = (ring_at + 1) % RING;
+        memcpy(slot, theta, sizeof(double) * p);
+        if (v)
+            memcpy(slot + p, v, sizeof(double) * p);
+        // (the device copy of theta is per slot as well: a kernel still running must not see the next evaluation's theta)
+        double *dth = d_ring + (size_t)((ring_at + RING - 1) % RING) * 2 * p;
+        if (hipMemcpyAsync(dth, slot, sizeof(double) * (size_t)(v ? 2 * p : p), hipMemcpyHostToDevice, st) != hipSuccess)
             return 1;
-        if (v && hipMemcpyAsync(d_theta + p, v, sizeof(double) * p, hipMemcpyHostToDevice, st) != hipSuccess)
-            return 1;
-        // (theta / v are the caller's vectors: the copies have to be over before it changes them)
-        if (hipStreamSynchronize(st) != hipSuccess)
-            return 1;
-        const double *th = d_theta, *dir = d_theta + p, *xx = d_x;
+        return launch_dev(mode, dth, dth + p, d_fval, d_J, st);
+    }
+    int launch_dev(int mode, const double *th, const double *dir, double *d_fval, double *d_J, hipStream_t st)
+    {
+        const double *xx = d_x;
         long long nn = n;
         int g = (int)((nn + 255) / 256);
         g = g > 2048 ? 2048 : (g < 1 ? 1 : g);
         void *args[] = {(void *)&th, (void *)&dir, (void *)&xx, (void *)&nn, (void *)&d_fval, (void *)&d_J};
         return hipModuleLaunchKernel(fn_mode[mode], g, 1, 1, 256, 1, 1, 0, st, args, nullptr) == hipSuccess ? 0 : 1;
     }
+    bool theta_on_device() const override { return true; }
+    int values_dev(const double *d_th, double *d_fval, hipStream_t st) override { return launch_dev(0, d_th, d_th, d_fval, nullptr, st); }
     int values(const double *theta, double *d_fval, hipStream_t st) override { return launch(0, theta, nullptr, d_fval, nullptr, st); }
     int jacobian(const double *theta, double *d_J, hipStream_t st) override
     {
@@ -87,25 +107,59 @@ int bd_formula_nls(const gslnls_model *fn, const double *y, int n, int jac, int 
 {
     if (!fn->expr || !fn->parnames || (fn->nx > 0 && !fn->xnames) || fn->nx > WIDE_NX || fn->p > BIG_MAX_P || fn->x_on_device)
         return fn->p > BIG_MAX_P || fn->nx > WIDE_NX || fn->x_on_device ? GSLNLS_E_UNSUPPORTED : GSLNLS_EINVAL;
+    const double t_a = now_s();
     std::vector<std::string> pn(fn->parnames, fn->parnames + fn->p), vn(fn->xnames, fn->xnames + fn->nx);
-    auto prog = std::make_unique<BigProgram>();
     const int nxm = fn->nx > 0 ? fn->nx : 1;
-    const std::string e = compile_expression_t(fn->expr, pn, vn, nxm, *prog);
-    if (!e.empty())
+    // The lowering of the expression (parse, symbolic gradient and second directional derivative, the row model as C++
+    // text) is kept per formula: at p = 500 it is 280 ms of a call whose whole fit is 7 -- measured, round 5 -- and a
+    // multi-start or a series of fits repeats it unchanged.  Key: expression + parameter and column names in order.
+    struct Lowered
     {
-        fprintf(stderr, "gslnls: cannot lower model expression: %s\n", e.c_str());
-        return GSLNLS_E_UNSUPPORTED;
+        std::string src;
+        int nfvv = 0;
+    };
+    static std::mutex cache_mu;
+    static std::map<std::string, std::shared_ptr<Lowered>> cache;
+    std::string key = std::string(fn->expr) + "\x01" + std::to_string(nxm);
+    for (const std::string &q : pn)
+        key += "\x02" + q;
+    for (const std::string &q : vn)
+        key += "\x03" + q;
+    std::shared_ptr<Lowered> low;
+    {
+        std::lock_guard<std::mutex> lock(cache_mu);
+        auto it = cache.find(key);
+        if (it != cache.end())
+            low = it->second;
     }
-    if (fvv && prog->nfvv == 0)
+    if (!low)
+    {
+        auto prog = std::make_unique<BigProgram>();
+        const std::string e = compile_expression_t(fn->expr, pn, vn, nxm, *prog);
+        if (!e.empty())
+        {
+            fprintf(stderr, "gslnls: cannot lower model expression: %s\n", e.c_str());
+            return GSLNLS_E_UNSUPPORTED;
+        }
+        low = std::make_shared<Lowered>();
+        low->nfvv = prog->nfvv;
+        low->src = "// generated by gslnls wide_models.hip (bd)\n#include \"bd_model_kernels.hpp\"\n";
+        low->src += rtc_emit_model(*prog, nxm);
+        std::lock_guard<std::mutex> lock(cache_mu);
+        if (cache.size() >= 8)
+            cache.erase(cache.begin());
+        cache[key] = low;
+    }
+    if (fvv && low->nfvv == 0)
         return GSLNLS_E_UNSUPPORTED;
+    const double t_b = now_s();
     BdFormulaModel m;
     m.n = n;
     m.p = fn->p;
     m.nx = nxm;
     m.has_jac = true;
-    m.has_fvv = prog->nfvv > 0;
-    std::string src = "// generated by gslnls wide_models.hip (bd)\n#include \"bd_model_kernels.hpp\"\n";
-    src += rtc_emit_model(*prog, nxm);
+    m.has_fvv = low->nfvv > 0;
+    const std::string &src = low->src;
     std::vector<std::string> exprs = {rtc_bd_expr(0), rtc_bd_expr(1)};
     if (m.has_fvv)
         exprs.push_back(rtc_bd_expr(2));
@@ -121,10 +175,13 @@ int bd_formula_nls(const gslnls_model *fn, const double *y, int n, int jac, int 
         fprintf(stderr, "gslnls: cannot build the kernels of a p = %d model (needs the in-process compiler): %s\n", fn->p, msg.c_str());
         return GSLNLS_E_UNSUPPORTED;
     }
+    const double t_c = now_s();
     const size_t nb = sizeof(double) * (size_t)n;
     GSLNLS_HIP_OK(hipMalloc(&m.d_x, nb * nxm));
     GSLNLS_HIP_OK(hipMalloc(&m.d_theta, sizeof(double) * (size_t)2 * fn->p + nb));
     m.d_scratch = m.d_theta + 2 * fn->p;
+    GSLNLS_HIP_OK(hipMalloc(&m.d_ring, sizeof(double) * (size_t)BdFormulaModel::RING * 2 * fn->p));
+    GSLNLS_HIP_OK(hipHostMalloc(&m.h_ring, sizeof(double) * (size_t)BdFormulaModel::RING * 2 * fn->p, hipHostMallocDefault));
     if (fn->nx > 0)
         GSLNLS_HIP_OK(hipMemcpy(m.d_x, fn->x, nb * nxm, hipMemcpyHostToDevice));
     else
@@ -133,6 +190,10 @@ int bd_formula_nls(const gslnls_model *fn, const double *y, int n, int jac, int 
     int rc = fit.init(n, fn->p, y, swts, &m);
     if (rc)
         return rc;
+    g_bd_prof.setup_ms = 1e3 * (now_s() - t_a);
+    if (getenv("GSLNLS_LARGE_PROF"))
+        fprintf(stderr, "[bd] p = %d: expression -> program %.2f ms, kernels (cache / in-process compiler) %.2f ms, buffers + upload %.2f ms\n", fn->p,
+                1e3 * (t_b - t_a), 1e3 * (t_c - t_b), 1e3 * (now_s() - t_c));
     if (start_is_matrix)
         return bd_mstart(fit, jac, fvv, start, lupars, ci, cd, has_start, comm, loss_rho, loss_cc, out);
     if (loss_rho != 0)
@@ -140,5 +201,17 @@ int bd_formula_nls(const gslnls_model *fn, const double *y, int n, int jac, int 
     return fit.solve(jac, fvv, start, lupars, ci, cd, out);
 }
 
+
+// gslnls_last_matrix_path_profile / gslnls_debug_bd_syrk_ms (include/gslnls_core.h)
+int bd_last_profile(double *v, int cap)
+{
+    const double a[12] = {g_bd_prof.setup_ms, g_bd_prof.loop_ms, g_bd_prof.solve_ms, g_bd_prof.jac_ms, g_bd_prof.resid_ms, g_bd_prof.covar_ms,
+                          g_bd_prof.down_ms,  g_bd_prof.cond_ms, (double)g_bd_prof.trial_steps, (double)g_bd_prof.jacobians,
+                          (double)g_bd_prof.fused, (double)g_bd_prof.p};
+    for (int k = 0; k < cap && k < 12; ++k)
+        v[k] = a[k];
+    return 12;
+}
+double bd_syrk_ms(int n, int p, int reps) { return bd_time_syrk(n, p, reps); }
 
 } // namespace gslnls

@@ -92,6 +92,8 @@ int bd_callback_nls(int n, int p, const double *y, gslnls_fn_cb f, gslnls_jac_cb
                     const double *start, int start_is_matrix, const int *has_start, const MsComm &comm, const double *swts,
                     const double *lupars, const int *ci, const double *cd, int loss_rho, const double *loss_cc,
                     gslnls_result *out); // bd_models.hip
+int bd_last_profile(double *v, int cap);     // bd_models.hip
+double bd_syrk_ms(int n, int p, int reps);   // bd_models.hip
 void trim_dense_expr();                                                                                         // vm_models.hip
 }
 
@@ -1221,6 +1223,15 @@ int gslnls_last_call_profile(double *ms, int cap)
         ms[k] = v[k];
     return 7;
 }
+
+int gslnls_last_matrix_path_profile(double *ms, int cap)
+{
+    if (!ms)
+        return GSLNLS_EINVAL;
+    return bd_last_profile(ms, cap);
+}
+
+double gslnls_debug_bd_syrk_ms(int n, int p, int reps) { return bd_syrk_ms(n, p, reps); }
 
 int gslnls_solver_served(const int *control_int, const gslnls_result *res)
 {

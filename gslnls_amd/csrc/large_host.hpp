@@ -234,6 +234,21 @@ int mchol_device_solve(int p, const double *A_host, const double *rhs_host, doub
 // ... with J^T J where the operators left it on the device (A = J^T J + mu D^2 is formed there)
 int mchol_device_solve_resident(int p, const double *jtj_dev, const double *diag_host, double mu, const double *rhs_host,
                                 double *sol_host);
+// ... and with more work enqueued BEHIND the back substitution on the solve's own stream, before the host is told: the
+// matrix path's trial step (bd_host.hpp, round 5) evaluates the model at x + dx, its residual and the rows of dx^T J^T J dx
+// there, and the solve's one host synchronisation brings all of it back -- `extra_n` doubles from `extra_dev` travel with
+// the solution into `extra_host`.  *tail_valid = 0 when the natural-order factorisation was refused (the pivoted routine
+// produced the solution after the tail had run on a discarded one): the caller repeats the tail's work its own way.
+struct MCholTail
+{
+    void (*enqueue)(void *ctx, void *stream, const double *d_sol) = nullptr;
+    void *ctx = nullptr;
+    const double *extra_dev = nullptr;
+    int extra_n = 0;
+    double *extra_host = nullptr;
+};
+int mchol_device_solve_resident_tail(int p, const double *jtj_dev, const double *diag_host, double mu, const double *rhs_host,
+                                     double *sol_host, const MCholTail *tail, int *tail_valid);
 // s = (J^T J) v with J^T J where it sits on the device (p doubles up, p doubles down): the row sums of the predicted
 // reduction v^T J^T J v, each in the order of the host loop (j ascending, product and sum rounded separately)
 int mchol_device_symv(int p, const double *jtj_dev, const double *v_host, double *s_host);

@@ -41,6 +41,7 @@ constexpr int MC_NB_MAX = 32;         // pivot steps per panel
 constexpr int MC_PMAX = 4096;
 constexpr int MC_RPT = 4;             // rows per thread at most (the block is sized to p: MC_RPT x blockDim.x >= p)
 constexpr int MC_LDS_BYTES = 150 * 1024;
+constexpr int MC_EXTRA_MAX = 2 * MC_PMAX + 2048; // doubles a tail may send to the host with the solution (MCholTail)
 
 struct MCholArgs
 {
@@ -1357,10 +1358,13 @@ __global__ void cholb_flag_kernel(const int *flag, double *dst)
 // through its mapping, then -- behind a system-scope fence -- the sequence number of the solve: the host polls that word
 // instead of waiting in hipStreamSynchronize (measured on the driver's box: 5.2 ms of wall time for 1.7 ms of device time
 // at p = 2000, most of it the wake-up of the waiting thread).
-__global__ __launch_bounds__(256) void cholb_publish_kernel(const double *sol, const int *flag, int p, double *h_out, unsigned long long seq)
+__global__ __launch_bounds__(256) void cholb_publish_kernel(const double *sol, const int *flag, int p, double *h_out, unsigned long long seq,
+                                                            const double *extra, int extra_n)
 {
     for (int j = threadIdx.x; j < p; j += 256)
         h_out[j] = sol[j];
+    for (int j = threadIdx.x; j < extra_n; j += 256) // (what a tail computed behind the solve: MCholTail)
+        h_out[p + 2 + j] = extra[j];
     if (threadIdx.x == 0)
         h_out[p] = (double)*flag;
     __threadfence_system();
@@ -1429,7 +1433,7 @@ struct MCholBuffers
     hipStream_t sq2 = nullptr;               // round 5: the trailing updates behind the next panel's column run beside that panel
     hipEvent_t evp[2] = {nullptr, nullptr}, evr[2] = {nullptr, nullptr}; // panel k done / rest of trailing update k done (ping-pong)
     hipEvent_t evdone = nullptr;             // behind the last kernel of a solve: polled beside the sequence word
-    double *down = nullptr, *down_dev = nullptr; // pinned + mapped, cap + 2 doubles: solution | flag | sequence number
+    double *down = nullptr, *down_dev = nullptr; // pinned + mapped: solution (cap) | flag | sequence number | a tail's extra (MC_EXTRA_MAX)
     unsigned long long seq = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr; // around the kernels of a solve: gslnls_debug_mchol_last_device_ms
     float last_device_ms = -1.f;
@@ -1445,10 +1449,12 @@ static MCholBuffers &mchol_buffers()
 // A_host != nullptr: the matrix itself from the host.  Otherwise jtj_dev (p x p on the device, left untouched) with
 // diag_host and mu: A = J^T J + mu D^2 is formed on the device -- the 8 p^2 bytes do not travel.
 static int mchol_device_solve_impl(int p, const double *A_host, const double *jtj_dev, const double *diag_host, double mu,
-                                   const double *rhs_host, double *sol_host)
+                                   const double *rhs_host, double *sol_host, const MCholTail *tail = nullptr, int *tail_valid = nullptr)
 {
-    if (p < 1 || p > MC_PMAX)
+    if (p < 1 || p > MC_PMAX || (tail && (tail->extra_n < 0 || tail->extra_n > MC_EXTRA_MAX)))
         return GSLNLS_E_UNSUPPORTED;
+    if (tail_valid)
+        *tail_valid = 0;
     const double t_entry = now_s();
     MCholBuffers &B = mchol_buffers();
     std::lock_guard<std::mutex> lock(B.mu);
@@ -1477,7 +1483,7 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
             hipMalloc(&B.Cg, sizeof(double) * (size_t)MC_NB_MAX * p) != hipSuccess ||
             hipMalloc(&B.vec, sizeof(double) * ((size_t)7 * p + MC_NB_MAX + 24)) != hipSuccess ||
             hipHostMalloc(&B.stage, sizeof(double) * ((size_t)3 * p + 8), hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc(&B.down, sizeof(double) * ((size_t)p + 2), hipHostMallocMapped) != hipSuccess ||
+            hipHostMalloc(&B.down, sizeof(double) * ((size_t)p + 2 + MC_EXTRA_MAX), hipHostMallocMapped) != hipSuccess ||
             hipHostGetDevicePointer((void **)&B.down_dev, B.down, 0) != hipSuccess ||
             hipMalloc(&B.ivec, sizeof(int) * ((size_t)2 * p + 4)) != hipSuccess)
         {
@@ -1664,7 +1670,10 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
                 (void)hipEventRecord(B.ev1, sq);
             B.seq += 1;
             B.down[p + 1] = 0.0; // (the word the device is about to write; any value but the new sequence number)
-            hipLaunchKernelGGL(cholb_publish_kernel, dim3(1), dim3(256), 0, sq, d_sol, d_flag, p, B.down_dev, B.seq);
+            if (tail && tail->enqueue)
+                tail->enqueue(tail->ctx, (void *)sq, d_sol); // (the caller's kernels, behind the back substitution on this stream)
+            hipLaunchKernelGGL(cholb_publish_kernel, dim3(1), dim3(256), 0, sq, d_sol, d_flag, p, B.down_dev, B.seq,
+                               tail ? tail->extra_dev : nullptr, tail ? tail->extra_n : 0);
             GSLNLS_HIP_OK(hipEventRecord(B.evdone, sq));
             const double t_enq = now_s();
             {
@@ -1697,6 +1706,10 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
             if (h_down[p] == 0.0)
             {
                 memcpy(sol_host, h_down, sizeof(double) * p);
+                if (tail && tail->extra_n > 0 && tail->extra_host)
+                    memcpy(tail->extra_host, h_down + p + 2, sizeof(double) * (size_t)tail->extra_n);
+                if (tail_valid)
+                    *tail_valid = tail != nullptr;
                 GSLNLS_HIP_OK(hipGetLastError());
                 return GSLNLS_SUCCESS;
             }
@@ -1778,6 +1791,13 @@ int mchol_device_solve_resident(int p, const double *jtj_dev, const double *diag
     if (!jtj_dev || !diag_host)
         return GSLNLS_EINVAL;
     return mchol_device_solve_impl(p, nullptr, jtj_dev, diag_host, mu, rhs_host, sol_host);
+}
+int mchol_device_solve_resident_tail(int p, const double *jtj_dev, const double *diag_host, double mu, const double *rhs_host,
+                                     double *sol_host, const MCholTail *tail, int *tail_valid)
+{
+    if (!jtj_dev || !diag_host)
+        return GSLNLS_EINVAL;
+    return mchol_device_solve_impl(p, nullptr, jtj_dev, diag_host, mu, rhs_host, sol_host, tail, tail_valid);
 }
 
 } // namespace gslnls

@@ -463,7 +463,8 @@ def gsl_nls(fn, data=None, start=None, algorithm="lm", control=None, jac=None, f
                                _dp(st), int(mat is not None), None if sw is None else sw.ctypes.data_as(C.c_void_p),
                                sw_is_matrix, _dp(lu), ci.ctypes.data_as(IP), _dp(cd), hs.ctypes.data_as(IP),
                                LOSSES.index(loss_cfg["rho"]), _dp(cc), C.byref(res))
-    if rc == _lib.E_UNSUPPORTED and mid == _lib.MODEL_EXPR and not sw_is_matrix and ALGORITHMS.index(algorithm) <= 1:
+    if (rc == _lib.E_UNSUPPORTED and mid == _lib.MODEL_EXPR and not sw_is_matrix and ALGORITHMS.index(algorithm) <= 1
+            and lowering == "auto"):  # (an explicit "vm" / "jit" asks for that form of the formula's device code or nothing)
         # The core cannot lower this right-hand side (a function outside stats::deriv's table -- ifelse, pmax, ... --, a
         # comparison, too long a program).  The reference never lowers anything: its .fn closure evaluates the expression
         # (R/nls.R:565) and, where stats::deriv fails, jac stays NULL with a warning (R/nls.R:588-599).  The same here:

@@ -218,6 +218,13 @@ size_t gslnls_format_trace(const gslnls_result *res, int n, int p, const int *co
  *   while the data uploads -- measured slower on the MI355X host, see csrc/dense_host.hpp; off by default.) */
 int gslnls_last_call_profile(double *ms, int cap);
 
+/* The same for the last fit on the matrix path (function models, formulas beyond 64 parameters; csrc/bd_host.hpp), 12 values:
+ *   [0] set-up (lowering of the formula, kernels from the cache / the in-process compiler, buffers, upload), [1] the solve
+ *   loop, of which [2] damped solves (with the fused trial evaluation behind them when [10] = 1), [3] Jacobians with
+ *   J^T J and J^T f, [4] residual evaluations outside the fused step; [5] covariance, [6] resid + grad to the host,
+ *   [7] condition diagnostic; [8] trial steps, [9] Jacobians, [10] 1 = one host synchronisation per trial step, [11] p. */
+int gslnls_last_matrix_path_profile(double *ms, int cap);
+
 /*
  * Model lowering: match the deparsed right-hand side of the model formula (formula[[3]], R/nls.R:565)
  * against the device registry, up to renaming of parameters / data columns and parameter order.
@@ -417,6 +424,9 @@ int gslnls_debug_mchol_solve(int p, const double *A, const double *diag, double 
 int gslnls_debug_device_alloc(void **p, size_t bytes);
 int gslnls_debug_device_free(void *p);
 int gslnls_debug_device_copy(void *dst, const void *src, size_t bytes, int to_device);
+/* device milliseconds of one J^T J of the matrix path (bd_syrk_kernel + its reduction) on an n x p matrix of noise, HIP
+ * events over `reps` repetitions; < 0 on error */
+double gslnls_debug_bd_syrk_ms(int n, int p, int reps);
 /* device milliseconds of the last natural-order solve (HIP events around its kernels), < 0 when not available */
 double gslnls_debug_mchol_last_device_ms(void);
 /* the same with J^T J resident in device memory (jtj_dev: p x p doubles, row-major, left as it is): the call of the lm step */
