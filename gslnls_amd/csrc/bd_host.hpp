@@ -163,6 +163,27 @@ static __global__ __launch_bounds__(256) void bd_trial_kernel(const double *x, c
     xt[k] = t;
 }
 
+// what a Jacobian evaluation sends home -- g = J^T f, diag(J^T J), the non-finite flags of an analytic Jacobian -- written
+// into pinned host memory through its mapping, the sequence number of the evaluation behind a system-scope fence: the host
+// polls that word (round 5: a copy engine's pitched copy of the diagonal plus two more copies and the wake-up of a
+// thread blocked in hipStreamSynchronize were ~40 us of every accepted point)
+static __global__ __launch_bounds__(256) void bd_publish_kernel(const double *g, const double *C, int p, const double *parts, int nparts,
+                                                                 double *h_out, unsigned long long seq)
+{
+    for (int k = threadIdx.x; k < p; k += 256)
+    {
+        h_out[k] = g[k];
+        h_out[p + k] = C[(size_t)k * p + k];
+    }
+    for (int k = threadIdx.x; k < nparts; k += 256)
+        h_out[2 * (size_t)p + k] = parts[k];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(h_out + 2 * (size_t)p + BD_MAXG), seq, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 struct BdFit
 {
     int n = 0, p = 0;
@@ -175,6 +196,9 @@ struct BdFit
     // the device; pinned staging for every small copy (a pageable destination makes an asynchronous copy a blocking one)
     double *d_pub = nullptr, *h_pin = nullptr;
     double *h_xmap = nullptr, *d_xmap = nullptr; // pinned + mapped, 3 p doubles: x | lower | upper bounds, read by bd_trial_kernel in place
+    double *h_jmap = nullptr, *d_jmap = nullptr; // pinned + mapped: g | diag(J^T J) | flags (BD_MAXG) | sequence word (bd_publish_kernel)
+    unsigned long long jseq = 0;
+    hipEvent_t ev_j = nullptr;
     int cur = 0;        // d_f[cur]: residual at the current point, d_f[cur ^ 1]: at the trial point
     std::vector<double> last_x;    // where the last solve ended (whatever its status)
     // more of the state the last solve ended in -- what gsl_multistart_driver reads out of the solver workspace after a
@@ -207,7 +231,12 @@ struct BdFit
             (void)hipHostFree(h_pin);
         if (h_xmap)
             (void)hipHostFree(h_xmap);
-        h_pin = h_xmap = d_xmap = nullptr;
+        if (h_jmap)
+            (void)hipHostFree(h_jmap);
+        h_pin = h_xmap = d_xmap = h_jmap = d_jmap = nullptr;
+        if (ev_j)
+            (void)hipEventDestroy(ev_j);
+        ev_j = nullptr;
         if (st)
             (void)hipStreamDestroy(st);
         st = nullptr;
@@ -252,6 +281,10 @@ struct BdFit
         GSLNLS_HIP_OK(hipMalloc(&d_pub, sizeof(double) * ((size_t)2 * p + BD_MAXG)));
         GSLNLS_HIP_OK(hipHostMalloc(&h_xmap, sizeof(double) * (size_t)3 * p, hipHostMallocMapped));
         GSLNLS_HIP_OK(hipHostGetDevicePointer((void **)&d_xmap, h_xmap, 0));
+        GSLNLS_HIP_OK(hipHostMalloc(&h_jmap, sizeof(double) * ((size_t)2 * p + BD_MAXG + 2), hipHostMallocMapped));
+        GSLNLS_HIP_OK(hipHostGetDevicePointer((void **)&d_jmap, h_jmap, 0));
+        GSLNLS_HIP_OK(hipEventCreateWithFlags(&ev_j, hipEventDisableTiming));
+        memset(h_jmap + 2 * (size_t)p + BD_MAXG, 0, 2 * sizeof(double)); // (the sequence word: jseq counts from 1)
         GSLNLS_HIP_OK(hipHostMalloc(&h_pin, sizeof(double) * ((size_t)4 * p + 2 * BD_MAXG), hipHostMallocDefault));
         h_part.resize(BD_MAXG);
         GSLNLS_HIP_OK(hipMemcpyAsync(d_y, y, nb, hipMemcpyHostToDevice, st));
@@ -309,7 +342,6 @@ struct BdFit
             hipLaunchKernelGGL(bd_weight_kernel, dim3(g), dim3(BD_T), 0, st, d_J, d_sw, (long long)n, p, d_part);
             // (its flags travel with g and the diagonal below: one synchronisation per Jacobian, not two)
             nbadparts = g;
-            GSLNLS_HIP_OK(hipMemcpyAsync(h_pin + 4 * (size_t)p, d_part, sizeof(double) * g, hipMemcpyDeviceToHost, st));
         }
         else
         {
@@ -346,28 +378,58 @@ struct BdFit
         hipLaunchKernelGGL(bd_syrk_kernel, dim3(npair, nslice), dim3(BD_T), 0, st, d_J, (long long)n, p, nslice, d_cpart);
         hipLaunchKernelGGL(bd_syrk_reduce_kernel, dim3(npair, 16), dim3(BD_T), 0, st, d_cpart, p, npair, nslice, d_C);
         hipLaunchKernelGGL(bd_gemv_t_kernel, dim3(p), dim3(BD_T), 0, st, d_J, d_fbase, (long long)n, p, d_pv);
-        // g and diag(J^T J) through the pinned staging area (h_pin: g | diagonal | .. | the weight kernel's flags)
-        GSLNLS_HIP_OK(hipMemcpyAsync(h_pin, d_pv, sizeof(double) * p, hipMemcpyDeviceToHost, st));
-        if (jtj_host)
+        if (jtj_host) // (the host factorises: the whole matrix comes down, and the stream's end covers everything)
+        {
+            GSLNLS_HIP_OK(hipMemcpyAsync(h_pin, d_pv, sizeof(double) * p, hipMemcpyDeviceToHost, st));
+            if (nbadparts)
+                GSLNLS_HIP_OK(hipMemcpyAsync(h_pin + 4 * (size_t)p, d_part, sizeof(double) * nbadparts, hipMemcpyDeviceToHost, st));
             GSLNLS_HIP_OK(hipMemcpyAsync(jtj_host, d_C, sizeof(double) * (size_t)p * p, hipMemcpyDeviceToHost, st));
-        else
-            GSLNLS_HIP_OK(hipMemcpy2DAsync(h_pin + p, sizeof(double), d_C, sizeof(double) * ((size_t)p + 1), sizeof(double), (size_t)p,
-                                           hipMemcpyDeviceToHost, st));
-        GSLNLS_HIP_OK(hipStreamSynchronize(st));
-        memcpy(g_out, h_pin, sizeof(double) * p);
-        if (jtj_host)
+            GSLNLS_HIP_OK(hipStreamSynchronize(st));
+            memcpy(g_out, h_pin, sizeof(double) * p);
             for (int j = 0; j < p; ++j)
                 djj_out[j] = jtj_host[(size_t)j * p + j];
-        else
-            memcpy(djj_out, h_pin + p, sizeof(double) * p);
+            if (nbadparts)
+            {
+                double b = 0.0;
+                for (int k = 0; k < nbadparts; ++k)
+                    b += h_pin[4 * (size_t)p + k];
+                *badj = (b == 0.0) ? 0.0 : 1.0;
+            }
+            GSLNLS_HIP_OK(hipGetLastError());
+            return GSLNLS_SUCCESS;
+        }
+        // g, diag(J^T J) and the flags through mapped host memory; the host polls the sequence word behind them
+        jseq += 1;
+        volatile unsigned long long *word = reinterpret_cast<volatile unsigned long long *>(h_jmap + 2 * (size_t)p + BD_MAXG);
+        hipLaunchKernelGGL(bd_publish_kernel, dim3(1), dim3(256), 0, st, d_pv, d_C, p, d_part, nbadparts, d_jmap, jseq);
+        GSLNLS_HIP_OK(hipEventRecord(ev_j, st));
+        for (;;)
+        {
+            if (*word == jseq)
+                break;
+            const hipError_t q = hipEventQuery(ev_j);
+            if (q == hipSuccess)
+            {
+                if (*word != jseq)
+                    GSLNLS_HIP_OK(hipStreamSynchronize(st));
+                break;
+            }
+            if (q != hipErrorNotReady)
+            {
+                (void)hipGetLastError();
+                return GSLNLS_E_NODEVICE;
+            }
+        }
+        __sync_synchronize();
+        memcpy(g_out, h_jmap, sizeof(double) * p);
+        memcpy(djj_out, h_jmap + p, sizeof(double) * p);
         if (nbadparts)
         {
             double b = 0.0;
             for (int k = 0; k < nbadparts; ++k)
-                b += h_pin[4 * (size_t)p + k];
+                b += h_jmap[2 * (size_t)p + k];
             *badj = (b == 0.0) ? 0.0 : 1.0;
         }
-        GSLNLS_HIP_OK(hipGetLastError());
         return GSLNLS_SUCCESS;
     }
 
