@@ -502,6 +502,31 @@ def function_model_bench():
 
 
 
+def streamed_large_n_bench(L, _lib, jac):
+    """lm_step_kernel where it is bound by HBM instead of by the latency of a launch: the same fused pass (x and y read once,
+    16 n bytes, nothing n-sized written) at n = 4e6 and 6.4e7 (64 MB / 1 GB of data: beyond the 256 MiB Infinity Cache at
+    the larger size), back-to-back launches timed with HIP events on the library's stream (gslnls_dense_time_pass)."""
+    out = []
+    th = np.array([4.0, 1.2, 0.8])
+    for nn in (4_000_000, 64_000_000):
+        x = 3.0 * np.arange(nn, dtype=np.float64) / (nn - 1)
+        y = 5.0 * np.exp(-1.5 * x) + 1.0
+        model = _lib.Model(1, 3, 1, x.ctypes.data_as(C.c_void_p), 0)
+        err = C.c_int(0)
+        h = L.gslnls_dense_create(C.byref(model), y.ctypes.data_as(C.c_void_p), nn, None, C.byref(err))
+        if not h:
+            out.append({"n": nn, "error": int(err.value)})
+            continue
+        ms = float(L.gslnls_dense_time_pass(h, jac, th.ctypes.data_as(_lib.DP), 200 if nn < 10_000_000 else 40))
+        L.gslnls_dense_destroy(h)
+        del x, y
+        gc.collect()
+        gbs = 16.0 * nn / (ms * 1e-3) / 1e9 if ms > 0 else None
+        out.append({"n": nn, "bytes_per_launch": 16.0 * nn, "ms_per_launch": ms, "GBs": gbs, "frac": gbs / HBM_PEAK_GBS if gbs else None})
+    L.gslnls_trim_cache()
+    return out
+
+
 def matrix_path_bench(_lib):
     """gsl_nls() on FORMULAS beyond 64 parameters (the matrix path, csrc/bd_host.hpp: no closure, rows by a kernel compiled for
     the formula, J^T J on the matrix cores, the damped solve on the device): sums of Gaussians with p = 99, 198, 501 -- wall
@@ -1190,6 +1215,11 @@ def main():
                    "note": "value/ms_per_step above are the repeated-fit loop (the best case)"}
             L.gslnls_dense_destroy(h2)
             return out
+        def streamed_large_n():
+            line["roofline"]["streamed_large_n"] = streamed_large_n_bench(L, _lib, jac)
+            return {"see": "roofline.streamed_large_n"}
+        if not args.headline_only:
+            side("streamed_large_n", streamed_large_n)
         side("other_jacobian", other_jacobian)
         side("one_shot_vs_repeated", one_shot_vs_repeated)
         side("end_to_end", end_to_end_bench, L, _lib, x, y, n, ci_p, cd_p)

@@ -235,6 +235,7 @@ struct WideFit : DenseBase
     unsigned long long *d_stamps = nullptr; // GSLNLS_WIDE_STAMPS=1 (developer): phase stamps of the fused kernel
     int fuse = WIDE_FUSE_STEP; // GSLNLS_WIDE_FUSE = 0: pass, reduce and advance as three launches (the round-3 chain)
     int spec = 1;              // GSLNLS_WIDE_SPEC = 0: no speculative solve of the step that follows a rejection
+    int spec_fault = 0;        // GSLNLS_WIDE_SPEC_FAULT = 1 / 2 / 3: test switch of the hand-off (wide_kernels.hpp, WPassArgs)
     int pivoted = 0;           // GSLNLS_WIDE_PIVOTED = 1: every damped solve by the reference's pivoted modified Cholesky
     double *d_ssrtrace = nullptr, *d_partrace = nullptr, *d_resid = nullptr, *d_grad = nullptr;
     int trace_cap = 0;
@@ -377,6 +378,8 @@ struct WideFit : DenseBase
             fuse = atoi(e) <= 0 ? WIDE_FUSE_NONE : WIDE_FUSE_STEP;
         if (const char *e = getenv("GSLNLS_WIDE_SPEC"))
             spec = atoi(e) != 0;
+        if (const char *e = getenv("GSLNLS_WIDE_SPEC_FAULT"))
+            spec_fault = atoi(e);
         if (const char *e = getenv("GSLNLS_WIDE_PIVOTED"))
             pivoted = atoi(e) != 0;
         if (getenv("GSLNLS_WIDE_STAMPS"))
@@ -526,6 +529,7 @@ struct WideFit : DenseBase
         a.fuse = WIDE_FUSE_NONE;
         a.G = G;
         a.spec = 0;
+        a.spec_fault = 0;
         a.gsums = d_gsums;
         a.totals = d_totals;
         a.fb = d_fb;
@@ -560,6 +564,7 @@ struct WideFit : DenseBase
         {
             pa.fuse = WIDE_FUSE_STEP;
             pa.spec = spec;
+            pa.spec_fault = spec_fault;
             pa.adv = adv;
             (void)hipModuleLaunchKernel(fn_step[jm], G + pa.spec, 1, 1, WIDE_T, 1, 1, 0, stream, args, nullptr);
             return;

@@ -67,6 +67,9 @@ struct WPassArgs
     int fuse;       // WIDE_FUSE_*
     int G;          // workgroups that own rows (the grid has spec more: workgroup 0 is then the speculator)
     int spec;       // 1: workgroup 0 solves the damped system of the step that FOLLOWS A REJECTION of this launch's trial
+    int spec_fault; // test switch (GSLNLS_WIDE_SPEC_FAULT): 1 the speculator publishes a payload that does not match its tag
+                    // (a half-written payload), 2 a tag of another launch (a stale epoch), 3 nothing at all -- in every
+                    // case the stepping workgroup must find "not there" and solve itself: the same fit bit for bit
     double *gsums;  // [WIDE_NGRP][NV] level-1 sums
     double *totals; // [NV]
     WFuseBuf *fb;
@@ -582,7 +585,7 @@ __device__ __forceinline__ void wide_pass_body(const WPassArgs &a)
     // (... and for the speculator's result, which by now has been there for a while: tag, then the payload.  Nothing orders
     // these loads against each other -- the fold in the tag and the bitwise comparison of mu below are what make a
     // half-new payload "not there")
-    unsigned long long pre_tag = 0;
+    unsigned long long pre_tag = 0, pre_tag2 = ~0ull;
     double pre_sv = 0.0, pre_smu = 0.0;
     if (a.fuse == WIDE_FUSE_STEP && wave == 0)
     {
@@ -592,6 +595,9 @@ __device__ __forceinline__ void wide_pass_body(const WPassArgs &a)
             pre_tag = __hip_atomic_load(&a.fb->spec_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             pre_sv = lane < P ? __hip_atomic_load(&a.fb->spec_vel[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
             pre_smu = __hip_atomic_load(&a.fb->spec_mu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (round 5, seqlock style: the tag once more BEHIND the payload -- a wavefront's loads are issued and returned in
+            // order, so a payload read between two equal tags of this launch is the payload that tag was written behind)
+            pre_tag2 = __hip_atomic_load(&a.fb->spec_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (!wide_arrive_last(&a.fb->ticket2, (unsigned int)ngrp, &flag_s))
@@ -643,8 +649,8 @@ __device__ __forceinline__ void wide_pass_body(const WPassArgs &a)
                     f ^= (unsigned int)__shfl_xor((int)f, m, 64);
                 return f;
             };
-            auto take = [&](unsigned long long tag, double sv, double smu) {
-                if ((unsigned int)(tag >> 32) == epoch && fold_of(sv) == (unsigned int)(tag & 0xffffffffull) &&
+            auto take = [&](unsigned long long tag, unsigned long long tag_behind, double sv, double smu) {
+                if (tag == tag_behind && (unsigned int)(tag >> 32) == epoch && fold_of(sv) == (unsigned int)(tag & 0xffffffffull) &&
                     __double_as_longlong(smu) == __double_as_longlong(ctx.mu))
                 {
                     if (lane < P)
@@ -656,7 +662,7 @@ __device__ __forceinline__ void wide_pass_body(const WPassArgs &a)
                 return false;
             };
             // what was asked for before the arrival (the common case: the speculator finished 10 us ago) ...
-            if (!take(pre_tag, pre_sv, pre_smu))
+            if (!take(pre_tag, pre_tag2, pre_sv, pre_smu))
             {
                 // ... else wait for the tag of this launch, then fetch the payload
                 const unsigned long long t0 = __builtin_readcyclecounter();
@@ -678,7 +684,8 @@ __device__ __forceinline__ void wide_pass_body(const WPassArgs &a)
                 {
                     const double sv = lane < P ? __hip_atomic_load(&a.fb->spec_vel[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
                     const double smu = __hip_atomic_load(&a.fb->spec_mu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    (void)take(tag, sv, smu);
+                    const unsigned long long tag2 = __hip_atomic_load(&a.fb->spec_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    (void)take(tag, tag2, sv, smu);
                 }
             }
         }
@@ -699,12 +706,16 @@ __device__ __forceinline__ void wide_pass_body(const WPassArgs &a)
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1)
             f ^= (unsigned int)__shfl_xor((int)f, m, 64);
-        if (lane < P)
-            wide_store_wt(&a.fb->spec_vel[lane], sv);
+        if (a.spec_fault == 3)
+            return; // (test: the speculator never publishes -- the stepping workgroup's bounded wait runs out)
+        if (lane < P) // (test, fault 1: a payload whose first half is not the one the tag was folded from)
+            wide_store_wt(&a.fb->spec_vel[lane], (a.spec_fault == 1 && lane < (P + 1) / 2) ? sv * 1.0000001 + 1e-9 : sv);
         if (lane == 0)
             wide_store_wt(&a.fb->spec_mu, mu_solve);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the payload has left before the tag says so
-        const unsigned int epoch = ((unsigned int)adv.seq << 16) ^ (unsigned int)(adv.launch_idx + 1);
+        unsigned int epoch = ((unsigned int)adv.seq << 16) ^ (unsigned int)(adv.launch_idx + 1);
+        if (a.spec_fault == 2)
+            epoch ^= 0x00010001u; // (test: the tag of some other launch)
         if (lane == 0)
             __hip_atomic_store(&a.fb->spec_tag, ((unsigned long long)epoch << 32) | f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;

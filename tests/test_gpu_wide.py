@@ -676,3 +676,34 @@ print(json.dumps(dict(par=[float(v) for v in fit["par"]], ssr=float(fit["ssr"]),
     assert a["conv"] == b["conv"] == 0 and a["ms"]["nsp"] == b["ms"]["nsp"] and a["ms"]["nwsp"] == b["ms"]["nwsp"]
     assert a["ms"]["iters"] == b["ms"]["iters"] and a["ms"]["stop"] == b["ms"]["stop"]
     assert np.allclose(a["par"], b["par"], rtol=1e-8) and abs(a["ssr"] - b["ssr"]) <= 1e-10 * b["ssr"]
+
+
+def test_speculative_hand_off_rejects_torn_stale_and_missing_payloads(amd, monkeypatch):
+    """Round 5 stress test of the speculative solve's hand-off (csrc/wide_kernels.hpp: the speculator workgroup solves for the
+    case "this trial is rejected" and publishes {payload, tag}; the stepping workgroup takes the payload only if the tag read
+    in front of AND behind it is this launch's, the payload folds to the tag and mu matches bit for bit).  The test switch
+    GSLNLS_WIDE_SPEC_FAULT makes the speculator publish (1) a payload half of which is not the one its tag was folded from,
+    (2) the tag of another launch, (3) nothing: in every case the stepping workgroup must find "not there", solve itself,
+    and the fit must be the same BIT FOR BIT as with the hand-off working (0) and as without speculation."""
+    pb = gaussians_problem(5, 1, 20_000, seed=3, pert=0.25)  # (far enough from the optimum for rejected trials)
+    start = dict(zip(pb["names"], pb["start"]))
+    fits = {}
+    for mode in ("0", "1", "2", "3", "off"):
+        if mode == "off":
+            monkeypatch.delenv("GSLNLS_WIDE_SPEC_FAULT", raising=False)
+            monkeypatch.setenv("GSLNLS_WIDE_SPEC", "0")
+        else:
+            monkeypatch.setenv("GSLNLS_WIDE_SPEC_FAULT", mode)
+            monkeypatch.delenv("GSLNLS_WIDE_SPEC", raising=False)
+        fits[mode] = amd.gsl_nls(pb["formula"], data=dict(x=pb["x"], y=pb["y"]), start=start, jac=True, lowering="jit",
+                                 control=dict(solver="cholesky", maxiter=60), trace=True)
+    monkeypatch.delenv("GSLNLS_WIDE_SPEC", raising=False)
+    monkeypatch.delenv("GSLNLS_WIDE_SPEC_FAULT", raising=False)
+    ref = fits["0"]
+    assert ref["code_path"] == 3 and ref["n_launches"] == ref["n_steps"]  # (the one-launch-per-step kernel ran)
+    rejected = ref["neval"]["f"] - 1 - ref["niter"]
+    assert rejected >= 3, rejected  # (the speculator's case occurred)
+    for mode, f in fits.items():
+        assert f["conv"] == ref["conv"] and f["niter"] == ref["niter"] and f["neval"] == ref["neval"], mode
+        assert np.array_equal(f["par"], ref["par"]) and f["ssr"] == ref["ssr"], mode
+        assert np.array_equal(f["partrace"], ref["partrace"]) and np.array_equal(f["ssrtrace"], ref["ssrtrace"]), mode
