@@ -619,7 +619,7 @@ def sparse_readme_bench():
         out[alg] = {"wall_ms": el * 1e3, "niter": int(fit["niter"]), "conv": int(fit["conv"]), "ssr": float(fit["ssr"]),
                     "device_passes": int(fit["n_passes"]), "ssr_target": 0.004778845}
     # ... and the two DENSE rows of the same table (README.md:1143-1144: the Jacobian closure returns a plain matrix)
-    Jd = np.zeros((p + 1, p))
+    Jd = np.zeros((p + 1, p), order="F")  # (column-major, as the R matrix of the README's closure is: it crosses as it is)
     Jd[np.arange(p), np.arange(p)] = a
 
     def jac_dense(th):

@@ -202,6 +202,31 @@ int bd_formula_nls(const gslnls_model *fn, const double *y, int n, int jac, int 
 }
 
 
+// J^T J of a dense n x p column-major block for the large path's dense operator (sparse_large.hpp): the matrix path's
+// SYRK on the matrix cores.  The scratch for the partial blocks belongs to the caller (grown here when too small).
+int bd_dense_jtj(const double *d_J, int n, int p, double *d_C, hipStream_t st, double **cpart, size_t *cpart_bytes)
+{
+    const int npanel = (p + 63) / 64, npair = npanel * (npanel + 1) / 2;
+    const long long ntile = ((long long)n + 63) / 64;
+    long long sl = (512 + npair - 1) / npair;
+    sl = sl > ntile ? ntile : sl;
+    sl = sl > 32 ? 32 : (sl < 1 ? 1 : sl);
+    const int nslice = (int)sl;
+    const size_t need = sizeof(double) * (size_t)nslice * npair * 4096;
+    if (*cpart_bytes < need)
+    {
+        if (*cpart)
+            (void)hipFree(*cpart);
+        *cpart = nullptr;
+        *cpart_bytes = 0;
+        GSLNLS_HIP_OK(hipMalloc(cpart, need));
+        *cpart_bytes = need;
+    }
+    hipLaunchKernelGGL(bd_syrk_kernel, dim3(npair, nslice), dim3(BD_T), 0, st, d_J, (long long)n, p, nslice, *cpart);
+    hipLaunchKernelGGL(bd_syrk_reduce_kernel, dim3(npair, 16), dim3(BD_T), 0, st, *cpart, p, npair, nslice, d_C);
+    return GSLNLS_SUCCESS;
+}
+
 // gslnls_last_matrix_path_profile / gslnls_debug_bd_syrk_ms (include/gslnls_core.h)
 int bd_last_profile(double *v, int cap)
 {

@@ -100,6 +100,70 @@ __global__ __launch_bounds__(SP_T) void sp_segment_kernel(const int *__restrict_
     }
 }
 
+// ---- the dense operator (GSLNLS_SPARSE_DENSE, round 5): J as an n x p block, column-major -------------------------------
+// out[i] = sum_k J[i + n k] vec[k]: a lane per row, coalesced over the rows of every column (dgemv, src/nls_large.c:629)
+static __global__ __launch_bounds__(SP_T) void dn_rows_kernel(const double *__restrict__ J, const double *__restrict__ vec, int n, int p,
+                                                              double *out, const int *flag, int run_when)
+{
+    if (flag && *flag != run_when)
+        return;
+    __shared__ double v_s[1024];
+    const int i = blockIdx.x * SP_T + threadIdx.x;
+    double a = 0.0;
+    for (int k0 = 0; k0 < p; k0 += 1024)
+    {
+        const int kn = p - k0 < 1024 ? p - k0 : 1024;
+        __syncthreads();
+        for (int k = threadIdx.x; k < kn; k += SP_T)
+            v_s[k] = vec[k0 + k];
+        __syncthreads();
+        if (i < n)
+            for (int k = 0; k < kn; ++k)
+                a = fma(J[(size_t)(k0 + k) * n + i], v_s[k], a);
+    }
+    if (i < n)
+        out[i] = a;
+}
+// out[c] = sum_i J[i + n c] vec[i], sq[c] = sum_i J[i + n c]^2: a workgroup per column (contiguous in memory)
+static __global__ __launch_bounds__(SP_T) void dn_cols_kernel(const double *__restrict__ J, const double *__restrict__ vec, int n, double *out,
+                                                              double *sq, const int *flag, int run_when)
+{
+    if (flag && *flag != run_when)
+        return;
+    __shared__ double lds[2 * (SP_T / 64)];
+    const double *col = J + (size_t)blockIdx.x * n;
+    double a = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < n; i += SP_T)
+    {
+        const double v = col[i];
+        a = fma(v, vec[i], a);
+        q = fma(v, v, q);
+    }
+    a = group_sum<64>(a);
+    q = group_sum<64>(q);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+    {
+        lds[wave] = a;
+        lds[SP_T / 64 + wave] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        double ta = 0.0, tq = 0.0;
+        for (int w = 0; w < SP_T / 64; ++w)
+        {
+            ta += lds[w];
+            tq += lds[SP_T / 64 + w];
+        }
+        out[blockIdx.x] = ta;
+        if (sq)
+            sq[blockIdx.x] = tq;
+    }
+}
+// J^T J of a dense n x p block on the matrix cores (bd_syrk_kernel + its reduction, bd_models.hip); *cpart: scratch kept by the caller
+int bd_dense_jtj(const double *d_J, int n, int p, double *d_C, hipStream_t st, double **cpart, size_t *cpart_bytes);
+
 // values in CSC order (one gather per Jacobian evaluation, so that both products stream contiguous arrays)
 __global__ __launch_bounds__(SP_T) void sp_permute_kernel(const double *val, const int *perm, long nnz, double *valc)
 {
@@ -314,7 +378,10 @@ struct SparseCbOps : LargeOps
         *d_lrows = nullptr, *d_lcols = nullptr;
     double *d_vecp = nullptr, *d_outp = nullptr, *d_sqp = nullptr, *d_w = nullptr, *d_part = nullptr, *d_jtj = nullptr;
     bool jtj_current = false; // d_jtj holds J^T J of the point the driver is at
-    long cap_nnz = 0, cap_hval = 0;
+    bool dense = false;       // the callback hands over dense blocks (GSLNLS_SPARSE_DENSE): d_val[b] = n x p column-major, no index arrays
+    double *d_cpart = nullptr; // scratch of the dense J^T J (partial 64 x 64 blocks of the row slices)
+    size_t cpart_bytes = 0;
+    long cap_nnz = 0, cap_hval = 0, dense_cap = 0;
     int cur = 0; // index of the accepted point's buffers; 1 - cur receives the trial
     // host staging in pinned memory: uploads of f (n) and the Jacobian values (nnz), p-sized vectors both ways
     double *h_f = nullptr, *h_val = nullptr, *h_pin_in = nullptr, *h_pin_out = nullptr, *h_pin_sq = nullptr;
@@ -421,7 +488,7 @@ struct SparseCbOps : LargeOps
         for (void *q : {(void *)d_y, (void *)d_sw_buf, (void *)d_f[0], (void *)d_f[1], (void *)d_val[0], (void *)d_val[1],
                         (void *)d_valc[0], (void *)d_valc[1], (void *)d_rowptr, (void *)d_colidx, (void *)d_colptr, (void *)d_rowidx, (void *)d_perm,
                         (void *)d_lrows, (void *)d_lcols, (void *)d_vecp, (void *)d_outp, (void *)d_sqp, (void *)d_w,
-                        (void *)d_part, (void *)d_jtj, (void *)d_cg, (void *)d_scal})
+                        (void *)d_part, (void *)d_jtj, (void *)d_cg, (void *)d_scal, (void *)d_cpart})
             if (q)
                 (void)hipFree(q);
         for (void *q : {(void *)h_f, (void *)h_val, (void *)h_pin_in, (void *)h_pin_out, (void *)h_pin_sq, (void *)h_pin_in2,
@@ -497,6 +564,15 @@ struct SparseCbOps : LargeOps
     // out[s] (and optionally sq[s]) over rows (transpose = false) or columns (transpose = true) of buffer b
     void segments(bool transpose, int b, const double *vec, double *out, double *sq)
     {
+        if (dense)
+        {
+            if (transpose)
+                hipLaunchKernelGGL(dn_cols_kernel, dim3(p), dim3(SP_T), 0, st, d_val[b], vec, n, out, sq, seg_flag, seg_run_when);
+            else
+                hipLaunchKernelGGL(dn_rows_kernel, dim3((n + SP_T - 1) / SP_T), dim3(SP_T), 0, st, d_val[b], vec, n, p, out, seg_flag,
+                                   seg_run_when);
+            return;
+        }
         const int nseg = transpose ? p : n;
         const int *ptr = transpose ? d_colptr : d_rowptr, *idx = transpose ? d_rowidx : d_colidx;
         const double *val = transpose ? d_valc[b] : d_val[b];
@@ -519,6 +595,8 @@ struct SparseCbOps : LargeOps
     }
     void permute_values(int b)
     {
+        if (dense)
+            return; // (column-major is the order both products stream)
         hipLaunchKernelGGL(sp_permute_kernel, dim3((unsigned)((pat.nnz + SP_T - 1) / SP_T)), dim3(SP_T), 0, st, d_val[b],
                            d_perm, pat.nnz, d_valc[b]);
     }
@@ -558,8 +636,57 @@ struct SparseCbOps : LargeOps
         memset(&J, 0, sizeof J);
         if (cb_jac(x_trial.data(), p, &J, user))
             return GSLNLS_EINVAL;
-        if (!sparse_same_pattern(J, pat))
+        if (J.format == GSLNLS_SPARSE_DENSE)
         {
+            // the n x p block as it is (src/nls_large.c:504, :625-633: dgemv / dsyrk on the dense J): one copy into the
+            // pinned staging area, one upload; no pattern, no index arrays, no permutation
+            if (J.nrow != n || J.ncol != p || !J.x)
+                return GSLNLS_EINVAL;
+            const long m = (long)n * p;
+            if (!dense || pat.nnz != m)
+            {
+                dense = true;
+                pat = SparsePattern();
+                pat.nnz = m;
+                if (m > dense_cap)
+                {
+                    for (void *q : {(void *)d_val[0], (void *)d_val[1]})
+                        if (q)
+                            (void)hipFree(q);
+                    d_val[0] = d_val[1] = nullptr;
+                    GSLNLS_HIP_OK(hipMalloc(&d_val[0], sizeof(double) * (size_t)m));
+                    GSLNLS_HIP_OK(hipMalloc(&d_val[1], sizeof(double) * (size_t)m));
+                    // (the sparse form's other arrays are allocated by upload_pattern when a sparse Jacobian arrives)
+                    for (void *q : {(void *)d_valc[0], (void *)d_valc[1], (void *)d_colidx, (void *)d_rowidx, (void *)d_perm})
+                        if (q)
+                            (void)hipFree(q);
+                    d_valc[0] = d_valc[1] = nullptr;
+                    d_colidx = d_rowidx = d_perm = nullptr;
+                    cap_nnz = 0; // (a sparse Jacobian later on re-allocates all of them)
+                    dense_cap = m;
+                }
+                if (!h_val || m > cap_hval)
+                {
+                    if (h_val)
+                        (void)hipHostFree(h_val);
+                    h_val = nullptr;
+                    cap_hval = m;
+                    GSLNLS_HIP_OK(hipHostMalloc(&h_val, sizeof(double) * (size_t)cap_hval));
+                }
+            }
+            memcpy(h_val, J.x, sizeof(double) * (size_t)m);
+        }
+        else if (dense || !sparse_same_pattern(J, pat))
+        {
+            if (dense)
+            {
+                dense = false;
+                (void)hipFree(d_val[0]);
+                (void)hipFree(d_val[1]);
+                d_val[0] = d_val[1] = nullptr;
+                cap_nnz = 0;
+                dense_cap = 0;
+            }
             // (a pattern that changes between points is rebuilt; the accepted point's values keep their old
             // layout, so a change is only meaningful before the first product with them -- not checked)
             const int rc = sparse_build_pattern(J, n, p, pat);
@@ -568,9 +695,12 @@ struct SparseCbOps : LargeOps
             if (upload_pattern())
                 return GSLNLS_E_NODEVICE;
         }
-        std::fill(h_val, h_val + pat.nnz, 0.0);
-        for (long e = 0; e < J.nnz; ++e)
-            h_val[pat.map[e]] += J.x[e];
+        if (!dense)
+        {
+            std::fill(h_val, h_val + pat.nnz, 0.0);
+            for (long e = 0; e < J.nnz; ++e)
+                h_val[pat.map[e]] += J.x[e];
+        }
         (void)hipEventRecord(e0, st);
         GSLNLS_HIP_OK(hipMemcpyAsync(d_val[t], h_val, sizeof(double) * (size_t)pat.nnz, hipMemcpyHostToDevice, st));
         // (the weights scale f only: GSL's multilarge eval_f applies sqrt(w), the Jacobian callback's result is used as it
@@ -692,10 +822,18 @@ struct SparseCbOps : LargeOps
         const size_t bytes = sizeof(double) * (size_t)p * p;
         if (!d_jtj)
             GSLNLS_HIP_OK(hipMalloc(&d_jtj, bytes));
-        GSLNLS_HIP_OK(hipMemsetAsync(d_jtj, 0, bytes, st));
-        const long threads = 64L * p;
-        hipLaunchKernelGGL(sp_jtj_kernel, dim3((unsigned)((threads + SP_T - 1) / SP_T)), dim3(SP_T), 0, st, d_colptr, d_rowidx,
-                           d_perm, d_rowptr, d_colidx, d_val[b], p, d_jtj);
+        if (dense)
+        {
+            if (const int rc = bd_dense_jtj(d_val[b], n, p, d_jtj, st, &d_cpart, &cpart_bytes))
+                return rc;
+        }
+        else
+        {
+            GSLNLS_HIP_OK(hipMemsetAsync(d_jtj, 0, bytes, st));
+            const long threads = 64L * p;
+            hipLaunchKernelGGL(sp_jtj_kernel, dim3((unsigned)((threads + SP_T - 1) / SP_T)), dim3(SP_T), 0, st, d_colptr, d_rowidx,
+                               d_perm, d_rowptr, d_colidx, d_val[b], p, d_jtj);
+        }
         jtj_current = false;
         if (!jtj_device_only)
             GSLNLS_HIP_OK(hipMemcpyAsync(jtj, d_jtj, bytes, hipMemcpyDeviceToHost, st));

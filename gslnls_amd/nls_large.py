@@ -133,7 +133,14 @@ class SparseLargeProblem(LargeProblem):
                 th = np.ctypeslib.as_array(theta, shape=(p_,)).copy()
                 M = jac(th)
                 if not sp.issparse(M):
-                    M = sp.csr_matrix(np.asarray(M, dtype=np.float64).reshape(n, pp))
+                    # a dense n x p array (base matrix / dgeMatrix in R): handed over as the block it is, column-major as R
+                    # holds it (GSLNLS_SPARSE_DENSE) -- no index arrays are built anywhere
+                    D = np.asfortranarray(np.asarray(M, dtype=np.float64).reshape(n, pp))
+                    s = J.contents
+                    s.format, s.nrow, s.ncol, s.nnz = 3, n, pp, n * pp
+                    s.x = D.ctypes.data_as(DP)
+                    self._keep = (D,)
+                    return 0
                 if M.shape != (n, pp):
                     raise ValueError("jac returned a %s matrix, expected %s" % (M.shape, (n, pp)))
                 fmt = M.getformat()

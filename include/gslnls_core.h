@@ -391,6 +391,9 @@ float gslnls_large_time_pass(gslnls_large *h, int mode, const double *x, const d
 #define GSLNLS_SPARSE_CSR 0 /* dgRMatrix: p = row pointers [nrow+1], j = column indices [nnz] */
 #define GSLNLS_SPARSE_CSC 1 /* dgCMatrix: p = column pointers [ncol+1], i = row indices [nnz] */
 #define GSLNLS_SPARSE_COO 2 /* dgTMatrix: i, j triplets [nnz]; duplicates are summed */
+#define GSLNLS_SPARSE_DENSE 3 /* base matrix / dgeMatrix (jacclass -2 / -1 of the reference, src/nls_large.c:504, :625-633):
+                                 x = the n x p block column-major as R holds it, nnz = n p; p, i, j unused.  No index arrays
+                                 exist anywhere: J u and J^T w are dense matrix-vector kernels, J^T J the matrix cores' SYRK */
 typedef struct gslnls_sparse
 {
     int format, nrow, ncol;

@@ -32,8 +32,6 @@ typedef struct
     SEXP fn, jac, env, parnames;
     SEXP keep;   /* last Jacobian object: its slots must stay valid until the next callback */
     int n, p, failed;
-    double *dense; /* scratch for base-matrix / dgeMatrix Jacobians turned into CSR */
-    int *dp, *dj;
 } shim_state;
 
 static SEXP named_par(const double *theta, shim_state *s)
@@ -101,27 +99,16 @@ static int shim_jac(const double *theta, int p, gslnls_sparse *J, void *user)
             J->j = INTEGER(R_do_slot(val, Rf_install("j")));
         return 0;
     }
-    /* dense n x p (column-major): every entry becomes a stored CSC entry; the index arrays are built once */
+    /* dense n x p (base matrix or dgeMatrix, jacclass -2 / -1 of src/nls_large.c:504): the column-major block as R holds
+     * it -- the core multiplies with it as a dense matrix (GSLNLS_SPARSE_DENSE), no index arrays */
     SEXP dx = Rf_inherits(val, "dgeMatrix") ? R_do_slot(val, Rf_install("x")) : val;
     if (!Rf_isReal(dx) || Rf_length(dx) != s->n * s->p)
     {
         s->failed = 1;
         return 1;
     }
-    if (!s->dp)
-    {
-        s->dp = (int *)R_alloc(s->p + 1, sizeof(int));
-        s->dj = (int *)R_alloc((size_t)s->n * s->p, sizeof(int));
-        for (int c = 0; c <= s->p; c++)
-            s->dp[c] = c * s->n;
-        for (int c = 0; c < s->p; c++)
-            for (int r = 0; r < s->n; r++)
-                s->dj[(size_t)c * s->n + r] = r;
-    }
-    J->format = GSLNLS_SPARSE_CSC;
+    J->format = GSLNLS_SPARSE_DENSE;
     J->nnz = (long)s->n * s->p;
-    J->p = s->dp;
-    J->i = s->dj;
     J->x = REAL(dx);
     return 0;
 }
@@ -135,7 +122,7 @@ SEXP C_nls_large_hip(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, 
 
     SEXP startvec = PROTECT(Rf_coerceVector(start, REALSXP));
     const int p = Rf_length(startvec), n = Rf_length(y);
-    shim_state s = {fn, jac, env, Rf_getAttrib(start, R_NamesSymbol), R_NilValue, n, p, 0, NULL, NULL, NULL};
+    shim_state s = {fn, jac, env, Rf_getAttrib(start, R_NamesSymbol), R_NilValue, n, p, 0};
 
     /* ---- the formula method: lower the right-hand side itself ---- */
     gslnls_model model;
