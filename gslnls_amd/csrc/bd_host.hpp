@@ -798,9 +798,8 @@ struct BdFit
                 {
                     // a failed fvv counts as a rejected step (src/trust.c:452-483, :530-545)
                     delta /= prm.factor_down;
-                    mu *= nu;
-                    nu *= 2.0;
-                    const int itstatus = (++bad_steps > 15) ? ST_ENOPROG : ST_CONTINUE;
+                    lmd_nielsen_reject(mu, nu);
+                    const int itstatus = (++bad_steps > LMD_MAX_REJECTS) ? ST_ENOPROG : ST_CONTINUE;
                     if (itstatus != ST_CONTINUE)
                         (void)end_iteration(itstatus);
                     continue;
@@ -868,8 +867,6 @@ struct BdFit
                 rho = -1.0;
             else
             {
-                const double finv = 1.0 / fnorm2;
-                const double ared = 1.0 - ssr_t * finv;
                 double vAv = 0.0, Dv2 = 0.0;
                 if (trial_done)
                     vAv = vAv_tail;
@@ -891,16 +888,10 @@ struct BdFit
                     const double ud = diag[i] * vel[i];
                     Dv2 += ud * ud;
                 }
-                const double pred = vAv * finv + 2.0 * mu * (Dv2 * finv);
-                rho = (pred > 0.0) ? ared / pred : -1.0;
+                rho = lmd_rho_of(ssr_t, fnorm2, vAv, Dv2, mu);
             }
-            bool found = rho > 0.0;
-            if (prm.trs == 1 && avratio > prm.avmax)
-                found = false;
-            if (rho > 0.75)
-                delta *= prm.factor_up;
-            else if (rho < 0.25)
-                delta /= prm.factor_down;
+            const bool found = lmd_step_found(rho, prm.trs, avratio, prm.avmax);
+            lmd_radius(rho, prm.factor_up, prm.factor_down, delta);
             int itstatus = ST_CONTINUE;
             if (found)
             {
@@ -932,18 +923,14 @@ struct BdFit
                     cur ^= 1;
                     fnorm2 = ssr_t;
                     scale(false);
-                    double b = 2.0 * rho - 1.0;
-                    b = 1.0 - b * b * b;
-                    nu = 2.0;
-                    mu *= fmax(0.333333333333333, b);
+                    lmd_nielsen_accept(rho, mu, nu);
                     bad_steps = 0;
                 }
             }
             else
             {
-                mu *= nu;
-                nu *= 2.0;
-                if (++bad_steps > 15)
+                lmd_nielsen_reject(mu, nu);
+                if (++bad_steps > LMD_MAX_REJECTS)
                     itstatus = ST_ENOPROG;
             }
             if (itstatus != ST_CONTINUE)

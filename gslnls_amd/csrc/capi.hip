@@ -1122,7 +1122,12 @@ int gslnls_nls(const gslnls_model *fn, const double *y, int n, int jac, int fvv,
     const double t0 = now_s();
     trace_begin(control_int && control_int[1] != 0);
 #ifndef GSLNLS_NO_EXPR
-    if (fn && fn->id == GSLNLS_MODEL_EXPR && fn->p > 64) // (WIDE_MAX_P, vm_program.hpp)
+    // (test switch GSLNLS_MATRIX_PATH_MIN_P: formulas from that many parameters on take the matrix path -- the wide path's
+    // state machine and the matrix path's can then be run on the same problem, tests/test_gpu_wide.py)
+    int matrix_min_p = 65;
+    if (const char *e = getenv("GSLNLS_MATRIX_PATH_MIN_P"))
+        matrix_min_p = atoi(e) > 1 ? atoi(e) : 65;
+    if (fn && fn->id == GSLNLS_MODEL_EXPR && fn->p >= matrix_min_p) // (default: beyond WIDE_MAX_P = 64, vm_program.hpp)
     {
         // more than 64 parameters: the Jacobian is a matrix in HBM (csrc/bd_host.hpp)
         if (loss_rho < 0 || loss_rho > 8 || (loss_rho != 0 && !loss_cc) || (start_is_matrix && !has_start))

@@ -553,10 +553,7 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
             }
             else if (st == ST_EBADFUNC)
                 return st;
-            if (rho > 0.75)
-                delta *= factor_up;
-            else if (rho < 0.25)
-                delta /= factor_down;
+            lmd_radius(rho, factor_up, factor_down, delta);
             if (found)
             {
                 // accepted: g, J^T J (diag) at x_trial came with the same EVAL pass (or are completed now)
@@ -576,17 +573,13 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
                 host_jtj_valid = !jtj_stays;
                 fnorm2 = ssr_t;
                 do_scale(false);
-                double b = 2.0 * rho - 1.0;
-                b = 1.0 - b * b * b;
-                nu = 2.0;
-                mu *= fmax(0.333333333333333, b);
+                lmd_nielsen_accept(rho, mu, nu);
                 bad_steps = 0;
             }
             else
             {
-                mu *= nu;
-                nu *= 2.0;
-                if (++bad_steps > 15)
+                lmd_nielsen_reject(mu, nu);
+                if (++bad_steps > LMD_MAX_REJECTS)
                 {
                     itstatus = ST_ENOPROG;
                     break;

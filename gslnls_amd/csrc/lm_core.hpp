@@ -35,6 +35,7 @@
 #else
 #define GSLNLS_HD inline
 #endif
+#include "lm_decide.hpp" // the scalar decisions of a trial, shared by every variant of the state machine
 
 namespace gslnls
 {
@@ -640,9 +641,8 @@ GSLNLS_HD void lm_advance(LmState<P> &s, const PassSums<P> &r, const LmParams &p
             // failed step as a rejected one (src/trust.c:452-483, :530-545): rho = -1, so the radius shrinks, mu grows,
             // and the loop tries again with the shorter velocity (which may make fvv finite) -- up to 15 times
             s.delta /= prm.factor_down;
-            s.mu *= s.nu;
-            s.nu *= 2.0;
-            const int itstatus = (++s.bad_steps > 15) ? ST_ENOPROG : ST_CONTINUE;
+            lmd_nielsen_reject(s.mu, s.nu);
+            const int itstatus = (++s.bad_steps > LMD_MAX_REJECTS) ? ST_ENOPROG : ST_CONTINUE;
             if ((itstatus == ST_CONTINUE) ? true : lm_end_iteration(s, prm, itstatus))
                 lm_begin_step(s, prm);
             return;
@@ -677,8 +677,6 @@ GSLNLS_HD void lm_advance(LmState<P> &s, const PassSums<P> &r, const LmParams &p
             rho = -1.0; // ||f_trial|| >= ||f|| (also catches +Inf residuals and NaN)
         else
         {
-            const double finv = 1.0 / s.fnorm2;
-            const double ared = 1.0 - r.ssr * finv;
             // lm_preduction: (||J v||/||f||)^2 + 2 mu (||D v||/||f||)^2 with v the velocity
             double vAv = 0.0, Dv2 = 0.0;
 #pragma unroll
@@ -692,18 +690,11 @@ GSLNLS_HD void lm_advance(LmState<P> &s, const PassSums<P> &r, const LmParams &p
                 const double u = s.diag[i] * s.vel[i];
                 Dv2 += u * u;
             }
-            const double pred = vAv * finv + 2.0 * s.mu * (Dv2 * finv);
-            rho = (pred > 0.0) ? ared / pred : -1.0;
+            rho = lmd_rho_of(r.ssr, s.fnorm2, vAv, Dv2, s.mu);
         }
         GSLNLS_ADV_STAMP(1);
-        bool found = rho > 0.0;
-        if (prm.trs == 1 && s.avratio > prm.avmax)
-            found = false;
-
-        if (rho > 0.75)
-            s.delta *= prm.factor_up;
-        else if (rho < 0.25)
-            s.delta /= prm.factor_down;
+        const bool found = lmd_step_found(rho, prm.trs, s.avratio, prm.avmax);
+        lmd_radius(rho, prm.factor_up, prm.factor_down, s.delta);
 
         int itstatus = ST_CONTINUE; // CONTINUE = the iteration is not over (rejected step, another trial follows)
         if (found)
@@ -721,20 +712,14 @@ GSLNLS_HD void lm_advance(LmState<P> &s, const PassSums<P> &r, const LmParams &p
             {
                 lm_take_point(s, r);
                 lm_scale(s, prm, false);
-                // nielsen_accept (src/trust.c:175-188)
-                double b = 2.0 * rho - 1.0;
-                b = 1.0 - b * b * b;
-                s.nu = 2.0;
-                s.mu *= fmax(0.333333333333333, b);
+                lmd_nielsen_accept(rho, s.mu, s.nu); // (src/trust.c:175-188)
                 s.bad_steps = 0;
             }
         }
         else
         {
-            // nielsen_reject (src/trust.c:190-199)
-            s.mu *= s.nu;
-            s.nu *= 2.0;
-            if (++s.bad_steps > 15)
+            lmd_nielsen_reject(s.mu, s.nu); // (src/trust.c:190-199)
+            if (++s.bad_steps > LMD_MAX_REJECTS)
                 itstatus = ST_ENOPROG;
         }
         GSLNLS_ADV_STAMP(2);

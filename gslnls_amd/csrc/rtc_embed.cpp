@@ -19,6 +19,7 @@ struct RtcHeader
 
 GSLNLS_EMBED(prelude, "rtc_prelude.hpp")
 GSLNLS_EMBED(lm_core, "lm_core.hpp")
+GSLNLS_EMBED(lm_decide, "lm_decide.hpp")
 GSLNLS_EMBED(devmath, "devmath.hpp")
 GSLNLS_EMBED(models, "models.hpp")
 GSLNLS_EMBED(rowops, "rowops.hpp")
@@ -34,6 +35,7 @@ const RtcHeader *rtc_embedded_headers(int *count)
     static const RtcHeader h[] = {
         {"rtc_prelude.hpp", gslnls_rtc_prelude_begin, gslnls_rtc_prelude_end},
         {"lm_core.hpp", gslnls_rtc_lm_core_begin, gslnls_rtc_lm_core_end},
+        {"lm_decide.hpp", gslnls_rtc_lm_decide_begin, gslnls_rtc_lm_decide_end},
         {"devmath.hpp", gslnls_rtc_devmath_begin, gslnls_rtc_devmath_end},
         {"models.hpp", gslnls_rtc_models_begin, gslnls_rtc_models_end},
         {"rowops.hpp", gslnls_rtc_rowops_begin, gslnls_rtc_rowops_end},

@@ -83,7 +83,76 @@ inline std::string rtc_emit_ops(const Prog &pr, int upto, bool sink = false)
     static const char *fn1[] = {"", "", "", "", "", "", "", "gexp", "log", "sin", "cos", "tan", "atan", "sqrt", "fabs", "tanh", "",
                                 "sinh", "cosh", "asin", "acos", "log1p", "expm1", "", "tgamma", "lgamma", "", "", "", "", ""};
     std::string s;
-    for (int i = 0; i < upto; ++i)
+    // The order of the statements.  Plain form: program order (the value's closure first, then the gradient's).  Sink form
+    // (round 5): the compiler schedules straight-line code for latency and, handed the whole value first, keeps every term's
+    // intermediates alive until the gradient entries that reuse them come by -- at p = 32 (ten Gaussians) the step kernel ran
+    // with 142 spilled registers and 464 B of scratch per lane, 245 MB of scratch writes per pass over 1e6 rows (PMC:
+    // profiles/r05_wide_pmc.json).  Here the statements are emitted gradient entry by gradient entry (depth first from each
+    // entry's root, the value's own sum last), every entry handed to the sink the moment it exists, and a scheduling barrier
+    // after every few entries keeps the compiler from pulling the next terms' chains in front: a few terms in flight, not
+    // all of them.  Same statements, same operands: the arithmetic does not change.  GSLNLS_RTC_SINK_GROUP: entries per
+    // group (0 = program order, no barriers).
+    std::vector<int> order;
+    std::vector<std::vector<int>> sets_of(upto);
+    std::vector<char> barrier_after(upto, 0);
+    int sink_group = 6;
+    if (const char *e = getenv("GSLNLS_RTC_SINK_GROUP"))
+        sink_group = atoi(e);
+    if (sink && sink_group > 0)
+    {
+        std::vector<char> seen(upto, 0);
+        std::vector<int> stack;
+        auto visit = [&](int root) {
+            if (root < base || root >= base + upto)
+                return;
+            stack.push_back(root - base);
+            while (!stack.empty())
+            {
+                const int i = stack.back();
+                if (seen[i] == 2)
+                {
+                    stack.pop_back();
+                    continue;
+                }
+                if (seen[i] == 0)
+                {
+                    seen[i] = 1;
+                    for (int opnd : {(int)pr.a[i], (int)pr.b[i]})
+                        if (opnd >= base && opnd < base + upto && seen[opnd - base] == 0)
+                            stack.push_back(opnd - base);
+                }
+                else
+                {
+                    seen[i] = 2;
+                    order.push_back(i);
+                    stack.pop_back();
+                }
+            }
+        };
+        int in_group = 0;
+        for (int k = 0; k < pr.p; ++k)
+        {
+            const int root = pr.grad_slot[k];
+            if (root < base || root >= base + upto)
+                continue; // (not the result of an instruction -- a parameter, a column, a constant: handed out at the end)
+            visit(root);
+            sets_of[root - base].push_back(k); // (handed out behind the statement that produces it: it is in `order` by now)
+            if (++in_group >= sink_group && !order.empty())
+            {
+                barrier_after[order.back()] = 1;
+                in_group = 0;
+            }
+        }
+        visit(pr.value_slot);
+        for (int i = 0; i < upto; ++i) // (anything the roots do not reach: dead code of the program, kept for completeness)
+            if (seen[i] == 0)
+                visit(base + i);
+    }
+    else
+        for (int i = 0; i < upto; ++i)
+            order.push_back(i);
+    const bool scheduled = sink && sink_group > 0;
+    for (int i : order)
     {
         const std::string a = ref(pr.a[i]), b = ref(pr.b[i]);
         std::string e;
@@ -103,7 +172,14 @@ inline std::string rtc_emit_ops(const Prog &pr, int upto, bool sink = false)
         default: e = std::string(fn1[pr.op[i]]) + "(" + a + ")"; break;
         }
         s += "        const double v" + std::to_string(i) + " = " + e + ";\n";
-        if (sink)
+        if (scheduled)
+        {
+            for (int k : sets_of[i])
+                s += "        out.set(" + std::to_string(k) + ", v" + std::to_string(i) + ");\n";
+            if (barrier_after[i])
+                s += "        __builtin_amdgcn_sched_barrier(0);\n";
+        }
+        else if (sink)
             for (int k = 0; k < pr.p; ++k)
                 if (pr.grad_slot[k] == base + i)
                     s += "        out.set(" + std::to_string(k) + ", v" + std::to_string(i) + ");\n";

@@ -1035,9 +1035,8 @@ __device__ __forceinline__ void wide_advance_pre(const WAdvanceArgs &a, WideLds 
         {
             // a failed fvv counts as a rejected step (src/trust.c:452-483, :530-545)
             delta /= prm.factor_down;
-            mu *= nu;
-            nu *= 2.0;
-            const int itstatus = (++bad_steps > 15) ? ST_ENOPROG : ST_CONTINUE;
+            lmd_nielsen_reject(mu, nu);
+            const int itstatus = (++bad_steps > LMD_MAX_REJECTS) ? ST_ENOPROG : ST_CONTINUE;
             step = (itstatus == ST_CONTINUE) ? true : end_iteration(itstatus);
         }
         else
@@ -1052,8 +1051,6 @@ __device__ __forceinline__ void wide_advance_pre(const WAdvanceArgs &a, WideLds 
             rho = -1.0;
         else
         {
-            const double finv = 1.0 / fnorm2;
-            const double ared = 1.0 - r_ssr * finv;
             // lm_preduction: v^T (J^T J) v, row i of the product by lane i (j ascending), the outer sums in index order
             double row = 0.0;
             if (mine)
@@ -1063,16 +1060,10 @@ __device__ __forceinline__ void wide_advance_pre(const WAdvanceArgs &a, WideLds 
             const double vAv = wide_seq_sum(row * vl, p);
             const double ud = mine ? L.diag[lane] * vl : 0.0;
             const double Dv2 = wide_seq_sum(ud * ud, p);
-            const double pred = vAv * finv + 2.0 * mu * (Dv2 * finv);
-            rho = (pred > 0.0) ? ared / pred : -1.0;
+            rho = lmd_rho_of(r_ssr, fnorm2, vAv, Dv2, mu);
         }
-        bool found = rho > 0.0;
-        if (prm.trs == 1 && avratio > prm.avmax)
-            found = false;
-        if (rho > 0.75)
-            delta *= prm.factor_up;
-        else if (rho < 0.25)
-            delta /= prm.factor_down;
+        const bool found = lmd_step_found(rho, prm.trs, avratio, prm.avmax);
+        lmd_radius(rho, prm.factor_up, prm.factor_down, delta);
         int itstatus = ST_CONTINUE;
         if (found)
         {
@@ -1089,18 +1080,14 @@ __device__ __forceinline__ void wide_advance_pre(const WAdvanceArgs &a, WideLds 
             {
                 take_point();
                 scale(false);
-                double b = 2.0 * rho - 1.0;
-                b = 1.0 - b * b * b;
-                nu = 2.0;
-                mu *= fmax(0.333333333333333, b);
+                lmd_nielsen_accept(rho, mu, nu);
                 bad_steps = 0;
             }
         }
         else
         {
-            mu *= nu;
-            nu *= 2.0;
-            if (++bad_steps > 15)
+            lmd_nielsen_reject(mu, nu);
+            if (++bad_steps > LMD_MAX_REJECTS)
                 itstatus = ST_ENOPROG;
             c.rejected = itstatus == ST_CONTINUE;
         }
