@@ -18,6 +18,11 @@ struct BdTheta
     const double *p;
     __device__ __forceinline__ double operator[](int k) const { return p[k]; }
 };
+struct BdPreOut
+{
+    double *p;
+    __device__ __forceinline__ void set(int k, double v) { p[k] = v; }
+};
 // gradient entry k of row i -> J[i + n k]: for every k the lanes of a wavefront write consecutive doubles
 struct BdJacSink
 {
@@ -33,6 +38,7 @@ __global__ __launch_bounds__(256) void bd_model_kernel(const double *theta, cons
 {
     constexpr int P = M::P, NX = M::NX;
     __shared__ double th_s[P], dir_s[MODE == 2 ? P : 1];
+    __shared__ double pre_s[(MODE == 1 && M::NPRE > 0) ? M::NPRE : 1];
     for (int k = threadIdx.x; k < P; k += 256)
     {
         th_s[k] = theta[k];
@@ -41,6 +47,15 @@ __global__ __launch_bounds__(256) void bd_model_kernel(const double *theta, cons
     }
     __syncthreads();
     const BdTheta th{th_s};
+    if constexpr (MODE == 1 && M::NPRE > 0)
+    {
+        // what depends on the parameters alone, once per workgroup (rtc_host.hpp: prologue / value_grad_sink_pre, round 5);
+        // every thread stores the same values
+        BdPreOut po{pre_s};
+        M::prologue(th, po);
+        __syncthreads();
+    }
+    const BdTheta pre{pre_s};
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
     {
         double xr[NX];
@@ -52,7 +67,7 @@ __global__ __launch_bounds__(256) void bd_model_kernel(const double *theta, cons
         else if constexpr (MODE == 1)
         {
             BdJacSink sink{J + i, n};
-            fval[i] = M::value_grad_sink(th, xr, sink);
+            fval[i] = M::value_grad_sink_pre(th, pre, xr, sink);
         }
         else
             fval[i] = M::fvv(th, BdTheta{dir_s}, xr);

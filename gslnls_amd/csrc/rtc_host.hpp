@@ -191,6 +191,205 @@ inline std::string rtc_emit_ops(const Prog &pr, int upto, bool sink = false)
     return s;
 }
 
+// ---- round 5: what depends on the parameters alone is computed ONCE, not per row -----------------------------------------
+// A row of a sum of ten Gaussians a exp(-((x - m) / s)^2) cost ~980 vector instructions (PMC, profiles/r05_wide_pmc*.json), most of
+// them the fp64 divisions by s, s^2, s^3 of the value and its gradient -- ~30 instructions each, on quantities that are the
+// same for every row.  The value + gradient closure handed to a sink is therefore split:
+//   prologue(th, pre)                 every instruction whose operands are parameters and constants only, plus 1 / d for
+//                                     every such d a row divides by; run once per wavefront, results in LDS;
+//   value_grad_sink_pre(th, pre, ..)  the rest, per row: a parameter-only result is read back from LDS (a broadcast, like
+//                                     theta itself), a division by a parameter-only d is a multiplication by its reciprocal.
+// x / d becomes x * (1 / d): one more rounding, at most an ulp per division -- this closure has no interpreted twin to
+// agree with bit for bit (the wide and the matrix path are always native), its results stay within the tolerances of
+// their tests against the oracle, and the other closures (value for difference Jacobians, fvv) are emitted as before.
+template <class Prog>
+struct RtcHoist
+{
+    int base = 0, nops = 0;
+    std::vector<char> po;          // instruction is parameter-only
+    std::vector<int> export_of;    // instruction -> index in pre[], or -1
+    std::vector<int> recip_of;     // slot (any kind) -> index in pre[] of its reciprocal, or -1
+    std::vector<int> recip_slots;  // the slots whose reciprocal is exported, in export order
+    int npre = 0;
+    void build(const Prog &pr)
+    {
+        base = 2 * pr.p + pr.nx + pr.nconst;
+        nops = pr.nops;
+        auto uniform = [&](int slot) {
+            if (slot < pr.p)
+                return true; // a parameter
+            if (slot < 2 * pr.p + pr.nx)
+                return false; // a data column, a component of the direction
+            if (slot < base)
+                return true; // a constant
+            return slot - base < nops && po[slot - base] != 0;
+        };
+        po.assign(nops, 0);
+        for (int i = 0; i < nops; ++i)
+            po[i] = uniform(pr.a[i]) && uniform(pr.b[i]);
+        export_of.assign(nops, -1);
+        recip_of.assign(base + nops, -1);
+        auto want = [&](int slot) {
+            if (slot >= base && slot - base < nops && po[slot - base] && export_of[slot - base] < 0)
+                export_of[slot - base] = npre++;
+        };
+        for (int i = 0; i < nops; ++i)
+        {
+            if (po[i])
+                continue;
+            if (pr.op[i] == VM_DIV && uniform(pr.b[i]))
+            {
+                if (recip_of[pr.b[i]] < 0)
+                {
+                    recip_of[pr.b[i]] = npre++;
+                    recip_slots.push_back(pr.b[i]);
+                }
+                want(pr.a[i]);
+                continue;
+            }
+            want(pr.a[i]);
+            want(pr.b[i]);
+        }
+        for (int k = 0; k < pr.p; ++k)
+            want(pr.grad_slot[k]);
+        want(pr.value_slot);
+    }
+};
+
+template <class Prog>
+inline std::string rtc_emit_hoisted(const Prog &pr)
+{
+    RtcHoist<Prog> H;
+    H.build(pr);
+    const int base = H.base, nops = H.nops;
+    static const char *fn1[] = {"", "", "", "", "", "", "", "gexp", "log", "sin", "cos", "tan", "atan", "sqrt", "fabs", "tanh", "",
+                                "sinh", "cosh", "asin", "acos", "log1p", "expm1", "", "tgamma", "lgamma", "", "", "", "", ""};
+    auto expr_of = [&](int i, const std::string &a, const std::string &b) -> std::string {
+        switch (pr.op[i])
+        {
+        case VM_ADD: return a + " + " + b;
+        case VM_SUB: return a + " - " + b;
+        case VM_MUL: return a + " * " + b;
+        case VM_DIV: return a + " / " + b;
+        case VM_NEG: return "-" + a;
+        case VM_POW: return "pow(" + a + ", " + b + ")";
+        case VM_SIGN: return "(" + a + " > 0.0 ? 1.0 : (" + a + " < 0.0 ? -1.0 : 0.0))";
+        case VM_PNORM: return "0.5 * erfc(-" + a + " * 0.70710678118654752440)";
+        case VM_PSI0: case VM_PSI1: case VM_PSI2: case VM_PSI3: case VM_PSI4:
+            return "gpsigamma(" + a + ", " + std::to_string((int)pr.op[i] - (int)VM_PSI0) + ")";
+        default: return std::string(fn1[pr.op[i]]) + "(" + a + ")";
+        }
+    };
+    // operands inside the prologue: parameters, constants, earlier parameter-only results
+    auto pref = [&](int slot) -> std::string {
+        if (slot < pr.p)
+            return "th[" + std::to_string(slot) + "]";
+        if (slot < base)
+            return rtc_fmt_double(pr.consts[slot - 2 * pr.p - pr.nx]);
+        return "u" + std::to_string(slot - base);
+    };
+    // operands inside the row closure
+    auto rref = [&](int slot) -> std::string {
+        if (slot < pr.p)
+            return "th[" + std::to_string(slot) + "]";
+        if (slot < pr.p + pr.nx)
+            return "xr[" + std::to_string(slot - pr.p) + "]";
+        if (slot < base)
+            return rtc_fmt_double(pr.consts[slot - 2 * pr.p - pr.nx]);
+        if (H.po[slot - base])
+            return "pre[" + std::to_string(H.export_of[slot - base]) + "]";
+        return "v" + std::to_string(slot - base);
+    };
+    const std::string off = "        _Pragma(\"clang fp contract(off)\")\n";
+    std::string s;
+    s += "    static constexpr int NPRE = " + std::to_string(H.npre) + ";\n";
+    s += "    template <class TH, class PRE> __device__ __forceinline__ static void prologue(const TH &th, PRE &pre) {\n" + off;
+    for (int i = 0; i < nops; ++i)
+    {
+        if (!H.po[i])
+            continue;
+        s += "        const double u" + std::to_string(i) + " = " + expr_of(i, pref(pr.a[i]), pref(pr.b[i])) + ";\n";
+        if (H.export_of[i] >= 0)
+            s += "        pre.set(" + std::to_string(H.export_of[i]) + ", u" + std::to_string(i) + ");\n";
+    }
+    for (int slot : H.recip_slots)
+        s += "        pre.set(" + std::to_string(H.recip_of[slot]) + ", 1.0 / " + pref(slot) + ");\n";
+    s += "    }\n";
+    // the row closure: gradient entry by gradient entry (see rtc_emit_ops), parameter-only instructions left out
+    std::vector<int> order;
+    std::vector<std::vector<int>> sets_of(nops);
+    std::vector<char> barrier_after(nops, 0), seen(nops, 0);
+    int sink_group = 6;
+    if (const char *e = getenv("GSLNLS_RTC_SINK_GROUP"))
+        sink_group = atoi(e) > 0 ? atoi(e) : 6;
+    std::vector<int> stack;
+    auto is_row = [&](int slot) { return slot >= base && slot - base < nops && !H.po[slot - base]; };
+    auto visit = [&](int root) {
+        if (!is_row(root))
+            return;
+        stack.push_back(root - base);
+        while (!stack.empty())
+        {
+            const int i = stack.back();
+            if (seen[i] == 2)
+            {
+                stack.pop_back();
+                continue;
+            }
+            if (seen[i] == 0)
+            {
+                seen[i] = 1;
+                for (int opnd : {(int)pr.a[i], (int)pr.b[i]})
+                    if (is_row(opnd) && seen[opnd - base] == 0)
+                        stack.push_back(opnd - base);
+            }
+            else
+            {
+                seen[i] = 2;
+                order.push_back(i);
+                stack.pop_back();
+            }
+        }
+    };
+    int in_group = 0;
+    std::vector<int> late_sets;
+    for (int k = 0; k < pr.p; ++k)
+    {
+        const int root = pr.grad_slot[k];
+        if (!is_row(root))
+        {
+            late_sets.push_back(k); // (a parameter, a column, a constant, a parameter-only result)
+            continue;
+        }
+        visit(root);
+        sets_of[root - base].push_back(k);
+        if (++in_group >= sink_group && !order.empty())
+        {
+            barrier_after[order.back()] = 1;
+            in_group = 0;
+        }
+    }
+    visit(pr.value_slot);
+    s += "    template <class TH, class PRE, class XR, class SINK> __device__ __forceinline__ static double value_grad_sink_pre(const TH &th, const PRE &pre, const XR &xr, SINK &out) {\n" + off;
+    for (int i : order)
+    {
+        std::string e;
+        if (pr.op[i] == VM_DIV && H.recip_of[pr.b[i]] >= 0)
+            e = rref(pr.a[i]) + " * pre[" + std::to_string(H.recip_of[pr.b[i]]) + "]";
+        else
+            e = expr_of(i, rref(pr.a[i]), rref(pr.b[i]));
+        s += "        const double v" + std::to_string(i) + " = " + e + ";\n";
+        for (int k : sets_of[i])
+            s += "        out.set(" + std::to_string(k) + ", v" + std::to_string(i) + ");\n";
+        if (barrier_after[i])
+            s += "        __builtin_amdgcn_sched_barrier(0);\n";
+    }
+    for (int k : late_sets)
+        s += "        out.set(" + std::to_string(k) + ", " + rref(pr.grad_slot[k]) + ");\n";
+    s += "        return " + rref(pr.value_slot) + ";\n    }\n";
+    return s;
+}
+
 // struct ModelJit: the row-model interface of models.hpp for this program.  One interpreted instruction = one
 // statement, contraction off inside the bodies: a product and the sum that follows it stay two roundings, as in the
 // interpreter -- that is what makes the native and the interpreted fit agree bit for bit.
@@ -226,6 +425,13 @@ inline std::string rtc_emit_model(const Prog &pr, int nx_model)
     s += "    template <class TH, class XR, class SINK> __device__ __forceinline__ static double value_grad_sink(const TH &th, const XR &xr, SINK &out) {\n" + off;
     s += rtc_emit_ops(pr, pr.nops, true);
     s += "        return " + ref(pr.value_slot) + ";\n    }\n";
+    // ... and the same closure with the parameter-only part hoisted (round 5; GSLNLS_RTC_NO_HOIST=1: NPRE = 0 and the
+    // kernels take the closure above)
+    if (getenv("GSLNLS_RTC_NO_HOIST"))
+        s += "    static constexpr int NPRE = 0;\n    template <class TH, class PRE> __device__ static void prologue(const TH &, PRE &) {}\n"
+             "    template <class TH, class PRE, class XR, class SINK> __device__ __forceinline__ static double value_grad_sink_pre(const TH &th, const PRE &, const XR &xr, SINK &out) { return value_grad_sink(th, xr, out); }\n";
+    else
+        s += rtc_emit_hoisted(pr);
     if (pr.nfvv > 0)
     {
         s += "    template <class TH, class DIR, class XR> __device__ __forceinline__ static double fvv(const TH &th, const DIR &dir, const XR &xr) {\n" + off;

@@ -100,6 +100,18 @@ struct WideThetaDir
     double h;
     __device__ __forceinline__ double operator[](int k) const { return p[k] + h * v[k]; }
 };
+// what depends on the parameters alone, computed once per wavefront by M::prologue (rtc_host.hpp, round 5) and read back
+// per row as broadcasts.  Every lane (and every wavefront of the workgroup) stores the same value to the same word.
+struct WidePre
+{
+    const double *p;
+    __device__ __forceinline__ double operator[](int k) const { return p[k]; }
+};
+struct WidePreOut
+{
+    double *p;
+    __device__ __forceinline__ void set(int k, double v) { p[k] = v; }
+};
 // gradient entry k of this lane's row -> tile[k][lane], weighted; the non-finite flag as in row_fj
 struct WideTileSink
 {
@@ -237,7 +249,7 @@ template <class M, int JAC, int PW, class LOAD>
 __device__ __forceinline__ void wide_rows_to_sums(const WPassArgs &a, int phase, long long t, long long tstride, long long ntile,
                                                   double (&xr_n)[M::NX], double &yy_n, double &sw_n, LOAD &&load_rows,
                                                   double (*tile)[PW * WIDE_LD], double (*ftile)[64], const double *th_s,
-                                                  const double *vel_s, const double *delta_s, double (*red_s)[2])
+                                                  const double *vel_s, const double *delta_s, double (*red_s)[2], double *pre_s)
 {
     constexpr int P = M::P, NX = M::NX, NB = PW / 16, NW = WIDE_T / 64, NQ = NB * (NB + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -247,6 +259,15 @@ __device__ __forceinline__ void wide_rows_to_sums(const WPassArgs &a, int phase,
     if (rst)
         rst[0] = __builtin_amdgcn_s_memrealtime();
     const WideTheta th{th_s};
+    if constexpr (JAC == JAC_ANALYTIC && M::NPRE > 0)
+    {
+        // the parameter-only part of value + gradient, once for all the tiles of this wavefront (the other wavefronts of
+        // the workgroup store the same values: no barrier, a wavefront reads what it has written itself)
+        WidePreOut po{pre_s};
+        M::prologue(th, po);
+        wide_lds_sync();
+    }
+    const WidePre pre{pre_s};
     double *const mytile = tile[wave];
     const int kk = lane >> 4, ii = lane & 15;
 
@@ -277,7 +298,7 @@ __device__ __forceinline__ void wide_rows_to_sums(const WPassArgs &a, int phase,
         if constexpr (JAC == JAC_ANALYTIC)
         {
             WideTileSink sink{mytile + lane, a.wf_only ? (live ? 1.0 : 0.0) : sw, bad};
-            const double m = M::value_grad_sink(th, xr, sink);
+            const double m = M::value_grad_sink_pre(th, pre, xr, sink);
             bad = sink.bad;
             f = (isfinite(m) ? m - yy : INFINITY) * sw;
         }
@@ -413,6 +434,7 @@ __device__ __forceinline__ void wide_pass_body(const WPassArgs &a)
     __shared__ __attribute__((aligned(16))) double lds_raw[LDS_D];
     __shared__ double ftile[NW][64];
     __shared__ double th_s[P], vel_s[P], delta_s[P];
+    __shared__ double pre_s[M::NPRE > 0 ? M::NPRE : 1];
     __shared__ double red_s[NW][2];
     __shared__ int flag_s;
     double(*const tile)[PW * WIDE_LD] = reinterpret_cast<double(*)[PW * WIDE_LD]>(lds_raw);
@@ -515,7 +537,7 @@ __device__ __forceinline__ void wide_pass_body(const WPassArgs &a)
         for (int e = lane; e < (PW - P) * WIDE_LD; e += 64)
             tile[wave][P * WIDE_LD + e] = 0.0;
     __syncthreads();
-    wide_rows_to_sums<M, JAC, PW>(a, phase, t, tstride, ntile, xr_n, yy_n, sw_n, load_rows, tile, ftile, th_s, vel_s, delta_s, red_s);
+    wide_rows_to_sums<M, JAC, PW>(a, phase, t, tstride, ntile, xr_n, yy_n, sw_n, load_rows, tile, ftile, th_s, vel_s, delta_s, red_s, pre_s);
     static_assert(NW == 4, "wide_sum4 adds four wavefronts");
     stamp(1); // rows done, workgroup sums staged
     double *out = a.partials + (size_t)rb * NVP;
@@ -775,6 +797,7 @@ __global__ __launch_bounds__(WIDE_T, GSLNLS_WIDE_WAVES(PW)) void wide_fit_kernel
     __shared__ __attribute__((aligned(16))) double lds_raw[LDS_D];
     __shared__ double ftile[NW][64];
     __shared__ double th_s[P], vel_s[P], delta_s[P];
+    __shared__ double pre_s[M::NPRE > 0 ? M::NPRE : 1];
     __shared__ double red_s[NW][2];
     __shared__ int phase_s;
     double(*const tile)[PW * WIDE_LD] = reinterpret_cast<double(*)[PW * WIDE_LD]>(lds_raw);
@@ -872,7 +895,7 @@ __global__ __launch_bounds__(WIDE_T, GSLNLS_WIDE_WAVES(PW)) void wide_fit_kernel
             load_rows(wave);
         __syncthreads();
         wide_rows_to_sums<M, JAC, PW>(a, phase, (long long)wave, (long long)NW, ntile, xr_n, yy_n, sw_n, load_rows, tile, ftile, th_s,
-                                      vel_s, delta_s, red_s);
+                                      vel_s, delta_s, red_s, pre_s);
         // the workgroup's sums are the totals of the pass: ssr, non-finite flag, packed lower J^T J, J^T f
         {
             if (tid == 0)
@@ -991,6 +1014,7 @@ __global__ __launch_bounds__(256) void wide_finalize_kernel(WPassArgs a, double 
 {
     constexpr int P = M::P, NX = M::NX;
     __shared__ double th_s[P], delta_s[P];
+    __shared__ double pre_s[M::NPRE > 0 ? M::NPRE : 1];
     const WState *S = a.state;
     for (int k = threadIdx.x; k < P; k += 256)
     {
@@ -1003,6 +1027,16 @@ __global__ __launch_bounds__(256) void wide_finalize_kernel(WPassArgs a, double 
     }
     __syncthreads();
     const WideTheta th{th_s};
+    if constexpr (JAC == JAC_ANALYTIC && M::NPRE > 0)
+    {
+        if (grad)
+        {
+            WidePreOut po{pre_s}; // (every thread stores the same values)
+            M::prologue(th, po);
+        }
+        __syncthreads();
+    }
+    const WidePre pre{pre_s};
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256)
     {
         double xr[NX];
@@ -1016,7 +1050,7 @@ __global__ __launch_bounds__(256) void wide_finalize_kernel(WPassArgs a, double 
             if (grad)
             {
                 WideGradSink sink{grad + i, a.n, sw};
-                const double m = M::value_grad_sink(th, xr, sink);
+                const double m = M::value_grad_sink_pre(th, pre, xr, sink);
                 f = (isfinite(m) ? m - yy : INFINITY) * sw;
             }
             else
