@@ -299,8 +299,9 @@ def large_bench(L, _lib, n=10_000_000, p=64):
             "full_jtj": {"ms_host_clock": ms_jtj, "what": "J^T J for the lm variant: v_mfma_f64_16x16x4 SYRK kernel + reduction of "
                          "the workgroup partials + 32 KB read-back; the kernel alone (glm_jtj_mfma_kernel<64,256>) is in the "
                          "profiles/ kernel tables (r02: 1.06-1.17 ms = 43.6-48 TFLOP/s executed on the 10 lower-triangle "
-                         "blocks, 91-100 % of the 47.7 TFLOP/s this instruction reaches back to back on the same device, "
-                         "scripts/mfma_probe/rate.hip; it streams A at 4.4-4.8 TB/s, so the matrix pipe, not HBM, bounds it)",
+                         "blocks = 0.61-0.67 of the 72 TFLOP/s this instruction reaches back to back on the same device, "
+                         "scripts/mfma_probe/overlap.hip -- rounds 2-4 quoted 47.7 for that rate: a probe artifact, DESIGN.md "
+                         "round 5; it streams A at 4.4-4.8 TB/s)",
                          "effective_TFLOPs_2np2": 2.0 * n * p * p / ms_jtj / 1e9},
             "fit": {"niter": int(fit["niter"]), "conv": int(fit["conv"]), "passes": int(fit["n_passes"]),
                     "wall_s": el, "outer_iterations_per_s": fit["niter"] / el, "ssr": float(fit["ssr"]),
@@ -417,7 +418,9 @@ def wide_dense_bench(_lib, n=100_000, ng=10):
                             "rows_per_s_one_step": nn / (ms_step * 1e-3),
                             "mfma_tile_GFLOPs_per_step": nq * 512.0 * nn / (ms_step * 1e-3) / 1e9,
                             "max_rel_err_vs_truth": float(np.max(np.abs(fit["par"] - truth) / np.abs(truth)))}
-    out["note"] = ("a row costs ten fp64 exp + the 32 gradient entries (vector pipe) and 3 MFMA tiles per four rows; one trial "
+    out["note"] = ("a row costs ten fp64 exp + the 32 gradient entries (vector instructions) and 3 MFMA tiles per four rows -- on "
+                   "this device fp64 MFMA and fp64 vector instructions share ONE pipe (scripts/mfma_probe/overlap.hip), so their issue "
+                   "times add: 48 x 64 + ~520 x 4 clocks per 64-row tile is the floor of the pass, not the larger of the two; one trial "
                    "step = ONE launch: rows -> per-workgroup sums -> two-level in-launch reduction (arrival tickets) -> the LM step "
                    "by the workgroup that completes the totals, natural-order L D L^T of the damped system on one wavefront "
                    "(gsl_linalg_mcholesky's pivoted form when a pivot is not safely positive), a speculative solve for the "
@@ -532,12 +535,12 @@ def matrix_path_bench(_lib):
     the formula, J^T J on the matrix cores, the damped solve on the device): sums of Gaussians with p = 99, 198, 501 -- wall
     time per trial step from the library's own profile of the call (gslnls_last_matrix_path_profile), split into the damped
     solve with the fused trial evaluation, the Jacobian + J^T J + J^T f of the accepted points and the rest; the device time
-    of one J^T J (HIP events) against the measured MFMA f64 rate 47.8 TFLOP/s; the device time of one damped solve."""
+    of one J^T J (HIP events) against the measured MFMA f64 rate 72 TFLOP/s (scripts/mfma_probe/overlap.hip); the device time of one damped solve."""
     import gslnls_amd as A
     L = _lib.lib()
     out = {"workload": "formula models with p > 64: sums of ng Gaussians a*exp(-((x-m)/w)^2), p = 3 ng, analytic Jacobian, lm, "
                        "solver = cholesky; one host synchronisation per trial step (the solve's), one more per accepted point",
-           "mfma_f64_measured_tflops": 47.8, "cases": []}
+           "mfma_f64_measured_tflops": 72.0, "cases": []}
     for ng, n in ((33, 3000), (66, 5000), (167, 20000)):
         pp = 3 * ng
         rng = np.random.Generator(np.random.PCG64(ng))
@@ -583,7 +586,7 @@ def matrix_path_bench(_lib):
             "per_call_ms": {"whole_call": el, "set_up": prof[0], "loop": prof[1], "covariance_host": prof[5],
                             "resid_and_grad_to_host": prof[6], "condition_diagnostic_host": prof[7]},
             "jtj_device_ms": syrk_ms, "jtj_tflops": 2.0 * n * pp * pp / (syrk_ms * 1e-3) / 1e12 / 2.0 if syrk_ms > 0 else None,
-            "jtj_frac_of_measured_mfma_rate": (n * pp * pp / (syrk_ms * 1e-3) / 1e12) / 47.8 if syrk_ms > 0 else None,
+            "jtj_frac_of_measured_mfma_rate": (n * pp * pp / (syrk_ms * 1e-3) / 1e12) / 72.0 if syrk_ms > 0 else None,
             "damped_solve_device_ms": float(np.median(sm))})
     out["note"] = ("J^T J flops counted as n p^2 (the lower triangle is computed: n p (p + 1) flops of the 2 n p^2 of the full product); "
                    "trial steps include the first evaluation's share of the loop")
@@ -666,12 +669,18 @@ def sparse_readme_bench():
             solr = np.zeros(pp)
             rargs = (pp, dA, dg.ctypes.data_as(_lib.DP), 1e-3, rhs.ctypes.data_as(_lib.DP), solr.ctypes.data_as(_lib.DP))
             rc2 = L.gslnls_debug_mchol_solve_resident(*rargs)
-            t0 = time.perf_counter()
-            dev_ms = []
+            dev_ms, wall_ms = [], []
             for _ in range(4 * reps):
+                t0 = time.perf_counter()
                 rc2 = L.gslnls_debug_mchol_solve_resident(*rargs) or rc2
+                wall_ms.append((time.perf_counter() - t0) * 1e3)
                 dev_ms.append(L.gslnls_debug_mchol_last_device_ms())
-            entry["ms_per_solve"] = (time.perf_counter() - t0) / (4 * reps) * 1e3
+            # median and mean of the host clock around each call: about one call in a few hundred takes milliseconds
+            # longer on the host (seen at p = 2000, 130 launches a solve: 17 ms once in 60 calls while the events show the
+            # same 1.17 ms of device work) -- both are reported
+            entry["ms_per_solve"] = float(np.median(wall_ms))
+            entry["ms_per_solve_mean"] = float(np.mean(wall_ms))
+            entry["ms_per_solve_max"] = float(np.max(wall_ms))
             # (HIP events around the kernels of each solve: what the device did, whatever else the host was busy with)
             entry["device_ms_per_solve"] = float(np.median(dev_ms))
             entry["rc_resident"] = int(rc2)

@@ -693,6 +693,9 @@ struct WideFit : DenseBase
                 const unsigned long long *r = &hs[(size_t)10 * 1024];
                 fprintf(stderr, "[wide stamps] first row block, last pass: start -> rows evaluated %.2f us | contraction %.2f | the four wavefronts' sums side by side %.2f\n",
                         (double)(r[1] - r[0]) * 0.01, (double)(r[2] - r[1]) * 0.01, (double)(r[4] - r[2]) * 0.01);
+                if (r[7] > 0)
+                    fprintf(stderr, "[wide stamps] first row block, last pass, first wavefront: %llu tiles, row phase %.2f us per tile, contraction %.2f us per tile\n",
+                            r[7], (double)r[5] * 0.01 / (double)r[7], (double)r[6] * 0.01 / (double)r[7]);
             }
             static const char *nm[8] = {"rows", "partial+arrive1", "reduce1", "arrive2", "reduce2", "advance_pre", "solve/spec", "post"};
             for (int kind = 0; kind < 2; ++kind)

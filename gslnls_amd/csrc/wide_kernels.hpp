@@ -140,6 +140,22 @@ __device__ __forceinline__ double wide_resid(const TH &th, const XR &xr, double 
     return f * sw;
 }
 
+// developer switches of the contraction loop (GSLNLS_RTC_EXTRA_FLAGS="-DGSLNLS_WIDE_CHUNK_AHEAD=3 ..."): how many 4-row
+// chunks ahead of the matrix instructions the LDS reads run, and the wavefront's issue priority while it feeds the matrix pipe
+#ifndef GSLNLS_WIDE_CHUNK_AHEAD
+#define GSLNLS_WIDE_CHUNK_AHEAD 2
+#endif
+#ifndef GSLNLS_WIDE_MFMA_PRIO
+#define GSLNLS_WIDE_MFMA_PRIO 0
+#endif
+struct wide_true
+{
+    static constexpr bool value = true;
+};
+struct wide_false
+{
+    static constexpr bool value = false;
+};
 #ifndef GSLNLS_WIDE_WAVES
 #define GSLNLS_WIDE_WAVES(PW) ((PW) <= 32 ? 2 : 1) // workgroups per CU the register budget is cut for (LDS allows 2 up to PW = 32)
 #endif
@@ -284,6 +300,8 @@ __device__ __forceinline__ void wide_rows_to_sums(const WPassArgs &a, int phase,
     for (; t < ntile; t += tstride)
     {
         // ---------------- row phase: lane = row ----------------
+        if (rst)
+            rst[8] = __builtin_amdgcn_s_memrealtime();
         const long long i = t * 64 + lane;
         const bool live = i < a.n;
         double xr[NX];
@@ -351,31 +369,68 @@ __device__ __forceinline__ void wide_rows_to_sums(const WPassArgs &a, int phase,
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         if (rst)
-            rst[1] = __builtin_amdgcn_s_memrealtime(); // (last tile's) rows evaluated, gradient entries in the tile
-        // ---------------- contraction phase: 16 chunks of 4 rows ----------------
-#pragma unroll 4
-        for (int c = 0; c < 16; ++c)
         {
-            double v[NB];
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-                v[b] = mytile[(b * 16 + ii) * WIDE_LD + c * 4 + kk];
-            const double fl = ftile[wave][c * 4 + kk];
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-                gacc[b] = fma(v[b], fl, gacc[b]);
-            if (phase != PH_FVV)
-            {
-                int q = 0;
-#pragma unroll
-                for (int ba = 0; ba < NB; ++ba)
-#pragma unroll
-                    for (int bb = 0; bb <= ba; ++bb, ++q)
-                        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[ba], v[bb], acc[q], 0, 0, 0);
-            }
+            rst[1] = __builtin_amdgcn_s_memrealtime(); // (last tile's) rows evaluated, gradient entries in the tile
+            rst[5] = (t < tstride ? 0ull : rst[5]) + (rst[1] - rst[8]); // row phases of this pass, summed
         }
+        // ---------------- contraction phase: 16 chunks of 4 rows ----------------
+#if GSLNLS_WIDE_MFMA_PRIO
+        __builtin_amdgcn_s_setprio(GSLNLS_WIDE_MFMA_PRIO);
+#endif
+        // The operands of chunk c + GSLNLS_WIDE_CHUNK_AHEAD are requested before the matrix instructions of chunk c issue
+        // (round 5: with "load, wait, three MFMAs" per chunk and the phase test inside the loop every chunk paid one
+        // LDS round trip in the open -- 138 clocks per MFMA where the pipe needs 64); the phase is tested once, outside.
+        const auto contract = [&](auto with_jtj) {
+            constexpr bool JTJ = decltype(with_jtj)::value;
+            constexpr int AH = GSLNLS_WIDE_CHUNK_AHEAD;
+            double v[AH + 1][NB], fl[AH + 1];
+#pragma unroll
+            for (int c = 0; c < AH; ++c)
+            {
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    v[c][b] = mytile[(b * 16 + ii) * WIDE_LD + c * 4 + kk];
+                fl[c] = ftile[wave][c * 4 + kk];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+            {
+                constexpr int R = AH + 1;
+                if (c + AH < 16)
+                {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+                        v[(c + AH) % R][b] = mytile[(b * 16 + ii) * WIDE_LD + (c + AH) * 4 + kk];
+                    fl[(c + AH) % R] = ftile[wave][(c + AH) * 4 + kk];
+                }
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    gacc[b] = fma(v[c % R][b], fl[c % R], gacc[b]);
+                if constexpr (JTJ)
+                {
+                    int q = 0;
+#pragma unroll
+                    for (int ba = 0; ba < NB; ++ba)
+#pragma unroll
+                        for (int bb = 0; bb <= ba; ++bb, ++q)
+                            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[c % R][ba], v[c % R][bb], acc[q], 0, 0, 0);
+                }
+            }
+        };
+        if (phase != PH_FVV)
+            contract(wide_true{});
+        else
+            contract(wide_false{});
+#if GSLNLS_WIDE_MFMA_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        if (rst)
+        {
+            rst[6] = (t < tstride ? 0ull : rst[6]) + (__builtin_amdgcn_s_memrealtime() - rst[1]); // contractions, summed
+            rst[7] = (t < tstride ? 0ull : rst[7]) + 1;
+        }
     }
 
     if (rst)

@@ -1,4 +1,10 @@
-// issue rate of v_mfma_f64_16x16x4_f64 on gfx950: one wave per SIMD, 10 independent accumulators, back to back
+// issue rate of v_mfma_f64_16x16x4_f64 on gfx950: one wave per SIMD, 10 independent accumulators, back to back.
+// ROUND 5 CORRECTION: the compiler keeps the 10 accumulators of this loop in AGPRs and moves all 80 registers to VGPRs and
+// back in EVERY iteration (80 v_accvgpr_write + 10 MFMA + 80 v_accvgpr_read per trip: see the ISA), so the 47.7 TFLOP/s
+// this probe reported in round 3 is the rate of that loop, not of the instruction.  overlap.hip (case A: four accumulators
+// that stay in VGPRs, no moves -- checked in its ISA) shows the instruction's own rate: 29 ns per MFMA per SIMD = 64
+// cycles at the 2.2 GHz the device holds under this load = 72 TFLOP/s.  This file is kept as the record of the old number
+// and for the vector pipe's rate below.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double v4f64_t __attribute__((ext_vector_type(4)));
