@@ -11,6 +11,9 @@
 // the model is a closure, and for p > 64 the p x p factorisation (hundreds of microseconds) hides a round trip.
 // Every n x p and p x p operation is a device kernel (bd_kernels.hpp; the damped solve: mchol_device.hip).
 #pragma once
+#include <atomic>
+#include <mutex>
+#include <map>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <algorithm>
@@ -25,6 +28,133 @@
 
 namespace gslnls
 {
+
+// ---- round 5: the matrix path's buffers are parked between fits ---------------------------------------------------------
+// A fit of the matrix path needs about fifteen device buffers (the n x p Jacobian among them) and four pinned ones; allocating
+// and freeing them per call was 6.5 ms of a p = 501 call whose LM loop takes 6.  bd_dev_alloc / bd_host_alloc hand back a
+// parked block of exactly the requested size on the same device when there is one (a second fit of the same shape allocates
+// nothing), bd_*_free park it again; beyond BD_POOL_DEV_BYTES / BD_POOL_HOST_BYTES parked, or BD_POOL_BLOCKS blocks, a
+// block is really freed.  Contents are whatever the last user left (hipMalloc promises nothing else either).
+// GSLNLS_BD_POOL=0 turns the parking off.  (The pool is never destroyed: no HIP calls during static teardown.)
+constexpr size_t BD_POOL_DEV_BYTES = (size_t)4 << 30, BD_POOL_HOST_BYTES = (size_t)256 << 20;
+constexpr int BD_POOL_BLOCKS = 96;
+struct BdPool
+{
+    struct Blk
+    {
+        void *ptr;
+        size_t bytes;
+        int dev;
+        unsigned flags;
+        bool host;
+    };
+    std::mutex mu;
+    std::vector<Blk> parked;
+    std::map<void *, Blk> live;
+    size_t dev_bytes = 0, host_bytes = 0;
+    bool on = true;
+    BdPool()
+    {
+        const char *e = getenv("GSLNLS_BD_POOL");
+        on = !(e && atoi(e) == 0);
+    }
+    hipError_t take(void **out, size_t bytes, bool host, unsigned flags)
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t k = 0; k < parked.size(); ++k)
+                if (parked[k].bytes == bytes && parked[k].host == host && parked[k].flags == flags && parked[k].dev == dev)
+                {
+                    Blk b = parked[k];
+                    parked.erase(parked.begin() + (long)k);
+                    (host ? host_bytes : dev_bytes) -= bytes;
+                    live[b.ptr] = b;
+                    *out = b.ptr;
+                    return hipSuccess;
+                }
+        }
+        void *q = nullptr;
+        const hipError_t e = host ? hipHostMalloc(&q, bytes, flags) : hipMalloc(&q, bytes);
+        if (e != hipSuccess)
+        {
+            // (the parked blocks may be what is in the way: let them go and try once more)
+            drain();
+            const hipError_t e2 = host ? hipHostMalloc(&q, bytes, flags) : hipMalloc(&q, bytes);
+            if (e2 != hipSuccess)
+                return e2;
+            (void)hipGetLastError();
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        live[q] = Blk{q, bytes, dev, flags, host};
+        *out = q;
+        return hipSuccess;
+    }
+    void give(void *q)
+    {
+        if (!q)
+            return;
+        Blk b{q, 0, 0, 0, false};
+        bool known = false, park = false;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = live.find(q);
+            if (it != live.end())
+            {
+                b = it->second;
+                live.erase(it);
+                known = true;
+                park = on && (int)parked.size() < BD_POOL_BLOCKS &&
+                       (b.host ? host_bytes + b.bytes <= BD_POOL_HOST_BYTES : dev_bytes + b.bytes <= BD_POOL_DEV_BYTES);
+                if (park)
+                {
+                    parked.push_back(b);
+                    (b.host ? host_bytes : dev_bytes) += b.bytes;
+                }
+            }
+        }
+        if (!park)
+        {
+            if (known && b.host)
+                (void)hipHostFree(q);
+            else
+                (void)hipFree(q);
+        }
+    }
+    void drain()
+    {
+        std::vector<Blk> all;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            all.swap(parked);
+            dev_bytes = host_bytes = 0;
+        }
+        for (const Blk &b : all)
+        {
+            if (b.host)
+                (void)hipHostFree(b.ptr);
+            else
+                (void)hipFree(b.ptr);
+        }
+    }
+};
+inline BdPool &bd_pool()
+{
+    static BdPool *pl = new BdPool;
+    return *pl;
+}
+template <class T>
+inline hipError_t bd_dev_alloc(T **out, size_t bytes)
+{
+    return bd_pool().take(reinterpret_cast<void **>(out), bytes, false, 0);
+}
+template <class T>
+inline hipError_t bd_host_alloc(T **out, size_t bytes, unsigned flags)
+{
+    return bd_pool().take(reinterpret_cast<void **>(out), bytes, true, flags);
+}
+inline void bd_pool_free(void *q) { bd_pool().give(q); }
 
 // 2-norm condition number of the column-scaled normal matrix for any p: Cholesky of C = S A S, lambda_max by power
 // iteration, lambda_min by inverse iteration through the factor (the boundary's solver-routing diagnostic,
@@ -195,6 +325,7 @@ struct BdFit
     // round 5: x, bounds and what a fused trial step sends home (x + dx | rows of dx^T J^T J dx | partial sums of ||f||^2) on
     // the device; pinned staging for every small copy (a pageable destination makes an asynchronous copy a blocking one)
     double *d_pub = nullptr, *h_pin = nullptr;
+    double *d_epi = nullptr; // round 5, allocated by the first fit's end that needs it: X = L^-1 (p^2) | (J^T J)^-1 (p^2) | four p-vectors | two norms
     double *h_xmap = nullptr, *d_xmap = nullptr; // pinned + mapped, 3 p doubles: x | lower | upper bounds, read by bd_trial_kernel in place
     double *h_jmap = nullptr, *d_jmap = nullptr; // pinned + mapped: g | diag(J^T J) | flags (BD_MAXG) | sequence word (bd_publish_kernel)
     unsigned long long jseq = 0;
@@ -221,18 +352,18 @@ struct BdFit
             (void)hipFree(irls_arena);
         irls_arena = nullptr;
         irls_arena_bytes = 0;
-        double *bufs[] = {d_y, d_sw, d_fval, d_f[0], d_f[1], d_fp, d_fm, d_J, d_C, d_cpart, d_part, d_pv, d_u, d_pub};
+        double *bufs[] = {d_y, d_sw, d_fval, d_f[0], d_f[1], d_fp, d_fm, d_J, d_C, d_cpart, d_part, d_pv, d_u, d_pub, d_epi};
         for (double *b : bufs)
             if (b)
-                (void)hipFree(b);
+                bd_pool_free(b);
         d_y = d_sw = d_fval = d_f[0] = d_f[1] = d_fp = d_fm = d_J = d_C = d_cpart = d_part = d_pv = d_u = nullptr;
-        d_pub = nullptr;
+        d_pub = d_epi = nullptr;
         if (h_pin)
-            (void)hipHostFree(h_pin);
+            bd_pool_free(h_pin);
         if (h_xmap)
-            (void)hipHostFree(h_xmap);
+            bd_pool_free(h_xmap);
         if (h_jmap)
-            (void)hipHostFree(h_jmap);
+            bd_pool_free(h_jmap);
         h_pin = h_xmap = d_xmap = h_jmap = d_jmap = nullptr;
         if (ev_j)
             (void)hipEventDestroy(ev_j);
@@ -266,31 +397,31 @@ struct BdFit
         sl = sl > ntile ? ntile : sl;
         sl = sl > 32 ? 32 : (sl < 1 ? 1 : sl);
         nslice = (int)sl;
-        GSLNLS_HIP_OK(hipMalloc(&d_y, nb));
-        GSLNLS_HIP_OK(hipMalloc(&d_fval, nb));
-        GSLNLS_HIP_OK(hipMalloc(&d_f[0], nb));
-        GSLNLS_HIP_OK(hipMalloc(&d_f[1], nb));
-        GSLNLS_HIP_OK(hipMalloc(&d_fp, nb));
-        GSLNLS_HIP_OK(hipMalloc(&d_fm, nb));
-        GSLNLS_HIP_OK(hipMalloc(&d_u, nb));
-        GSLNLS_HIP_OK(hipMalloc(&d_J, nb * p));
-        GSLNLS_HIP_OK(hipMalloc(&d_C, sizeof(double) * (size_t)p * p));
-        GSLNLS_HIP_OK(hipMalloc(&d_cpart, sizeof(double) * (size_t)nslice * npair * 4096));
-        GSLNLS_HIP_OK(hipMalloc(&d_part, sizeof(double) * BD_MAXG));
-        GSLNLS_HIP_OK(hipMalloc(&d_pv, sizeof(double) * (size_t)4 * p));
-        GSLNLS_HIP_OK(hipMalloc(&d_pub, sizeof(double) * ((size_t)2 * p + BD_MAXG)));
-        GSLNLS_HIP_OK(hipHostMalloc(&h_xmap, sizeof(double) * (size_t)3 * p, hipHostMallocMapped));
+        GSLNLS_HIP_OK(bd_dev_alloc(&d_y, nb));
+        GSLNLS_HIP_OK(bd_dev_alloc(&d_fval, nb));
+        GSLNLS_HIP_OK(bd_dev_alloc(&d_f[0], nb));
+        GSLNLS_HIP_OK(bd_dev_alloc(&d_f[1], nb));
+        GSLNLS_HIP_OK(bd_dev_alloc(&d_fp, nb));
+        GSLNLS_HIP_OK(bd_dev_alloc(&d_fm, nb));
+        GSLNLS_HIP_OK(bd_dev_alloc(&d_u, nb));
+        GSLNLS_HIP_OK(bd_dev_alloc(&d_J, nb * p));
+        GSLNLS_HIP_OK(bd_dev_alloc(&d_C, sizeof(double) * (size_t)p * p));
+        GSLNLS_HIP_OK(bd_dev_alloc(&d_cpart, sizeof(double) * (size_t)nslice * npair * 4096));
+        GSLNLS_HIP_OK(bd_dev_alloc(&d_part, sizeof(double) * BD_MAXG));
+        GSLNLS_HIP_OK(bd_dev_alloc(&d_pv, sizeof(double) * (size_t)4 * p));
+        GSLNLS_HIP_OK(bd_dev_alloc(&d_pub, sizeof(double) * ((size_t)2 * p + BD_MAXG)));
+        GSLNLS_HIP_OK(bd_host_alloc(&h_xmap, sizeof(double) * (size_t)3 * p, hipHostMallocMapped));
         GSLNLS_HIP_OK(hipHostGetDevicePointer((void **)&d_xmap, h_xmap, 0));
-        GSLNLS_HIP_OK(hipHostMalloc(&h_jmap, sizeof(double) * ((size_t)2 * p + BD_MAXG + 2), hipHostMallocMapped));
+        GSLNLS_HIP_OK(bd_host_alloc(&h_jmap, sizeof(double) * ((size_t)2 * p + BD_MAXG + 2), hipHostMallocMapped));
         GSLNLS_HIP_OK(hipHostGetDevicePointer((void **)&d_jmap, h_jmap, 0));
         GSLNLS_HIP_OK(hipEventCreateWithFlags(&ev_j, hipEventDisableTiming));
         memset(h_jmap + 2 * (size_t)p + BD_MAXG, 0, 2 * sizeof(double)); // (the sequence word: jseq counts from 1)
-        GSLNLS_HIP_OK(hipHostMalloc(&h_pin, sizeof(double) * ((size_t)4 * p + 2 * BD_MAXG), hipHostMallocDefault));
+        GSLNLS_HIP_OK(bd_host_alloc(&h_pin, sizeof(double) * ((size_t)4 * p + 2 * BD_MAXG), hipHostMallocDefault));
         h_part.resize(BD_MAXG);
         GSLNLS_HIP_OK(hipMemcpyAsync(d_y, y, nb, hipMemcpyHostToDevice, st));
         if (swts)
         {
-            GSLNLS_HIP_OK(hipMalloc(&d_sw, nb));
+            GSLNLS_HIP_OK(bd_dev_alloc(&d_sw, nb));
             GSLNLS_HIP_OK(hipMemcpyAsync(d_sw, swts, nb, hipMemcpyHostToDevice, st));
         }
         GSLNLS_HIP_OK(hipStreamSynchronize(st));
@@ -481,6 +612,89 @@ struct BdFit
     }
 
     // det_cholesky_jtj (src/nls_utils.c:55-73): (prod L_ii)^2 of the plain Cholesky factor, 0 when it does not exist
+    // ---- round 5: (J^T J)^-1 and the solver-routing diagnostic at a fit's end, on the device ----
+    // The damped solve's kernels factor J^T J (mu = 0, zero right-hand side: natural-order blocked Cholesky); behind them,
+    // in the same submission: X = L^-1 column by column (bd_trinv_kernel), (J^T J)^-1 = X^T X on the matrix cores
+    // (bd_syrk_kernel, the kernel of J^T J itself), and the two power iterations of bd_scaled_cond -- 60 products with
+    // C = S A S, 60 with C^-1 = S^-1 A^-1 S^-1 -- whose norms come home with the solve's one synchronisation.  Until
+    // round 5 both were host loops, cubic in p: 25.6 + 18.5 ms of a 76 ms call at p = 501, where the LM loop takes 6.
+    // Returns non-zero (and touches nothing) when the factorisation was refused -- a pivot not safely positive -- or the
+    // device routine does not take the size: the caller keeps the host routines, whose rank rules then decide.
+    int device_epilogue(double *covar_out, double *cond_out)
+    {
+        const size_t pp = (size_t)p * p;
+        if (!d_epi)
+        {
+            if (bd_dev_alloc(&d_epi, sizeof(double) * (2 * pp + 4 * (size_t)p + 8)) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                d_epi = nullptr;
+                return GSLNLS_E_NODEVICE;
+            }
+        }
+        const int nblk = (p + 63) / 64;
+        const size_t lds_ti = sizeof(double) * ((size_t)64 * nblk + 64 * BD_TI_LD + 64);
+        static std::atomic<size_t> lds_set{0};
+        if (lds_set.load() < lds_ti)
+        {
+            if (hipFuncSetAttribute((const void *)bd_trinv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ti) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                return GSLNLS_E_NODEVICE;
+            }
+            lds_set.store(lds_ti);
+        }
+        struct Ctx
+        {
+            BdFit *fit;
+            size_t lds_ti;
+        } cx{this, lds_ti};
+        auto enq = [](void *ctx, void *stream, const double *d_L, const double *d_dinv, int pq) {
+            Ctx &c = *static_cast<Ctx *>(ctx);
+            BdFit &f = *c.fit;
+            hipStream_t s2 = (hipStream_t)stream;
+            const size_t ppq = (size_t)pq * pq;
+            double *d_X = f.d_epi, *d_cov = d_X + ppq, *d_w = d_cov + ppq, *d_nrm = d_w + 4 * (size_t)pq;
+            hipLaunchKernelGGL(bd_trinv_kernel, dim3(pq), dim3(BD_T), c.lds_ti, s2, d_L, d_dinv, pq, d_X);
+            long long sl = (512 + f.npair - 1) / f.npair;
+            const long long ntile = (pq + 63) / 64;
+            sl = sl > ntile ? ntile : sl;
+            sl = sl > 32 ? 32 : (sl < 1 ? 1 : sl);
+            sl = sl > f.nslice ? f.nslice : sl; // (d_cpart holds nslice partial sets)
+            hipLaunchKernelGGL(bd_syrk_kernel, dim3(f.npair, (int)sl), dim3(BD_T), 0, s2, d_X, (long long)pq, pq, (int)sl, f.d_cpart);
+            hipLaunchKernelGGL(bd_syrk_reduce_kernel, dim3(f.npair, 16), dim3(BD_T), 0, s2, f.d_cpart, pq, f.npair, (int)sl, d_cov);
+            hipLaunchKernelGGL(bd_power_start_kernel, dim3((pq + 255) / 256), dim3(256), 0, s2, pq, d_w, d_w + 2 * (size_t)pq);
+            const int gw = (pq + BD_T / 64 - 1) / (BD_T / 64);
+            for (int run = 0; run < 2; ++run)
+            {
+                double *wa = d_w + 2 * (size_t)run * pq, *wb = wa + pq;
+                // 60 products; the 61st launch only delivers the norm of the last one
+                for (int it = 0; it <= 60; ++it)
+                    hipLaunchKernelGGL(bd_power_kernel, dim3(gw), dim3(BD_T), sizeof(double) * pq, s2, run ? d_cov : f.d_C, f.d_C, pq, run,
+                                       (it & 1) ? wb : wa, (it & 1) ? wa : wb, d_nrm + run);
+            }
+        };
+        std::vector<double> zero(p, 0.0), sol(p, 0.0);
+        double nrm[2] = {NAN, NAN};
+        MCholTail tail;
+        tail.enqueue_factor = enq;
+        tail.ctx = &cx;
+        tail.extra_dev = d_epi + 2 * pp + 4 * (size_t)p;
+        tail.extra_n = 2;
+        tail.extra_host = nrm;
+        int valid = 0;
+        const int rc = mchol_device_solve_resident_tail(p, d_C, zero.data(), 0.0, zero.data(), sol.data(), &tail, &valid);
+        if (rc)
+            return rc;
+        if (!valid)
+            return GSLNLS_FAILURE;
+        if (covar_out)
+            GSLNLS_HIP_OK(hipMemcpy(covar_out, d_epi + pp, sizeof(double) * pp, hipMemcpyDeviceToHost)); // (symmetric: either storage order)
+        const double c = nrm[0] * nrm[1];
+        *cond_out = std::isfinite(c) && c > 0.0 ? c : INFINITY;
+        return GSLNLS_SUCCESS;
+    }
+
     static double det_chol(std::vector<double> &M)
     {
         const int q = (int)llround(sqrt((double)M.size()));
@@ -984,8 +1198,14 @@ struct BdFit
                 out->par[k] = ok ? x[k] : start[k];
         // NOTE: after a failed last Jacobian (EBADFUNC at an accepted point) d_J / d_C hold that point's matrices; the
         // result is NaN-filled then, as the reference's is
+        // round 5: both from the device when the damped solve runs there (device_epilogue above); the host routines below
+        // when it does not, or when the natural-order factorisation refuses the matrix (GSLNLS_BD_HOST_EPILOGUE=1 forces them)
+        bool epi_dev = false;
+        double cond_dev = NAN;
+        if (ok && dev_solve && !getenv("GSLNLS_BD_HOST_EPILOGUE"))
+            epi_dev = device_epilogue(out->covar, &cond_dev) == GSLNLS_SUCCESS;
         std::vector<double> Afin; // J^T J at the final point: covariance and the solver-routing diagnostic
-        if (ok)
+        if (ok && !epi_dev)
         {
             Afin.resize((size_t)p * p);
             if (dev_solve)
@@ -993,7 +1213,7 @@ struct BdFit
             else
                 Afin = A;
         }
-        if (out->covar)
+        if (out->covar && !epi_dev)
         {
             bool good = ok;
             std::vector<double> Ci;
@@ -1040,7 +1260,7 @@ struct BdFit
         out->loop_ms = (float)loop_ms;
         out->n_launches = 0;
         out->n_steps = (int)steps;
-        out->jtj_cond = ok ? bd_scaled_cond(p, Afin) : NAN;
+        out->jtj_cond = !ok ? NAN : (epi_dev ? cond_dev : bd_scaled_cond(p, Afin));
         if (!point_fit)
         {
             g_bd_prof.loop_ms = loop_ms;

@@ -278,4 +278,141 @@ __global__ __launch_bounds__(BD_T) void bd_syrk_reduce_kernel(const double *cpar
     }
 }
 
+// ---- round 5: the covariance and the solver-routing diagnostic of a fit's end, on the device -------------------------------
+// (until then host code, cubic in p: at p = 501 the two took 44 of a call's 76 ms, the LM loop itself 6)
+//
+// wavefront sum by xor butterflies (every lane ends with the total)
+__device__ __forceinline__ double bd_wave_sum(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+    {
+        const long long bits = __double_as_longlong(v);
+        const int lo = __shfl_xor((int)(bits & 0xffffffffll), m, 64), hi = __shfl_xor((int)(bits >> 32), m, 64);
+        v += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    }
+    return v;
+}
+__device__ __forceinline__ double bd_lane_bcast(double v, int src)
+{
+    const long long bits = __double_as_longlong(v);
+    const int lo = __shfl((int)(bits & 0xffffffffll), src, 64), hi = __shfl((int)(bits >> 32), src, 64);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Column j of X = L^-1 (L: the factor the damped solve's kernels leave, p x p row-major lower triangle, dinv[c] = 1 / L_cc):
+// workgroup j solves L x = e_j by blocked forward substitution -- 64 rows at a time, the part of a row in front of the
+// block as a coalesced dot product with the x found so far (16 rows per wavefront), the block's own 64 x 64 triangle from
+// LDS by the first wavefront (lane = row, x_c broadcast, 64 steps) -- and writes x below the zeros of rows < j into
+// X[. + p j] (column-major p x p: the operand J of bd_syrk_kernel, so that (J^T J)^-1 = X^T X comes from the matrix cores).
+// Dynamic LDS: 64 ceil((p - j) / 64) + 64 * 65 + 64 doubles.
+constexpr int BD_TI_LD = 65;
+__global__ __launch_bounds__(BD_T) void bd_trinv_kernel(const double *Lf, const double *dinv, int p, double *X)
+{
+    extern __shared__ double bd_ti_lds[];
+    const int j = blockIdx.x, m = p - j, nblk = (m + 63) / 64;
+    double *xs = bd_ti_lds, *D = xs + 64 * nblk, *ts = D + 64 * BD_TI_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int b = 0; b < nblk; ++b)
+    {
+        const int r0 = j + 64 * b; // first row and column of this block
+        for (int e = tid; e < 4096; e += BD_T)
+        {
+            const int r = e >> 6, c = e & 63;
+            const bool ok = r0 + r < p && c <= r;
+            const double v = Lf[ok ? (size_t)(r0 + r) * p + r0 + c : 0];
+            D[r * BD_TI_LD + c] = ok ? v : 0.0;
+        }
+        // t_r = (e_j)_r - sum_{k < 64 b} L[r0 + r][j + k] x_k, four rows of a wavefront in flight
+        for (int rr = wave * 16; rr < wave * 16 + 16; rr += 4)
+        {
+            double s[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int k = lane; k < 64 * b; k += 64)
+            {
+                const double xk = xs[k];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                {
+                    const bool ok = r0 + rr + u < p;
+                    const double l = Lf[ok ? (size_t)(r0 + rr + u) * p + j + k : 0];
+                    s[u] += (ok ? l : 0.0) * xk;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+            {
+                const double tot = bd_wave_sum(s[u]);
+                if (lane == 0)
+                    ts[rr + u] = ((b == 0 && rr + u == 0) ? 1.0 : 0.0) - tot;
+            }
+        }
+        __syncthreads();
+        if (wave == 0)
+        {
+            double t = ts[lane], xv = 0.0;
+            const double dv = r0 + lane < p ? dinv[r0 + lane] : 0.0;
+            for (int c = 0; c < 64; ++c)
+            {
+                const double xc = bd_lane_bcast(t, c) * bd_lane_bcast(dv, c);
+                xv = lane == c ? xc : xv;
+                t -= D[lane * BD_TI_LD + c] * xc; // (zero above the diagonal; lane c's own t is not read again)
+            }
+            xs[64 * b + lane] = xv;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < p; i += BD_T)
+        X[(size_t)p * j + i] = i < j ? 0.0 : xs[i - j];
+}
+
+// One step of a power iteration on S M S: w_out = S M S (w_in / |w_in|), *nrm_out = |w_in| (the norm the host loop of
+// bd_scaled_cond takes after its product).  mode 0: M = A = J^T J, s_i = 1 / sqrt(A_ii) -- the column-scaled normal matrix
+// C; mode 1: M = A^-1 (the covariance), s_i = sqrt(A_ii) -- C^-1 = S^-1 A^-1 S^-1, whose largest eigenvalue is 1 /
+// lambda_min(C).  Every workgroup forms the norm and the scaled vector itself (same sums in the same order: same bits),
+// then one row per wavefront.  Dynamic LDS: p doubles.
+__global__ __launch_bounds__(BD_T) void bd_power_kernel(const double *M, const double *A, int p, int mode, const double *w_in, double *w_out,
+                                                        double *nrm_out)
+{
+    extern __shared__ double bd_pw_lds[];
+    __shared__ double red_s[BD_T / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double q = 0.0;
+    for (int k = tid; k < p; k += BD_T)
+        q += w_in[k] * w_in[k];
+    const double nrm = sqrt(bd_block_sum(q, red_s));
+    for (int k = tid; k < p; k += BD_T)
+    {
+        const double d = A[(size_t)k * p + k];
+        bd_pw_lds[k] = (mode ? sqrt(d) : 1.0 / sqrt(d)) * (w_in[k] / nrm);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && tid == 0)
+        *nrm_out = nrm;
+    const int i = blockIdx.x * (BD_T / 64) + wave;
+    if (i >= p)
+        return;
+    const double *row = M + (size_t)i * p;
+    double s = 0.0;
+    for (int k = lane; k < p; k += 64)
+        s += row[k] * bd_pw_lds[k];
+    s = bd_wave_sum(s);
+    if (lane == 0)
+    {
+        const double d = A[(size_t)i * p + i];
+        w_out[i] = (mode ? sqrt(d) : 1.0 / sqrt(d)) * s;
+    }
+}
+
+// the two start vectors of bd_scaled_cond: (1, 1, ...) / sqrt(p) and (+1, -1, ...) / sqrt(p)
+__global__ void bd_power_start_kernel(int p, double *v0, double *v1)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < p)
+    {
+        const double u = 1.0 / sqrt((double)p);
+        v0[k] = u;
+        v1[k] = (k & 1) ? -u : u;
+    }
+}
+
 } // namespace gslnls

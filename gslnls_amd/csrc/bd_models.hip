@@ -52,13 +52,13 @@ struct BdFormulaModel : BdModel
     ~BdFormulaModel() override
     {
         if (d_x)
-            (void)hipFree(d_x);
+            bd_pool_free(d_x);
         if (d_theta)
-            (void)hipFree(d_theta);
+            bd_pool_free(d_theta);
         if (d_ring)
-            (void)hipFree(d_ring);
+            bd_pool_free(d_ring);
         if (h_ring)
-            (void)hipHostFree(h_ring);
+            bd_pool_free(h_ring);
     }
     // theta / v are the caller's vectors and may change as soon as this returns: they go through a ring of pinned slots
     // (one asynchronous copy each, no synchronisation -- round 5; the ring is longer than the evaluations a Jacobian by
@@ -177,11 +177,11 @@ int bd_formula_nls(const gslnls_model *fn, const double *y, int n, int jac, int 
     }
     const double t_c = now_s();
     const size_t nb = sizeof(double) * (size_t)n;
-    GSLNLS_HIP_OK(hipMalloc(&m.d_x, nb * nxm));
-    GSLNLS_HIP_OK(hipMalloc(&m.d_theta, sizeof(double) * (size_t)2 * fn->p + nb));
+    GSLNLS_HIP_OK(bd_dev_alloc(&m.d_x, nb * nxm));
+    GSLNLS_HIP_OK(bd_dev_alloc(&m.d_theta, sizeof(double) * (size_t)2 * fn->p + nb));
     m.d_scratch = m.d_theta + 2 * fn->p;
-    GSLNLS_HIP_OK(hipMalloc(&m.d_ring, sizeof(double) * (size_t)BdFormulaModel::RING * 2 * fn->p));
-    GSLNLS_HIP_OK(hipHostMalloc(&m.h_ring, sizeof(double) * (size_t)BdFormulaModel::RING * 2 * fn->p, hipHostMallocDefault));
+    GSLNLS_HIP_OK(bd_dev_alloc(&m.d_ring, sizeof(double) * (size_t)BdFormulaModel::RING * 2 * fn->p));
+    GSLNLS_HIP_OK(bd_host_alloc(&m.h_ring, sizeof(double) * (size_t)BdFormulaModel::RING * 2 * fn->p, hipHostMallocDefault));
     if (fn->nx > 0)
         GSLNLS_HIP_OK(hipMemcpy(m.d_x, fn->x, nb * nxm, hipMemcpyHostToDevice));
     else
@@ -238,5 +238,6 @@ int bd_last_profile(double *v, int cap)
     return 12;
 }
 double bd_syrk_ms(int n, int p, int reps) { return bd_time_syrk(n, p, reps); }
+void bd_trim_pool() { bd_pool().drain(); }
 
 } // namespace gslnls

@@ -94,6 +94,7 @@ int bd_callback_nls(int n, int p, const double *y, gslnls_fn_cb f, gslnls_jac_cb
                     gslnls_result *out); // bd_models.hip
 int bd_last_profile(double *v, int cap);     // bd_models.hip
 double bd_syrk_ms(int n, int p, int reps);   // bd_models.hip
+void bd_trim_pool();                          // bd_models.hip: the matrix path's parked buffers
 void trim_dense_expr();                                                                                         // vm_models.hip
 }
 
@@ -1305,6 +1306,7 @@ void gslnls_trim_cache(void)
 {
     delete g_parked_sparse;
     g_parked_sparse = nullptr;
+    bd_trim_pool();
     DenseFit<ModelExpDecay>::trim_pool();
     DenseFit<ModelMisra1a>::trim_pool();
     DenseFit<ModelGaussPeak>::trim_pool();

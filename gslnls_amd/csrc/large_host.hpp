@@ -242,6 +242,9 @@ int mchol_device_solve_resident(int p, const double *jtj_dev, const double *diag
 struct MCholTail
 {
     void (*enqueue)(void *ctx, void *stream, const double *d_sol) = nullptr;
+    // (round 5) the same, with the factor the solve leaves on the device: L (p x p row-major, lower triangle) and 1 / L_jj
+    // -- the covariance at a fit's end is built from it (bd_host.hpp); only meaningful when *tail_valid comes back 1
+    void (*enqueue_factor)(void *ctx, void *stream, const double *d_L, const double *d_dinv, int p) = nullptr;
     void *ctx = nullptr;
     const double *extra_dev = nullptr;
     int extra_n = 0;

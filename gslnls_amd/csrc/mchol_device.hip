@@ -1672,6 +1672,8 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
             B.down[p + 1] = 0.0; // (the word the device is about to write; any value but the new sequence number)
             if (tail && tail->enqueue)
                 tail->enqueue(tail->ctx, (void *)sq, d_sol); // (the caller's kernels, behind the back substitution on this stream)
+            if (tail && tail->enqueue_factor)
+                tail->enqueue_factor(tail->ctx, (void *)sq, B.Lg, a.dinv, p);
             hipLaunchKernelGGL(cholb_publish_kernel, dim3(1), dim3(256), 0, sq, d_sol, d_flag, p, B.down_dev, B.seq,
                                tail ? tail->extra_dev : nullptr, tail ? tail->extra_n : 0);
             GSLNLS_HIP_OK(hipEventRecord(B.evdone, sq));

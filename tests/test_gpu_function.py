@@ -10,6 +10,7 @@ import time
 
 import numpy as np
 import pytest
+from conftest import record_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -236,6 +237,32 @@ def test_formula_with_100_parameters_matches_the_oracle(amd, gslref, jac):
     assert abs(fit["ssr"] - ref["ssr"]) <= 1e-9 * ref["ssr"]
     assert np.allclose(fit["resid"], ref["resid"], rtol=0, atol=1e-7)
     REPORT.append("formula p=100 jac=%s %.1e" % (jac, _rel(fit["par"], ref["par"])))
+
+
+@pytest.mark.parametrize("ng,n", [(22, 2000), (33, 3000), (66, 5000)])
+def test_covariance_and_condition_from_the_device_equal_the_host_routines(amd, gslref, monkeypatch, ng, n):
+    """Round 5: at a fit's end (J^T J)^-1 and the solver-routing diagnostic kappa(S J^T J S) come from the device (L^-1 column by
+    column behind the damped solve's factorisation, X^T X on the matrix cores, two power iterations); the host routines they
+    replace stay as the fallback for matrices the natural-order factorisation refuses.  Same fit through both: the
+    covariance to 1e-10 of its scale, the condition number to 1e-8, and the oracle's covariance as before."""
+    x, y, model, jac, start, truth = gaussians(ng, n, 4300 + ng)
+    p = len(start)
+    ctrl = dict(solver="cholesky")
+    dev = amd.gsl_nls(model, y=y, start=start, jac=jac, control=ctrl)
+    monkeypatch.setenv("GSLNLS_BD_HOST_EPILOGUE", "1")
+    host = amd.gsl_nls(model, y=y, start=start, jac=jac, control=ctrl)
+    monkeypatch.delenv("GSLNLS_BD_HOST_EPILOGUE")
+    assert dev["conv"] == 0 and host["conv"] == 0 and dev["code_path"] == 4
+    assert np.array_equal(dev["par"], host["par"]) and dev["niter"] == host["niter"]
+    cd, ch = np.asarray(dev["covar"]), np.asarray(host["covar"])
+    assert np.array_equal(cd, cd.T)
+    scale = np.sqrt(np.outer(np.diag(ch), np.diag(ch)))
+    err = float(np.max(np.abs(cd - ch) / scale))
+    record_parity("matrix path p=%d covariance device vs host" % p, err, 1e-10)
+    assert err < 1e-10, err
+    assert abs(dev["jtj_cond"] - host["jtj_cond"]) <= 1e-8 * host["jtj_cond"], (dev["jtj_cond"], host["jtj_cond"])
+    ref = gslref.nls(n, p, start, fn=lambda th: model(th) - y, jac=jac, ctrl=gslref.control(**ctrl))
+    assert np.allclose(np.diag(cd), np.diag(ref["covar"]), rtol=1e-6)
 
 
 @pytest.mark.parametrize("loss", ["huber", "bisquare", "welsh", "hampel"])
