@@ -583,8 +583,8 @@ def matrix_path_bench(_lib):
                                             "jacobian_jtj_jtf_of_accepted_points": 1e3 * prof[3] / steps,
                                             "residuals_outside_the_fused_step": 1e3 * prof[4] / steps,
                                             "host_vectors_and_decisions": 1e3 * (prof[1] - prof[2] - prof[3] - prof[4]) / steps},
-            "per_call_ms": {"whole_call": el, "set_up": prof[0], "loop": prof[1], "covariance_host": prof[5],
-                            "resid_and_grad_to_host": prof[6], "condition_diagnostic_host": prof[7]},
+            "per_call_ms": {"whole_call": el, "set_up": prof[0], "loop": prof[1], "covariance_and_condition_diagnostic": prof[5] + prof[7],
+                            "resid_and_grad_to_host": prof[6]},
             "jtj_device_ms": syrk_ms, "jtj_tflops": 2.0 * n * pp * pp / (syrk_ms * 1e-3) / 1e12 / 2.0 if syrk_ms > 0 else None,
             "jtj_frac_of_measured_mfma_rate": (n * pp * pp / (syrk_ms * 1e-3) / 1e12) / 72.0 if syrk_ms > 0 else None,
             "damped_solve_device_ms": float(np.median(sm))})
@@ -1142,7 +1142,7 @@ def main():
     streamed = 16.0 * n / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else None
     traffic = None
     traffic_source = None
-    tpath = next((os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+    tpath = next((os.path.join(ROOT, "profiles", f) for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
                   if os.path.exists(os.path.join(ROOT, "profiles", f))), "")
     if os.path.exists(tpath):
         traffic_source = "committed profile %s (separate rocprofv3 --pmc passes), NOT measured in this run" % os.path.relpath(tpath, ROOT)
