@@ -918,6 +918,78 @@ __device__ __forceinline__ void cholb_trsm_steps_v(double (&r)[16], const CholbP
     }
 }
 
+// The part of a panel step behind its inputs (shared by cholb_panel4_kernel and cholb_step_kernel): wavefronts 0 .. 3 factor
+// the diagonal block from Lt, wavefronts 4 .. 7 solve the workgroup's rows rr of the panel a column behind; workgroup 0
+// stores L11 and solves the right-hand side's slice (from yhead in LDS when the caller has updated it there, else yv).
+__device__ __forceinline__ void cholb_panel4_body(const double *Lt, CholbPub &P, int *ready_sp, double (&rr)[16], double *Lf, int p, int k0,
+                                                  int nb, int r0, int prow, int cls, const double *dorig, int *flag, double *yv,
+                                                  double *dinvg, const double *yhead)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int &ready_s = *ready_sp;
+    if (wave < 4)
+    {
+        __builtin_amdgcn_s_setprio(3); // (the chain of pivots is the critical path of the launch)
+        bool bad;
+        switch (wave)
+        {
+        case 0: bad = cholb_diag_wave<0>(Lt, P, &ready_s, dorig, k0, nb, lane); break;
+        case 1: bad = cholb_diag_wave<1>(Lt, P, &ready_s, dorig, k0, nb, lane); break;
+        case 2: bad = cholb_diag_wave<2>(Lt, P, &ready_s, dorig, k0, nb, lane); break;
+        default: bad = cholb_diag_wave<3>(Lt, P, &ready_s, dorig, k0, nb, lane); break;
+        }
+        if (blockIdx.x != 0)
+            return;
+        if (bad && lane == 0)
+            *flag = 1;
+        if (wave != 0)
+            return;
+        // the right-hand side rides along as one more row of the matrix: its slice of this step, L11 y = b
+        while (__hip_atomic_load(&ready_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < CB)
+            __builtin_amdgcn_s_sleep(2);
+        double v = lane < nb ? (yhead ? yhead[lane] : yv[k0 + lane]) : 0.0;
+        for (int j = 0; j < nb; ++j)
+        {
+            const double rs = P.invd[j];
+            const double yj = wide_bcast(v, j) * rs;
+            if (lane == j)
+                v = yj;
+            else if (lane > j && lane < nb)
+                v -= __dmul_rn(P.V[j * CB + lane], rs) * yj;
+        }
+        if (lane < nb)
+            yv[k0 + lane] = v;
+        return;
+    }
+    if (blockIdx.x == 0)
+    {
+        // workgroup 0 has no rows of the panel: its wavefronts 4 .. 7 store L11 once it is complete
+        while (__hip_atomic_load(&ready_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < CB)
+            __builtin_amdgcn_s_sleep(4);
+        for (int e = tid - 256; e < CB * CB; e += CBQ_T - 256)
+        {
+            const int i = e >> 6, j = e & 63;
+            if (i < nb && j <= i)
+                Lf[(size_t)(k0 + i) * p + k0 + j] = i == j ? P.ldiag[j] : __dmul_rn(P.V[j * CB + i], P.invd[j]);
+        }
+        if (tid - 256 < nb)
+            dinvg[k0 + tid - 256] = P.invd[tid - 256]; // 1 / L_jj for the back substitution
+        return;
+    }
+    // rows r0 .. r0 + 63 of the panel: X L11^T = W21, a column behind the factorisation
+    cholb_trsm_steps_v<0>(rr, P, lane & 15, cls, &ready_s, 0);
+    if (r0 + prow < p)
+    {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+        {
+            const int c = cls + 4 * q;
+            if (c < nb)
+                Lf[(size_t)(r0 + prow) * p + k0 + c] = rr[q];
+        }
+    }
+}
+
 __global__ __launch_bounds__(CBQ_T) void cholb_panel4_kernel(const double *W, double *Lf, int p, int k0, const double *dorig, int *flag,
                                                              double *yv, double *dinvg)
 {
@@ -959,67 +1031,7 @@ __global__ __launch_bounds__(CBQ_T) void cholb_panel4_kernel(const double *W, do
         }
     }
     __syncthreads(); // (the only one: from here on the wavefronts meet through `ready`; Lt is only read after it)
-    if (wave < 4)
-    {
-        __builtin_amdgcn_s_setprio(3); // (the chain of pivots is the critical path of the launch)
-        bool bad;
-        switch (wave)
-        {
-        case 0: bad = cholb_diag_wave<0>(Lt, P, &ready_s, dorig, k0, nb, lane); break;
-        case 1: bad = cholb_diag_wave<1>(Lt, P, &ready_s, dorig, k0, nb, lane); break;
-        case 2: bad = cholb_diag_wave<2>(Lt, P, &ready_s, dorig, k0, nb, lane); break;
-        default: bad = cholb_diag_wave<3>(Lt, P, &ready_s, dorig, k0, nb, lane); break;
-        }
-        if (blockIdx.x != 0)
-            return;
-        if (bad && lane == 0)
-            *flag = 1;
-        if (wave != 0)
-            return;
-        // the right-hand side rides along as one more row of the matrix: its slice of this step, L11 y = b
-        while (__hip_atomic_load(&ready_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < CB)
-            __builtin_amdgcn_s_sleep(2);
-        double v = lane < nb ? yv[k0 + lane] : 0.0;
-        for (int j = 0; j < nb; ++j)
-        {
-            const double rs = P.invd[j];
-            const double yj = wide_bcast(v, j) * rs;
-            if (lane == j)
-                v = yj;
-            else if (lane > j && lane < nb)
-                v -= __dmul_rn(P.V[j * CB + lane], rs) * yj;
-        }
-        if (lane < nb)
-            yv[k0 + lane] = v;
-        return;
-    }
-    if (blockIdx.x == 0)
-    {
-        // workgroup 0 has no rows of the panel: its wavefronts 4 .. 7 store L11 once it is complete
-        while (__hip_atomic_load(&ready_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < CB)
-            __builtin_amdgcn_s_sleep(4);
-        for (int e = tid - 256; e < CB * CB; e += CBQ_T - 256)
-        {
-            const int i = e >> 6, j = e & 63;
-            if (i < nb && j <= i)
-                Lf[(size_t)(k0 + i) * p + k0 + j] = i == j ? P.ldiag[j] : __dmul_rn(P.V[j * CB + i], P.invd[j]);
-        }
-        if (tid - 256 < nb)
-            dinvg[k0 + tid - 256] = P.invd[tid - 256]; // 1 / L_jj for the back substitution
-        return;
-    }
-    // rows r0 .. r0 + 63 of the panel: X L11^T = W21, a column behind the factorisation
-    cholb_trsm_steps_v<0>(rr, P, lane & 15, cls, &ready_s, 0);
-    if (r0 + prow < p)
-    {
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-        {
-            const int c = cls + 4 * q;
-            if (c < nb)
-                Lf[(size_t)(r0 + prow) * p + k0 + c] = rr[q];
-        }
-    }
+    cholb_panel4_body(Lt, P, &ready_s, rr, Lf, p, k0, nb, r0, prow, cls, dorig, flag, yv, dinvg, nullptr);
 }
 
 // W[I][J] -= L[I][kblk] L[J][kblk]^T for the tiles I >= J behind the panel (tile index from blockIdx.x, lower triangle)
@@ -1136,6 +1148,221 @@ __global__ __launch_bounds__(256, 2) void cholb_trail_kernel(double *W, const do
             if (gi < p && gj < p && gj <= gi)
                 W[(size_t)gi * p + gj] = wv[b * 4 + r] - acc[b][r];
         }
+}
+
+// ---- round 5: one launch per step -----------------------------------------------------------------------------------------------
+// cholb_step_kernel(k0) = the panel of column block k0 AND what is left of the trailing update of the panel before it
+// (kp = k0 - 64), side by side in one launch:
+//   workgroups 0 .. nrb - 1   the panel (cholb_panel4_kernel's work).  Their inputs -- the diagonal tile and each
+//                             workgroup's own tile of column block k0 -- still lack the update of panel kp: they apply it
+//                             themselves, on the fly, from L's column block kp (the tile arithmetic of cholb_trail_kernel:
+//                             same staging, same MFMA chain, w - acc), into LDS / registers; nothing of column block k0 is
+//                             written back to W (nobody reads it again).  Workgroup 0 also takes the update of the
+//                             right-hand side's slice (wavefront 4, while the others update tiles).
+//   the next nrest            tiles (I, J), 1 <= J <= I, behind column block k0: W -= L[I][kp] L[J][kp]^T in place, one
+//                             tile per workgroup and trip (eight wavefronts: two column blocks each -- the same chains);
+//   the last nrhs             y[i] -= L[i][kp] . y[kp] for the rows behind the panel, 512 per workgroup.
+// The panel's chain of 64 pivots (19.6 us) no longer waits for the whole trailing update (6 - 17 us) and a launch: a step
+// is one launch of max(panel + its own update, rest) instead of two launches end to end.  Same bits as the two-launch
+// form (GSLNLS_LARGE_STEP_V1=1 keeps it).
+__device__ __forceinline__ double cholb_row_dot(const double *row, const double *yk)
+{
+    double rv[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+        rv[c] = row[c];
+    double s0 = 0.0;
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+        s0 += rv[c] * yk[c];
+    return s0;
+}
+
+__global__ __launch_bounds__(CBQ_T) void cholb_step_kernel(double *W, double *Lf, int p, int k0, const double *dorig, int *flag, double *yv,
+                                                           double *dinvg, int nrb, int nrest, int ntile_rest)
+{
+    constexpr int TILE = CB * CBT_LD;
+    constexpr int PUBD = (int)(sizeof(CholbPub) / sizeof(double));
+    static_assert(PUBD <= 2 * TILE, "the published columns alias the two staged tiles, not the third");
+    __shared__ double Lt[CB * CB_LD];
+    __shared__ __attribute__((aligned(16))) double stage[3 * TILE];
+    __shared__ double yk_s[CB], yhead_s[CB];
+    __shared__ int ready_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, ii = lane & 15;
+    const int kp = k0 - CB;
+    double *tD = stage, *tR = stage + TILE, *tOut = stage + 2 * TILE;
+    if ((int)blockIdx.x >= nrb + nrest)
+    {
+        // ---- the right-hand side behind the panel ----
+        if (tid < CB)
+            yk_s[tid] = yv[kp + tid];
+        __syncthreads();
+        const int i = k0 + CB + ((int)blockIdx.x - nrb - nrest) * CBQ_T + tid;
+        if (i < p)
+            yv[i] -= cholb_row_dot(Lf + (size_t)i * p + kp, yk_s);
+        return;
+    }
+    if ((int)blockIdx.x >= nrb)
+    {
+        // ---- tiles behind column block k0 ----
+        const int w4 = wave & 3, bh = (wave >> 2) * 2; // rows 16 w4 .. of the tile, column blocks bh, bh + 1
+        for (int t = (int)blockIdx.x - nrb; t < ntile_rest; t += nrest)
+        {
+            int I = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+            while (I * (I + 1) / 2 > t)
+                --I;
+            while ((I + 1) * (I + 2) / 2 <= t)
+                ++I;
+            const int J = t - I * (I + 1) / 2 + 1;
+            I += 1;
+            const int ri = k0 + CB * I, rj = k0 + CB * J;
+            double wv[8], li[8], lj[8];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                {
+                    const int gi = ri + w4 * 16 + 4 * r + kk, gj = rj + (bh + b) * 16 + ii;
+                    const bool ok = gi < p && gj < p && gj <= gi;
+                    wv[b * 4 + r] = W[ok ? (size_t)gi * p + gj : 0];
+                }
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+            {
+                const int e = tid + CBQ_T * it, r = e >> 6, c = e & 63;
+                li[it] = Lf[ri + r < p ? (size_t)(ri + r) * p + kp + c : 0];
+                lj[it] = Lf[rj + r < p ? (size_t)(rj + r) * p + kp + c : 0];
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+            {
+                const int e = tid + CBQ_T * it, r = e >> 6, c = e & 63;
+                tD[r * CBT_LD + c] = ri + r < p ? li[it] : 0.0;
+                tR[r * CBT_LD + c] = rj + r < p ? lj[it] : 0.0;
+            }
+            __syncthreads();
+            cb_v4f64 acc[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                acc[b] = (cb_v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+            for (int c = 0; c < 16; ++c)
+            {
+                const double va = tD[(w4 * 16 + ii) * CBT_LD + c * 4 + kk];
+                double vb[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    vb[b] = tR[((bh + b) * 16 + ii) * CBT_LD + c * 4 + kk];
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va, vb[b], acc[b], 0, 0, 0);
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                {
+                    const int gi = ri + w4 * 16 + 4 * r + kk, gj = rj + (bh + b) * 16 + ii;
+                    if (gi < p && gj < p && gj <= gi)
+                        W[(size_t)gi * p + gj] = wv[b * 4 + r] - acc[b][r];
+                }
+            __syncthreads(); // (the staged tiles are rewritten by the next trip)
+        }
+        return;
+    }
+    // ---- the panel of column block k0, its inputs updated on the fly ----
+    const int nb = p - k0 < CB ? p - k0 : CB;
+    CholbPub &P = *reinterpret_cast<CholbPub *>(stage);
+    if (tid == 0)
+        ready_s = 0;
+    const int r0 = k0 + CB * (int)blockIdx.x;
+    const int prow = 16 * (wave - 4) + (lane & 15), cls = lane >> 4;
+    const bool own = blockIdx.x > 0;
+    {
+        // wavefronts 0 .. 3: the diagonal tile (k0, k0); wavefronts 4 .. 7: this workgroup's tile (r0, k0).  Every global load
+        // before the first wait, as in cholb_trail_kernel.
+        const int w4 = wave & 3;
+        const int rt = wave < 4 ? k0 : r0; // first row of the tile this wavefront updates
+        const bool work = wave < 4 || own;
+        double wv[16], ld[8], lr[8];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+                const int gi = rt + w4 * 16 + 4 * r + kk, gj = k0 + b * 16 + ii;
+                const bool ok = work && gi < p && gj < p && gj <= gi;
+                wv[b * 4 + r] = W[ok ? (size_t)gi * p + gj : 0];
+            }
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+        {
+            const int e = tid + CBQ_T * it, r = e >> 6, c = e & 63;
+            ld[it] = Lf[k0 + r < p ? (size_t)(k0 + r) * p + kp + c : 0];
+            lr[it] = Lf[(own && r0 + r < p) ? (size_t)(r0 + r) * p + kp + c : 0];
+        }
+        if (tid < CB)
+            yk_s[tid] = yv[kp + tid];
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+        {
+            const int e = tid + CBQ_T * it, r = e >> 6, c = e & 63;
+            tD[r * CBT_LD + c] = k0 + r < p ? ld[it] : 0.0;
+            tR[r * CBT_LD + c] = (own && r0 + r < p) ? lr[it] : 0.0;
+        }
+        __syncthreads();
+        if (work)
+        {
+            const double *tI = wave < 4 ? tD : tR;
+            cb_v4f64 acc[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                acc[b] = (cb_v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+            for (int c = 0; c < 16; ++c)
+            {
+                const double va = tI[(w4 * 16 + ii) * CBT_LD + c * 4 + kk];
+                double vb[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    vb[b] = tD[(b * 16 + ii) * CBT_LD + c * 4 + kk];
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va, vb[b], acc[b], 0, 0, 0);
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                {
+                    const int i = w4 * 16 + 4 * r + kk, j = b * 16 + ii; // element of the tile
+                    const double u = wv[b * 4 + r] - acc[b][r];
+                    if (wave < 4)
+                        Lt[i * CB_LD + j] = (i < nb && j <= i) ? u : (i == j ? 1.0 : 0.0); // (identity beyond nb, zero above the diagonal)
+                    else
+                        tOut[i * CBT_LD + j] = (r0 + i < p && j < nb) ? u : 0.0;
+                }
+        }
+        else if (wave == 4)
+        {
+            // workgroup 0 has no tile of its own: its fifth wavefront takes the right-hand side's slice through the update
+            const int i = k0 + lane;
+            double yi = 0.0;
+            if (i < p)
+                yi = yv[i] - cholb_row_dot(Lf + (size_t)i * p + kp, yk_s);
+            yhead_s[lane] = yi;
+        }
+    }
+    __syncthreads(); // (Lt, tOut and yhead_s complete; tD / tR are dead: the published columns P take their place)
+    double rr[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+    {
+        const int c = cls + 4 * q;
+        const bool ok = wave >= 4 && own && r0 + prow < p && c < nb;
+        rr[q] = ok ? tOut[prow * CBT_LD + c] : 0.0;
+    }
+    cholb_panel4_body(Lt, P, &ready_s, rr, Lf, p, k0, nb, r0, prow, cls, dorig, flag, yv, dinvg, yhead_s);
 }
 
 // One block of the back substitution L^T x = y (blocks from the last to the first): every workgroup solves the block's
@@ -1603,6 +1830,31 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
             const bool lookahead = getenv("GSLNLS_LARGE_LOOKAHEAD") != nullptr;
             const bool back_v1 = getenv("GSLNLS_LARGE_BACK_V1") != nullptr; // (developer switch: the one-workgroup back substitution, same bits)
             int nrest = 0; // launches on the second stream so far
+            // round 5: from the second panel on, ONE launch per step -- the panel with its inputs updated on the fly beside
+            // the rest of the previous panel's trailing update (cholb_step_kernel).  GSLNLS_LARGE_STEP_V1=1: panel and
+            // trailing update as two launches (same bits); the developer switches above imply it.
+            const bool step_v1 = getenv("GSLNLS_LARGE_STEP_V1") != nullptr || panel_v1 || lookahead;
+            if (!step_v1)
+            {
+                int ncu = 256;
+                (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+                for (int k0 = 0; k0 < p; k0 += CB)
+                {
+                    const int nrb = (p - k0 + CB - 1) / CB;
+                    if (k0 == 0)
+                        hipLaunchKernelGGL(cholb_panel4_kernel, dim3(nrb), dim3(CBQ_T), 0, sq, B.A, B.Lg, p, k0, a.dcur, d_flag, d_work, a.dinv);
+                    else
+                    {
+                        const int ntile_rest = (nrb - 1) * nrb / 2;
+                        int nrestwg = ntile_rest < 2 * ncu ? ntile_rest : 2 * ncu;
+                        const int rows_behind = p - k0 - CB;
+                        const int nrhs = rows_behind > 0 ? (rows_behind + CBQ_T - 1) / CBQ_T : 0;
+                        hipLaunchKernelGGL(cholb_step_kernel, dim3(nrb + nrestwg + nrhs), dim3(CBQ_T), 0, sq, B.A, B.Lg, p, k0, a.dcur, d_flag,
+                                           d_work, a.dinv, nrb, nrestwg, ntile_rest);
+                    }
+                }
+            }
+            else
             for (int k0 = 0, step = 0; k0 < p; k0 += CB, ++step)
             {
                 const int nrb = (p - k0 + CB - 1) / CB; // row blocks from the diagonal block down

@@ -1,6 +1,6 @@
 """developer aid (round 5): the damped solve with J^T J resident on the device (the lm step's call) -- wall time per solve,
 device milliseconds by HIP events, the relative residual, and the solution compared bit for bit with the previous forms of
-the kernels (GSLNLS_LARGE_PANEL_V1=1: the one-wavefront diagonal block; GSLNLS_LARGE_LOOKAHEAD=1: second stream; GSLNLS_LARGE_BACK_V1=1: the one-workgroup back substitution).
+the kernels (GSLNLS_LARGE_PANEL_V1=1: the one-wavefront diagonal block; GSLNLS_LARGE_LOOKAHEAD=1: second stream; GSLNLS_LARGE_BACK_V1=1: the one-workgroup back substitution; GSLNLS_LARGE_STEP_V1=1: panel and trailing update as two launches per step).
 Usage: python scripts/dev_time_mchol_r05.py [reps [p ...]]"""
 import sys, os, time, ctypes as C
 import numpy as np
@@ -12,7 +12,7 @@ DP = C.POINTER(C.c_double)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 sizes = [int(a) for a in sys.argv[2:]] or [65, 100, 128, 200, 333, 500, 1000, 2000]
 rng = np.random.default_rng(7)
-SWITCHES = ["GSLNLS_LARGE_PANEL_V1", "GSLNLS_LARGE_LOOKAHEAD", "GSLNLS_LARGE_BACK_V1", "GSLNLS_LARGE_BACKUPD_V1"]
+SWITCHES = ["GSLNLS_LARGE_STEP_V1", "GSLNLS_LARGE_PANEL_V1", "GSLNLS_LARGE_LOOKAHEAD", "GSLNLS_LARGE_BACK_V1", "GSLNLS_LARGE_BACKUPD_V1"]
 for p in sizes:
     J = rng.standard_normal((p + 50, p))
     A = np.ascontiguousarray(J.T @ J)
