@@ -571,9 +571,11 @@ def matrix_path_bench(_lib):
         L.gslnls_debug_device_copy(dA, Am.ctypes.data_as(C.c_void_p), Am.nbytes, 1)
         d, r, sol = np.sqrt(np.diag(Am)).copy(), rng.standard_normal(pp), np.zeros(pp)
         sm = []
+        L.gslnls_debug_mchol_timing(1)  # (the solves' event pair: off in the product path)
         for _ in range(12):
             L.gslnls_debug_mchol_solve_resident(pp, dA, d.ctypes.data_as(_lib.DP), 1e-3, r.ctypes.data_as(_lib.DP), sol.ctypes.data_as(_lib.DP))
             sm.append(L.gslnls_debug_mchol_last_device_ms())
+        L.gslnls_debug_mchol_timing(0)
         L.gslnls_debug_device_free(dA)
         out["cases"].append({
             "p": pp, "n": n, "niter": int(fit["niter"]), "conv": int(fit["conv"]), "trial_steps": int(prof[8]), "jacobians": int(njac),
@@ -674,7 +676,11 @@ def sparse_readme_bench():
                 t0 = time.perf_counter()
                 rc2 = L.gslnls_debug_mchol_solve_resident(*rargs) or rc2
                 wall_ms.append((time.perf_counter() - t0) * 1e3)
+            L.gslnls_debug_mchol_timing(1)  # (the event pair around a solve's kernels: off in the product path and in the wall times above)
+            for _ in range(2 * reps):
+                rc2 = L.gslnls_debug_mchol_solve_resident(*rargs) or rc2
                 dev_ms.append(L.gslnls_debug_mchol_last_device_ms())
+            L.gslnls_debug_mchol_timing(0)
             # median and mean of the host clock around each call: about one call in a few hundred takes milliseconds
             # longer on the host (seen at p = 2000, 130 launches a solve: 17 ms once in 60 calls while the events show the
             # same 1.17 ms of device work) -- both are reported

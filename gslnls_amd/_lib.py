@@ -142,6 +142,7 @@ _SIGNATURES = {
     "gslnls_debug_mchol_solve": (C.c_int, [C.c_int, DP, DP, C.c_double, DP, DP]),
     "gslnls_debug_mchol_solve_resident": (C.c_int, [C.c_int, C.c_void_p, DP, C.c_double, DP, DP]),
     "gslnls_debug_mchol_last_device_ms": (C.c_double, []),
+    "gslnls_debug_mchol_timing": (None, [C.c_int]),
     "gslnls_debug_device_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "gslnls_debug_device_free": (C.c_int, [C.c_void_p]),
     "gslnls_debug_device_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),

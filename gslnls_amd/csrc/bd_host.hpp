@@ -270,6 +270,34 @@ struct BdModel
         (void)st;
         return 1;
     }
+    // round 5: f = sqrt(w) (m(theta) - y) and the partial sums of its squares (bd_resid_kernel's, bit for bit) by the kernel that
+    // evaluates m, theta on the device.  -1: not offered (values_dev + bd_resid_kernel serve)
+    virtual int resid_dev(const double *d_theta, const double *d_y, const double *d_sw, double *d_f, double *d_parts, int g, hipStream_t st)
+    {
+        (void)d_theta;
+        (void)d_y;
+        (void)d_sw;
+        (void)d_f;
+        (void)d_parts;
+        (void)g;
+        (void)st;
+        return -1;
+    }
+    // round 5: the analytic Jacobian with the rows' sqrt(w) applied and one non-finite flag per workgroup written to d_part
+    // (*nparts of them) by the kernel that produces the rows; theta from d_theta when non-null.  -1: not offered (the
+    // caller runs jacobian() and bd_weight_kernel), > 0: failure.
+    virtual int jacobian_flagged(const double *theta, const double *d_theta, double *d_J, const double *d_sw, double *d_part, int *nparts,
+                                 hipStream_t st)
+    {
+        (void)theta;
+        (void)d_theta;
+        (void)d_J;
+        (void)d_sw;
+        (void)d_part;
+        (void)nparts;
+        (void)st;
+        return -1;
+    }
 };
 
 // xt = x + dx, a component that would leave its bound moved to x + dx / max(|dx|, delta) |x - bound| (trust_trial_step_lu,
@@ -291,6 +319,35 @@ static __global__ __launch_bounds__(256) void bd_trial_kernel(const double *x, c
             t = __dadd_rn(xk, __dmul_rn(dk / fmax(fabs(dk), delta), fabs(xk - up[k])));
     }
     xt[k] = t;
+}
+
+// bd_trial_kernel and bd_quad_kernel in one launch (round 5): workgroup i takes row i of dx^T (J^T J) dx, its first thread
+// component i of the trial point -- each the arithmetic of its own kernel
+static __global__ __launch_bounds__(BD_T) void bd_trial_quad_kernel(const double *x, const double *dx, const double *lo, const double *up, double delta,
+                                                                     int has_bounds, int p, double *xt, const double *C, double *quad)
+{
+    __shared__ double red_s[BD_T / 64];
+    const int i = blockIdx.x;
+    if (threadIdx.x == 0)
+    {
+        const double xk = x[i], dk = dx[i];
+        double t = xk + dk;
+        if (has_bounds)
+        {
+            if (t < lo[i])
+                t = __dadd_rn(xk, __dmul_rn(dk / fmax(fabs(dk), delta), fabs(xk - lo[i])));
+            else if (t > up[i])
+                t = __dadd_rn(xk, __dmul_rn(dk / fmax(fabs(dk), delta), fabs(xk - up[i])));
+        }
+        xt[i] = t;
+    }
+    const double *row = C + (size_t)i * p;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < p; j += BD_T)
+        s += row[j] * dx[j];
+    s = bd_block_sum(s, red_s);
+    if (threadIdx.x == 0)
+        quad[i] = s * dx[i];
 }
 
 // what a Jacobian evaluation sends home -- g = J^T f, diag(J^T J), the non-finite flags of an analytic Jacobian -- written
@@ -330,6 +387,7 @@ struct BdFit
     double *h_jmap = nullptr, *d_jmap = nullptr; // pinned + mapped: g | diag(J^T J) | flags (BD_MAXG) | sequence word (bd_publish_kernel)
     unsigned long long jseq = 0;
     hipEvent_t ev_j = nullptr;
+    const double *jac_theta_dev = nullptr; // set around a jac_at() whose point is already on the device (the accepted x + dx of a fused trial step)
     int cur = 0;        // d_f[cur]: residual at the current point, d_f[cur ^ 1]: at the trial point
     std::vector<double> last_x;    // where the last solve ended (whatever its status)
     // more of the state the last solve ended in -- what gsl_multistart_driver reads out of the solver workspace after a
@@ -393,7 +451,7 @@ struct BdFit
         npair = npanel * (npanel + 1) / 2;
         const long long ntile = ((long long)n + 63) / 64;
         // enough workgroups for the chip (512 = two per CU), at most one slice per row tile and 32 partial blocks per block
-        long long sl = (512 + npair - 1) / npair;
+        long long sl = 512 / npair; // (npair x slices workgroups in ONE round of the chip's 512 slots: rounding up left 5 % of them to a second round that doubled the kernel's time, round 5)
         sl = sl > ntile ? ntile : sl;
         sl = sl > 32 ? 32 : (sl < 1 ? 1 : sl);
         nslice = (int)sl;
@@ -463,7 +521,16 @@ struct BdFit
     {
         *badj = 0.0;
         int nbadparts = 0;
-        if (prm.jac_analytic)
+        int fl = -1;
+        if (prm.jac_analytic && !getenv("GSLNLS_BD_STEPWISE"))
+        {
+            fl = model->jacobian_flagged(theta, jac_theta_dev, d_J, d_sw, d_part, &nbadparts, st);
+            if (fl > 0)
+                return GSLNLS_EBADFUNC;
+        }
+        if (fl == 0)
+            ; // (rows, weights and flags by one kernel)
+        else if (prm.jac_analytic)
         {
             if (model->jacobian(theta, d_J, st))
                 return GSLNLS_EBADFUNC;
@@ -656,7 +723,7 @@ struct BdFit
             const size_t ppq = (size_t)pq * pq;
             double *d_X = f.d_epi, *d_cov = d_X + ppq, *d_w = d_cov + ppq, *d_nrm = d_w + 4 * (size_t)pq;
             hipLaunchKernelGGL(bd_trinv_kernel, dim3(pq), dim3(BD_T), c.lds_ti, s2, d_L, d_dinv, pq, d_X);
-            long long sl = (512 + f.npair - 1) / f.npair;
+            long long sl = 512 / f.npair;
             const long long ntile = (pq + 63) / 64;
             sl = sl > ntile ? ntile : sl;
             sl = sl > 32 ? 32 : (sl < 1 ? 1 : sl);
@@ -951,11 +1018,16 @@ struct BdFit
             hipStream_t s2 = (hipStream_t)stream;
             const int p = f.p;
             double *d_xt = f.d_pub, *d_quad = f.d_pub + p, *d_parts = f.d_pub + 2 * (size_t)p;
-            hipLaunchKernelGGL(bd_trial_kernel, dim3((p + 255) / 256), dim3(256), 0, s2, f.d_xmap, d_sol, f.d_xmap + p, f.d_xmap + 2 * (size_t)p,
-                               t.delta, t.has_bounds, p, d_xt);
-            (void)f.model->values_dev(d_xt, f.d_fval, s2);
-            hipLaunchKernelGGL(bd_resid_kernel, dim3(t.g), dim3(BD_T), 0, s2, f.d_fval, f.d_y, f.d_sw, (long long)f.n, f.d_f[f.cur ^ 1], d_parts);
-            hipLaunchKernelGGL(bd_quad_kernel, dim3(p), dim3(BD_T), 0, s2, f.d_C, d_sol, p, d_quad);
+            // two launches: [trial point | rows of the quadratic form], then [model value, residual, partial sums] -- four until
+            // round 5's kernel timeline (profiles/r05_matrix_step_timeline.txt: 5 us each); a model without the fused
+            // residual kernel keeps values_dev + bd_resid_kernel
+            hipLaunchKernelGGL(bd_trial_quad_kernel, dim3(p), dim3(BD_T), 0, s2, f.d_xmap, d_sol, f.d_xmap + p, f.d_xmap + 2 * (size_t)p, t.delta,
+                               t.has_bounds, p, d_xt, f.d_C, d_quad);
+            if (f.model->resid_dev(d_xt, f.d_y, f.d_sw, f.d_f[f.cur ^ 1], d_parts, t.g, s2) < 0)
+            {
+                (void)f.model->values_dev(d_xt, f.d_fval, s2);
+                hipLaunchKernelGGL(bd_resid_kernel, dim3(t.g), dim3(BD_T), 0, s2, f.d_fval, f.d_y, f.d_sw, (long long)f.n, f.d_f[f.cur ^ 1], d_parts);
+            }
         };
         std::vector<double> pub(fused_trial ? (size_t)2 * p + tt.g : 0);
         double prof_solve = 0.0, prof_jac = 0.0, prof_resid = 0.0;
@@ -1111,7 +1183,9 @@ struct BdFit
             {
                 itstatus = ST_SUCCESS;
                 const double t_j0 = now_s();
+                jac_theta_dev = trial_done ? d_pub : nullptr; // (x + dx as bd_trial_kernel left it: the bits xt was read from)
                 rc = jac_at(xt.data(), d_f[cur ^ 1], prm, gt.data(), djjt.data(), &badj, dev_solve ? nullptr : A.data());
+                jac_theta_dev = nullptr;
                 prof_jac += now_s() - t_j0;
                 prof_njac += 1;
                 if (rc == GSLNLS_EBADFUNC)
@@ -1747,7 +1821,7 @@ inline double bd_time_syrk(int n, int p, int reps)
         return -1.0;
     const int npanel = (p + 63) / 64, npair = npanel * (npanel + 1) / 2;
     const long long ntile = ((long long)n + 63) / 64;
-    long long sl = (512 + npair - 1) / npair;
+    long long sl = 512 / npair; // (npair x slices workgroups in ONE round of the chip's 512 slots: rounding up left 5 % of them to a second round that doubled the kernel's time, round 5)
     sl = sl > ntile ? ntile : sl;
     sl = sl > 32 ? 32 : (sl < 1 ? 1 : sl);
     const int nslice = (int)sl;

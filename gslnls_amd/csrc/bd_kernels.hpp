@@ -213,20 +213,37 @@ __global__ __launch_bounds__(BD_T, 2) void bd_syrk_kernel(const double *J, long 
     for (int b = 0; b < 4; ++b)
         acc[b] = (bd_v4f64){0.0, 0.0, 0.0, 0.0};
     const long long ntile = (n + 63) / 64;
+    // Round 5: every load of a tile is issued before the first is waited for, and the next tile's loads are in flight while
+    // the matrix instructions of the current one run.  (`x = cond ? load : 0` in a loop compiles to a branch and a wait per
+    // load -- 32 serial round trips per tile; the kernel timeline of the matrix path showed 23 us for the one or two tiles
+    // a workgroup has at n = 3000.)  Rows and columns that do not exist read element 0 and are discarded.
+    double la[16], lb[16];
+    auto fetch = [&](long long t) {
+        const long long r = t * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+        {
+            const int c = wave + 4 * q, cI = I * 64 + c, cJ = Jb * 64 + c;
+            la[q] = J[(t < ntile && r < n && cI < p) ? (size_t)cI * n + r : 0];
+            lb[q] = J[(t < ntile && !diagblk && r < n && cJ < p) ? (size_t)cJ * n + r : 0];
+        }
+    };
+    fetch(slice);
     for (long long t = slice; t < ntile; t += nslice)
     {
-        const long long r0 = t * 64;
+        const long long r = t * 64 + lane;
         __syncthreads(); // the previous tile has been consumed
-        // stage: wavefront w loads columns w, w + 4, ... of each panel, lane = row (512 contiguous bytes per instruction)
-        for (int c = wave; c < 64; c += 4)
+        // stage: wavefront w holds columns w, w + 4, ... of each panel, lane = row (512 contiguous bytes per load instruction)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
         {
-            const long long r = r0 + lane;
-            const int cI = I * 64 + c, cJ = Jb * 64 + c;
-            tile[0][c * BD_LD + lane] = (r < n && cI < p) ? J[(size_t)cI * n + r] : 0.0;
+            const int c = wave + 4 * q, cI = I * 64 + c, cJ = Jb * 64 + c;
+            tile[0][c * BD_LD + lane] = (r < n && cI < p) ? la[q] : 0.0;
             if (!diagblk)
-                tile[1][c * BD_LD + lane] = (r < n && cJ < p) ? J[(size_t)cJ * n + r] : 0.0;
+                tile[1][c * BD_LD + lane] = (r < n && cJ < p) ? lb[q] : 0.0;
         }
         __syncthreads();
+        fetch(t + nslice);
         const double *tA = tile[0], *tB = diagblk ? tile[0] : tile[1];
 #pragma unroll 4
         for (int c = 0; c < 16; ++c)

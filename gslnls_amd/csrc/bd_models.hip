@@ -48,7 +48,7 @@ struct BdFormulaModel : BdModel
     int n = 0, p = 0, nx = 1;
     double *d_x = nullptr, *d_theta = nullptr, *d_ring = nullptr;
     std::shared_ptr<RtcEntry> rtc;
-    hipFunction_t fn_mode[3] = {nullptr, nullptr, nullptr};
+    hipFunction_t fn_mode[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // values | + J | D^2 m[v, v] | + J weighted and flagged | weighted residual + partial sums
     ~BdFormulaModel() override
     {
         if (d_x)
@@ -79,14 +79,46 @@ struct BdFormulaModel : BdModel
             return 1;
         return launch_dev(mode, dth, dth + p, d_fval, d_J, st);
     }
-    int launch_dev(int mode, const double *th, const double *dir, double *d_fval, double *d_J, hipStream_t st)
+    int launch_dev(int mode, const double *th, const double *dir, double *d_fval, double *d_J, hipStream_t st, const double *sw = nullptr,
+                   double *part = nullptr, int *nparts = nullptr)
     {
         const double *xx = d_x;
         long long nn = n;
         int g = (int)((nn + 255) / 256);
         g = g > 2048 ? 2048 : (g < 1 ? 1 : g);
-        void *args[] = {(void *)&th, (void *)&dir, (void *)&xx, (void *)&nn, (void *)&d_fval, (void *)&d_J};
+        if (mode == 3)
+            g = g > BD_MAXG ? BD_MAXG : g; // (one flag per workgroup travels home with g and the diagonal)
+        if (mode == 4)
+            g = *nparts; // (bd_resid_kernel's grid: the partial sums are added on the host in that order)
+        if (nparts)
+            *nparts = g;
+        void *args[] = {(void *)&th, (void *)&dir, (void *)&xx, (void *)&nn, (void *)&d_fval, (void *)&d_J, (void *)&sw, (void *)&part};
         return hipModuleLaunchKernel(fn_mode[mode], g, 1, 1, 256, 1, 1, 0, st, args, nullptr) == hipSuccess ? 0 : 1;
+    }
+    // model value, weighted residual and the partial sums of its squares in one kernel (theta on the device)
+    int resid_dev(const double *d_theta, const double *d_y, const double *d_sw, double *d_f, double *d_parts, int g, hipStream_t st) override
+    {
+        if (!fn_mode[4])
+            return -1;
+        int gg = g;
+        return launch_dev(4, d_theta, d_theta, d_f, const_cast<double *>(d_y), st, d_sw, d_parts, &gg);
+    }
+    // the Jacobian with the rows' sqrt(w) and the non-finite flags in one kernel; theta from the device when the caller has
+    // it there (the accepted trial point of a fused trial step: no upload)
+    int jacobian_flagged(const double *theta, const double *d_theta, double *d_J, const double *d_sw, double *d_part, int *nparts,
+                         hipStream_t st) override
+    {
+        if (!fn_mode[3])
+            return -1;
+        if (d_theta)
+            return launch_dev(3, d_theta, d_theta, d_scratch, d_J, st, d_sw, d_part, nparts);
+        double *slot = h_ring + (size_t)ring_at * 2 * p;
+        ring_at = (ring_at + 1) % RING;
+        memcpy(slot, theta, sizeof(double) * p);
+        double *dth = d_ring + (size_t)((ring_at + RING - 1) % RING) * 2 * p;
+        if (hipMemcpyAsync(dth, slot, sizeof(double) * (size_t)p, hipMemcpyHostToDevice, st) != hipSuccess)
+            return 1;
+        return launch_dev(3, dth, dth, d_scratch, d_J, st, d_sw, d_part, nparts);
     }
     bool theta_on_device() const override { return true; }
     int values_dev(const double *d_th, double *d_fval, hipStream_t st) override { return launch_dev(0, d_th, d_th, d_fval, nullptr, st); }
@@ -160,17 +192,20 @@ int bd_formula_nls(const gslnls_model *fn, const double *y, int n, int jac, int 
     m.has_jac = true;
     m.has_fvv = low->nfvv > 0;
     const std::string &src = low->src;
-    std::vector<std::string> exprs = {rtc_bd_expr(0), rtc_bd_expr(1)};
+    std::vector<std::string> exprs = {rtc_bd_expr(0), rtc_bd_expr(1), rtc_bd_expr(3), rtc_bd_expr(4)};
     if (m.has_fvv)
         exprs.push_back(rtc_bd_expr(2));
     m.rtc = rtc_request(src, exprs, true);
     std::string msg;
     if (m.rtc->state.load() == RTC_READY)
         for (size_t k = 0; k < exprs.size(); ++k)
-            m.fn_mode[k] = rtc_function(*m.rtc, exprs[k], msg);
+        {
+            const int mode = k == 0 ? 0 : (k == 1 ? 1 : (k == 2 ? 3 : (k == 3 ? 4 : 2)));
+            m.fn_mode[mode] = rtc_function(*m.rtc, exprs[k], msg);
+        }
     else
         msg = m.rtc->log;
-    if (!m.fn_mode[0] || !m.fn_mode[1] || (m.has_fvv && !m.fn_mode[2]))
+    if (!m.fn_mode[0] || !m.fn_mode[1] || !m.fn_mode[3] || !m.fn_mode[4] || (m.has_fvv && !m.fn_mode[2]))
     {
         fprintf(stderr, "gslnls: cannot build the kernels of a p = %d model (needs the in-process compiler): %s\n", fn->p, msg.c_str());
         return GSLNLS_E_UNSUPPORTED;
@@ -208,7 +243,7 @@ int bd_dense_jtj(const double *d_J, int n, int p, double *d_C, hipStream_t st, d
 {
     const int npanel = (p + 63) / 64, npair = npanel * (npanel + 1) / 2;
     const long long ntile = ((long long)n + 63) / 64;
-    long long sl = (512 + npair - 1) / npair;
+    long long sl = 512 / npair; // (npair x slices workgroups in ONE round of the chip's 512 slots: rounding up left 5 % of them to a second round that doubled the kernel's time, round 5)
     sl = sl > ntile ? ntile : sl;
     sl = sl > 32 ? 32 : (sl < 1 ? 1 : sl);
     const int nslice = (int)sl;

@@ -26,6 +26,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
 #include <mutex>
 #include "../../include/gslnls_core.h"
 #include "dense_host.hpp"
@@ -1656,6 +1657,7 @@ struct MCholBuffers
     double *A = nullptr, *Lg = nullptr, *Cg = nullptr, *vec = nullptr; // vec: ainvg | dcur | b | dinv | scal | rhs | sol
     int *ivec = nullptr;                                              // pos | ord | flag of the natural-order factorisation
     double *stage = nullptr; // pinned, 3 cap + 8 doubles: [rhs | diag] on the way up, [sol | flag] on the way down
+    double *stage_dev = nullptr; // its device address (mapped): the natural-order init kernel reads rhs | diag in place
     hipStream_t sq = nullptr;                // the stream of every copy and kernel of a solve
     hipStream_t sq2 = nullptr;               // round 5: the trailing updates behind the next panel's column run beside that panel
     hipEvent_t evp[2] = {nullptr, nullptr}, evr[2] = {nullptr, nullptr}; // panel k done / rest of trailing update k done (ping-pong)
@@ -1666,6 +1668,7 @@ struct MCholBuffers
     float last_device_ms = -1.f;
     bool attr_set = false;
 };
+static std::atomic<bool> g_mchol_timing{false}; // gslnls_debug_mchol_timing(1): the solves carry the event pair of gslnls_debug_mchol_last_device_ms
 static MCholBuffers &mchol_buffers()
 {
     static MCholBuffers *b = new MCholBuffers; // (never destroyed: no HIP calls during static teardown)
@@ -1698,6 +1701,7 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
         if (B.stage)
             (void)hipHostFree(B.stage);
         B.stage = nullptr;
+        B.stage_dev = nullptr;
         if (B.down)
             (void)hipHostFree(B.down);
         B.down = B.down_dev = nullptr;
@@ -1709,7 +1713,8 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
         if (hipMalloc(&B.A, sizeof(double) * pp) != hipSuccess || hipMalloc(&B.Lg, sizeof(double) * pp) != hipSuccess ||
             hipMalloc(&B.Cg, sizeof(double) * (size_t)MC_NB_MAX * p) != hipSuccess ||
             hipMalloc(&B.vec, sizeof(double) * ((size_t)7 * p + MC_NB_MAX + 24)) != hipSuccess ||
-            hipHostMalloc(&B.stage, sizeof(double) * ((size_t)3 * p + 8), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&B.stage, sizeof(double) * ((size_t)3 * p + 8), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void **)&B.stage_dev, B.stage, 0) != hipSuccess ||
             hipHostMalloc(&B.down, sizeof(double) * ((size_t)p + 2 + MC_EXTRA_MAX), hipHostMallocMapped) != hipSuccess ||
             hipHostGetDevicePointer((void **)&B.down_dev, B.down, 0) != hipSuccess ||
             hipMalloc(&B.ivec, sizeof(int) * ((size_t)2 * p + 4)) != hipSuccess)
@@ -1789,13 +1794,33 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
     memcpy(B.stage, rhs_host, sizeof(double) * p);
     if (!A_host)
         memcpy(B.stage + p, diag_host, sizeof(double) * p);
-    GSLNLS_HIP_OK(hipMemcpyAsync(d_rhs, B.stage, sizeof(double) * (size_t)(A_host ? p : 2 * p), hipMemcpyHostToDevice, sq));
-    if (!B.ev0 && (hipEventCreate(&B.ev0) != hipSuccess || hipEventCreate(&B.ev1) != hipSuccess))
+    // With J^T J resident the natural-order init kernel reads the 2 p doubles where they are, through the staging area's
+    // mapping (round 5: the copy was a copy-engine kernel of 3 us and a 6 us wait of the init kernel for it, in every trial
+    // step of the matrix path -- profiles/r05_matrix_step_timeline.txt).  The pivoted routine and the debug entry that
+    // brings the whole matrix from the host keep the copy.
+    bool uploaded = false;
+    auto upload = [&]() -> int {
+        if (!uploaded)
+            GSLNLS_HIP_OK(hipMemcpyAsync(d_rhs, B.stage, sizeof(double) * (size_t)(A_host ? p : 2 * p), hipMemcpyHostToDevice, sq));
+        uploaded = true;
+        return GSLNLS_SUCCESS;
+    };
+    const bool in_place = !A_host && B.stage_dev != nullptr && !getenv("GSLNLS_LARGE_UPLOAD_COPY");
+    if (!in_place)
+        if (const int e = upload())
+            return e;
+    // (the event pair of gslnls_debug_mchol_last_device_ms only once somebody has asked for it: each record is a marker
+    // packet the kernels behind it wait for -- 6 us between the back substitution and a caller's tail, measured in the
+    // kernel timeline of the matrix path, profiles/r05_matrix_step_timeline.txt)
+    const bool timed = g_mchol_timing.load();
+    if (timed && !B.ev0 && (hipEventCreate(&B.ev0) != hipSuccess || hipEventCreate(&B.ev1) != hipSuccess))
         B.ev0 = B.ev1 = nullptr;
     B.last_device_ms = -1.f;
-    if (B.ev0)
+    if (timed && B.ev0)
         (void)hipEventRecord(B.ev0, sq);
     auto pivoted_init = [&]() -> int {
+        if (const int e = upload())
+            return e;
         GSLNLS_HIP_OK(hipMemsetAsync(a.scal, 0, sizeof(double) * 8, sq));
         long long g = ((long long)p * p + 256 * 8 - 1) / (256 * 8);
         g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
@@ -1819,7 +1844,8 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
             // inside the factorisation), the flag: one launch
             {
                 const int nb64 = (p + CB - 1) / CB, ntile = A_host ? 0 : nb64 * (nb64 + 1) / 2;
-                hipLaunchKernelGGL(cholb_init_kernel, dim3(ntile + 1), dim3(256), 0, sq, A_host ? nullptr : jtj_dev, B.A, p, d_dmp, mu, d_rhs,
+                hipLaunchKernelGGL(cholb_init_kernel, dim3(ntile + 1), dim3(256), 0, sq, A_host ? nullptr : jtj_dev, B.A, p,
+                                   in_place ? B.stage_dev + p : d_dmp, mu, in_place ? B.stage_dev : d_rhs,
                                    d_work, a.dcur, d_flag, ntile);
             }
             const bool panel_v1 = getenv("GSLNLS_LARGE_PANEL_V1") != nullptr; // (developer switch: the one-wavefront diagonal block, same bits)
@@ -1918,7 +1944,7 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
                     }
                 }
             }
-            if (B.ev0)
+            if (timed && B.ev0)
                 (void)hipEventRecord(B.ev1, sq);
             B.seq += 1;
             B.down[p + 1] = 0.0; // (the word the device is about to write; any value but the new sequence number)
@@ -1956,7 +1982,7 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
             double *h_down = B.down;
             if (getenv("GSLNLS_LARGE_PROF"))
                 fprintf(stderr, "[mchol] p = %d: enqueue %.3f ms, wait %.3f ms\n", p, 1e3 * (t_enq - t_entry), 1e3 * (now_s() - t_enq));
-            B.last_device_ms = -2.f; // (read on demand: gslnls_debug_mchol_last_device_ms -- no event wait inside a solve)
+            B.last_device_ms = timed ? -2.f : -1.f; // (read on demand: gslnls_debug_mchol_last_device_ms -- no event wait inside a solve)
             if (h_down[p] == 0.0)
             {
                 memcpy(sol_host, h_down, sizeof(double) * p);
@@ -2103,6 +2129,8 @@ extern "C" int gslnls_debug_device_copy(void *dst, const void *src, size_t bytes
     }
     return GSLNLS_SUCCESS;
 }
+
+extern "C" void gslnls_debug_mchol_timing(int on) { gslnls::g_mchol_timing.store(on != 0); }
 
 // milliseconds between the upload of the vectors and the download of the solution of the LAST natural-order solve of this
 // process (HIP events around its kernels: what the device did, whatever the host was busy with); < 0: not available

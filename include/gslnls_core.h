@@ -430,8 +430,11 @@ int gslnls_debug_device_copy(void *dst, const void *src, size_t bytes, int to_de
 /* device milliseconds of one J^T J of the matrix path (bd_syrk_kernel + its reduction) on an n x p matrix of noise, HIP
  * events over `reps` repetitions; < 0 on error */
 double gslnls_debug_bd_syrk_ms(int n, int p, int reps);
-/* device milliseconds of the last natural-order solve (HIP events around its kernels), < 0 when not available */
+/* device milliseconds of the last natural-order solve (HIP events around its kernels), < 0 when not available.  The
+ * events are recorded only between gslnls_debug_mchol_timing(1) and gslnls_debug_mchol_timing(0): they cost a solve ~6 us
+ * (a marker packet in front of a caller's tail), so the product path runs without them */
 double gslnls_debug_mchol_last_device_ms(void);
+void gslnls_debug_mchol_timing(int on);
 /* the same with J^T J resident in device memory (jtj_dev: p x p doubles, row-major, left as it is): the call of the lm step */
 int gslnls_debug_mchol_solve_resident(int p, const double *jtj_dev, const double *diag, double mu, const double *rhs,
                                       double *sol);

@@ -42,9 +42,11 @@ for p in sizes:
             rc = L.gslnls_debug_mchol_solve_resident(*rargs) or rc
         el = (time.perf_counter() - t0) / reps
         dev = []
-        for _ in range(reps):  # (the device time is read on demand: an event wait, kept out of the wall-time loop)
+        L.gslnls_debug_mchol_timing(1)  # (the event pair around a solve's kernels: off in the product path, 6 us per solve)
+        for _ in range(reps):
             rc = L.gslnls_debug_mchol_solve_resident(*rargs) or rc
             dev.append(L.gslnls_debug_mchol_last_device_ms())
+        L.gslnls_debug_mchol_timing(0)
         if base is None:
             base = sol.copy()
         print("p = %4d  %-26s rc %d  wall %.3f ms  device %.3f ms (min %.3f)  rel. residual %.2e  same bits as default: %s" % (
