@@ -245,17 +245,32 @@ __global__ __launch_bounds__(BD_T, 2) void bd_syrk_kernel(const double *J, long 
         __syncthreads();
         fetch(t + nslice);
         const double *tA = tile[0], *tB = diagblk ? tile[0] : tile[1];
-#pragma unroll 4
+        // (the LDS reads of chunk c + 2 are requested before the matrix instructions of chunk c issue: "read, wait, four
+        // MFMAs" per chunk left the pipe idle for an LDS round trip sixteen times per tile)
+        constexpr int AH = 2;
+        double va[AH + 1], vb[AH + 1][4];
+#pragma unroll
+        for (int c = 0; c < AH; ++c)
+        {
+            va[c] = tA[(wave * 16 + ii) * BD_LD + c * 4 + kk];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                vb[c][b] = tB[(b * 16 + ii) * BD_LD + c * 4 + kk];
+        }
+#pragma unroll
         for (int c = 0; c < 16; ++c)
         {
-            const double va = tA[(wave * 16 + ii) * BD_LD + c * 4 + kk];
-            double vb[4];
+            constexpr int R = AH + 1;
+            if (c + AH < 16)
+            {
+                va[(c + AH) % R] = tA[(wave * 16 + ii) * BD_LD + (c + AH) * 4 + kk];
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    vb[(c + AH) % R][b] = tB[(b * 16 + ii) * BD_LD + (c + AH) * 4 + kk];
+            }
 #pragma unroll
             for (int b = 0; b < 4; ++b)
-                vb[b] = tB[(b * 16 + ii) * BD_LD + c * 4 + kk];
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va, vb[b], acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[c % R], vb[c % R][b], acc[b], 0, 0, 0);
         }
     }
     // block row `wave`: element (16 wave + 4 r + kk, 16 b + ii)
