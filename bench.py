@@ -681,9 +681,10 @@ def sparse_readme_bench():
                 rc2 = L.gslnls_debug_mchol_solve_resident(*rargs) or rc2
                 dev_ms.append(L.gslnls_debug_mchol_last_device_ms())
             L.gslnls_debug_mchol_timing(0)
-            # median and mean of the host clock around each call: about one call in a few hundred takes milliseconds
-            # longer on the host (seen at p = 2000, 130 launches a solve: 17 ms once in 60 calls while the events show the
-            # same 1.17 ms of device work) -- both are reported
+            # median, mean and max of the host clock around each call: in THIS process one call in twenty at p = 2000 takes tens
+            # of milliseconds longer on the host while the events show the same device work; 300 consecutive solves in a
+            # process of their own show no such call (scripts/dev_mchol_stalls.py: median = mean = 1.05 ms, max 1.1) -- the
+            # pauses are this interpreter's (collector, the other legs' threads), not the solve's
             entry["ms_per_solve"] = float(np.median(wall_ms))
             entry["ms_per_solve_mean"] = float(np.mean(wall_ms))
             entry["ms_per_solve_max"] = float(np.max(wall_ms))
