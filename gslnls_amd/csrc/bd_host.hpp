@@ -250,6 +250,105 @@ static __global__ __launch_bounds__(256) void bd_unweight_keys_kernel(const doub
     }
 }
 
+// ---- round 5: (J^T J)^-1 and the solver-routing diagnostic at a fit's end, on the device ----
+// The damped solve's kernels factor A = J^T J (mu = 0, zero right-hand side: natural-order blocked Cholesky); behind them,
+// in the same submission: X = L^-1 column by column (bd_trinv_kernel), A^-1 = X^T X on the matrix cores (bd_syrk_kernel,
+// the kernel of J^T J itself) and, when cond_out is given, the two power iterations of bd_scaled_cond -- 60 products with
+// C = S A S, 60 with C^-1 = S^-1 A^-1 S^-1 -- whose norms come home with the solve's one synchronisation.  Until round 5
+// both were host loops, cubic in p: 25.6 + 18.5 ms of a 76 ms matrix-path call at p = 501 where the LM loop takes 6, and
+// 15 ms of every gsl_nls_large call at p = 500.  d_A: p x p on the device, symmetric, left as it is.  Scratch from the
+// parked pool.  Returns non-zero (and writes nothing) when the factorisation was refused -- a pivot not safely positive --
+// or the device routine does not take the size: the caller keeps its host routine, whose rank rules then decide.
+inline int bd_device_inverse(int p, const double *d_A, double *covar_host, double *cond_out)
+{
+    if (p < 1 || p > 4096 || !d_A)
+        return GSLNLS_E_UNSUPPORTED;
+    const size_t pp = (size_t)p * p;
+    const int npanel = (p + 63) / 64, npair = npanel * (npanel + 1) / 2;
+    long long sl = 512 / npair;
+    sl = sl > npanel ? npanel : sl; // (p rows: npanel row tiles)
+    sl = sl > 32 ? 32 : (sl < 1 ? 1 : sl);
+    const int nslice = (int)sl;
+    struct Scratch
+    {
+        double *epi = nullptr, *cpart = nullptr;
+        ~Scratch()
+        {
+            bd_pool_free(epi);
+            bd_pool_free(cpart);
+        }
+    } sc;
+    if (bd_dev_alloc(&sc.epi, sizeof(double) * (2 * pp + 4 * (size_t)p + 8)) != hipSuccess ||
+        bd_dev_alloc(&sc.cpart, sizeof(double) * (size_t)nslice * npair * 4096) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return GSLNLS_E_NODEVICE;
+    }
+    const int nblk = (p + 63) / 64;
+    const size_t lds_ti = sizeof(double) * ((size_t)64 * nblk + 64 * BD_TI_LD + 64);
+    static std::atomic<size_t> lds_set{0};
+    if (lds_set.load() < lds_ti)
+    {
+        if (hipFuncSetAttribute((const void *)bd_trinv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ti) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            return GSLNLS_E_NODEVICE;
+        }
+        lds_set.store(lds_ti);
+    }
+    struct Ctx
+    {
+        const double *d_A;
+        double *epi, *cpart;
+        size_t lds_ti;
+        int npair, nslice;
+        bool cond;
+    } cx{d_A, sc.epi, sc.cpart, lds_ti, npair, nslice, cond_out != nullptr};
+    auto enq = [](void *ctx, void *stream, const double *d_L, const double *d_dinv, int pq) {
+        Ctx &c = *static_cast<Ctx *>(ctx);
+        hipStream_t s2 = (hipStream_t)stream;
+        const size_t ppq = (size_t)pq * pq;
+        double *d_X = c.epi, *d_cov = d_X + ppq, *d_w = d_cov + ppq, *d_nrm = d_w + 4 * (size_t)pq;
+        hipLaunchKernelGGL(bd_trinv_kernel, dim3(pq), dim3(BD_T), c.lds_ti, s2, d_L, d_dinv, pq, d_X);
+        hipLaunchKernelGGL(bd_syrk_kernel, dim3(c.npair, c.nslice), dim3(BD_T), 0, s2, d_X, (long long)pq, pq, c.nslice, c.cpart);
+        hipLaunchKernelGGL(bd_syrk_reduce_kernel, dim3(c.npair, 16), dim3(BD_T), 0, s2, c.cpart, pq, c.npair, c.nslice, d_cov);
+        if (!c.cond)
+            return;
+        hipLaunchKernelGGL(bd_power_start_kernel, dim3((pq + 255) / 256), dim3(256), 0, s2, pq, d_w, d_w + 2 * (size_t)pq);
+        const int gw = (pq + BD_T / 64 - 1) / (BD_T / 64);
+        for (int run = 0; run < 2; ++run)
+        {
+            double *wa = d_w + 2 * (size_t)run * pq, *wb = wa + pq;
+            // 60 products; the 61st launch only delivers the norm of the last one
+            for (int it = 0; it <= 60; ++it)
+                hipLaunchKernelGGL(bd_power_kernel, dim3(gw), dim3(BD_T), sizeof(double) * pq, s2, run ? d_cov : c.d_A, c.d_A, pq, run,
+                                   (it & 1) ? wb : wa, (it & 1) ? wa : wb, d_nrm + run);
+        }
+    };
+    std::vector<double> zero(p, 0.0), sol(p, 0.0);
+    double nrm[2] = {NAN, NAN};
+    MCholTail tail;
+    tail.enqueue_factor = enq;
+    tail.ctx = &cx;
+    tail.extra_dev = sc.epi + 2 * pp + 4 * (size_t)p;
+    tail.extra_n = cond_out ? 2 : 0;
+    tail.extra_host = nrm;
+    int valid = 0;
+    const int rc = mchol_device_solve_resident_tail(p, d_A, zero.data(), 0.0, zero.data(), sol.data(), &tail, &valid);
+    if (rc)
+        return rc;
+    if (!valid)
+        return GSLNLS_FAILURE;
+    if (covar_host)
+        GSLNLS_HIP_OK(hipMemcpy(covar_host, sc.epi + pp, sizeof(double) * pp, hipMemcpyDeviceToHost)); // (symmetric: either storage order)
+    if (cond_out)
+    {
+        const double c = nrm[0] * nrm[1];
+        *cond_out = std::isfinite(c) && c > 0.0 ? c : INFINITY;
+    }
+    return GSLNLS_SUCCESS;
+}
+
 struct BdModel
 {
     virtual ~BdModel() {}
@@ -382,7 +481,6 @@ struct BdFit
     // round 5: x, bounds and what a fused trial step sends home (x + dx | rows of dx^T J^T J dx | partial sums of ||f||^2) on
     // the device; pinned staging for every small copy (a pageable destination makes an asynchronous copy a blocking one)
     double *d_pub = nullptr, *h_pin = nullptr;
-    double *d_epi = nullptr; // round 5, allocated by the first fit's end that needs it: X = L^-1 (p^2) | (J^T J)^-1 (p^2) | four p-vectors | two norms
     double *h_xmap = nullptr, *d_xmap = nullptr; // pinned + mapped, 3 p doubles: x | lower | upper bounds, read by bd_trial_kernel in place
     double *h_jmap = nullptr, *d_jmap = nullptr; // pinned + mapped: g | diag(J^T J) | flags (BD_MAXG) | sequence word (bd_publish_kernel)
     unsigned long long jseq = 0;
@@ -410,12 +508,12 @@ struct BdFit
             (void)hipFree(irls_arena);
         irls_arena = nullptr;
         irls_arena_bytes = 0;
-        double *bufs[] = {d_y, d_sw, d_fval, d_f[0], d_f[1], d_fp, d_fm, d_J, d_C, d_cpart, d_part, d_pv, d_u, d_pub, d_epi};
+        double *bufs[] = {d_y, d_sw, d_fval, d_f[0], d_f[1], d_fp, d_fm, d_J, d_C, d_cpart, d_part, d_pv, d_u, d_pub};
         for (double *b : bufs)
             if (b)
                 bd_pool_free(b);
         d_y = d_sw = d_fval = d_f[0] = d_f[1] = d_fp = d_fm = d_J = d_C = d_cpart = d_part = d_pv = d_u = nullptr;
-        d_pub = d_epi = nullptr;
+        d_pub = nullptr;
         if (h_pin)
             bd_pool_free(h_pin);
         if (h_xmap)
@@ -679,88 +777,8 @@ struct BdFit
     }
 
     // det_cholesky_jtj (src/nls_utils.c:55-73): (prod L_ii)^2 of the plain Cholesky factor, 0 when it does not exist
-    // ---- round 5: (J^T J)^-1 and the solver-routing diagnostic at a fit's end, on the device ----
-    // The damped solve's kernels factor J^T J (mu = 0, zero right-hand side: natural-order blocked Cholesky); behind them,
-    // in the same submission: X = L^-1 column by column (bd_trinv_kernel), (J^T J)^-1 = X^T X on the matrix cores
-    // (bd_syrk_kernel, the kernel of J^T J itself), and the two power iterations of bd_scaled_cond -- 60 products with
-    // C = S A S, 60 with C^-1 = S^-1 A^-1 S^-1 -- whose norms come home with the solve's one synchronisation.  Until
-    // round 5 both were host loops, cubic in p: 25.6 + 18.5 ms of a 76 ms call at p = 501, where the LM loop takes 6.
-    // Returns non-zero (and touches nothing) when the factorisation was refused -- a pivot not safely positive -- or the
-    // device routine does not take the size: the caller keeps the host routines, whose rank rules then decide.
-    int device_epilogue(double *covar_out, double *cond_out)
-    {
-        const size_t pp = (size_t)p * p;
-        if (!d_epi)
-        {
-            if (bd_dev_alloc(&d_epi, sizeof(double) * (2 * pp + 4 * (size_t)p + 8)) != hipSuccess)
-            {
-                (void)hipGetLastError();
-                d_epi = nullptr;
-                return GSLNLS_E_NODEVICE;
-            }
-        }
-        const int nblk = (p + 63) / 64;
-        const size_t lds_ti = sizeof(double) * ((size_t)64 * nblk + 64 * BD_TI_LD + 64);
-        static std::atomic<size_t> lds_set{0};
-        if (lds_set.load() < lds_ti)
-        {
-            if (hipFuncSetAttribute((const void *)bd_trinv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ti) != hipSuccess)
-            {
-                (void)hipGetLastError();
-                return GSLNLS_E_NODEVICE;
-            }
-            lds_set.store(lds_ti);
-        }
-        struct Ctx
-        {
-            BdFit *fit;
-            size_t lds_ti;
-        } cx{this, lds_ti};
-        auto enq = [](void *ctx, void *stream, const double *d_L, const double *d_dinv, int pq) {
-            Ctx &c = *static_cast<Ctx *>(ctx);
-            BdFit &f = *c.fit;
-            hipStream_t s2 = (hipStream_t)stream;
-            const size_t ppq = (size_t)pq * pq;
-            double *d_X = f.d_epi, *d_cov = d_X + ppq, *d_w = d_cov + ppq, *d_nrm = d_w + 4 * (size_t)pq;
-            hipLaunchKernelGGL(bd_trinv_kernel, dim3(pq), dim3(BD_T), c.lds_ti, s2, d_L, d_dinv, pq, d_X);
-            long long sl = 512 / f.npair;
-            const long long ntile = (pq + 63) / 64;
-            sl = sl > ntile ? ntile : sl;
-            sl = sl > 32 ? 32 : (sl < 1 ? 1 : sl);
-            sl = sl > f.nslice ? f.nslice : sl; // (d_cpart holds nslice partial sets)
-            hipLaunchKernelGGL(bd_syrk_kernel, dim3(f.npair, (int)sl), dim3(BD_T), 0, s2, d_X, (long long)pq, pq, (int)sl, f.d_cpart);
-            hipLaunchKernelGGL(bd_syrk_reduce_kernel, dim3(f.npair, 16), dim3(BD_T), 0, s2, f.d_cpart, pq, f.npair, (int)sl, d_cov);
-            hipLaunchKernelGGL(bd_power_start_kernel, dim3((pq + 255) / 256), dim3(256), 0, s2, pq, d_w, d_w + 2 * (size_t)pq);
-            const int gw = (pq + BD_T / 64 - 1) / (BD_T / 64);
-            for (int run = 0; run < 2; ++run)
-            {
-                double *wa = d_w + 2 * (size_t)run * pq, *wb = wa + pq;
-                // 60 products; the 61st launch only delivers the norm of the last one
-                for (int it = 0; it <= 60; ++it)
-                    hipLaunchKernelGGL(bd_power_kernel, dim3(gw), dim3(BD_T), sizeof(double) * pq, s2, run ? d_cov : f.d_C, f.d_C, pq, run,
-                                       (it & 1) ? wb : wa, (it & 1) ? wa : wb, d_nrm + run);
-            }
-        };
-        std::vector<double> zero(p, 0.0), sol(p, 0.0);
-        double nrm[2] = {NAN, NAN};
-        MCholTail tail;
-        tail.enqueue_factor = enq;
-        tail.ctx = &cx;
-        tail.extra_dev = d_epi + 2 * pp + 4 * (size_t)p;
-        tail.extra_n = 2;
-        tail.extra_host = nrm;
-        int valid = 0;
-        const int rc = mchol_device_solve_resident_tail(p, d_C, zero.data(), 0.0, zero.data(), sol.data(), &tail, &valid);
-        if (rc)
-            return rc;
-        if (!valid)
-            return GSLNLS_FAILURE;
-        if (covar_out)
-            GSLNLS_HIP_OK(hipMemcpy(covar_out, d_epi + pp, sizeof(double) * pp, hipMemcpyDeviceToHost)); // (symmetric: either storage order)
-        const double c = nrm[0] * nrm[1];
-        *cond_out = std::isfinite(c) && c > 0.0 ? c : INFINITY;
-        return GSLNLS_SUCCESS;
-    }
+    // (J^T J)^-1 and the solver-routing diagnostic at a fit's end, on the device: bd_device_inverse below
+    int device_epilogue(double *covar_out, double *cond_out) { return bd_device_inverse(p, d_C, covar_out, cond_out); }
 
     static double det_chol(std::vector<double> &M)
     {

@@ -275,4 +275,25 @@ int bd_last_profile(double *v, int cap)
 double bd_syrk_ms(int n, int p, int reps) { return bd_time_syrk(n, p, reps); }
 void bd_trim_pool() { bd_pool().drain(); }
 
+// (J^T J)^-1 of a p x p SPD matrix by the device routine above, for the large path's covariance (capi.hip): from where the
+// matrix sits on the device, or uploaded from the host first.  Non-zero: the caller keeps its host routine.
+int bd_spd_inverse(int p, const double *d_A, const double *A_host, double *covar_host)
+{
+    if (d_A)
+        return bd_device_inverse(p, d_A, covar_host, nullptr);
+    if (!A_host)
+        return GSLNLS_EINVAL;
+    double *d_tmp = nullptr;
+    if (bd_dev_alloc(&d_tmp, sizeof(double) * (size_t)p * p) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return GSLNLS_E_NODEVICE;
+    }
+    int rc = hipMemcpy(d_tmp, A_host, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice) == hipSuccess ? 0 : GSLNLS_E_NODEVICE;
+    if (!rc)
+        rc = bd_device_inverse(p, d_tmp, covar_host, nullptr);
+    bd_pool_free(d_tmp);
+    return rc;
+}
+
 } // namespace gslnls

@@ -95,6 +95,7 @@ int bd_callback_nls(int n, int p, const double *y, gslnls_fn_cb f, gslnls_jac_cb
 int bd_last_profile(double *v, int cap);     // bd_models.hip
 double bd_syrk_ms(int n, int p, int reps);   // bd_models.hip
 void bd_trim_pool();                          // bd_models.hip: the matrix path's parked buffers
+int bd_spd_inverse(int p, const double *d_A, const double *A_host, double *covar_host); // bd_models.hip
 void trim_dense_expr();                                                                                         // vm_models.hip
 }
 
@@ -470,15 +471,43 @@ int gslnls_large_solve(gslnls_large *h, const double *start, const int *control_
         bool good = ok;
         if (good)
         {
-            // gsl_multilarge_nlinear_covar (src/nls_large.c:255): (J^T J)^-1 at the final point
+            // gsl_multilarge_nlinear_covar (src/nls_large.c:255): (J^T J)^-1 at the final point.  From p = 65 on the inverse
+            // comes from the device (round 5: the host's factor-and-invert was 15 ms of every call at p = 500) -- from
+            // where J^T J sits when the operator keeps it there, else uploaded; the host routine when the natural-order
+            // factorisation refuses the matrix
             std::vector<double> A((size_t)p * p);
-            good = ops.full_jtj(R.x.data(), A.data()) == 0 && lg_chol(p, A);
-            if (good)
+            bool done = false;
+            const bool try_dev = p >= 65 && p <= 4096 && !getenv("GSLNLS_BD_HOST_EPILOGUE");
+            if (try_dev && ops.can_keep_jtj_on_device())
             {
-                lg_chol_invert(p, A);
-                for (int i = 0; i < p; ++i)
-                    for (int k = 0; k < p; ++k)
-                        out->covar[i + (size_t)p * k] = A[(size_t)i * p + k];
+                ops.jtj_device_only = true;
+                const int rj = ops.full_jtj(R.x.data(), A.data());
+                ops.jtj_device_only = false;
+                good = rj == 0;
+                if (good)
+                {
+                    if (const double *jd = ops.jtj_device())
+                        done = bd_spd_inverse(p, jd, nullptr, out->covar) == 0;
+                    if (!done)
+                        good = ops.jtj_download(A.data()) == GSLNLS_SUCCESS;
+                }
+            }
+            else
+            {
+                good = ops.full_jtj(R.x.data(), A.data()) == 0;
+                if (good && try_dev)
+                    done = bd_spd_inverse(p, nullptr, A.data(), out->covar) == 0;
+            }
+            if (good && !done)
+            {
+                good = lg_chol(p, A);
+                if (good)
+                {
+                    lg_chol_invert(p, A);
+                    for (int i = 0; i < p; ++i)
+                        for (int k = 0; k < p; ++k)
+                            out->covar[i + (size_t)p * k] = A[(size_t)i * p + k];
+                }
             }
         }
         if (!good)

@@ -255,6 +255,9 @@ int mchol_device_solve_resident_tail(int p, const double *jtj_dev, const double 
 // s = (J^T J) v with J^T J where it sits on the device (p doubles up, p doubles down): the row sums of the predicted
 // reduction v^T J^T J v, each in the order of the host loop (j ascending, product and sum rounded separately)
 int mchol_device_symv(int p, const double *jtj_dev, const double *v_host, double *s_host);
+// the damped solve with those row sums for v = its own solution behind it, in one submission (round 5)
+int mchol_device_solve_resident_symv(int p, const double *jtj_dev, const double *diag_host, double mu, const double *rhs_host,
+                                     double *sol_host, double *rows_host, int *rows_valid);
 
 struct LargeResult
 {
@@ -428,7 +431,10 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
         return ST_EMAXITER;
     };
 
+    std::vector<double> symv_rows; // rows of (J^T J) dx that came home with the lm step's solution, when symv_valid
+    bool symv_valid = false;
     auto lm_step = [&]() -> int {
+        symv_valid = false;
         std::vector<double> A, rhs(p);
         for (int i = 0; i < p; ++i)
             rhs[i] = -g[i];
@@ -451,7 +457,14 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
         if (dev_min > 0 && p >= dev_min)
         {
             if (const double *jd = ops.jtj_device())
-                drc = mchol_device_solve_resident(p, jd, diag.data(), mu, rhs.data(), vel.data());
+            {
+                // (with J^T J kept on the device the rows of the predicted reduction ride behind the solve)
+                int rv = 0;
+                symv_rows.resize(p);
+                drc = jtj_stays ? mchol_device_solve_resident_symv(p, jd, diag.data(), mu, rhs.data(), vel.data(), symv_rows.data(), &rv)
+                                : mchol_device_solve_resident(p, jd, diag.data(), mu, rhs.data(), vel.data());
+                symv_valid = jtj_stays && drc == GSLNLS_SUCCESS && rv != 0;
+            }
             else
             {
                 if (const int e = damped())
@@ -527,7 +540,12 @@ inline int large_solve(LargeOps &ops, const double *start, const int *ci, const 
                         bool rows_done = false;
                         if (jtj_stays)
                         {
-                            if (const double *jd = ops.jtj_device())
+                            if (symv_valid)
+                            {
+                                wp = symv_rows; // (they came home with the step's solution)
+                                rows_done = true;
+                            }
+                            else if (const double *jd = ops.jtj_device())
                                 rows_done = mchol_device_symv(p, jd, vel.data(), wp.data()) == GSLNLS_SUCCESS;
                             if (!rows_done && !host_jtj_valid)
                             {

@@ -2032,9 +2032,20 @@ __global__ __launch_bounds__(256) void mchol_symv_kernel(const double *A, const 
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= p)
         return;
+    // (64 loads in flight per trip: with eight the p / 8 dependent round trips to L2 were 20 us at p = 500, behind every solve)
     double acc = 0.0;
-#pragma unroll 8
-    for (int j = 0; j < p; ++j)
+    int j = 0;
+    for (; j + 64 <= p; j += 64)
+    {
+        double a[64];
+#pragma unroll
+        for (int u = 0; u < 64; ++u)
+            a[u] = A[(size_t)(j + u) * p + i];
+#pragma unroll
+        for (int u = 0; u < 64; ++u)
+            acc = __dadd_rn(acc, __dmul_rn(a[u], v[j + u]));
+    }
+    for (; j < p; ++j)
         acc = __dadd_rn(acc, __dmul_rn(A[(size_t)j * p + i], v[j]));
     s[i] = acc;
 }
@@ -2059,6 +2070,38 @@ int mchol_device_symv(int p, const double *jtj_dev, const double *v_host, double
     GSLNLS_HIP_OK(hipStreamSynchronize(B.sq));
     memcpy(s_host, h_down, sizeof(double) * p);
     return GSLNLS_SUCCESS;
+}
+
+// The damped solve and, behind it in the same submission, the row sums s = (J^T J) v of the predicted reduction for v = the
+// solution (mchol_symv_kernel on the device's copy of it: the bits the host receives) -- they come home with the solution:
+// no second upload / kernel / download / synchronisation per trial step (round 5: 35 us of every lm step at p = 500).
+// *rows_valid = 0 when the pivoted routine produced the solution (the rows belong to a discarded one).
+int mchol_device_solve_resident_symv(int p, const double *jtj_dev, const double *diag_host, double mu, const double *rhs_host,
+                                     double *sol_host, double *rows_host, int *rows_valid)
+{
+    if (!jtj_dev || !diag_host || !rows_host || !rows_valid)
+        return GSLNLS_EINVAL;
+    if (p > MC_EXTRA_MAX)
+        return GSLNLS_E_UNSUPPORTED;
+    struct Ctx
+    {
+        MCholTail tail;
+        const double *jtj;
+        int p;
+    } cx;
+    cx.jtj = jtj_dev;
+    cx.p = p;
+    cx.tail.ctx = &cx;
+    cx.tail.extra_n = p;
+    cx.tail.extra_host = rows_host;
+    cx.tail.enqueue = [](void *ctx, void *stream, const double *d_sol) {
+        Ctx &c = *static_cast<Ctx *>(ctx);
+        MCholBuffers &B = mchol_buffers(); // (the caller holds its lock; the buffers are final for this solve)
+        double *d_s = B.Cg;                // (the back substitution's partial sums: idle behind it)
+        hipLaunchKernelGGL(mchol_symv_kernel, dim3((c.p + 255) / 256), dim3(256), 0, (hipStream_t)stream, c.jtj, d_sol, c.p, d_s);
+        c.tail.extra_dev = d_s;
+    };
+    return mchol_device_solve_impl(p, nullptr, jtj_dev, diag_host, mu, rhs_host, sol_host, &cx.tail, rows_valid);
 }
 
 int mchol_device_solve(int p, const double *A_host, const double *rhs_host, double *sol_host)

@@ -265,3 +265,38 @@ def test_lm_with_jtj_kept_on_the_device_is_the_fit_with_the_host_copy(amd, monke
     assert a["conv"] == b["conv"] == 0 and a["niter"] == b["niter"]
     assert np.array_equal(np.asarray(a["par"]), np.asarray(b["par"])) and a["ssr"] == b["ssr"]
     assert abs(a["ssr"] - 0.004778845) < 5e-10
+
+
+@pytest.mark.parametrize("alg,dense", [("cgst", False), ("lm", False), ("cgst", True)])
+def test_large_path_covariance_from_the_device_equals_the_host_routine(amd, monkeypatch, alg, dense):
+    """gsl_multilarge_nlinear_covar at a fit's end (src/nls_large.c:255): from p = 65 on (J^T J)^-1 comes from the device -- the
+    damped solve's factorisation, L^-1 column by column, X^T X on the matrix cores (round 5; the host's factor-and-invert
+    was 15 ms of every call at p = 500).  GSLNLS_BD_HOST_EPILOGUE=1 keeps the host routine: same fit, covariance to 1e-10
+    of its scale."""
+    p = 500
+    fn, jac = penalty(p, "csc")
+    if dense:
+        Jd = np.asfortranarray(np.vstack([np.sqrt(1e-5) * np.eye(p), np.zeros((1, p))]))
+
+        def jac(th, _J=Jd):  # noqa: F811
+            _J[p, :] = 2.0 * th
+            return _J
+    fits = {}
+    for mode in ("device", "host"):
+        if mode == "host":
+            monkeypatch.setenv("GSLNLS_BD_HOST_EPILOGUE", "1")
+        else:
+            monkeypatch.delenv("GSLNLS_BD_HOST_EPILOGUE", raising=False)
+        fits[mode] = amd.gsl_nls_large(fn, y=np.zeros(p + 1), start=np.arange(1.0, p + 1), algorithm=alg, jac=jac,
+                                       control=dict(maxiter=500))
+    monkeypatch.delenv("GSLNLS_BD_HOST_EPILOGUE", raising=False)
+    a, b = fits["device"], fits["host"]
+    assert a["conv"] == b["conv"] == 0 and a["niter"] == b["niter"]
+    assert np.array_equal(np.asarray(a["par"]), np.asarray(b["par"]))
+    ca, cb = np.asarray(a["covar"]), np.asarray(b["covar"])
+    assert np.all(np.isfinite(ca)) and np.array_equal(ca, ca.T)
+    scale = np.sqrt(np.outer(np.diag(cb), np.diag(cb)))
+    err = float(np.max(np.abs(ca - cb) / scale))
+    from conftest import record_parity
+    record_parity("large path p=500 %s%s covariance device vs host" % (alg, " dense" if dense else ""), err, 1e-10)
+    assert err < 1e-10, err
