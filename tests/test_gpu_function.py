@@ -265,6 +265,32 @@ def test_covariance_and_condition_from_the_device_equal_the_host_routines(amd, g
     assert np.allclose(np.diag(cd), np.diag(ref["covar"]), rtol=1e-6)
 
 
+def test_function_model_with_1500_parameters_end_of_fit_on_the_device(amd, monkeypatch):
+    """p = 1500 (a model linear in its parameters, so that the answer is known): every panel of the blocked Cholesky, the
+    one-launch-per-step kernel with trailing tiles, L^-1 by forward substitution over 24 blocks, X^T X and the power iterations
+    at a size no other test reaches -- X^T X cov = I to 1e-12, covariance and condition number equal to the host routines'."""
+    p, n = 1500, 1700
+    rng = np.random.default_rng(p)
+    X = rng.standard_normal((n, p)) + 0.1
+    truth = rng.standard_normal(p)
+    y = X @ truth
+    Xf = np.asfortranarray(X)
+    fit = amd.gsl_nls(lambda th: X @ th, y=y, start=np.zeros(p), jac=lambda th: Xf, control=dict(solver="cholesky"))
+    assert fit["conv"] == 0 and fit["code_path"] == 4
+    assert np.max(np.abs(fit["par"] - truth)) < 1e-8
+    cov = np.asarray(fit["covar"])
+    assert np.array_equal(cov, cov.T)
+    assert np.max(np.abs(X.T @ (X @ cov[:, :16]) - np.eye(p)[:, :16])) < 1e-12
+    monkeypatch.setenv("GSLNLS_BD_HOST_EPILOGUE", "1")
+    host = amd.gsl_nls(lambda th: X @ th, y=y, start=np.zeros(p), jac=lambda th: Xf, control=dict(solver="cholesky"))
+    monkeypatch.delenv("GSLNLS_BD_HOST_EPILOGUE")
+    ch = np.asarray(host["covar"])
+    err = float(np.max(np.abs(cov - ch) / np.sqrt(np.outer(np.diag(ch), np.diag(ch)))))
+    record_parity("matrix path p=1500 covariance device vs host", err, 1e-10)
+    assert err < 1e-10
+    assert abs(fit["jtj_cond"] - host["jtj_cond"]) <= 1e-8 * host["jtj_cond"]
+
+
 @pytest.mark.parametrize("loss", ["huber", "bisquare", "welsh", "hampel"])
 def test_robust_losses_on_a_function_model_match_the_oracle(amd, gslref, loss):
     """gsl_nls(fn = <function>, loss = ...): the IRLS driver (src/nls_irls.c:412-546) around the matrix-path solve
