@@ -590,6 +590,13 @@ def matrix_path_bench(_lib):
             "jtj_device_ms": syrk_ms, "jtj_tflops": 2.0 * n * pp * pp / (syrk_ms * 1e-3) / 1e12 / 2.0 if syrk_ms > 0 else None,
             "jtj_frac_of_measured_mfma_rate": (n * pp * pp / (syrk_ms * 1e-3) / 1e12) / 72.0 if syrk_ms > 0 else None,
             "damped_solve_device_ms": float(np.median(sm))})
+    # the J^T J kernel alone at sizes the formula cases do not reach (function models go to p = 4096): 128-column blocks from
+    # p = 384 and n = 2048 on (bd_syrk128_kernel), 64-column blocks below
+    out["jtj_kernel"] = []
+    for n, pp in ((20000, 501), (50000, 1000), (20000, 2000), (4300, 4096)):
+        ms = float(L.gslnls_debug_bd_syrk_ms(n, pp, 10))
+        out["jtj_kernel"].append({"n": n, "p": pp, "device_ms": ms, "tflops_n_p2": n * pp * pp / (ms * 1e-3) / 1e12 if ms > 0 else None,
+                                  "frac_of_measured_mfma_rate": n * pp * pp / (ms * 1e-3) / 1e12 / 72.0 if ms > 0 else None})
     out["note"] = ("J^T J flops counted as n p^2 (the lower triangle is computed: n p (p + 1) flops of the 2 n p^2 of the full product); "
                    "trial steps include the first evaluation's share of the loop")
     return out

@@ -264,11 +264,7 @@ inline int bd_device_inverse(int p, const double *d_A, double *covar_host, doubl
     if (p < 1 || p > 4096 || !d_A)
         return GSLNLS_E_UNSUPPORTED;
     const size_t pp = (size_t)p * p;
-    const int npanel = (p + 63) / 64, npair = npanel * (npanel + 1) / 2;
-    long long sl = 512 / npair;
-    sl = sl > npanel ? npanel : sl; // (p rows: npanel row tiles)
-    sl = sl > 32 ? 32 : (sl < 1 ? 1 : sl);
-    const int nslice = (int)sl;
+    const BdSyrkGeom geom = bd_syrk_geom(p, p); // (X^T X of the p x p inverse factor)
     struct Scratch
     {
         double *epi = nullptr, *cpart = nullptr;
@@ -279,7 +275,7 @@ inline int bd_device_inverse(int p, const double *d_A, double *covar_host, doubl
         }
     } sc;
     if (bd_dev_alloc(&sc.epi, sizeof(double) * (2 * pp + 4 * (size_t)p + 8)) != hipSuccess ||
-        bd_dev_alloc(&sc.cpart, sizeof(double) * (size_t)nslice * npair * 4096) != hipSuccess)
+        bd_dev_alloc(&sc.cpart, sizeof(double) * geom.scratch) != hipSuccess)
     {
         (void)hipGetLastError();
         return GSLNLS_E_NODEVICE;
@@ -301,17 +297,16 @@ inline int bd_device_inverse(int p, const double *d_A, double *covar_host, doubl
         const double *d_A;
         double *epi, *cpart;
         size_t lds_ti;
-        int npair, nslice;
+        BdSyrkGeom geom;
         bool cond;
-    } cx{d_A, sc.epi, sc.cpart, lds_ti, npair, nslice, cond_out != nullptr};
+    } cx{d_A, sc.epi, sc.cpart, lds_ti, geom, cond_out != nullptr};
     auto enq = [](void *ctx, void *stream, const double *d_L, const double *d_dinv, int pq) {
         Ctx &c = *static_cast<Ctx *>(ctx);
         hipStream_t s2 = (hipStream_t)stream;
         const size_t ppq = (size_t)pq * pq;
         double *d_X = c.epi, *d_cov = d_X + ppq, *d_w = d_cov + ppq, *d_nrm = d_w + 4 * (size_t)pq;
         hipLaunchKernelGGL(bd_trinv_kernel, dim3(pq), dim3(BD_T), c.lds_ti, s2, d_L, d_dinv, pq, d_X);
-        hipLaunchKernelGGL(bd_syrk_kernel, dim3(c.npair, c.nslice), dim3(BD_T), 0, s2, d_X, (long long)pq, pq, c.nslice, c.cpart);
-        hipLaunchKernelGGL(bd_syrk_reduce_kernel, dim3(c.npair, 16), dim3(BD_T), 0, s2, c.cpart, pq, c.npair, c.nslice, d_cov);
+        bd_syrk_launch(d_X, (long long)pq, pq, d_cov, c.cpart, c.geom, s2);
         if (!c.cond)
             return;
         hipLaunchKernelGGL(bd_power_start_kernel, dim3((pq + 255) / 256), dim3(256), 0, s2, pq, d_w, d_w + 2 * (size_t)pq);
@@ -497,7 +492,7 @@ struct BdFit
     const double *last_f = nullptr; // its weighted residual there, on the device
     void *irls_arena = nullptr;
     size_t irls_arena_bytes = 0;
-    int npanel = 0, npair = 0, nslice = 1;
+    BdSyrkGeom geom; // how J^T J of this fit's n x p Jacobian is formed (bd_syrk_geom)
     long nevalf = 0, nevaldf = 0, nevalfvv = 0;
     int device_ordinal = -1;
 
@@ -545,14 +540,7 @@ struct BdFit
         (void)hipGetDevice(&device_ordinal);
         GSLNLS_HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         const size_t nb = sizeof(double) * (size_t)n;
-        npanel = (p + 63) / 64;
-        npair = npanel * (npanel + 1) / 2;
-        const long long ntile = ((long long)n + 63) / 64;
-        // enough workgroups for the chip (512 = two per CU), at most one slice per row tile and 32 partial blocks per block
-        long long sl = 512 / npair; // (npair x slices workgroups in ONE round of the chip's 512 slots: rounding up left 5 % of them to a second round that doubled the kernel's time, round 5)
-        sl = sl > ntile ? ntile : sl;
-        sl = sl > 32 ? 32 : (sl < 1 ? 1 : sl);
-        nslice = (int)sl;
+        geom = bd_syrk_geom(n, p);
         GSLNLS_HIP_OK(bd_dev_alloc(&d_y, nb));
         GSLNLS_HIP_OK(bd_dev_alloc(&d_fval, nb));
         GSLNLS_HIP_OK(bd_dev_alloc(&d_f[0], nb));
@@ -562,7 +550,7 @@ struct BdFit
         GSLNLS_HIP_OK(bd_dev_alloc(&d_u, nb));
         GSLNLS_HIP_OK(bd_dev_alloc(&d_J, nb * p));
         GSLNLS_HIP_OK(bd_dev_alloc(&d_C, sizeof(double) * (size_t)p * p));
-        GSLNLS_HIP_OK(bd_dev_alloc(&d_cpart, sizeof(double) * (size_t)nslice * npair * 4096));
+        GSLNLS_HIP_OK(bd_dev_alloc(&d_cpart, sizeof(double) * geom.scratch));
         GSLNLS_HIP_OK(bd_dev_alloc(&d_part, sizeof(double) * BD_MAXG));
         GSLNLS_HIP_OK(bd_dev_alloc(&d_pv, sizeof(double) * (size_t)4 * p));
         GSLNLS_HIP_OK(bd_dev_alloc(&d_pub, sizeof(double) * ((size_t)2 * p + BD_MAXG)));
@@ -671,8 +659,7 @@ struct BdFit
                 th[j] = theta[j];
             }
         }
-        hipLaunchKernelGGL(bd_syrk_kernel, dim3(npair, nslice), dim3(BD_T), 0, st, d_J, (long long)n, p, nslice, d_cpart);
-        hipLaunchKernelGGL(bd_syrk_reduce_kernel, dim3(npair, 16), dim3(BD_T), 0, st, d_cpart, p, npair, nslice, d_C);
+        bd_syrk_launch(d_J, (long long)n, p, d_C, d_cpart, geom, st);
         hipLaunchKernelGGL(bd_gemv_t_kernel, dim3(p), dim3(BD_T), 0, st, d_J, d_fbase, (long long)n, p, d_pv);
         if (jtj_host) // (the host factorises: the whole matrix comes down, and the stream's end covers everything)
         {
@@ -1837,18 +1824,13 @@ inline double bd_time_syrk(int n, int p, int reps)
 {
     if (n < 1 || p < 1 || p > 4096 || reps < 1)
         return -1.0;
-    const int npanel = (p + 63) / 64, npair = npanel * (npanel + 1) / 2;
-    const long long ntile = ((long long)n + 63) / 64;
-    long long sl = 512 / npair; // (npair x slices workgroups in ONE round of the chip's 512 slots: rounding up left 5 % of them to a second round that doubled the kernel's time, round 5)
-    sl = sl > ntile ? ntile : sl;
-    sl = sl > 32 ? 32 : (sl < 1 ? 1 : sl);
-    const int nslice = (int)sl;
+    const BdSyrkGeom geom = bd_syrk_geom(n, p);
     double *dJ = nullptr, *dC = nullptr, *dpart = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipStream_t st = nullptr;
     double ms = -1.0;
     if (hipMalloc(&dJ, sizeof(double) * (size_t)n * p) == hipSuccess && hipMalloc(&dC, sizeof(double) * (size_t)p * p) == hipSuccess &&
-        hipMalloc(&dpart, sizeof(double) * (size_t)nslice * npair * 4096) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
+        hipMalloc(&dpart, sizeof(double) * geom.scratch) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
         hipEventCreate(&e1) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess)
     {
         std::vector<double> h((size_t)n * p);
@@ -1865,8 +1847,7 @@ inline double bd_time_syrk(int n, int p, int reps)
         {
             if (r == 2)
                 (void)hipEventRecord(e0, st);
-            hipLaunchKernelGGL(bd_syrk_kernel, dim3(npair, nslice), dim3(BD_T), 0, st, dJ, (long long)n, p, nslice, dpart);
-            hipLaunchKernelGGL(bd_syrk_reduce_kernel, dim3(npair, 16), dim3(BD_T), 0, st, dpart, p, npair, nslice, dC);
+            bd_syrk_launch(dJ, (long long)n, p, dC, dpart, geom, st);
         }
         (void)hipEventRecord(e1, st);
         float f = 0.f;

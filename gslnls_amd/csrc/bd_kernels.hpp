@@ -17,6 +17,7 @@
 //   bd_cooks_kernel    hat values and Cook's distances of the robust multi-start second pass (src/nls_utils.c:88-150).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "lm_core.hpp"
 
 namespace gslnls
@@ -307,6 +308,155 @@ __global__ __launch_bounds__(BD_T) void bd_syrk_reduce_kernel(const double *cpar
             C[(size_t)gi * p + gj] = s;
             C[(size_t)gj * p + gi] = s;
         }
+    }
+}
+
+// ---- round 5: J^T J in 128-column blocks ------------------------------------------------------------------------------------------
+// bd_syrk_kernel moves 64 + 64 columns per 64 x 64 block of products: at p = 501 it pulls 3.7 TB/s out of L2 / Infinity Cache
+// for 25 TFLOP/s (n p^2) -- bandwidth, not the matrix pipe, is its limit.  Here a workgroup owns a 128 x 128 block (I2, J2),
+// J2 <= I2: per 32-row stage it stages 128 + 128 columns (the same 64 KB as a 64-row stage of the kernel above) for four
+// times the products of a 64 x 64 block's stage -- twice the flops per byte.  Wavefront w owns rows 32 w .. 32 w + 31 of the
+// block: two A' operands and eight B operands per 4-row chunk, sixteen accumulators.  Two workgroups per CU (LDS 72 KB each):
+// one stages while the other multiplies.  Used from p = 384 and n = 2048 on (bd_syrk_geom); partial blocks summed in slice order by
+// bd_syrk128_reduce_kernel -- no atomics, bit-identical run to run (not to the 64-column kernel: other slices, other sums).
+constexpr int BD_LD32 = 36; // leading dimension of a 32-row stage (doubles): same bank pattern as BD_LD (36 = 68 = 4 mod 32)
+__global__ __launch_bounds__(BD_T, 2) void bd_syrk128_kernel(const double *J, long long n, int p, int nslice, double *cpart)
+{
+    __shared__ double tile[2][128 * BD_LD32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kk = lane >> 4, ii = lane & 15;
+    const int pair = blockIdx.x;
+    int I = (int)((sqrt(8.0 * pair + 1.0) - 1.0) * 0.5);
+    while (I * (I + 1) / 2 > pair)
+        --I;
+    while ((I + 1) * (I + 2) / 2 <= pair)
+        ++I;
+    const int Jb = pair - I * (I + 1) / 2;
+    const int slice = blockIdx.y;
+    const bool diagblk = I == Jb;
+    bd_v4f64 acc[2][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            acc[a][b] = (bd_v4f64){0.0, 0.0, 0.0, 0.0};
+    const long long nstage = (n + 31) / 32;
+    const int row = tid & 31, cg = tid >> 5; // this thread stages row `row` of columns cg, cg + 8, ... of each side
+    for (long long t = slice; t < nstage; t += nslice)
+    {
+        const long long r = t * 32 + row;
+        // every load of the stage before the first wait (element 0 where a row or a column does not exist)
+        double la[16], lb[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+        {
+            const int c = cg + 8 * q, cI = I * 128 + c, cJ = Jb * 128 + c;
+            la[q] = J[(r < n && cI < p) ? (size_t)cI * n + r : 0];
+            lb[q] = J[(!diagblk && r < n && cJ < p) ? (size_t)cJ * n + r : 0];
+        }
+        __syncthreads(); // the previous stage has been consumed
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+        {
+            const int c = cg + 8 * q, cI = I * 128 + c, cJ = Jb * 128 + c;
+            tile[0][c * BD_LD32 + row] = (r < n && cI < p) ? la[q] : 0.0;
+            if (!diagblk)
+                tile[1][c * BD_LD32 + row] = (r < n && cJ < p) ? lb[q] : 0.0;
+        }
+        __syncthreads();
+        const double *tA = tile[0], *tB = diagblk ? tile[0] : tile[1];
+#pragma unroll 2
+        for (int c = 0; c < 8; ++c)
+        {
+            double va[2], vb[8];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                va[a] = tA[((2 * wave + a) * 16 + ii) * BD_LD32 + c * 4 + kk];
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                vb[b] = tB[(b * 16 + ii) * BD_LD32 + c * 4 + kk];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[a], vb[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    // element (32 wave + 16 a + 4 r + kk, 16 b + ii) of the 128 x 128 block
+    double *out = cpart + ((size_t)slice * gridDim.x + pair) * 16384;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                out[(wave * 32 + a * 16 + 4 * r + kk) * 128 + b * 16 + ii] = acc[a][b][r];
+}
+
+// C[i][j] = sum over the slices (in slice order) of the 128 x 128 partial blocks; both triangles are written
+__global__ __launch_bounds__(BD_T) void bd_syrk128_reduce_kernel(const double *cpart, int p, int npair, int nslice, double *C)
+{
+    const int pair = blockIdx.x;
+    int I = (int)((sqrt(8.0 * pair + 1.0) - 1.0) * 0.5);
+    while (I * (I + 1) / 2 > pair)
+        --I;
+    while ((I + 1) * (I + 2) / 2 <= pair)
+        ++I;
+    const int Jb = pair - I * (I + 1) / 2;
+    for (int e = blockIdx.y * BD_T + threadIdx.x; e < 16384; e += gridDim.y * BD_T)
+    {
+        const int r = e >> 7, c = e & 127;
+        const int gi = I * 128 + r, gj = Jb * 128 + c;
+        if (gi >= p || gj >= p)
+            continue;
+        if (I == Jb && gj > gi)
+            continue;
+        double s = cpart[(size_t)pair * 16384 + e];
+        for (int sl = 1; sl < nslice; ++sl)
+            s += cpart[((size_t)sl * npair + pair) * 16384 + e];
+        C[(size_t)gi * p + gj] = s;
+        C[(size_t)gj * p + gi] = s;
+    }
+}
+
+// which of the two kernels forms J^T J of an n x p matrix, with how many workgroups, and the scratch it needs
+struct BdSyrkGeom
+{
+    int wide = 0;      // 1: 128-column blocks (bd_syrk128_kernel), 0: 64-column blocks (bd_syrk_kernel)
+    int npair = 0, nslice = 1;
+    size_t scratch = 0; // doubles of partial blocks
+};
+inline BdSyrkGeom bd_syrk_geom(long long n, int p)
+{
+    BdSyrkGeom g;
+    const char *e = getenv("GSLNLS_BD_SYRK64"); // developer switch: the 64-column kernel at every p
+    // (measured, gpurun_out r05: n = 5000, p = 198: 33 us against 46; n = 501, p = 500: 17 against 22 -- small problems want
+    // the many small blocks; n = 20000, p = 501: 197 against 178; p = 1000 / 2000: 1.97 / 3.80 ms against 1.27 / 2.15)
+    g.wide = (p >= 384 && n >= 2048 && !(e && atoi(e) != 0)) ? 1 : 0;
+    const int bw = g.wide ? 128 : 64, rows = g.wide ? 32 : 64;
+    const int npanel = (p + bw - 1) / bw;
+    g.npair = npanel * (npanel + 1) / 2;
+    const long long nt = (n + rows - 1) / rows;
+    // npair x slices workgroups in ONE round of the chip's 512 slots (two per CU)
+    long long sl = 512 / g.npair;
+    sl = sl > nt ? nt : sl;
+    const long long cap = g.wide ? 48 : 32;
+    sl = sl > cap ? cap : (sl < 1 ? 1 : sl);
+    g.nslice = (int)sl;
+    g.scratch = (size_t)g.nslice * g.npair * (g.wide ? 16384 : 4096);
+    return g;
+}
+inline void bd_syrk_launch(const double *d_J, long long n, int p, double *d_C, double *d_cpart, const BdSyrkGeom &g, hipStream_t st)
+{
+    if (g.wide)
+    {
+        hipLaunchKernelGGL(bd_syrk128_kernel, dim3(g.npair, g.nslice), dim3(BD_T), 0, st, d_J, n, p, g.nslice, d_cpart);
+        hipLaunchKernelGGL(bd_syrk128_reduce_kernel, dim3(g.npair, 64), dim3(BD_T), 0, st, d_cpart, p, g.npair, g.nslice, d_C);
+    }
+    else
+    {
+        hipLaunchKernelGGL(bd_syrk_kernel, dim3(g.npair, g.nslice), dim3(BD_T), 0, st, d_J, n, p, g.nslice, d_cpart);
+        hipLaunchKernelGGL(bd_syrk_reduce_kernel, dim3(g.npair, 16), dim3(BD_T), 0, st, d_cpart, p, g.npair, g.nslice, d_C);
     }
 }
 

@@ -241,13 +241,8 @@ int bd_formula_nls(const gslnls_model *fn, const double *y, int n, int jac, int 
 // SYRK on the matrix cores.  The scratch for the partial blocks belongs to the caller (grown here when too small).
 int bd_dense_jtj(const double *d_J, int n, int p, double *d_C, hipStream_t st, double **cpart, size_t *cpart_bytes)
 {
-    const int npanel = (p + 63) / 64, npair = npanel * (npanel + 1) / 2;
-    const long long ntile = ((long long)n + 63) / 64;
-    long long sl = 512 / npair; // (npair x slices workgroups in ONE round of the chip's 512 slots: rounding up left 5 % of them to a second round that doubled the kernel's time, round 5)
-    sl = sl > ntile ? ntile : sl;
-    sl = sl > 32 ? 32 : (sl < 1 ? 1 : sl);
-    const int nslice = (int)sl;
-    const size_t need = sizeof(double) * (size_t)nslice * npair * 4096;
+    const BdSyrkGeom geom = bd_syrk_geom(n, p);
+    const size_t need = sizeof(double) * geom.scratch;
     if (*cpart_bytes < need)
     {
         if (*cpart)
@@ -257,8 +252,7 @@ int bd_dense_jtj(const double *d_J, int n, int p, double *d_C, hipStream_t st, d
         GSLNLS_HIP_OK(hipMalloc(cpart, need));
         *cpart_bytes = need;
     }
-    hipLaunchKernelGGL(bd_syrk_kernel, dim3(npair, nslice), dim3(BD_T), 0, st, d_J, (long long)n, p, nslice, *cpart);
-    hipLaunchKernelGGL(bd_syrk_reduce_kernel, dim3(npair, 16), dim3(BD_T), 0, st, *cpart, p, npair, nslice, d_C);
+    bd_syrk_launch(d_J, (long long)n, p, d_C, *cpart, geom, st);
     return GSLNLS_SUCCESS;
 }
 

@@ -291,6 +291,32 @@ def test_function_model_with_1500_parameters_end_of_fit_on_the_device(amd, monke
     assert abs(fit["jtj_cond"] - host["jtj_cond"]) <= 1e-8 * host["jtj_cond"]
 
 
+def test_jtj_in_128_column_blocks_equals_the_64_column_kernel(amd, monkeypatch):
+    """From p = 384 and n = 2048 on J^T J is formed in 128 x 128 blocks (bd_syrk128_kernel: twice the products per byte staged);
+    GSLNLS_BD_SYRK64=1 keeps the 64-column kernel.  Same fit of a model linear in its 400 parameters through both: the answer
+    (known), the same iterations, coefficients to 1e-12, covariance X^T X cov = I."""
+    p, n = 400, 2500
+    rng = np.random.default_rng(p)
+    X = rng.standard_normal((n, p)) + 0.05
+    truth = rng.standard_normal(p)
+    y = X @ truth
+    Xf = np.asfortranarray(X)
+    fits = {}
+    for mode in ("wide", "narrow"):
+        if mode == "narrow":
+            monkeypatch.setenv("GSLNLS_BD_SYRK64", "1")
+        else:
+            monkeypatch.delenv("GSLNLS_BD_SYRK64", raising=False)
+        fits[mode] = amd.gsl_nls(lambda th: X @ th, y=y, start=np.zeros(p), jac=lambda th: Xf, control=dict(solver="cholesky"))
+    monkeypatch.delenv("GSLNLS_BD_SYRK64", raising=False)
+    a, b = fits["wide"], fits["narrow"]
+    assert a["conv"] == 0 and b["conv"] == 0 and a["niter"] == b["niter"]
+    assert np.max(np.abs(a["par"] - truth)) < 1e-9 and _rel(a["par"], b["par"]) < 1e-12
+    cov = np.asarray(a["covar"])
+    assert np.max(np.abs(X.T @ (X @ cov[:, :16]) - np.eye(p)[:, :16])) < 1e-12
+    record_parity("matrix path p=400 J'J 128- vs 64-column blocks, par", _rel(a["par"], b["par"]), 1e-12)
+
+
 @pytest.mark.parametrize("loss", ["huber", "bisquare", "welsh", "hampel"])
 def test_robust_losses_on_a_function_model_match_the_oracle(amd, gslref, loss):
     """gsl_nls(fn = <function>, loss = ...): the IRLS driver (src/nls_irls.c:412-546) around the matrix-path solve
