@@ -2026,28 +2026,48 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
 }
 
 // s_i = sum_j A[j][i] v_j, j ascending, product and sum rounded separately: for the symmetric J^T J (sp_jtj_kernel forms
-// both triangles by the same sums) this is the host's row walk sum_j A[i][j] v_j bit for bit, read coalesced
+// both triangles by the same sums) this is the host's row walk sum_j A[i][j] v_j bit for bit, read coalesced.
+// Round 5: a workgroup owns 16 columns i; 256 rows j at a time come in through LDS -- every thread has 16 loads in flight,
+// the next 256 rows are requested before the current ones are added -- and one thread per column adds them in order.  (One
+// thread per column reading its p entries eight at a time was p / 8 dependent round trips: 24.7 us at p = 500, behind every
+// lm step's solve.)
+constexpr int SYMV_C = 16, SYMV_R = 256;
 __global__ __launch_bounds__(256) void mchol_symv_kernel(const double *A, const double *v, int p, double *s)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= p)
-        return;
-    // (64 loads in flight per trip: with eight the p / 8 dependent round trips to L2 were 20 us at p = 500, behind every solve)
+    __shared__ double tile[SYMV_R * (SYMV_C + 1)];
+    __shared__ double vs[SYMV_R];
+    const int tid = threadIdx.x, ii = tid & 15, jj = tid >> 4, i0 = blockIdx.x * SYMV_C;
+    double la[16], lv = 0.0;
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+        {
+            const int j = j0 + jj + 16 * u;
+            la[u] = A[(j < p && i0 + ii < p) ? (size_t)j * p + i0 + ii : 0];
+        }
+        lv = v[j0 + tid < p ? j0 + tid : 0];
+    };
+    fetch(0);
     double acc = 0.0;
-    int j = 0;
-    for (; j + 64 <= p; j += 64)
+    for (int j0 = 0; j0 < p; j0 += SYMV_R)
     {
-        double a[64];
+        __syncthreads(); // the rows before have been added
 #pragma unroll
-        for (int u = 0; u < 64; ++u)
-            a[u] = A[(size_t)(j + u) * p + i];
-#pragma unroll
-        for (int u = 0; u < 64; ++u)
-            acc = __dadd_rn(acc, __dmul_rn(a[u], v[j + u]));
+        for (int u = 0; u < 16; ++u)
+            tile[(jj + 16 * u) * (SYMV_C + 1) + ii] = la[u];
+        vs[tid] = lv;
+        __syncthreads();
+        if (j0 + SYMV_R < p)
+            fetch(j0 + SYMV_R);
+        if (tid < SYMV_C)
+        {
+            const int nj = p - j0 < SYMV_R ? p - j0 : SYMV_R;
+            for (int j = 0; j < nj; ++j)
+                acc = __dadd_rn(acc, __dmul_rn(tile[j * (SYMV_C + 1) + tid], vs[j]));
+        }
     }
-    for (; j < p; ++j)
-        acc = __dadd_rn(acc, __dmul_rn(A[(size_t)j * p + i], v[j]));
-    s[i] = acc;
+    if (tid < SYMV_C && i0 + tid < p)
+        s[i0 + tid] = acc;
 }
 
 int mchol_device_symv(int p, const double *jtj_dev, const double *v_host, double *s_host)
@@ -2064,7 +2084,7 @@ int mchol_device_symv(int p, const double *jtj_dev, const double *v_host, double
     double *d_v = B.vec + MC_NB_MAX + 3 * (size_t)B.cap + 8, *d_s = d_v + 2 * (size_t)B.cap;
     memcpy(B.stage, v_host, sizeof(double) * p);
     GSLNLS_HIP_OK(hipMemcpyAsync(d_v, B.stage, sizeof(double) * p, hipMemcpyHostToDevice, B.sq));
-    hipLaunchKernelGGL(mchol_symv_kernel, dim3((p + 255) / 256), dim3(256), 0, B.sq, jtj_dev, d_v, p, d_s);
+    hipLaunchKernelGGL(mchol_symv_kernel, dim3((p + SYMV_C - 1) / SYMV_C), dim3(256), 0, B.sq, jtj_dev, d_v, p, d_s);
     double *h_down = B.stage + 2 * (size_t)B.cap;
     GSLNLS_HIP_OK(hipMemcpyAsync(h_down, d_s, sizeof(double) * p, hipMemcpyDeviceToHost, B.sq));
     GSLNLS_HIP_OK(hipStreamSynchronize(B.sq));
@@ -2098,7 +2118,7 @@ int mchol_device_solve_resident_symv(int p, const double *jtj_dev, const double 
         Ctx &c = *static_cast<Ctx *>(ctx);
         MCholBuffers &B = mchol_buffers(); // (the caller holds its lock; the buffers are final for this solve)
         double *d_s = B.Cg;                // (the back substitution's partial sums: idle behind it)
-        hipLaunchKernelGGL(mchol_symv_kernel, dim3((c.p + 255) / 256), dim3(256), 0, (hipStream_t)stream, c.jtj, d_sol, c.p, d_s);
+        hipLaunchKernelGGL(mchol_symv_kernel, dim3((c.p + SYMV_C - 1) / SYMV_C), dim3(256), 0, (hipStream_t)stream, c.jtj, d_sol, c.p, d_s);
         c.tail.extra_dev = d_s;
     };
     return mchol_device_solve_impl(p, nullptr, jtj_dev, diag_host, mu, rhs_host, sol_host, &cx.tail, rows_valid);
