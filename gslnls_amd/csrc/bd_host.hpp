@@ -685,12 +685,19 @@ struct BdFit
         jseq += 1;
         volatile unsigned long long *word = reinterpret_cast<volatile unsigned long long *>(h_jmap + 2 * (size_t)p + BD_MAXG);
         hipLaunchKernelGGL(bd_publish_kernel, dim3(1), dim3(256), 0, st, d_pv, d_C, p, d_part, nbadparts, d_jmap, jseq);
-        GSLNLS_HIP_OK(hipEventRecord(ev_j, st));
-        for (;;)
+        // (the word is polled; the stream is asked only now and then -- to notice a launch failure or a device fault, which
+        // would never write the word.  Until round 5 an event was recorded behind the kernel and queried in every turn of
+        // the loop: a marker packet on the device and a runtime call per poll on the host, for nothing in the good case)
+        for (unsigned spin = 1;; ++spin)
         {
             if (*word == jseq)
                 break;
-            const hipError_t q = hipEventQuery(ev_j);
+            if (spin & 255u)
+            {
+                __builtin_ia32_pause();
+                continue;
+            }
+            const hipError_t q = hipStreamQuery(st);
             if (q == hipSuccess)
             {
                 if (*word != jseq)

@@ -1954,17 +1954,22 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
                 tail->enqueue_factor(tail->ctx, (void *)sq, B.Lg, a.dinv, p);
             hipLaunchKernelGGL(cholb_publish_kernel, dim3(1), dim3(256), 0, sq, d_sol, d_flag, p, B.down_dev, B.seq,
                                tail ? tail->extra_dev : nullptr, tail ? tail->extra_n : 0);
-            GSLNLS_HIP_OK(hipEventRecord(B.evdone, sq));
             const double t_enq = now_s();
             {
-                // the device writes the sequence number behind the solution: poll it (the event beside it only to notice a
-                // launch failure or a device fault, which would never write the word)
+                // the device writes the sequence number behind the solution: poll it; the stream is asked now and then only to
+                // notice a launch failure or a device fault, which would never write the word (an event recorded behind the
+                // last kernel and queried in every turn until round 5: a marker packet and a runtime call per poll)
                 volatile unsigned long long *word = reinterpret_cast<volatile unsigned long long *>(B.down + p + 1);
-                for (;;)
+                for (unsigned spin = 1;; ++spin)
                 {
                     if (*word == B.seq)
                         break;
-                    const hipError_t q = hipEventQuery(B.evdone);
+                    if (spin & 255u)
+                    {
+                        __builtin_ia32_pause();
+                        continue;
+                    }
+                    const hipError_t q = hipStreamQuery(sq);
                     if (q == hipSuccess)
                     {
                         if (*word != B.seq)
