@@ -659,8 +659,13 @@ struct BdFit
                 th[j] = theta[j];
             }
         }
-        bd_syrk_launch(d_J, (long long)n, p, d_C, d_cpart, geom, st);
-        hipLaunchKernelGGL(bd_gemv_t_kernel, dim3(p), dim3(BD_T), 0, st, d_J, d_fbase, (long long)n, p, d_pv);
+        if (getenv("GSLNLS_BD_STEPWISE"))
+        {
+            bd_syrk_launch(d_J, (long long)n, p, d_C, d_cpart, geom, st);
+            hipLaunchKernelGGL(bd_gemv_t_kernel, dim3(p), dim3(BD_T), 0, st, d_J, d_fbase, (long long)n, p, d_pv);
+        }
+        else
+            bd_syrk_gemv_launch(d_J, (long long)n, p, d_C, d_cpart, geom, d_fbase, d_pv, st);
         if (jtj_host) // (the host factorises: the whole matrix comes down, and the stream's end covers everything)
         {
             GSLNLS_HIP_OK(hipMemcpyAsync(h_pin, d_pv, sizeof(double) * p, hipMemcpyDeviceToHost, st));

@@ -283,18 +283,17 @@ __global__ __launch_bounds__(BD_T, 2) void bd_syrk_kernel(const double *J, long 
             out[(wave * 16 + 4 * r + kk) * 64 + b * 16 + ii] = acc[b][r];
 }
 
-// C[i][j] = sum over the slices (in slice order) of the partial blocks; both triangles are written (C p x p row-major)
-__global__ __launch_bounds__(BD_T) void bd_syrk_reduce_kernel(const double *cpart, int p, int npair, int nslice, double *C)
+// C[i][j] = sum over the slices (in slice order) of the partial blocks; both triangles are written (C p x p row-major).
+// Workgroup (pair, y of ny): 256 elements of the 64 x 64 block per trip, one per thread.
+__device__ __forceinline__ void bd_syrk_reduce_body(const double *cpart, int p, int npair, int nslice, double *C, int pair, int y, int ny)
 {
-    const int pair = blockIdx.x;
     int I = (int)((sqrt(8.0 * pair + 1.0) - 1.0) * 0.5);
     while (I * (I + 1) / 2 > pair)
         --I;
     while ((I + 1) * (I + 2) / 2 <= pair)
         ++I;
     const int Jb = pair - I * (I + 1) / 2;
-    // (grid.y = 16: 256 elements of the 64 x 64 block per workgroup, one per thread)
-    for (int e = blockIdx.y * BD_T + threadIdx.x; e < 4096; e += gridDim.y * BD_T)
+    for (int e = y * BD_T + threadIdx.x; e < 4096; e += ny * BD_T)
     {
         const int r = e >> 6, c = e & 63;
         const int gi = I * 64 + r, gj = Jb * 64 + c;
@@ -309,6 +308,10 @@ __global__ __launch_bounds__(BD_T) void bd_syrk_reduce_kernel(const double *cpar
             C[(size_t)gj * p + gi] = s;
         }
     }
+}
+__global__ __launch_bounds__(BD_T) void bd_syrk_reduce_kernel(const double *cpart, int p, int npair, int nslice, double *C)
+{
+    bd_syrk_reduce_body(cpart, p, npair, nslice, C, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
 // ---- round 5: J^T J in 128-column blocks ------------------------------------------------------------------------------------------
@@ -394,16 +397,15 @@ __global__ __launch_bounds__(BD_T, 2) void bd_syrk128_kernel(const double *J, lo
 }
 
 // C[i][j] = sum over the slices (in slice order) of the 128 x 128 partial blocks; both triangles are written
-__global__ __launch_bounds__(BD_T) void bd_syrk128_reduce_kernel(const double *cpart, int p, int npair, int nslice, double *C)
+__device__ __forceinline__ void bd_syrk128_reduce_body(const double *cpart, int p, int npair, int nslice, double *C, int pair, int y, int ny)
 {
-    const int pair = blockIdx.x;
     int I = (int)((sqrt(8.0 * pair + 1.0) - 1.0) * 0.5);
     while (I * (I + 1) / 2 > pair)
         --I;
     while ((I + 1) * (I + 2) / 2 <= pair)
         ++I;
     const int Jb = pair - I * (I + 1) / 2;
-    for (int e = blockIdx.y * BD_T + threadIdx.x; e < 16384; e += gridDim.y * BD_T)
+    for (int e = y * BD_T + threadIdx.x; e < 16384; e += ny * BD_T)
     {
         const int r = e >> 7, c = e & 127;
         const int gi = I * 128 + r, gj = Jb * 128 + c;
@@ -417,6 +419,10 @@ __global__ __launch_bounds__(BD_T) void bd_syrk128_reduce_kernel(const double *c
         C[(size_t)gi * p + gj] = s;
         C[(size_t)gj * p + gi] = s;
     }
+}
+__global__ __launch_bounds__(BD_T) void bd_syrk128_reduce_kernel(const double *cpart, int p, int npair, int nslice, double *C)
+{
+    bd_syrk128_reduce_body(cpart, p, npair, nslice, C, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
 // which of the two kernels forms J^T J of an n x p matrix, with how many workgroups, and the scratch it needs
@@ -458,6 +464,43 @@ inline void bd_syrk_launch(const double *d_J, long long n, int p, double *d_C, d
         hipLaunchKernelGGL(bd_syrk_kernel, dim3(g.npair, g.nslice), dim3(BD_T), 0, st, d_J, n, p, g.nslice, d_cpart);
         hipLaunchKernelGGL(bd_syrk_reduce_kernel, dim3(g.npair, 16), dim3(BD_T), 0, st, d_cpart, p, g.npair, g.nslice, d_C);
     }
+}
+
+// the reduction of the partial blocks and J^T f in ONE launch (round 5: they do not depend on each other -- the first
+// `nred` workgroups are the reduction's, the other p are bd_gemv_t_kernel's, each with its own kernel's arithmetic)
+__global__ __launch_bounds__(BD_T) void bd_reduce_gemv_kernel(const double *cpart, int p, int npair, int nslice, int wide, double *C, int ny, int nred,
+                                                              const double *J, const double *f, long long n, double *g)
+{
+    const int b = blockIdx.x;
+    if (b < nred)
+    {
+        if (wide)
+            bd_syrk128_reduce_body(cpart, p, npair, nslice, C, b / ny, b % ny, ny);
+        else
+            bd_syrk_reduce_body(cpart, p, npair, nslice, C, b / ny, b % ny, ny);
+        return;
+    }
+    __shared__ double red_s[BD_T / 64];
+    const int k = b - nred;
+    const double *col = J + (size_t)k * n;
+    double s = 0.0;
+    for (long long i = threadIdx.x; i < n; i += BD_T)
+        s += col[i] * f[i];
+    s = bd_block_sum(s, red_s);
+    if (threadIdx.x == 0)
+        g[k] = s;
+}
+// J^T J (into d_C) and g = J^T f in two launches: the products, then [reduction | J^T f]
+inline void bd_syrk_gemv_launch(const double *d_J, long long n, int p, double *d_C, double *d_cpart, const BdSyrkGeom &g, const double *d_f,
+                                double *d_g, hipStream_t st)
+{
+    if (g.wide)
+        hipLaunchKernelGGL(bd_syrk128_kernel, dim3(g.npair, g.nslice), dim3(BD_T), 0, st, d_J, n, p, g.nslice, d_cpart);
+    else
+        hipLaunchKernelGGL(bd_syrk_kernel, dim3(g.npair, g.nslice), dim3(BD_T), 0, st, d_J, n, p, g.nslice, d_cpart);
+    const int ny = g.wide ? 64 : 16, nred = g.npair * ny;
+    hipLaunchKernelGGL(bd_reduce_gemv_kernel, dim3(nred + p), dim3(BD_T), 0, st, d_cpart, p, g.npair, g.nslice, g.wide, d_C, ny, nred, d_J, d_f, n,
+                       d_g);
 }
 
 // ---- round 5: the covariance and the solver-routing diagnostic of a fit's end, on the device -------------------------------

@@ -1650,6 +1650,57 @@ __global__ __launch_bounds__(256) void cholb_init_kernel(const double *src, doub
     }
 }
 
+// cholb_init_kernel with rhs | diag in the KERNEL ARGUMENTS (round 5, p <= CBV_MAX): the 2 p doubles travel with the launch
+// packet instead of being read by the kernel through the staging area's mapping -- a PCIe round trip in front of every
+// damped solve of the matrix path (init 6 -> 12 us when the copy-engine upload was dropped; back to 6 with this)
+constexpr int CBV_MAX = 224;
+struct CholbVecArg
+{
+    double v[2 * CBV_MAX]; // rhs[0 .. p) | diag[0 .. p)
+};
+__global__ __launch_bounds__(256) void cholb_init_arg_kernel(const double *src, double *W, int p, CholbVecArg va, double mu, double *work,
+                                                             double *dorig, int *flag, int ntile)
+{
+    const int tid = threadIdx.x, t = blockIdx.x;
+    const double *rhs = va.v, *dmp = va.v + p;
+    if (t >= ntile)
+    {
+        for (int r = tid; r < p; r += 256)
+        {
+            dorig[r] = __dadd_rn(src[(size_t)r * p + r], __dmul_rn(__dmul_rn(mu, dmp[r]), dmp[r]));
+            work[r] = rhs[r];
+        }
+        if (tid == 0)
+            *flag = 0;
+        return;
+    }
+    int I = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while (I * (I + 1) / 2 > t)
+        --I;
+    while ((I + 1) * (I + 2) / 2 <= t)
+        ++I;
+    const int J = t - I * (I + 1) / 2;
+    double v[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it)
+    {
+        const int e = tid + 256 * it, i = I * CB + (e >> 6), k = J * CB + (e & 63);
+        v[it] = src[(i < p && k < p) ? (size_t)i * p + k : 0];
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it)
+    {
+        const int e = tid + 256 * it, i = I * CB + (e >> 6), k = J * CB + (e & 63);
+        if (i < p && k <= i)
+        {
+            double x = v[it];
+            if (i == k)
+                x = __dadd_rn(x, __dmul_rn(__dmul_rn(mu, dmp[i]), dmp[i])); // (rounded like the host's A[i][i] += mu d d)
+            W[(size_t)i * p + k] = x;
+        }
+    }
+}
+
 struct MCholBuffers
 {
     std::mutex mu;
@@ -1844,6 +1895,14 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
             // inside the factorisation), the flag: one launch
             {
                 const int nb64 = (p + CB - 1) / CB, ntile = A_host ? 0 : nb64 * (nb64 + 1) / 2;
+                if (in_place && p <= CBV_MAX)
+                {
+                    CholbVecArg va;
+                    memcpy(va.v, rhs_host, sizeof(double) * p);
+                    memcpy(va.v + p, diag_host, sizeof(double) * p);
+                    hipLaunchKernelGGL(cholb_init_arg_kernel, dim3(ntile + 1), dim3(256), 0, sq, jtj_dev, B.A, p, va, mu, d_work, a.dcur, d_flag, ntile);
+                }
+                else
                 hipLaunchKernelGGL(cholb_init_kernel, dim3(ntile + 1), dim3(256), 0, sq, A_host ? nullptr : jtj_dev, B.A, p,
                                    in_place ? B.stage_dev + p : d_dmp, mu, in_place ? B.stage_dev : d_rhs,
                                    d_work, a.dcur, d_flag, ntile);
