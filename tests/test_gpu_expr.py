@@ -618,3 +618,27 @@ def test_formula_outside_the_vocabulary_is_served_through_its_closure(amd, gslre
     ref = gslref.nls(n, 4, list(start.values()), fn=lambda t: model(t) - yo, ctrl=gslref.control(**ctrl), loss="huber")
     assert fit["conv"] == ref["conv"] == 0 and fit["irls"]["irls_niter"] == ref["irls"]["irls_niter"]
     assert rel_err(fit["par"], ref["par"]) < 1e-6
+
+
+def test_formula_beyond_512_parameters_is_served_by_the_closure_route(amd):
+    """The expression compiler takes formulas up to 512 parameters (the in-process compiler's time beyond that is not a
+    caller's: 85 s measured at p = 750).  A longer formula is not refused: like a right-hand side that cannot be
+    differentiated, its closure goes to the callback route of the matrix path (finite-difference Jacobian, the
+    reference's warning) -- the reference serves any p (src/nls.c:266)."""
+    import warnings
+    ng, n = 180, 1200
+    rng = np.random.Generator(np.random.PCG64(ng))
+    x = np.linspace(0.0, 10.0 * ng, n)
+    amp, mid, wid = rng.uniform(2.0, 6.0, ng), 10.0 * np.arange(ng) + rng.uniform(3.0, 7.0, ng), rng.uniform(1.5, 2.4, ng)
+    y = np.sum(amp * np.exp(-((x[:, None] - mid) / wid) ** 2), axis=1)
+    rhs = " + ".join("a%d * exp(-((x - m%d) / w%d)^2)" % (g, g, g) for g in range(ng))
+    start = {}
+    for g in range(ng):
+        start["a%d" % g], start["m%d" % g], start["w%d" % g] = 0.95 * amp[g], mid[g] + 0.05, 1.05 * wid[g]
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        fit = amd.gsl_nls("y ~ " + rhs, data=dict(x=x, y=y), start=start, jac=True, control=dict(solver="cholesky"))
+    assert fit["conv"] == 0 and fit["lowered"] is False and fit["code_path"] == 4
+    assert any("symbolically derive" in str(w.message) for w in wl)
+    truth = np.stack([amp, mid, wid], axis=1).reshape(-1)
+    assert np.max(np.abs(np.asarray(fit["par"]) - truth) / np.abs(truth)) < 1e-6
