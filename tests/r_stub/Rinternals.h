@@ -2,8 +2,10 @@
  * Rinternals.h -- DECLARATION-ONLY stand-in for R's C API, for ONE purpose: `gcc -fsyntax-only -Wall` of the
  * reference-side shims in integration/r_shim/ inside an image that has no R.  It declares the
  * subset of the public API (R >= 4.1, "Writing R Extensions" section 5/6) those two files use, with R's
- * documented signatures.  Nothing here is ever linked or executed: the shims are compiled for real only inside the R
- * package, against R's own headers.  Test infrastructure (tests/test_abi.py, __graft_entry__.build()).
+ * documented signatures.  The shims are compiled for real only inside the R package, against R's own headers; since round 5
+ * tests/r_mini/rmini.c IMPLEMENTS the part of these declarations the dense shim's `function`-model route uses, so that the
+ * shim can be executed by tests/test_gpu_r_shim.py / tests/test_r_shim_cpu.py.  Test infrastructure (tests/test_abi.py,
+ * __graft_entry__.build()).
  */
 #ifndef GSLNLS_TEST_RINTERNALS_STUB_H
 #define GSLNLS_TEST_RINTERNALS_STUB_H

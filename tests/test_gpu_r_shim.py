@@ -1,0 +1,177 @@
+"""The reference-side shim, EXECUTED: integration/r_shim/gslnls_hip_shim.c compiled against tests/r_mini/rmini.c -- a small
+functional implementation of the slice of R's C API the shim uses on its `function`-model route (this image has no R,
+SURVEY.md 0.4; until round 5 the shim was only type-checked) -- and called the way .Call(C_nls, ...) calls it: twelve SEXP
+arguments in, the list of src/nls.c:632-812 out.  The closures are Python functions behind ctypes callbacks.
+
+What it pins: the marshalling of the callback route for p > 64 (where a p-sized scratch of the shim was once left
+uninitialised), the returned slots, names and dimnames, the trace text through Rprintf, start ranges
+(gslnls_nls_fn_mstart) and that nothing falls through to C_nls.  The numbers are compared with the Python mirror's call of
+the same core: bit for bit."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_gpu_function import gaussians
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import gslnls_amd
+    from gslnls_amd import _lib
+    assert _lib.lib().gslnls_device_count() >= 1, "no MI355X visible: the HIP path cannot be tested"
+    return gslnls_amd
+
+
+@pytest.fixture(scope="module")
+def rshim(amd):
+    out = os.path.join(ROOT, "tests", "r_mini", "_build")
+    os.makedirs(out, exist_ok=True)
+    so = os.path.join(out, "rshim_test.so")
+    cmd = ["gcc", "-std=gnu11", "-Wall", "-O1", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "tests", "r_stub"),
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "integration", "r_shim"),
+           os.path.join(ROOT, "tests", "r_mini", "rmini.c"), os.path.join(ROOT, "integration", "r_shim", "gslnls_hip_shim.c"),
+           "-o", so, "-L" + os.path.join(ROOT, "gslnls_amd"), "-lgslnls_hip", "-Wl,-rpath," + os.path.join(ROOT, "gslnls_amd")]
+    subprocess.run(cmd, check=True, capture_output=True)
+    L = C.CDLL(so)
+    P = C.c_void_p
+    for name, res, args in [("rm_nil", P, []), ("rm_real", P, [C.c_int, C.c_void_p]), ("rm_int", P, [C.c_int, C.c_void_p, C.c_int]),
+                            ("rm_strings", P, [C.c_int, C.POINTER(C.c_char_p)]), ("rm_set_names", None, [P, P]),
+                            ("rm_set_dim", None, [P, C.c_int, C.c_int, P, P]), ("rm_list", P, [C.c_int]),
+                            ("rm_list_set", None, [P, C.c_int, P]), ("rm_list_get", P, [P, C.c_int]), ("rm_env", P, []),
+                            ("rm_closure", P, [C.c_void_p, C.c_void_p, P]), ("rm_type", C.c_int, [P]), ("rm_length", C.c_int, [P]),
+                            ("rm_real_ptr", C.POINTER(C.c_double), [P]), ("rm_int_ptr", C.POINTER(C.c_int), [P]),
+                            ("rm_string", C.c_char_p, [P, C.c_int]), ("rm_names", P, [P]), ("rm_dimnames", P, [P]),
+                            ("rm_nrow", C.c_int, [P]), ("rm_ncol", C.c_int, [P]), ("rm_warnings", C.c_char_p, []),
+                            ("rm_printed", C.c_char_p, []), ("rm_fell_through", C.c_int, []), ("rm_reset", None, []),
+                            ("C_nls_hip", P, [P] * 12)]:
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+    return L
+
+
+CB = C.CFUNCTYPE(C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p)
+
+
+def _real(L, v):
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    return L.rm_real(len(v), v.ctypes.data_as(C.c_void_p))
+
+
+def _strs(L, names):
+    arr = (C.c_char_p * len(names))(*[s.encode() for s in names])
+    return L.rm_strings(len(names), arr)
+
+
+def _vec(L, s):
+    n = L.rm_length(s)
+    return np.ctypeslib.as_array(L.rm_real_ptr(s), shape=(n,)).copy()
+
+
+def _call(L, amd, fn, jac, y, start, names, trace=False, ranges=None, has=None):
+    """build the twelve arguments of .Call(C_nls, ...) (R/nls.R:716-720) and call the shim"""
+    from gslnls_amd.control import gsl_nls_control, pack_control
+    p, n = len(names), len(y)
+    seen = {}
+
+    def wrap(f, matrix):
+        def cb(args, nargs, user):
+            th = _vec(L, args[0])
+            seen.setdefault("names", [L.rm_string(L.rm_names(args[0]), k).decode() for k in (0, p - 1)])
+            v = np.asarray(f(th), dtype=np.float64)
+            if matrix:
+                s = _real(L, np.asfortranarray(v).reshape(-1, order="F"))
+                L.rm_set_dim(s, v.shape[0], v.shape[1], L.rm_nil(), L.rm_nil())
+                return s
+            return _real(L, v)
+        return CB(cb)
+    keep = [wrap(fn, False), wrap(jac, True) if jac is not None else None]
+    env = L.rm_env()
+    fn_s = L.rm_closure(C.cast(keep[0], C.c_void_p), None, env)
+    jac_s = L.rm_closure(C.cast(keep[1], C.c_void_p), None, env) if jac is not None else L.rm_nil()
+    ci, cd = pack_control(gsl_nls_control(solver="cholesky"), "lm", trace, True, False)
+    nm = _strs(L, names)
+    if ranges is None:
+        st = _real(L, start)
+        L.rm_set_names(st, nm)
+        hs = L.rm_int(p, np.ones(p, dtype=np.int32).ctypes.data_as(C.c_void_p), 1)
+    else:
+        st = _real(L, np.asarray(ranges, dtype=np.float64).reshape(-1))  # 2 x p column-major: (lower, upper) per parameter
+        L.rm_set_dim(st, 2, p, L.rm_nil(), nm)
+        hsv = np.ascontiguousarray(has, dtype=np.int32)
+        hs = L.rm_int(2 * p, hsv.ctypes.data_as(C.c_void_p), 1)
+        L.rm_set_dim(hs, 2, p, L.rm_nil(), L.rm_nil())
+    loss = L.rm_list(2)
+    L.rm_list_set(loss, 0, L.rm_int(1, np.zeros(1, dtype=np.int32).ctypes.data_as(C.c_void_p), 0))
+    L.rm_list_set(loss, 1, _real(L, [0.0]))
+    L.rm_reset()
+    ans = L.C_nls_hip(fn_s, _real(L, y), jac_s, L.rm_nil(), env, st, L.rm_nil(), L.rm_nil(),
+                      L.rm_int(len(ci), ci.ctypes.data_as(C.c_void_p), 0), _real(L, cd), hs, loss)
+    return ans, seen, keep
+
+
+def _slots(L, ans):
+    nm = L.rm_names(ans)
+    return [L.rm_string(nm, k).decode() for k in range(L.rm_length(ans))]
+
+
+def test_function_model_with_100_parameters_through_the_shim(amd, rshim):
+    L = rshim
+    x, y, model, jac, start, truth = gaussians(33, 3000, 4233)
+    p = len(start)
+    names = ["th%d" % (k + 1) for k in range(p)]
+    ans, seen, keep = _call(L, amd, model, jac, y, start, names)
+    assert L.rm_fell_through() == 0 and L.rm_warnings() == b""
+    assert _slots(L, ans) == ["par", "covar", "resid", "grad", "niter", "status", "conv", "ssr", "ssrtol", "algorithm", "neval", "irls"]
+    assert seen["names"] == ["th1", "th%d" % p]  # `par` reaches the closures as a named vector, every name in place
+    par = L.rm_list_get(ans, 0)
+    assert [L.rm_string(L.rm_names(par), k).decode() for k in (0, 64, 65, p - 1)] == ["th1", "th65", "th66", "th%d" % p]
+    ref = amd.gsl_nls(model, y=y, start=start, jac=jac, control=dict(solver="cholesky"))
+    assert np.array_equal(_vec(L, par), np.asarray(ref["par"]))
+    assert L.rm_int_ptr(L.rm_list_get(ans, 4))[0] == ref["niter"] and L.rm_int_ptr(L.rm_list_get(ans, 6))[0] == 0
+    assert L.rm_real_ptr(L.rm_list_get(ans, 7))[0] == ref["ssr"]
+    assert L.rm_string(L.rm_list_get(ans, 5), 0).decode() == "success"
+    cov, grad = L.rm_list_get(ans, 1), L.rm_list_get(ans, 3)
+    assert (L.rm_nrow(cov), L.rm_ncol(cov), L.rm_nrow(grad), L.rm_ncol(grad)) == (p, p, len(y), p)
+    assert np.array_equal(_vec(L, cov).reshape(p, p, order="F"), np.asarray(ref["covar"]))
+    assert np.array_equal(_vec(L, L.rm_list_get(ans, 2)), np.asarray(ref["resid"]))
+    dn = L.rm_dimnames(grad)
+    assert L.rm_string(L.rm_list_get(dn, 1), p - 1).decode() == "th%d" % p
+    ne = L.rm_list_get(ans, 10)
+    assert [L.rm_int_ptr(ne)[k] for k in range(3)] == [ref["neval"]["f"], ref["neval"]["J"], ref["neval"]["fvv"]]
+
+
+def test_trace_text_reaches_rprintf_and_wrong_results_become_warnings(amd, rshim):
+    L = rshim
+    x, y, model, jac, start, truth = gaussians(22, 2000, 4222)
+    p = len(start)
+    names = ["b%d" % k for k in range(p)]
+    ans, seen, keep = _call(L, amd, model, jac, y, start, names, trace=True)
+    assert _slots(L, ans)[-2:] == ["partrace", "ssrtrace"]
+    out = L.rm_printed().decode()
+    assert out.startswith("iter   1: ssr = ") and "summary from method 'multifit/levenberg-marquardt'" in out
+    niter = L.rm_int_ptr(L.rm_list_get(ans, 4))[0]
+    assert out.count("\niter ") + 1 == niter  # (one line per iteration, as the reference's callback prints them)
+    # a closure that returns the wrong length: EBADFUNC, NA-filled result, the reference's warning -- raised after the core returned
+    ans, seen, keep = _call(L, amd, lambda th: model(th)[:-1], None, y, start, names)
+    assert b"does not return numeric vector of expected length n" in L.rm_warnings()
+    assert L.rm_int_ptr(L.rm_list_get(ans, 6))[0] != 0
+    assert np.all(np.isnan(_vec(L, L.rm_list_get(ans, 2)))) and L.rm_fell_through() == 0
+
+
+def test_start_ranges_of_a_function_model_through_the_shim(amd, rshim):
+    L = rshim
+    from test_gpu_function_mstart import madsen  # noqa: F401  (the reference's unit test 4.2.x model)
+    fn, jac = madsen()
+    y = np.zeros(3)
+    names = ["x1", "x2"]
+    ranges = np.array([[-1.0, 1.0], [-1.0, 1.0]])  # (lower, upper) per parameter
+    ans, seen, keep = _call(L, amd, fn, jac, y, None, names, ranges=ranges.reshape(-1), has=np.ones(4, dtype=np.int32))
+    assert L.rm_fell_through() == 0 and L.rm_int_ptr(L.rm_list_get(ans, 6))[0] == 0
+    ref = amd.gsl_nls(fn, y=y, start={"x1": [-1.0, 1.0], "x2": [-1.0, 1.0]}, jac=jac, control=dict(solver="cholesky"))
+    assert np.array_equal(_vec(L, L.rm_list_get(ans, 0)), np.asarray(ref["par"]))
