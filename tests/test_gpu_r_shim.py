@@ -73,7 +73,7 @@ def _vec(L, s):
     return np.ctypeslib.as_array(L.rm_real_ptr(s), shape=(n,)).copy()
 
 
-def _call(L, amd, fn, jac, y, start, names, trace=False, ranges=None, has=None):
+def _call(L, amd, fn, jac, y, start, names, trace=False, ranges=None, has=None, startisnum=True):
     """build the twelve arguments of .Call(C_nls, ...) (R/nls.R:716-720) and call the shim"""
     from gslnls_amd.control import gsl_nls_control, pack_control
     p, n = len(names), len(y)
@@ -81,7 +81,11 @@ def _call(L, amd, fn, jac, y, start, names, trace=False, ranges=None, has=None):
 
     def wrap(f, matrix):
         def cb(args, nargs, user):
-            th = _vec(L, args[0])
+            if L.rm_type(args[0]) == 19:  # a named list of scalars: start was a list (control_int[13] == 0, src/nls.c:163-171)
+                seen["par_is_list"] = True
+                th = np.array([L.rm_real_ptr(L.rm_list_get(args[0], k))[0] for k in range(p)])
+            else:
+                th = _vec(L, args[0])
             seen.setdefault("names", [L.rm_string(L.rm_names(args[0]), k).decode() for k in (0, p - 1)])
             v = np.asarray(f(th), dtype=np.float64)
             if matrix:
@@ -94,7 +98,7 @@ def _call(L, amd, fn, jac, y, start, names, trace=False, ranges=None, has=None):
     env = L.rm_env()
     fn_s = L.rm_closure(C.cast(keep[0], C.c_void_p), None, env)
     jac_s = L.rm_closure(C.cast(keep[1], C.c_void_p), None, env) if jac is not None else L.rm_nil()
-    ci, cd = pack_control(gsl_nls_control(solver="cholesky"), "lm", trace, True, False)
+    ci, cd = pack_control(gsl_nls_control(solver="cholesky"), "lm", trace, startisnum, False)
     nm = _strs(L, names)
     if ranges is None:
         st = _real(L, start)
@@ -175,3 +179,14 @@ def test_start_ranges_of_a_function_model_through_the_shim(amd, rshim):
     assert L.rm_fell_through() == 0 and L.rm_int_ptr(L.rm_list_get(ans, 6))[0] == 0
     ref = amd.gsl_nls(fn, y=y, start={"x1": [-1.0, 1.0], "x2": [-1.0, 1.0]}, jac=jac, control=dict(solver="cholesky"))
     assert np.array_equal(_vec(L, L.rm_list_get(ans, 0)), np.asarray(ref["par"]))
+
+
+def test_par_as_a_list_of_scalars_when_start_was_a_list(amd, rshim):
+    """start given as a list: the reference hands the closures a named LIST of scalars (src/nls.c:163-171, control_int[13] == 0)"""
+    L = rshim
+    x, y, model, jac, start, truth = gaussians(2, 300, 4202)
+    names = ["p%d" % k for k in range(len(start))]
+    ans, seen, keep = _call(L, amd, model, jac, y, start, names, startisnum=False)
+    assert seen.get("par_is_list") and seen["names"] == ["p0", "p%d" % (len(start) - 1)]
+    ref = amd.gsl_nls(model, y=y, start=start, jac=jac, control=dict(solver="cholesky"))
+    assert L.rm_int_ptr(L.rm_list_get(ans, 6))[0] == 0 and np.array_equal(_vec(L, L.rm_list_get(ans, 0)), np.asarray(ref["par"]))
