@@ -1,6 +1,6 @@
 /*
- * rmini.c -- a small FUNCTIONAL implementation of the slice of R's C API that integration/r_shim/gslnls_hip_shim.c uses on
- * its `function`-model route, so that the shim can be EXECUTED in an image that has no R ("the
+ * rmini.c -- a small FUNCTIONAL implementation of the slice of R's C API that integration/r_shim/gslnls_hip_shim.c and
+ * gslnls_hip_large_shim.c use on their `function`-model routes (incl. Matrix-package objects by class and slot, as.matrix()), so that the shim can be EXECUTED in an image that has no R ("the
  * shim has only ever been type-checked").  tests/test_gpu_r_shim.py compiles this file together with the shim against the
  * declarations in tests/r_stub/, links libgslnls_hip.so, builds the twelve .Call arguments out of the rm_* helpers below
  * (closures are C callbacks supplied through ctypes) and reads the returned list back.
@@ -26,12 +26,14 @@ struct SEXPREC
     rm_cb cb;                      /* CLOSXP */
     void *user;
     SEXP env;                      /* CLOENV of a closure; ENVSXP: data = SEXP[2 * len] (symbol, value) */
+    const char *klass;             /* class of an S4-like object made by rm_s4 (Matrix package: dgCMatrix, dgRMatrix, dgTMatrix, dgeMatrix) */
+    SEXP slots;                    /* its slots: a named list */
 };
 
-static struct SEXPREC nil_rec = {NILSXP, 0, 0, 0, 0, 0, 0, 0, 0}, unbound_rec = {NILSXP, 0, 0, 0, 0, 0, 0, 0, 0};
-static struct SEXPREC baseenv_rec = {ENVSXP, 0, 0, 0, 0, 0, 0, 0, 0};
-static struct SEXPREC sym_names = {SYMSXP, 0, (void *)"names", 0, 0, 0, 0, 0, 0}, sym_dimnames = {SYMSXP, 0, (void *)"dimnames", 0, 0, 0, 0, 0, 0},
-                      sym_dim = {SYMSXP, 0, (void *)"dim", 0, 0, 0, 0, 0, 0};
+static struct SEXPREC nil_rec = {NILSXP, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, unbound_rec = {NILSXP, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static struct SEXPREC baseenv_rec = {ENVSXP, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static struct SEXPREC sym_names = {SYMSXP, 0, (void *)"names", 0, 0, 0, 0, 0, 0, 0, 0}, sym_dimnames = {SYMSXP, 0, (void *)"dimnames", 0, 0, 0, 0, 0, 0, 0, 0},
+                      sym_dim = {SYMSXP, 0, (void *)"dim", 0, 0, 0, 0, 0, 0, 0, 0};
 SEXP R_NilValue = &nil_rec, R_UnboundValue = &unbound_rec, R_BaseEnv = &baseenv_rec, R_GlobalEnv = &baseenv_rec;
 SEXP R_NamesSymbol = &sym_names, R_DimNamesSymbol = &sym_dimnames, R_DimSymbol = &sym_dim;
 double R_NaReal;
@@ -48,7 +50,7 @@ static SEXP new_rec(int type, int len, size_t bytes)
     s->len = len;
     s->data = bytes ? calloc(1, bytes) : NULL;
     s->names = s->dim = s->dimnames = R_NilValue;
-    s->env = R_NilValue;
+    s->env = s->slots = R_NilValue;
     return s;
 }
 __attribute__((constructor)) static void rm_init(void)
@@ -57,7 +59,7 @@ __attribute__((constructor)) static void rm_init(void)
     memcpy(&R_NaReal, &na, sizeof(na));
     SEXP statics[] = {&nil_rec, &unbound_rec, &baseenv_rec, &sym_names, &sym_dimnames, &sym_dim};
     for (int k = 0; k < 6; k++) /* (static initialisers cannot name R_NilValue: the attribute slots are set here) */
-        statics[k]->names = statics[k]->dim = statics[k]->dimnames = statics[k]->env = &nil_rec;
+        statics[k]->names = statics[k]->dim = statics[k]->dimnames = statics[k]->env = statics[k]->slots = &nil_rec;
 }
 
 SEXP Rf_protect(SEXP s) { return s; }
@@ -179,11 +181,14 @@ SEXP CADR(SEXP call) { return call->type == LANGSXP && call->len > 1 ? ((SEXP *)
 SEXP CADDR(SEXP call) { return call->type == LANGSXP && call->len > 2 ? ((SEXP *)call->data)[2] : R_NilValue; }
 SEXP CLOENV(SEXP f) { return f->env; }
 
+static SEXP rm_as_matrix(SEXP x);
 SEXP R_tryEval(SEXP call, SEXP rho, int *err)
 {
     (void)rho;
     if (err)
         *err = 0;
+    if (call->type == LANGSXP && ((SEXP *)call->data)[0]->type == SYMSXP && !strcmp((const char *)((SEXP *)call->data)[0]->data, "as.matrix"))
+        return rm_as_matrix(((SEXP *)call->data)[1]); /* (the one base function the large shim asks R for) */
     if (call->type != LANGSXP || ((SEXP *)call->data)[0]->type != CLOSXP)
     {
         fprintf(stderr, "rmini: only calls of rm_closure objects can be evaluated (the formula route of the shim needs R itself)\n");
@@ -226,7 +231,49 @@ SEXP Rf_setAttrib(SEXP x, SEXP what, SEXP v)
     return v;
 }
 SEXP Rf_GetOption1(SEXP sym) { (void)sym; return R_NilValue; }
-SEXP R_do_slot(SEXP x, SEXP s) { (void)x; (void)s; return R_NilValue; }
+SEXP R_do_slot(SEXP x, SEXP sym)
+{
+    if (x->slots != R_NilValue)
+        for (int k = 0; k < x->slots->len; k++)
+            if (!strcmp((const char *)((SEXP *)x->slots->names->data)[k]->data, (const char *)sym->data))
+                return ((SEXP *)x->slots->data)[k];
+    fprintf(stderr, "rmini: no slot %s\n", (const char *)sym->data);
+    abort();
+}
+/* as.matrix() of a Matrix-package object made by rm_s4 (slots as the package names them), or of a base matrix (itself) */
+static SEXP rm_as_matrix(SEXP x)
+{
+    if (!x->klass)
+        return x;
+    const int *Dim = (const int *)R_do_slot(x, Rf_install("Dim"))->data;
+    const int nr = Dim[0], nc = Dim[1];
+    SEXP m = Rf_allocMatrix(REALSXP, nr, nc), xs = R_do_slot(x, Rf_install("x"));
+    double *d = (double *)m->data;
+    const double *v = (const double *)xs->data;
+    if (!strcmp(x->klass, "dgeMatrix"))
+        memcpy(d, v, sizeof(double) * (size_t)nr * nc);
+    else if (!strcmp(x->klass, "dgCMatrix"))
+    {
+        const int *pp = (const int *)R_do_slot(x, Rf_install("p"))->data, *ii = (const int *)R_do_slot(x, Rf_install("i"))->data;
+        for (int c = 0; c < nc; c++)
+            for (int e = pp[c]; e < pp[c + 1]; e++)
+                d[ii[e] + (size_t)nr * c] += v[e];
+    }
+    else if (!strcmp(x->klass, "dgRMatrix"))
+    {
+        const int *pp = (const int *)R_do_slot(x, Rf_install("p"))->data, *jj = (const int *)R_do_slot(x, Rf_install("j"))->data;
+        for (int r = 0; r < nr; r++)
+            for (int e = pp[r]; e < pp[r + 1]; e++)
+                d[r + (size_t)nr * jj[e]] += v[e];
+    }
+    else
+    {
+        const int *ii = (const int *)R_do_slot(x, Rf_install("i"))->data, *jj = (const int *)R_do_slot(x, Rf_install("j"))->data;
+        for (int e = 0; e < xs->len; e++)
+            d[ii[e] + (size_t)nr * jj[e]] += v[e];
+    }
+    return m;
+}
 R_len_t Rf_length(SEXP x) { return x->len; }
 int Rf_nrows(SEXP x) { return x->dim != R_NilValue ? ((int *)x->dim->data)[0] : x->len; }
 int Rf_ncols(SEXP x) { return x->dim != R_NilValue ? ((int *)x->dim->data)[1] : 1; }
@@ -237,7 +284,7 @@ Rboolean Rf_isString(SEXP x) { return x->type == STRSXP ? TRUE : FALSE; }
 Rboolean Rf_isFunction(SEXP x) { return x->type == CLOSXP ? TRUE : FALSE; }
 Rboolean Rf_isEnvironment(SEXP x) { return x->type == ENVSXP ? TRUE : FALSE; }
 Rboolean Rf_isNewList(SEXP x) { return x->type == VECSXP ? TRUE : FALSE; }
-Rboolean Rf_inherits(SEXP x, const char *c) { (void)x; (void)c; return FALSE; }
+Rboolean Rf_inherits(SEXP x, const char *c) { return (x->klass && !strcmp(x->klass, c)) ? TRUE : FALSE; }
 int TYPEOF(SEXP x) { return x->type; }
 double *REAL(SEXP x) { return (double *)x->data; }
 int *INTEGER(SEXP x) { return (int *)x->data; }
@@ -295,7 +342,23 @@ SEXP C_nls(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP swts,
     return R_NilValue;
 }
 
+SEXP C_nls_large(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP weights, SEXP control_int, SEXP control_dbl)
+{
+    (void)fn; (void)y; (void)jac; (void)fvv; (void)env; (void)start; (void)weights; (void)control_int; (void)control_dbl;
+    fell_through += 1;
+    return R_NilValue;
+}
+
 /* ---- what the test builds its arguments with and reads the answer by ---- */
+SEXP rm_s4(const char *klass, SEXP named_slots)
+{
+    SEXP s = new_rec(25 /* S4SXP */, 0, 0);
+    char *k = (char *)malloc(strlen(klass) + 1);
+    strcpy(k, klass);
+    s->klass = k;
+    s->slots = named_slots;
+    return s;
+}
 SEXP rm_nil(void) { return R_NilValue; }
 SEXP rm_real(int n, const double *v)
 {

@@ -36,6 +36,7 @@ def rshim(amd):
     cmd = ["gcc", "-std=gnu11", "-Wall", "-O1", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "tests", "r_stub"),
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "integration", "r_shim"),
            os.path.join(ROOT, "tests", "r_mini", "rmini.c"), os.path.join(ROOT, "integration", "r_shim", "gslnls_hip_shim.c"),
+           os.path.join(ROOT, "integration", "r_shim", "gslnls_hip_large_shim.c"),
            "-o", so, "-L" + os.path.join(ROOT, "gslnls_amd"), "-lgslnls_hip", "-Wl,-rpath," + os.path.join(ROOT, "gslnls_amd")]
     subprocess.run(cmd, check=True, capture_output=True)
     L = C.CDLL(so)
@@ -49,7 +50,7 @@ def rshim(amd):
                             ("rm_string", C.c_char_p, [P, C.c_int]), ("rm_names", P, [P]), ("rm_dimnames", P, [P]),
                             ("rm_nrow", C.c_int, [P]), ("rm_ncol", C.c_int, [P]), ("rm_warnings", C.c_char_p, []),
                             ("rm_printed", C.c_char_p, []), ("rm_fell_through", C.c_int, []), ("rm_reset", None, []),
-                            ("C_nls_hip", P, [P] * 12)]:
+                            ("rm_s4", P, [C.c_char_p, P]), ("C_nls_hip", P, [P] * 12), ("C_nls_large_hip", P, [P] * 9)]:
         f = getattr(L, name)
         f.restype, f.argtypes = res, args
     return L
@@ -190,3 +191,82 @@ def test_par_as_a_list_of_scalars_when_start_was_a_list(amd, rshim):
     assert seen.get("par_is_list") and seen["names"] == ["p0", "p%d" % (len(start) - 1)]
     ref = amd.gsl_nls(model, y=y, start=start, jac=jac, control=dict(solver="cholesky"))
     assert L.rm_int_ptr(L.rm_list_get(ans, 6))[0] == 0 and np.array_equal(_vec(L, L.rm_list_get(ans, 0)), np.asarray(ref["par"]))
+
+
+def _int(L, v, logical=0):
+    v = np.ascontiguousarray(v, dtype=np.int32)
+    return L.rm_int(len(v), v.ctypes.data_as(C.c_void_p), logical)
+
+
+@pytest.mark.parametrize("kind,alg", [("dgCMatrix", "cgst"), ("dgCMatrix", "lm"), ("dgRMatrix", "cgst"), ("matrix", "cgst")])
+def test_gsl_nls_large_through_the_large_shim(amd, rshim, kind, alg):
+    """.Call(C_nls_large, ...) (src/nls_large.c:66-75) on the reference's own sparse example (README.md:1040-1146, penalty function I,
+    p = 500): the Jacobian closure returns a Matrix-package object -- its slots read in place by the shim -- or a base matrix;
+    the answer is the list of src/nls_large.c:275-416, `grad` = as.matrix() of the last Jacobian, numbers bit for bit the
+    mirror's call of the same core."""
+    import scipy.sparse as sp
+    from gslnls_amd.control import gsl_nls_control
+    from gslnls_amd.nls_large import pack_control_large
+    L = rshim
+    p = 500
+    a = np.sqrt(1e-5)
+    J0 = sp.vstack([sp.identity(p, format="csr") * a, sp.csr_matrix(np.ones((1, p)))])
+    J0 = (J0.tocsr() if kind == "dgRMatrix" else J0.tocsc())
+    J0.sort_indices()
+    last = np.flatnonzero(J0.indices == p) if kind != "dgRMatrix" else np.arange(J0.indptr[p], J0.indptr[p + 1])
+    names = ["x%d" % (k + 1) for k in range(p)]
+    nm = _strs(L, names)
+    seen = {}
+
+    def fn(th):
+        return np.concatenate([a * (th - 1.0), [np.sum(th ** 2) - 0.25]])
+
+    def jac_py(th):
+        J0.data[last] = 2.0 * th
+        return J0
+
+    def f_cb(args, nargs, user):
+        seen.setdefault("names", [L.rm_string(L.rm_names(args[0]), k).decode() for k in (0, p - 1)])
+        return _real(L, fn(_vec(L, args[0])))
+
+    def j_cb(args, nargs, user):
+        J = jac_py(_vec(L, args[0]))
+        if kind == "matrix":
+            D = np.asfortranarray(J.toarray())
+            s = _real(L, D.reshape(-1, order="F"))
+            L.rm_set_dim(s, p + 1, p, L.rm_nil(), L.rm_nil())
+            return s
+        slots = L.rm_list(4)
+        L.rm_list_set(slots, 0, _int(L, J.indices))
+        L.rm_list_set(slots, 1, _int(L, J.indptr))
+        L.rm_list_set(slots, 2, _real(L, J.data))
+        L.rm_list_set(slots, 3, _int(L, [p + 1, p]))
+        L.rm_set_names(slots, _strs(L, ["j" if kind == "dgRMatrix" else "i", "p", "x", "Dim"]))
+        return L.rm_s4(kind.encode(), slots)
+    keep = [CB(f_cb), CB(j_cb)]
+    env = L.rm_env()
+    fn_s = L.rm_closure(C.cast(keep[0], C.c_void_p), None, env)
+    jac_s = L.rm_closure(C.cast(keep[1], C.c_void_p), None, env)
+    ci, cd = pack_control_large(gsl_nls_control(maxiter=500), alg, False)
+    st = _real(L, np.arange(1.0, p + 1))
+    L.rm_set_names(st, nm)
+    L.rm_reset()
+    ans = L.C_nls_large_hip(fn_s, _real(L, np.zeros(p + 1)), jac_s, L.rm_nil(), env, st, L.rm_nil(), _int(L, ci), _real(L, cd))
+    assert L.rm_fell_through() == 0 and seen["names"] == ["x1", "x%d" % p]
+    assert _slots(L, ans) == ["par", "covar", "resid", "grad", "niter", "status", "conv", "ssr", "ssrtol", "algorithm", "neval"]
+    ref = amd.gsl_nls_large(fn, y=np.zeros(p + 1), start=np.arange(1.0, p + 1), algorithm=alg,
+                            jac=(lambda th: np.asfortranarray(jac_py(th).toarray())) if kind == "matrix" else jac_py,
+                            control=dict(maxiter=500))
+    par = _vec(L, L.rm_list_get(ans, 0))
+    assert L.rm_int_ptr(L.rm_list_get(ans, 6))[0] == 0 and np.array_equal(par, np.asarray(ref["par"]))
+    assert L.rm_int_ptr(L.rm_list_get(ans, 4))[0] == ref["niter"] and abs(L.rm_real_ptr(L.rm_list_get(ans, 7))[0] - 0.004778845) < 5e-10
+    assert L.rm_string(L.rm_list_get(ans, 9), 0).decode() == ref["algorithm"]
+    grad = L.rm_list_get(ans, 3)
+    assert (L.rm_nrow(grad), L.rm_ncol(grad)) == (p + 1, p)
+    assert np.array_equal(_vec(L, grad).reshape(p + 1, p, order="F"), jac_py(par).toarray())
+    assert L.rm_string(L.rm_list_get(L.rm_dimnames(grad), 1), p - 1).decode() == "x%d" % p
+    ne = L.rm_list_get(ans, 10)
+    assert [L.rm_string(L.rm_names(ne), k).decode() for k in range(4)] == ["f", "dfu", "df2", "fvv"]
+    assert [L.rm_int_ptr(ne)[k] for k in range(3)] == [ref["neval"]["f"], ref["neval"]["dfu"], ref["neval"]["df2"]]
+    cov = _vec(L, L.rm_list_get(ans, 1)).reshape(p, p, order="F")
+    assert np.array_equal(cov, np.asarray(ref["covar"]))
