@@ -187,8 +187,23 @@ SEXP R_tryEval(SEXP call, SEXP rho, int *err)
     (void)rho;
     if (err)
         *err = 0;
-    if (call->type == LANGSXP && ((SEXP *)call->data)[0]->type == SYMSXP && !strcmp((const char *)((SEXP *)call->data)[0]->data, "as.matrix"))
-        return rm_as_matrix(((SEXP *)call->data)[1]); /* (the one base function the large shim asks R for) */
+    if (call->type == LANGSXP && ((SEXP *)call->data)[0]->type == SYMSXP)
+    {
+        /* the four base functions the shims ask R for: as.matrix(J); quote(e), deparse1(quote(e)), all.vars(quote(e)) with e
+         * the right-hand side of a formula -- here an object made by rm_expr that carries its own text and symbols */
+        const char *f = (const char *)((SEXP *)call->data)[0]->data;
+        SEXP a = ((SEXP *)call->data)[1];
+        if (!strcmp(f, "as.matrix"))
+            return rm_as_matrix(a);
+        if (a->type == LANGSXP && ((SEXP *)a->data)[0]->type == SYMSXP && !strcmp((const char *)((SEXP *)a->data)[0]->data, "quote"))
+            a = ((SEXP *)a->data)[1];
+        if (!strcmp(f, "quote"))
+            return a;
+        if (a->type == 99 && !strcmp(f, "deparse1"))
+            return Rf_mkString((const char *)a->data);
+        if (a->type == 99 && !strcmp(f, "all.vars"))
+            return a->slots;
+    }
     if (call->type != LANGSXP || ((SEXP *)call->data)[0]->type != CLOSXP)
     {
         fprintf(stderr, "rmini: only calls of rm_closure objects can be evaluated (the formula route of the shim needs R itself)\n");
@@ -350,6 +365,24 @@ SEXP C_nls_large(SEXP fn, SEXP y, SEXP jac, SEXP fvv, SEXP env, SEXP start, SEXP
 }
 
 /* ---- what the test builds its arguments with and reads the answer by ---- */
+/* the right-hand side of a formula as R would hold it, reduced to what the shims ask about it: its text (deparse1) and its
+ * symbols in order of appearance (all.vars) */
+SEXP rm_expr(const char *text, SEXP vars)
+{
+    SEXP s = new_rec(99, 0, strlen(text) + 1);
+    strcpy((char *)s->data, text);
+    s->slots = vars;
+    return s;
+}
+SEXP rm_formula(SEXP lhs, SEXP rhs) { return lang(3, Rf_install("~"), lhs, rhs); }
+void rm_env_set(SEXP env, const char *name, SEXP value)
+{
+    if (env->len >= 16)
+        abort();
+    ((SEXP *)env->data)[2 * env->len] = Rf_install(name);
+    ((SEXP *)env->data)[2 * env->len + 1] = value;
+    env->len += 1;
+}
 SEXP rm_s4(const char *klass, SEXP named_slots)
 {
     SEXP s = new_rec(25 /* S4SXP */, 0, 0);

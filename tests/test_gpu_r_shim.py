@@ -50,7 +50,8 @@ def rshim(amd):
                             ("rm_string", C.c_char_p, [P, C.c_int]), ("rm_names", P, [P]), ("rm_dimnames", P, [P]),
                             ("rm_nrow", C.c_int, [P]), ("rm_ncol", C.c_int, [P]), ("rm_warnings", C.c_char_p, []),
                             ("rm_printed", C.c_char_p, []), ("rm_fell_through", C.c_int, []), ("rm_reset", None, []),
-                            ("rm_s4", P, [C.c_char_p, P]), ("C_nls_hip", P, [P] * 12), ("C_nls_large_hip", P, [P] * 9)]:
+                            ("rm_s4", P, [C.c_char_p, P]), ("rm_expr", P, [C.c_char_p, P]), ("rm_formula", P, [P, P]),
+                            ("rm_env_set", None, [P, C.c_char_p, P]), ("C_nls_hip", P, [P] * 12), ("C_nls_large_hip", P, [P] * 9)]:
         f = getattr(L, name)
         f.restype, f.argtypes = res, args
     return L
@@ -270,3 +271,61 @@ def test_gsl_nls_large_through_the_large_shim(amd, rshim, kind, alg):
     assert [L.rm_int_ptr(ne)[k] for k in range(3)] == [ref["neval"]["f"], ref["neval"]["dfu"], ref["neval"]["df2"]]
     cov = _vec(L, L.rm_list_get(ans, 1)).reshape(p, p, order="F")
     assert np.array_equal(cov, np.asarray(ref["covar"]))
+
+
+def _formula_env(L, rhs, data):
+    """the frame gsl_nls.formula evaluates .fn in (R/nls.R:565): it binds `formula` and the model frame `mf`"""
+    from gslnls_amd import formula as F
+    env = L.rm_env()
+    vars_ = F.symbols(F.parse_expr(rhs))
+    L.rm_env_set(env, b"formula", L.rm_formula(L.rm_nil(), L.rm_expr(rhs.encode(), _strs(L, vars_))))
+    mf = L.rm_list(len(data))
+    for k, (name, col) in enumerate(data.items()):
+        L.rm_list_set(mf, k, _real(L, col))
+    L.rm_set_names(mf, _strs(L, list(data)))
+    L.rm_env_set(env, b"mf", mf)
+    return env
+
+
+@pytest.mark.parametrize("rhs,start", [
+    ("A * exp(-lam * x) + b", {"b": 0.0, "A": 1.0, "lam": 1.0}),         # a hand-written device model, parameters in another order
+    ("a * exp(-b * x) + c * sin(d * x)", {"a": 4.0, "b": 1.0, "c": 0.4, "d": 2.9}),  # the expression itself (GSLNLS_MODEL_EXPR)
+])
+def test_formula_route_of_the_shim(amd, rshim, rhs, start):
+    """gsl_nls(y ~ f(x, theta), data, start): the shim finds `formula` and `mf` in the closure's frame, asks R for the text and the
+    symbols of the right-hand side (here: rmini's stand-ins for deparse1 / all.vars), lowers the formula, takes the data
+    columns out of the model frame, permutes start into the device model's parameter order and the result back -- no closure is
+    evaluated.  Bit for bit the mirror's gsl_nls(formula)."""
+    from gslnls_amd.control import gsl_nls_control, pack_control
+    L = rshim
+    n = 400
+    rng = np.random.default_rng(5)
+    x = np.linspace(0.0, 3.0, n)
+    if "sin" in rhs:
+        y = 5.0 * np.exp(-1.5 * x) + 0.5 * np.sin(3.0 * x) + 0.01 * rng.standard_normal(n)
+    else:
+        y = 5.0 * np.exp(-1.5 * x) + 1.0 + 0.01 * rng.standard_normal(n)
+    names = list(start)
+    p = len(names)
+    env = _formula_env(L, rhs, {"y": y, "x": x})
+    called = []
+    cb = CB(lambda args, nargs, user: called.append(1) or None)
+    fn_s = L.rm_closure(C.cast(cb, C.c_void_p), None, env)
+    ci, cd = pack_control(gsl_nls_control(), "lm", False, True, False)
+    st = _real(L, list(start.values()))
+    L.rm_set_names(st, _strs(L, names))
+    loss = L.rm_list(2)
+    L.rm_list_set(loss, 0, _int(L, [0]))
+    L.rm_list_set(loss, 1, _real(L, [0.0]))
+    L.rm_reset()
+    ans = L.C_nls_hip(fn_s, _real(L, y), L.rm_nil(), L.rm_nil(), env, st, L.rm_nil(), L.rm_nil(), _int(L, ci), _real(L, cd),
+                      _int(L, np.ones(p), 1), loss)
+    assert L.rm_fell_through() == 0 and not called and L.rm_warnings() == b""
+    ref = amd.gsl_nls("y ~ " + rhs, data=dict(x=x, y=y), start=start)
+    par = L.rm_list_get(ans, 0)
+    assert [L.rm_string(L.rm_names(par), k).decode() for k in range(p)] == names
+    assert L.rm_int_ptr(L.rm_list_get(ans, 6))[0] == 0 and L.rm_int_ptr(L.rm_list_get(ans, 4))[0] == ref["niter"]
+    assert np.array_equal(_vec(L, par), np.asarray(ref["par"]))
+    assert np.array_equal(_vec(L, L.rm_list_get(ans, 1)).reshape(p, p, order="F"), np.asarray(ref["covar"]))
+    assert np.array_equal(_vec(L, L.rm_list_get(ans, 3)).reshape(n, p, order="F"), np.asarray(ref["grad"]))
+    assert np.array_equal(_vec(L, L.rm_list_get(ans, 2)), np.asarray(ref["resid"]))
