@@ -943,28 +943,38 @@ __device__ __forceinline__ void cholb_panel4_body(const double *Lt, CholbPub &P,
             return;
         if (bad && lane == 0)
             *flag = 1;
-        if (wave != 0)
-            return;
-        // the right-hand side rides along as one more row of the matrix: its slice of this step, L11 y = b
-        while (__hip_atomic_load(&ready_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < CB)
-            __builtin_amdgcn_s_sleep(2);
-        double v = lane < nb ? (yhead ? yhead[lane] : yv[k0 + lane]) : 0.0;
-        for (int j = 0; j < nb; ++j)
-        {
-            const double rs = P.invd[j];
-            const double yj = wide_bcast(v, j) * rs;
-            if (lane == j)
-                v = yj;
-            else if (lane > j && lane < nb)
-                v -= __dmul_rn(P.V[j * CB + lane], rs) * yj;
-        }
-        if (lane < nb)
-            yv[k0 + lane] = v;
         return;
     }
     if (blockIdx.x == 0)
     {
-        // workgroup 0 has no rows of the panel: its wavefronts 4 .. 7 store L11 once it is complete
+        // workgroup 0 has no rows of the panel.  Its fifth wavefront takes the right-hand side through this step -- it rides
+        // along as one more row of the matrix: L11 y = b for its slice -- A COLUMN BEHIND the factorisation, like the panel
+        // rows of the other workgroups.  (Until the end of round 5 the first wavefront did this AFTER its part of the
+        // factorisation and after the last column: 64 dependent steps of two LDS reads, a broadcast and a multiply-add,
+        // 280 clocks each -- in-kernel stamps: 18 k of the launch's 47 k clocks, the tail every panel step waited for.)
+        if (wave == 4)
+        {
+            double v = lane < nb ? (yhead ? yhead[lane] : yv[k0 + lane]) : 0.0;
+            int seen = 0;
+            for (int j = 0; j < nb; ++j)
+            {
+                while (seen <= j)
+                {
+                    seen = __hip_atomic_load(&ready_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (seen <= j)
+                        __builtin_amdgcn_s_sleep(1);
+                }
+                const double rs = P.invd[j];
+                const double yj = wide_bcast(v, j) * rs;
+                if (lane == j)
+                    v = yj;
+                else if (lane > j && lane < nb)
+                    v -= __dmul_rn(P.V[j * CB + lane], rs) * yj;
+            }
+            if (lane < nb)
+                yv[k0 + lane] = v;
+        }
+        // ... and wavefronts 4 .. 7 store L11 once it is complete
         while (__hip_atomic_load(&ready_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < CB)
             __builtin_amdgcn_s_sleep(4);
         for (int e = tid - 256; e < CB * CB; e += CBQ_T - 256)
