@@ -1446,7 +1446,7 @@ __device__ __forceinline__ void cholb_back_steps(double &v, double di, const dou
 // segment's contributions from cholb_backupd_kernel, spread over many workgroups -- as ONE workgroup the update of all
 // p^2 / 2 entries of L^T was 0.47 ms of a 1.55 ms solve at p = 2000.  Same sums in the same order whichever way it is cut.
 __global__ __launch_bounds__(CBA_T) void cholb_backall_kernel(const double *Lf, int p, double *yv, double *sol,
-                                                              const double *dinvg, int kb_lo, int kb_hi)
+                                                              const double *dinvg, int kb_lo, int kb_hi, int pipelined)
 {
     extern __shared__ double ys_seg[]; // 64 (kb_hi - kb_lo) doubles: y of the segment (zeros behind p), block by block overwritten by x
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1471,6 +1471,68 @@ __global__ __launch_bounds__(CBA_T) void cholb_backall_kernel(const double *Lf, 
         load_block(nblk - 1 - wave);
     __syncthreads();
     constexpr int H = 16; // rows of L per round of loads in the update
+    // y[j] -= sum_r L[k0 + r][j] x_r, r ascending, for one component j of the segment in front of block (k0, nb): the sums of
+    // every form of this kernel
+    auto take_out = [&](int j, int k0, int nb) -> double {
+        double s0 = 0.0;
+#pragma unroll 1
+        for (int r0 = 0; r0 < CB; r0 += H)
+        {
+            double lv[H];
+#pragma unroll
+            for (int r = 0; r < H; ++r)
+                lv[r] = r0 + r < nb ? Lf[(size_t)(k0 + r0 + r) * p + j] : 0.0;
+#pragma unroll
+            for (int r = 0; r < H; ++r)
+                s0 += lv[r] * ys[k0 + r0 + r];
+        }
+        return s0;
+    };
+    if (pipelined)
+    {
+        // Round 5, end: the blocks one behind the other WITHOUT the workgroup waiting for each block's update.  While seven
+        // wavefronts take x of block kb out of the components further in front, the eighth -- the one whose turn is next --
+        // takes it out of the 64 components of block kb - 1 only and solves that block at once: a block costs its 64
+        // components' update + its triangle (3 us) instead of triangle, barrier, the whole update, barrier (5.9 us).  Every
+        // component receives the same sums in the same order.
+        if (wave == 0)
+        {
+            const int kb = nblk - 1, k0 = kb * CB, nb = p - k0 < CB ? p - k0 : CB;
+            double v = lane < nb ? ys[k0 + lane] : 0.0;
+            cholb_back_steps<CB - 1>(v, di, c, lane);
+            if (lane < nb)
+            {
+                ys[k0 + lane] = v;
+                sol[k0 + lane] = v;
+            }
+            if (CBA_W < nseg)
+                load_block(nblk - 1 - CBA_W);
+        }
+        __syncthreads();
+        for (int s = 0; s + 1 < nseg; ++s)
+        {
+            const int kb = nblk - 1 - s, k0 = kb * CB, nb = p - k0 < CB ? p - k0 : CB; // x of this block is in ys
+            const int kn0 = k0 - CB;                                                   // the next block: always a full one
+            const int wn = (s + 1) % CBA_W;
+            if (wave == wn)
+            {
+                double v = ys[kn0 + lane] - take_out(kn0 + lane, k0, nb);
+                cholb_back_steps<CB - 1>(v, di, c, lane);
+                ys[kn0 + lane] = v;
+                sol[kn0 + lane] = v;
+                if (s + 1 + CBA_W < nseg)
+                    load_block(nblk - 1 - (s + 1 + CBA_W)); // this wavefront's next block: eight turns to arrive
+            }
+            else
+            {
+                const int rank = wave < wn ? wave : wave - 1; // 0 .. 6 among the seven
+                for (int j = jbase + rank * 64 + lane; j < kn0; j += (CBA_W - 1) * 64)
+                    ys[j] -= take_out(j, k0, nb);
+            }
+            __syncthreads();
+        }
+        return;
+    }
     for (int s = 0; s < nseg; ++s)
     {
         const int kb = nblk - 1 - s, k0 = kb * CB, nb = p - k0 < CB ? p - k0 : CB;
@@ -1924,6 +1986,7 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
             // a barrier packet whose latency exceeds the 7-10 us of trailing update it hides.  Off by default.
             const bool lookahead = getenv("GSLNLS_LARGE_LOOKAHEAD") != nullptr;
             const bool back_v1 = getenv("GSLNLS_LARGE_BACK_V1") != nullptr; // (developer switch: the one-workgroup back substitution, same bits)
+            const bool back_pipe = getenv("GSLNLS_LARGE_BACK_STEPWISE") == nullptr; // (developer switch off: a block's update between two barriers, same bits)
             int nrest = 0; // launches on the second stream so far
             // round 5: from the second panel on, ONE launch per step -- the panel with its inputs updated on the fly beside
             // the rest of the previous panel's trailing update (cholb_step_kernel).  GSLNLS_LARGE_STEP_V1=1: panel and
@@ -2002,7 +2065,7 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
                 {
                     const int lo = hi - seg > 0 ? hi - seg : 0;
                     hipLaunchKernelGGL(cholb_backall_kernel, dim3(1), dim3(CBA_T), sizeof(double) * (size_t)CB * (hi - lo), sq, B.Lg, p, d_work,
-                                       d_sol, a.dinv, lo, hi);
+                                       d_sol, a.dinv, lo, hi, back_pipe ? 1 : 0);
                     if (lo > 0 && getenv("GSLNLS_LARGE_BACKUPD_V1")) // (developer switch: the blocks of a segment one after the other, same bits)
                         hipLaunchKernelGGL(cholb_backupd_kernel, dim3((lo * CB + 63) / 64), dim3(64), 0, sq, B.Lg, p, d_work, d_sol, lo, hi);
                     else if (lo > 0)
