@@ -2060,7 +2060,11 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
                 const int nblk = (p + CB - 1) / CB;
                 // (measured, gpurun_out mchol_r05_d.txt: up to 8 blocks one segment is fastest -- p = 500: 0.260 ms against 0.265
                 // cut in two --, from 16 blocks on the cut pays: p = 1000 0.536 against 0.577, p = 2000 1.16 against 1.39)
-                const int seg = back_v1 ? nblk : (nblk <= 8 ? nblk : (nblk <= 16 ? (nblk + 1) / 2 : (nblk + 3) / 4));
+                // (measured again with the pipelined walk, gpurun_out r05: 22 blocks 0.740 ms cut in six, 0.715 in eleven; 32 blocks
+                // 1.080 / 1.077 / 1.088 at 8 / 11 / 16; 64 blocks 2.750 / 2.743 / 2.752 / 2.908 at 8 / 11 / 16 / 32)
+                int seg = back_v1 ? nblk : (nblk <= 8 ? nblk : (nblk <= 16 ? (nblk + 1) / 2 : 11));
+                if (const char *e = getenv("GSLNLS_LARGE_BACK_SEG")) // (developer switch: blocks per segment)
+                    seg = atoi(e) > 0 ? (atoi(e) < nblk ? atoi(e) : nblk) : seg;
                 for (int hi = nblk; hi > 0; hi -= seg)
                 {
                     const int lo = hi - seg > 0 ? hi - seg : 0;
