@@ -1376,6 +1376,228 @@ __global__ __launch_bounds__(CBQ_T) void cholb_step_kernel(double *W, double *Lf
     cholb_panel4_body(Lt, P, &ready_s, rr, Lf, p, k0, nb, r0, prow, cls, dorig, flag, yv, dinvg, yhead_s);
 }
 
+// rhs | diag of a solve in the KERNEL ARGUMENTS (p <= CBV_MAX): see cholb_init_arg_kernel
+constexpr int CBV_MAX = 224;
+struct CholbVecArg
+{
+    double v[2 * CBV_MAX]; // rhs[0 .. p) | diag[0 .. p)
+};
+
+// ---- round 5: 64 < p <= 128 in ONE launch ---------------------------------------------------------------------------------------
+// Two panels: init, panel, step were three launches of 8 + 20 + 21 us for work whose dependent part is two chains of 64 pivots
+// (11 us each).  Here one workgroup of nine wavefronts does all of it without going back to memory in between: W = J^T J +
+// mu D^2 straight from J^T J and the kernel arguments (rhs | diag), panel 0 (wavefronts 0 - 3 factor, 4 - 7 solve rows 64 ..
+// p - 1 a column behind, wavefront 8 takes the right-hand side through), L10 staged in LDS, the (1, 1) tile and the right-hand
+// side's second slice updated from it (the tile arithmetic of cholb_trail_kernel / cholb_step_kernel), panel 1.  The same
+// device functions on the same operands in the same order as the general path: same bits (GSLNLS_LARGE_SMALL_OFF=1 keeps the
+// three launches).  L, 1 / L_jj and y are left where the back substitution and a caller's tail expect them.
+constexpr int CBS_T = 576;
+__global__ __launch_bounds__(CBS_T) void cholb_small_kernel(const double *src, int p, CholbVecArg va, double mu, double *Lf, double *yv,
+                                                            double *dinvg, int *flag)
+{
+    __shared__ double Lt[CB * CB_LD];
+    __shared__ __attribute__((aligned(16))) double stage[CB * CBT_LD];
+    __shared__ CholbPub P;
+    __shared__ double dor[2 * CB], ys[2 * CB];
+    __shared__ int ready_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, ii = lane & 15;
+    const double *rhs = va.v, *dmp = va.v + p;
+    const int nb2 = p - CB; // 1 .. 64 columns in the second block
+    if (tid == 0)
+    {
+        ready_s = 0;
+        *flag = 0;
+    }
+    for (int r = tid; r < 2 * CB; r += CBS_T)
+    {
+        const double a = src[r < p ? (size_t)r * p + r : 0], d = dmp[r < p ? r : 0];
+        dor[r] = r < p ? __dadd_rn(a, __dmul_rn(__dmul_rn(mu, d), d)) : 0.0;
+        ys[r] = r < p ? rhs[r] : 0.0;
+    }
+    {
+        // the diagonal tile (0, 0), lower triangle; every load before the first wait
+        constexpr int NL = (CB * CB + CBS_T - 1) / CBS_T;
+        double dv[NL];
+#pragma unroll
+        for (int it = 0; it < NL; ++it)
+        {
+            const int e = tid + CBS_T * it, i = e >> 6, j = e & 63;
+            dv[it] = src[(e < CB * CB && j <= i) ? (size_t)i * p + j : 0];
+        }
+#pragma unroll
+        for (int it = 0; it < NL; ++it)
+        {
+            const int e = tid + CBS_T * it, i = e >> 6, j = e & 63;
+            if (e < CB * CB)
+            {
+                double x = dv[it];
+                if (i == j)
+                    x = __dadd_rn(x, __dmul_rn(__dmul_rn(mu, dmp[i]), dmp[i]));
+                Lt[i * CB_LD + j] = j <= i ? x : 0.0;
+            }
+        }
+    }
+    // rows 64 .. p - 1 of column block 0: thread (row = 16 (wave - 4) + lane % 16, class = lane / 16) of wavefronts 4 .. 7
+    const int prow = 16 * (wave - 4) + (lane & 15), cls = lane >> 4;
+    double rr[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+    {
+        const int c = cls + 4 * q;
+        const bool ok = wave >= 4 && wave < 8 && CB + prow < p;
+        rr[q] = src[ok ? (size_t)(CB + prow) * p + c : 0];
+        rr[q] = ok ? rr[q] : 0.0;
+    }
+    __syncthreads();
+    // ---- panel 0 ----
+    auto rhs_slice = [&](int k0, int nb) {
+        // L y = b for the slice of this panel, a column behind the factorisation (wavefront 8)
+        double v = lane < nb ? ys[k0 + lane] : 0.0;
+        int seen = 0;
+        for (int j = 0; j < nb; ++j)
+        {
+            while (seen <= j)
+            {
+                seen = __hip_atomic_load(&ready_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (seen <= j)
+                    __builtin_amdgcn_s_sleep(1);
+            }
+            const double rs = P.invd[j];
+            const double yj = wide_bcast(v, j) * rs;
+            if (lane == j)
+                v = yj;
+            else if (lane > j && lane < nb)
+                v -= __dmul_rn(P.V[j * CB + lane], rs) * yj;
+        }
+        if (lane < nb)
+            ys[k0 + lane] = v;
+    };
+    auto factor = [&](int k0, int nb) -> bool {
+        __builtin_amdgcn_s_setprio(3);
+        bool bad;
+        switch (wave)
+        {
+        case 0: bad = cholb_diag_wave<0>(Lt, P, &ready_s, dor, k0, nb, lane); break;
+        case 1: bad = cholb_diag_wave<1>(Lt, P, &ready_s, dor, k0, nb, lane); break;
+        case 2: bad = cholb_diag_wave<2>(Lt, P, &ready_s, dor, k0, nb, lane); break;
+        default: bad = cholb_diag_wave<3>(Lt, P, &ready_s, dor, k0, nb, lane); break;
+        }
+        __builtin_amdgcn_s_setprio(0);
+        return bad;
+    };
+    if (wave < 4)
+    {
+        if (factor(0, CB) && lane == 0)
+            *flag = 1;
+    }
+    else if (wave < 8)
+        cholb_trsm_steps_v<0>(rr, P, lane & 15, cls, &ready_s, 0);
+    else
+        rhs_slice(0, CB);
+    __syncthreads();
+    // ---- L11, L10 and 1 / L_jj out; L10 staged; what the (1, 1) tile starts from ----
+    for (int e = tid; e < CB * CB; e += CBS_T)
+    {
+        const int i = e >> 6, j = e & 63;
+        if (j <= i)
+            Lf[(size_t)i * p + j] = i == j ? P.ldiag[j] : __dmul_rn(P.V[j * CB + i], P.invd[j]);
+    }
+    if (tid < CB)
+        dinvg[tid] = P.invd[tid];
+    if (wave >= 4 && wave < 8)
+    {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+        {
+            const int c = cls + 4 * q;
+            stage[prow * CBT_LD + c] = rr[q]; // (zero for the rows behind p)
+            if (CB + prow < p)
+                Lf[(size_t)(CB + prow) * p + c] = rr[q];
+        }
+    }
+    double wv[16];
+    if (wave < 4)
+    {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+                const int i = wave * 16 + 4 * r + kk, j = b * 16 + ii;
+                const bool ok = i < nb2 && j <= i;
+                double x = src[ok ? (size_t)(CB + i) * p + CB + j : 0];
+                if (ok && i == j)
+                    x = __dadd_rn(x, __dmul_rn(__dmul_rn(mu, dmp[CB + i]), dmp[CB + i]));
+                wv[b * 4 + r] = x;
+            }
+    }
+    __syncthreads();
+    if (tid == 0)
+        ready_s = 0;
+    if (wave < 4)
+    {
+        cb_v4f64 acc[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            acc[b] = (cb_v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+        for (int c = 0; c < 16; ++c)
+        {
+            const double vaa = stage[(wave * 16 + ii) * CBT_LD + c * 4 + kk];
+            double vb[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                vb[b] = stage[(b * 16 + ii) * CBT_LD + c * 4 + kk];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(vaa, vb[b], acc[b], 0, 0, 0);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+                const int i = wave * 16 + 4 * r + kk, j = b * 16 + ii;
+                const double u = wv[b * 4 + r] - acc[b][r];
+                Lt[i * CB_LD + j] = (i < nb2 && j <= i) ? u : (i == j ? 1.0 : 0.0);
+            }
+    }
+    else if (wave == 8)
+    {
+        // the right-hand side's second slice through the update: y[i] -= L[i][0 .. 63] . y[0 .. 63], the sums of cholb_row_dot
+        double rv[CB];
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+            rv[c] = stage[lane * CBT_LD + c];
+        double s0 = 0.0;
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+            s0 += rv[c] * ys[c];
+        if (lane < nb2)
+            ys[CB + lane] = ys[CB + lane] - s0;
+    }
+    __syncthreads();
+    // ---- panel 1 ----
+    if (wave < 4)
+    {
+        if (factor(CB, nb2) && lane == 0)
+            *flag = 1;
+    }
+    else if (wave == 8)
+        rhs_slice(CB, nb2);
+    __syncthreads();
+    for (int e = tid; e < CB * CB; e += CBS_T)
+    {
+        const int i = e >> 6, j = e & 63;
+        if (i < nb2 && j <= i)
+            Lf[(size_t)(CB + i) * p + CB + j] = i == j ? P.ldiag[j] : __dmul_rn(P.V[j * CB + i], P.invd[j]);
+    }
+    if (tid < nb2)
+        dinvg[CB + tid] = P.invd[tid];
+    for (int r = tid; r < p; r += CBS_T)
+        yv[r] = ys[r];
+}
+
 // One block of the back substitution L^T x = y (blocks from the last to the first): every workgroup solves the block's
 // 64 x 64 transposed triangle for x_k (redundantly: same bits, no hand-off); workgroup 0 stores x_k, workgroup g > 0
 // takes x_k out of 256 of the components in front of the block: y[j] -= sum_r L[k0 + r][j] x_r (coalesced over j).
@@ -1725,11 +1947,6 @@ __global__ __launch_bounds__(256) void cholb_init_kernel(const double *src, doub
 // cholb_init_kernel with rhs | diag in the KERNEL ARGUMENTS (round 5, p <= CBV_MAX): the 2 p doubles travel with the launch
 // packet instead of being read by the kernel through the staging area's mapping -- a PCIe round trip in front of every
 // damped solve of the matrix path (init 6 -> 12 us when the copy-engine upload was dropped; back to 6 with this)
-constexpr int CBV_MAX = 224;
-struct CholbVecArg
-{
-    double v[2 * CBV_MAX]; // rhs[0 .. p) | diag[0 .. p)
-};
 __global__ __launch_bounds__(256) void cholb_init_arg_kernel(const double *src, double *W, int p, CholbVecArg va, double mu, double *work,
                                                              double *dorig, int *flag, int ntile)
 {
@@ -1963,8 +2180,13 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
         {
             int *d_flag = B.ivec + 2 * p;
             double *d_work = d_sol + p + 8;
+            // 64 < p <= 128: init, the two panels and the update between them in ONE launch (cholb_small_kernel); off with any
+            // of the developer switches that select an older form of a step
+            const bool small = in_place && p > CB && p <= 2 * CB && p <= CBV_MAX && !getenv("GSLNLS_LARGE_SMALL_OFF") &&
+                               !getenv("GSLNLS_LARGE_STEP_V1") && !getenv("GSLNLS_LARGE_PANEL_V1") && !getenv("GSLNLS_LARGE_LOOKAHEAD");
             // the lower triangle of A, the diagonal, the right-hand side as one more row of the matrix (L y = b happens
             // inside the factorisation), the flag: one launch
+            if (!small)
             {
                 const int nb64 = (p + CB - 1) / CB, ntile = A_host ? 0 : nb64 * (nb64 + 1) / 2;
                 if (in_place && p <= CBV_MAX)
@@ -1992,7 +2214,14 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
             // the rest of the previous panel's trailing update (cholb_step_kernel).  GSLNLS_LARGE_STEP_V1=1: panel and
             // trailing update as two launches (same bits); the developer switches above imply it.
             const bool step_v1 = getenv("GSLNLS_LARGE_STEP_V1") != nullptr || panel_v1 || lookahead;
-            if (!step_v1)
+            if (small)
+            {
+                CholbVecArg va;
+                memcpy(va.v, rhs_host, sizeof(double) * p);
+                memcpy(va.v + p, diag_host, sizeof(double) * p);
+                hipLaunchKernelGGL(cholb_small_kernel, dim3(1), dim3(CBS_T), 0, sq, jtj_dev, p, va, mu, B.Lg, d_work, a.dinv, d_flag);
+            }
+            else if (!step_v1)
             {
                 int ncu = 256;
                 (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);

@@ -12,7 +12,7 @@ DP = C.POINTER(C.c_double)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 sizes = [int(a) for a in sys.argv[2:]] or [65, 100, 128, 200, 333, 500, 1000, 2000]
 rng = np.random.default_rng(7)
-SWITCHES = ["GSLNLS_LARGE_BACK_STEPWISE", "GSLNLS_LARGE_STEP_V1", "GSLNLS_LARGE_PANEL_V1", "GSLNLS_LARGE_LOOKAHEAD", "GSLNLS_LARGE_BACK_V1", "GSLNLS_LARGE_BACKUPD_V1"]
+SWITCHES = ["GSLNLS_LARGE_SMALL_OFF", "GSLNLS_LARGE_BACK_STEPWISE", "GSLNLS_LARGE_STEP_V1", "GSLNLS_LARGE_PANEL_V1", "GSLNLS_LARGE_LOOKAHEAD", "GSLNLS_LARGE_BACK_V1", "GSLNLS_LARGE_BACKUPD_V1"]
 for p in sizes:
     J = rng.standard_normal((p + 50, p))
     A = np.ascontiguousarray(J.T @ J)

@@ -322,3 +322,44 @@ def test_glm_fit_with_weights_matches_oracle(amd, gslref, alg):
     assert np.allclose(fit["par"], o["par"], rtol=1e-6, atol=1e-9)
     assert abs(fit["ssr"] - o["ssr"]) <= 1e-9 * o["ssr"]
     assert np.allclose(fit["covar"], o["covar"], rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.parametrize("p", [65, 100, 128, 129, 500, 1100])
+def test_round5_forms_of_the_damped_solve_give_the_same_bits(amd, monkeypatch, p):
+    """csrc/mchol_device.hip, round 5: the one-launch solve for 64 < p <= 128 (cholb_small_kernel), one launch per panel step
+    (cholb_step_kernel), the right-hand side a column behind, the pipelined back substitution, rhs | diag in the kernel
+    arguments or read in place -- each has a developer switch that selects the form before it.  With J^T J resident (the lm
+    step's and the matrix path's call) every form returns the same solution, bit for bit, and it solves the system."""
+    import ctypes as C
+    from gslnls_amd import _lib
+    L = _lib.lib()
+    rng = np.random.Generator(np.random.PCG64(7 + p))
+    J = rng.standard_normal((p + 40, p))
+    A = np.ascontiguousarray(J.T @ J)
+    diag = np.sqrt(np.diag(A)).copy()
+    rhs = rng.standard_normal(p)
+    mu = 1e-3
+    dA = C.c_void_p()
+    assert L.gslnls_debug_device_alloc(C.byref(dA), A.nbytes) == 0
+    switches = ["GSLNLS_LARGE_SMALL_OFF", "GSLNLS_LARGE_STEP_V1", "GSLNLS_LARGE_BACK_STEPWISE", "GSLNLS_LARGE_UPLOAD_COPY",
+                "GSLNLS_LARGE_PANEL_V1", "GSLNLS_LARGE_BACK_V1"]
+    try:
+        assert L.gslnls_debug_device_copy(dA, A.ctypes.data_as(C.c_void_p), A.nbytes, 1) == 0
+        sols = {}
+        for mode in ["default"] + switches:
+            for s in switches:
+                monkeypatch.delenv(s, raising=False)
+            if mode != "default":
+                monkeypatch.setenv(mode, "1")
+            sol = np.zeros(p)
+            assert L.gslnls_debug_mchol_solve_resident(p, dA, diag.ctypes.data_as(_lib.DP), mu, rhs.ctypes.data_as(_lib.DP),
+                                                       sol.ctypes.data_as(_lib.DP)) == 0
+            sols[mode] = sol
+        for s in switches:
+            monkeypatch.delenv(s, raising=False)
+    finally:
+        L.gslnls_debug_device_free(dA)
+    for mode in switches:
+        assert np.array_equal(sols["default"], sols[mode]), mode
+    M = A + mu * np.diag(diag ** 2)
+    assert np.linalg.norm(M @ sols["default"] - rhs) <= 1e-12 * np.linalg.norm(rhs) * np.linalg.cond(M)
