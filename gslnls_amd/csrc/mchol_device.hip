@@ -1392,8 +1392,10 @@ struct CholbVecArg
 // device functions on the same operands in the same order as the general path: same bits (GSLNLS_LARGE_SMALL_OFF=1 keeps the
 // three launches).  L, 1 / L_jj and y are left where the back substitution and a caller's tail expect them.
 constexpr int CBS_T = 576;
+template <int J>
+__device__ __forceinline__ void cholb_back_steps(double &v, double di, const double (&c)[CB], int lane); // (defined with cholb_backall_kernel)
 __global__ __launch_bounds__(CBS_T) void cholb_small_kernel(const double *src, int p, CholbVecArg va, double mu, double *Lf, double *yv,
-                                                            double *dinvg, int *flag)
+                                                            double *dinvg, int *flag, double *sol)
 {
     __shared__ double Lt[CB * CB_LD];
     __shared__ __attribute__((aligned(16))) double stage[CB * CBT_LD];
@@ -1596,6 +1598,56 @@ __global__ __launch_bounds__(CBS_T) void cholb_small_kernel(const double *src, i
         dinvg[CB + tid] = P.invd[tid];
     for (int r = tid; r < p; r += CBS_T)
         yv[r] = ys[r];
+    // ---- L^T x = y, two blocks, in this launch: the sums of cholb_backall_kernel (its pipelined walk: block 1's triangle,
+    // then block 0's 64 components updated and its triangle solved by the wavefront whose turn it is) ----
+    // Wavefront 6 takes block 1, wavefront 5 block 0; each holds its block's triangle c[r] = L[k0 + r][k0 + lane], r > lane, in
+    // ONE register array (two arrays in this kernel spill its factoring wavefronts): block 1's from the published columns
+    // (the product that was stored), block 0's from memory, requested while wavefront 6 solves.
+    double c[CB], di = 0.0;
+#pragma unroll
+    for (int r = 0; r < CB; ++r)
+        c[r] = 0.0;
+    if (wave == 6)
+    {
+#pragma unroll
+        for (int r = 0; r < CB; ++r)
+            c[r] = (r < nb2 && lane < r) ? __dmul_rn(P.V[lane * CB + r], P.invd[lane]) : 0.0;
+        di = lane < nb2 ? P.invd[lane] : 0.0;
+    }
+    else if (wave == 5)
+    {
+#pragma unroll
+        for (int r = 0; r < CB; ++r)
+            c[r] = Lf[lane < r ? (size_t)r * p + lane : 0];
+#pragma unroll
+        for (int r = 0; r < CB; ++r)
+            c[r] = lane < r ? c[r] : 0.0;
+        di = dinvg[lane];
+    }
+    if (wave == 6)
+    {
+        double v = lane < nb2 ? ys[CB + lane] : 0.0;
+        cholb_back_steps<CB - 1>(v, di, c, lane);
+        if (lane < nb2)
+        {
+            ys[CB + lane] = v;
+            sol[CB + lane] = v;
+        }
+    }
+    __syncthreads();
+    if (wave == 5)
+    {
+        double s0 = 0.0;
+#pragma unroll 16
+        for (int r = 0; r < CB; ++r)
+        {
+            const double l = r < nb2 ? stage[r * CBT_LD + lane] : 0.0; // L[64 + r][lane]
+            s0 += l * ys[CB + r];
+        }
+        double v = ys[lane] - s0;
+        cholb_back_steps<CB - 1>(v, di, c, lane);
+        sol[lane] = v;
+    }
 }
 
 // One block of the back substitution L^T x = y (blocks from the last to the first): every workgroup solves the block's
@@ -2183,7 +2235,9 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
             // 64 < p <= 128: init, the two panels and the update between them in ONE launch (cholb_small_kernel); off with any
             // of the developer switches that select an older form of a step
             const bool small = in_place && p > CB && p <= 2 * CB && p <= CBV_MAX && !getenv("GSLNLS_LARGE_SMALL_OFF") &&
-                               !getenv("GSLNLS_LARGE_STEP_V1") && !getenv("GSLNLS_LARGE_PANEL_V1") && !getenv("GSLNLS_LARGE_LOOKAHEAD");
+                               !getenv("GSLNLS_LARGE_STEP_V1") && !getenv("GSLNLS_LARGE_PANEL_V1") && !getenv("GSLNLS_LARGE_LOOKAHEAD") &&
+                               !getenv("GSLNLS_LARGE_BACK_V1") && !getenv("GSLNLS_LARGE_BACK_BLOCKS") && !getenv("GSLNLS_LARGE_BACK_STEPWISE") &&
+                               !getenv("GSLNLS_LARGE_BACKUPD_V1");
             // the lower triangle of A, the diagonal, the right-hand side as one more row of the matrix (L y = b happens
             // inside the factorisation), the flag: one launch
             if (!small)
@@ -2219,7 +2273,7 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
                 CholbVecArg va;
                 memcpy(va.v, rhs_host, sizeof(double) * p);
                 memcpy(va.v + p, diag_host, sizeof(double) * p);
-                hipLaunchKernelGGL(cholb_small_kernel, dim3(1), dim3(CBS_T), 0, sq, jtj_dev, p, va, mu, B.Lg, d_work, a.dinv, d_flag);
+                hipLaunchKernelGGL(cholb_small_kernel, dim3(1), dim3(CBS_T), 0, sq, jtj_dev, p, va, mu, B.Lg, d_work, a.dinv, d_flag, d_sol);
             }
             else if (!step_v1)
             {
@@ -2279,7 +2333,9 @@ static int mchol_device_solve_impl(int p, const double *A_host, const double *jt
                     }
                 }
             }
-            if (getenv("GSLNLS_LARGE_BACK_BLOCKS")) // (developer switch: the launch-per-block form, same bits)
+            if (small)
+                ; // (the two blocks' back substitution ran at the end of cholb_small_kernel)
+            else if (getenv("GSLNLS_LARGE_BACK_BLOCKS")) // (developer switch: the launch-per-block form, same bits)
                 for (int k0 = ((p - 1) / CB) * CB; k0 >= 0; k0 -= CB)
                     hipLaunchKernelGGL(cholb_back_kernel, dim3(1 + (k0 + 255) / 256), dim3(256), 0, sq, B.Lg, p, k0, d_work, d_sol, a.dinv);
             else
