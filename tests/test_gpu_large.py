@@ -363,3 +363,33 @@ def test_round5_forms_of_the_damped_solve_give_the_same_bits(amd, monkeypatch, p
         assert np.array_equal(sols["default"], sols[mode]), mode
     M = A + mu * np.diag(diag ** 2)
     assert np.linalg.norm(M @ sols["default"] - rhs) <= 1e-12 * np.linalg.norm(rhs) * np.linalg.cond(M)
+
+
+@pytest.mark.parametrize("p", [70, 128, 300])
+def test_resident_solve_of_a_rank_deficient_matrix_reaches_the_pivoted_routine(amd, p):
+    """a matrix the natural-order factorisation must refuse (rank p - 5): the one-launch solve for p <= 128 and the panel steps
+    beyond raise the flag, the pivoted modified Cholesky (gsl_linalg_mcholesky's) produces the solution -- the same as for
+    the matrix brought from the host, bit for bit, and finite"""
+    import ctypes as C
+    from gslnls_amd import _lib
+    L = _lib.lib()
+    rng = np.random.Generator(np.random.PCG64(1234 + p))
+    J = rng.standard_normal((p - 5, p))
+    A = np.ascontiguousarray(J.T @ J)
+    diag = np.sqrt(np.diag(A)).copy()
+    rhs = rng.standard_normal(p)
+    mu = 0.0
+    M = np.ascontiguousarray(A + mu * np.diag(diag ** 2))
+    ref = np.zeros(p)
+    assert L.gslnls_debug_mchol_solve(p, M.ctypes.data_as(_lib.DP), diag.ctypes.data_as(_lib.DP), mu, rhs.ctypes.data_as(_lib.DP),
+                                      ref.ctypes.data_as(_lib.DP)) == 0
+    dA = C.c_void_p()
+    assert L.gslnls_debug_device_alloc(C.byref(dA), A.nbytes) == 0
+    try:
+        assert L.gslnls_debug_device_copy(dA, A.ctypes.data_as(C.c_void_p), A.nbytes, 1) == 0
+        sol = np.zeros(p)
+        assert L.gslnls_debug_mchol_solve_resident(p, dA, diag.ctypes.data_as(_lib.DP), mu, rhs.ctypes.data_as(_lib.DP),
+                                                   sol.ctypes.data_as(_lib.DP)) == 0
+    finally:
+        L.gslnls_debug_device_free(dA)
+    assert np.all(np.isfinite(sol)) and np.array_equal(sol, ref)
